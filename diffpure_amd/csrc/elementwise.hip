@@ -1,0 +1,274 @@
+// HBM-bound elementwise / row kernels of the purification loop: solver steps (fused drift +
+// diffusion + in-kernel Philox noise), SiLU, axpby, sinusoidal embedding, row softmax.
+// All are float4-vectorised, grid-stride, and sized to ~2048 workgroups (256 CUs x 8).
+#include <stdarg.h>
+
+#include "dp_common.h"
+
+// ---- error plumbing (shared by every translation unit) ----------------------------------------
+static thread_local char g_dp_err[512] = "";
+void dp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_dp_err, sizeof(g_dp_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dp_last_error(void) { return g_dp_err; }
+extern "C" int dp_abi_version(void) { return 1; }
+
+namespace {
+
+inline unsigned grid_for(long long work_items, int block = 256, int cap = 2048) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011) + Box-Muller ---------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += W0;
+        k1 += W1;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) {  // (0,1), 24 random bits, never 0 or 1
+    return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// 4 standard normals for element quad q of (sample, step) under `seed`
+__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, long long sample, int step, uint32_t q) {
+    U4 c{q, (uint32_t)(step + 1), (uint32_t)((unsigned long long)sample & 0xffffffffu),
+         (uint32_t)((unsigned long long)sample >> 32)};
+    const U4 r = philox4x32_10(c, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32));
+    const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
+    const float a0 = 6.283185307179586f * u01(r.y), a1 = 6.283185307179586f * u01(r.w);
+    float s0, c0, s1, c1;
+    sincosf(a0, &s0, &c0);
+    sincosf(a1, &s1, &c1);
+    return f32x4{r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+}
+
+__global__ void philox_normal_kernel(float* out, int B, long long per_sample, unsigned long long seed,
+                                     long long sample0, int step) {
+    const long long q_per = per_sample / 4, total = (long long)B * q_per;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / q_per, q = i - b * q_per;
+        *reinterpret_cast<f32x4*>(out + b * per_sample + q * 4) = philox_normal4(seed, sample0 + b, step, (uint32_t)q);
+    }
+}
+
+// ---- solver steps ----------------------------------------------------------------------------
+// One thread handles 4 consecutive state elements (flat index within a sample: e = pix*C + c).
+// eps is read at [pix][eps_ld] channel c (first C channels of the network output).
+struct EmArgs {
+    const float* x;
+    const float* eps;
+    const float* noise;
+    float* x_out;
+    int eps_ld, B, HW, C;
+    float nhb, gg, sc, h, g, sqrt_h;
+    int score_div;
+    unsigned long long seed;
+    long long sample0;
+    int step;
+};
+
+__global__ void em_step_kernel(EmArgs p) {
+    const long long per = (long long)p.HW * p.C, q_per = per / 4, total = (long long)p.B * q_per;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / q_per, q = i - b * q_per;
+        const long long base = b * per + q * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + base);
+        f32x4 ev;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long e = q * 4 + j;
+            const long long pix = e / p.C;
+            const int c = (int)(e - pix * p.C);
+            ev[j] = p.eps[(b * p.HW + pix) * p.eps_ld + c];
+        }
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (p.g != 0.f) {
+            z = p.noise ? *reinterpret_cast<const f32x4*>(p.noise + base)
+                        : philox_normal4(p.seed, p.sample0 + b, p.step, (uint32_t)q);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float score = p.score_div ? (-ev[j]) / p.sc : p.sc * ev[j];
+            const float drift = p.nhb * xv[j] - p.gg * score;
+            o[j] = xv[j] + (-drift) * p.h + p.g * (z[j] * p.sqrt_h);
+        }
+        *reinterpret_cast<f32x4*>(p.x_out + base) = o;
+    }
+}
+
+struct DdpmArgs {
+    const float* x;
+    const float* out6;
+    const float* noise;
+    float* x_out;
+    int B, HW, C;
+    float sr, srm1, c1, c2, min_log, max_log;
+    int nonzero;
+    unsigned long long seed;
+    long long sample0;
+    int step;
+};
+
+__global__ void ddpm_step_kernel(DdpmArgs p) {
+    const long long per = (long long)p.HW * p.C, q_per = per / 4, total = (long long)p.B * q_per;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / q_per, q = i - b * q_per;
+        const long long base = b * per + q * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + base);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (p.nonzero) {
+            z = p.noise ? *reinterpret_cast<const f32x4*>(p.noise + base)
+                        : philox_normal4(p.seed, p.sample0 + b, p.step, (uint32_t)q);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long e = q * 4 + j;
+            const long long pix = e / p.C;
+            const int c = (int)(e - pix * p.C);
+            const float* row = p.out6 + (b * p.HW + pix) * (2 * p.C);
+            const float eps = row[c], v = row[p.C + c];
+            const float frac = (v + 1.f) / 2.f;
+            const float logvar = frac * p.max_log + (1.f - frac) * p.min_log;
+            float x0 = p.sr * xv[j] - p.srm1 * eps;
+            x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            const float mean = p.c1 * x0 + p.c2 * xv[j];
+            o[j] = mean + (p.nonzero ? 1.f : 0.f) * expf(0.5f * logvar) * z[j];
+        }
+        *reinterpret_cast<f32x4*>(p.x_out + base) = o;
+    }
+}
+
+// ---- misc ------------------------------------------------------------------------------------
+__global__ void silu_kernel(const float* x, float* y, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = dp_silu_f(x[i]);
+}
+__global__ void axpby_kernel(const float* x, float a, const float* y, float b, float* out, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = x[i] * a + y[i] * b;
+}
+__global__ void temb_kernel(const float* t, int n, const float* freqs, int half, int cos_first, float* emb) {
+    const int total = n * half;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / half, f = i - r * half;
+        const float a = t[r] * freqs[f];
+        float s, c;
+        sincosf(a, &s, &c);
+        float* row = emb + (size_t)r * 2 * half;
+        row[f] = cos_first ? c : s;
+        row[half + f] = cos_first ? s : c;
+    }
+}
+
+// one wave per row; 4 rows per 256-thread workgroup
+__global__ void softmax_rows_kernel(float* x, long long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = x + row * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float e = expf(r[c] - m);
+        r[c] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < cols; c += 64) r[c] *= inv;
+}
+
+}  // namespace
+
+extern "C" int dp_silu(const float* x, float* y, long long n, void* stream) {
+    DP_REQUIRE(x && y && n >= 0, "dp_silu: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    DP_LAUNCH_CHECK("silu");
+    return 0;
+}
+
+extern "C" int dp_axpby(const float* x, float a, const float* y, float b, float* out, long long n, void* stream) {
+    DP_REQUIRE(x && y && out && n >= 0, "dp_axpby: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, b, out, n);
+    DP_LAUNCH_CHECK("axpby");
+    return 0;
+}
+
+extern "C" int dp_timestep_embedding(const float* t, int n, const float* freqs, int half, int cos_first, float* emb,
+                                     void* stream) {
+    DP_REQUIRE(t && freqs && emb && n > 0 && half > 0, "dp_timestep_embedding: bad args");
+    hipLaunchKernelGGL(temb_kernel, dim3(grid_for((long long)n * half)), dim3(256), 0, (hipStream_t)stream, t, n,
+                       freqs, half, cos_first, emb);
+    DP_LAUNCH_CHECK("timestep_embedding");
+    return 0;
+}
+
+extern "C" int dp_softmax_rows(float* x, long long rows, int cols, void* stream) {
+    DP_REQUIRE(x && rows > 0 && cols > 0, "dp_softmax_rows: bad args");
+    const long long grid = (rows + 3) / 4;
+    DP_REQUIRE(grid < (1ll << 31), "dp_softmax_rows: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, rows, cols);
+    DP_LAUNCH_CHECK("softmax_rows");
+    return 0;
+}
+
+extern "C" int dp_philox_normal(float* out, int B, long long per_sample, unsigned long long seed, long long sample0,
+                                int step, void* stream) {
+    DP_REQUIRE(out && B > 0 && per_sample > 0 && per_sample % 4 == 0, "dp_philox_normal: per_sample must be a positive multiple of 4");
+    DP_REQUIRE(per_sample / 4 < (1ll << 32) && dp_aligned16(out), "dp_philox_normal: sample too large or misaligned");
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for(B * (per_sample / 4))), dim3(256), 0, (hipStream_t)stream,
+                       out, B, per_sample, seed, sample0, step);
+    DP_LAUNCH_CHECK("philox_normal");
+    return 0;
+}
+
+extern "C" int dp_em_step(const float* x, const float* eps, int eps_ld, int B, int HW, int C, float neg_half_beta,
+                          float gg, float score_coef, int score_div, float h, float g, float sqrt_h,
+                          const float* noise, unsigned long long seed, long long sample0, int step, float* x_out,
+                          void* stream) {
+    DP_REQUIRE(x && eps && x_out && B > 0 && HW > 0 && C > 0 && eps_ld >= C, "dp_em_step: bad args");
+    DP_REQUIRE(((long long)HW * C) % 4 == 0, "dp_em_step: HW*C must be a multiple of 4");
+    DP_REQUIRE(dp_aligned16(x) && dp_aligned16(x_out) && (!noise || dp_aligned16(noise)), "dp_em_step: misaligned state");
+    EmArgs p{x, eps, noise, x_out, eps_ld, B, HW, C, neg_half_beta, gg, score_coef, h, g, sqrt_h, score_div, seed, sample0, step};
+    hipLaunchKernelGGL(em_step_kernel, dim3(grid_for((long long)B * HW * C / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    DP_LAUNCH_CHECK("em_step");
+    return 0;
+}
+
+extern "C" int dp_ddpm_step(const float* x, const float* out6, int B, int HW, int C, float sqrt_recip_ac,
+                            float sqrt_recipm1_ac, float coef1, float coef2, float min_log, float max_log, int nonzero,
+                            const float* noise, unsigned long long seed, long long sample0, int step, float* x_out,
+                            void* stream) {
+    DP_REQUIRE(x && out6 && x_out && B > 0 && HW > 0 && C > 0, "dp_ddpm_step: bad args");
+    DP_REQUIRE(((long long)HW * C) % 4 == 0, "dp_ddpm_step: HW*C must be a multiple of 4");
+    DP_REQUIRE(dp_aligned16(x) && dp_aligned16(x_out) && (!noise || dp_aligned16(noise)), "dp_ddpm_step: misaligned state");
+    DdpmArgs p{x, out6, noise, x_out, B, HW, C, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, min_log, max_log, nonzero, seed, sample0, step};
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for((long long)B * HW * C / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    DP_LAUNCH_CHECK("ddpm_step");
+    return 0;
+}

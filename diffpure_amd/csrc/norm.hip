@@ -1,0 +1,208 @@
+// GroupNorm over NHWC activations, split in three HBM-bound launches:
+//   stats    : every workgroup owns one (sample, pixel-slab); each thread owns ONE channel quad
+//              (float4, coalesced 16 B/lane along C) and strides over the slab's pixels, so the
+//              whole read is full 64-B..8-KB contiguous rows; per-group sums are combined through
+//              LDS in a fixed order (no float atomics -> bitwise reproducible for any sharding).
+//   finalize : (mean, rstd) per (sample, group), slabs combined in double.
+//   apply    : y = resample(act(FiLM(norm(x)))), float4 in / float4 out, with the channel
+//              concatenation of two sources and the 2x nearest-up / 2x2-mean-down of the
+//              resampling ResBlocks folded into the same pass.
+#include "dp_common.h"
+
+namespace {
+
+struct StatsArgs {
+    const float* x1;
+    const float* x2;
+    int C1, C2, B, HW, G, nsplit;
+    float* partial;
+    int C4, ppb, cpg4;
+};
+
+__global__ void gn_stats_kernel(StatsArgs p) {
+    __shared__ float red_s[1024];
+    __shared__ float red_q[1024];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / p.nsplit, sp = blockIdx.x - b * p.nsplit;
+    const int per = (p.HW + p.nsplit - 1) / p.nsplit;
+    const int p0 = sp * per, p1 = min(p.HW, p0 + per);
+    const int pl = t / p.C4, cq = t - pl * p.C4;
+    const int c = cq * 4;
+    float s = 0.f, q = 0.f;
+    if (pl < p.ppb) {
+        const bool first = c < p.C1;
+        const float* base = first ? (p.x1 + (size_t)b * p.HW * p.C1 + c) : (p.x2 + (size_t)b * p.HW * p.C2 + (c - p.C1));
+        const int Cs = first ? p.C1 : p.C2;
+        for (int px = p0 + pl; px < p1; px += p.ppb) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)px * Cs);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    red_s[t] = s;
+    red_q[t] = q;
+    __syncthreads();
+    if (t < p.G) {
+        double ds = 0.0, dq = 0.0;
+        for (int l = 0; l < p.ppb; ++l)
+            for (int k = 0; k < p.cpg4; ++k) {
+                const int idx = l * p.C4 + t * p.cpg4 + k;
+                ds += red_s[idx];
+                dq += red_q[idx];
+            }
+        float* dst = p.partial + ((size_t)(b * p.nsplit + sp) * p.G + t) * 2;
+        dst[0] = (float)ds;
+        dst[1] = (float)dq;
+    }
+}
+
+__global__ void gn_finalize_kernel(const float* partial, int B, int nsplit, int G, double inv_count, float eps,
+                                   float* stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    double s = 0.0, q = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float* src = partial + ((size_t)(b * nsplit + sp) * G + g) * 2;
+        s += src[0];
+        q += src[1];
+    }
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[i * 2] = (float)mean;
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+struct ApplyArgs {
+    const float* x1;
+    const float* x2;
+    int C1, C2, B, H, W, G;
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    const float* fscale;
+    const float* fshift;
+    int film_stride, act, resample;
+    float* y;
+    int C4, cpg, Ho, Wo;
+};
+
+__device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) {
+    const float* src = (c < p.C1) ? (p.x1 + pix * p.C1 + c) : (p.x2 + pix * p.C2 + (c - p.C1));
+    return *reinterpret_cast<const f32x4*>(src);
+}
+
+__global__ void gn_apply_kernel(ApplyArgs p) {
+    const long long total = (long long)p.B * p.Ho * p.Wo * p.C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % p.C4);
+        const long long opix = i / p.C4;
+        const int ox = (int)(opix % p.Wo);
+        const long long t2 = opix / p.Wo;
+        const int oy = (int)(t2 % p.Ho), b = (int)(t2 / p.Ho);
+        const int c = cq * 4;
+
+        f32x4 a = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};  // y = x*a + d before act
+        if (p.gamma) {
+            const int g = c / p.cpg;
+            const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = rstd * ga[j];
+                d[j] = be[j] - mean * a[j];
+            }
+        }
+        if (p.fscale) {
+            const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
+            const f32x4 fh = *reinterpret_cast<const f32x4*>(p.fshift + (size_t)b * p.film_stride + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m = 1.f + fs[j];
+                a[j] *= m;
+                d[j] = d[j] * m + fh[j];
+            }
+        }
+        auto xf = [&](size_t pix) {
+            f32x4 v = gn_load(p, pix, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j] * a[j] + d[j];
+                v[j] = p.act ? dp_silu_f(u) : u;
+            }
+            return v;
+        };
+        f32x4 o;
+        if (p.resample == 0) {
+            o = xf(((size_t)b * p.H + oy) * p.W + ox);
+        } else if (p.resample == 1) {
+            o = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
+        } else {
+            const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
+            const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+        }
+        *reinterpret_cast<f32x4*>(p.y + (size_t)opix * (p.C4 * 4) + c) = o;
+    }
+}
+
+inline unsigned grid_cap(long long items, int block, int cap) {
+    long long g = (items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int dp_gn_stats(const float* x1, int C1, const float* x2, int C2, int B, int HW, int G, int nsplit,
+                           float* partial, void* stream) {
+    const int C = C1 + C2;
+    DP_REQUIRE(x1 && partial && B > 0 && HW > 0 && G > 0 && nsplit > 0, "dp_gn_stats: bad args");
+    DP_REQUIRE(C2 == 0 || x2, "dp_gn_stats: x2 missing");
+    DP_REQUIRE(C % (4 * G) == 0 && C1 % 4 == 0, "dp_gn_stats: need C %% (4*G) == 0 and C1 %% 4 == 0 (C=%d, G=%d)", C, G);
+    DP_REQUIRE(C / 4 <= 1024 && G <= C / 4, "dp_gn_stats: C=%d too wide", C);
+    DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)), "dp_gn_stats: misaligned input");
+    StatsArgs p{x1, x2, C1, C2, B, HW, G, nsplit, partial, C / 4, 1, C / 4 / G};
+    p.ppb = p.C4 >= 256 ? 1 : 256 / p.C4;
+    const int block = p.C4 * p.ppb;
+    DP_REQUIRE(block >= G && block <= 1024, "dp_gn_stats: internal block size %d", block);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(B * nsplit)), dim3(block), 0, (hipStream_t)stream, p);
+    DP_LAUNCH_CHECK("gn_stats");
+    return 0;
+}
+
+extern "C" int dp_gn_finalize(const float* partial, int B, int nsplit, int G, long long count, float eps, float* stats,
+                              void* stream) {
+    DP_REQUIRE(partial && stats && B > 0 && nsplit > 0 && G > 0 && count > 0, "dp_gn_finalize: bad args");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, B,
+                       nsplit, G, 1.0 / (double)count, eps, stats);
+    DP_LAUNCH_CHECK("gn_finalize");
+    return 0;
+}
+
+extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+                           const float* stats, const float* gamma, const float* beta, const float* fscale,
+                           const float* fshift, int film_stride, int act, int resample, float* y, void* stream) {
+    const int C = C1 + C2;
+    DP_REQUIRE(x1 && y && B > 0 && H > 0 && W > 0, "dp_gn_apply: bad args");
+    DP_REQUIRE(C2 == 0 || x2, "dp_gn_apply: x2 missing");
+    DP_REQUIRE(C % 4 == 0 && C1 % 4 == 0, "dp_gn_apply: channel counts must be multiples of 4");
+    DP_REQUIRE(!gamma || (beta && stats && G > 0 && C % (4 * G) == 0), "dp_gn_apply: need beta, stats and C %% (4*G) == 0");
+    DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply: FiLM scale and shift come together");
+    DP_REQUIRE(resample >= 0 && resample <= 2, "dp_gn_apply: resample mode %d", resample);
+    DP_REQUIRE(resample != 2 || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply: 2x2 mean needs even H, W");
+    DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(y), "dp_gn_apply: misaligned tensor");
+    DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply: misaligned FiLM rows");
+    ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, y,
+                C / 4, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
+                resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W)};
+    const long long total = (long long)B * p.Ho * p.Wo * p.C4;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    DP_LAUNCH_CHECK("gn_apply");
+    return 0;
+}

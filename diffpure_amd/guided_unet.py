@@ -1,0 +1,309 @@
+"""MI355X engine for the guided-diffusion score network (ImageNet 256x256 UNet).
+
+Same function as guided_diffusion.unet.UNetModel.forward (/root/reference/guided_diffusion/
+unet.py:642-671, topology :484-626) and it loads the same `state_dict` keys, but it is not a
+module tree: the network is flattened once into a list of block records over NHWC fp32
+activations, and every record runs on the HIP kernels of libdiffpure_hip.so:
+
+  ResBlock (unet.py:244-264)   = gn_stats -> gn_apply(+SiLU, +2x up/down) -> conv3x3(+bias)
+                                 -> gn_stats -> gn_apply(FiLM (1+scale), shift, +SiLU)
+                                 -> conv3x3(+bias, +residual [identity | fused 1x1 skip])
+  AttentionBlock (:307-313)    = gn -> conv1x1(qkv) -> QK^T -> softmax -> PV -> conv1x1(+residual)
+  skip concatenation (:667)    never materialised: GroupNorm and the convolutions read the two
+                               source tensors directly (channel-split loaders).
+  timestep conditioning        all 40+ per-block `emb_layers` Linear layers (unet.py:209-217) are
+                               one packed GEMM per forward; each block reads its FiLM rows from
+                               that table (broadcast over the batch when the timestep is uniform,
+                               which it always is inside the purification loop).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+
+def parse_config(model_cfg):
+    """yaml/`model_and_diffusion_defaults` dict -> resolved hyper-parameters, as
+    guided_diffusion/script_util.py:138-192 (create_model) resolves them."""
+    image_size = int(model_cfg["image_size"])
+    cm = model_cfg.get("channel_mult", "")
+    if cm is None or cm == "":
+        table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+        if image_size not in table:
+            raise ValueError(f"unsupported image size: {image_size}")
+        cm = table[image_size]
+    elif isinstance(cm, str):
+        cm = tuple(int(v) for v in cm.split(","))
+    att = model_cfg.get("attention_resolutions", "16,8")
+    if isinstance(att, str):
+        att = tuple(image_size // int(r) for r in att.split(","))
+    nh = int(model_cfg.get("num_heads", 4))
+    nhu = int(model_cfg.get("num_heads_upsample", -1))
+    return dict(
+        image_size=image_size,
+        in_channels=3,
+        model_channels=int(model_cfg["num_channels"]),
+        out_channels=6 if model_cfg.get("learn_sigma", False) else 3,
+        channel_mult=tuple(cm),
+        num_res_blocks=int(model_cfg["num_res_blocks"]),
+        attention_ds=tuple(att),
+        num_heads=nh,
+        num_heads_upsample=nh if nhu == -1 else nhu,
+        num_head_channels=int(model_cfg.get("num_head_channels", -1)),
+        resblock_updown=bool(model_cfg.get("resblock_updown", False)),
+        use_scale_shift_norm=bool(model_cfg.get("use_scale_shift_norm", True)),
+        use_new_attention_order=bool(model_cfg.get("use_new_attention_order", False)),
+    )
+
+
+def _plan(cfg):
+    """Flatten the UNet into records. Each record: dict(kind, name, ...)."""
+    mc, nrb, mults = cfg["model_channels"], cfg["num_res_blocks"], cfg["channel_mult"]
+    if not cfg["resblock_updown"] or not cfg["use_scale_shift_norm"]:
+        raise NotImplementedError("engine covers the DiffPure ImageNet family: resblock_updown + scale-shift norm")
+
+    def heads(ch, up):
+        if cfg["num_head_channels"] == -1:
+            return cfg["num_heads_upsample"] if up else cfg["num_heads"]
+        return ch // cfg["num_head_channels"]
+
+    inp, out = [], []
+    ch = int(mults[0] * mc)
+    chans = [ch]
+    inp.append([dict(kind="stem", name="input_blocks.0.0", cin=cfg["in_channels"], cout=ch)])
+    idx, ds = 1, 1
+    for level, mult in enumerate(mults):
+        for _ in range(nrb):
+            co = int(mult * mc)
+            blk = [dict(kind="res", name=f"input_blocks.{idx}.0", cin=ch, cout=co, mode=0)]
+            ch = co
+            if ds in cfg["attention_ds"]:
+                blk.append(dict(kind="attn", name=f"input_blocks.{idx}.1", ch=ch, heads=heads(ch, False)))
+            inp.append(blk)
+            chans.append(ch)
+            idx += 1
+        if level != len(mults) - 1:
+            inp.append([dict(kind="res", name=f"input_blocks.{idx}.0", cin=ch, cout=ch, mode=ops.RESAMPLE_DOWN)])
+            chans.append(ch)
+            idx += 1
+            ds *= 2
+    mid = [
+        dict(kind="res", name="middle_block.0", cin=ch, cout=ch, mode=0),
+        dict(kind="attn", name="middle_block.1", ch=ch, heads=heads(ch, False)),
+        dict(kind="res", name="middle_block.2", cin=ch, cout=ch, mode=0),
+    ]
+    oidx = 0
+    for level, mult in list(enumerate(mults))[::-1]:
+        for i in range(nrb + 1):
+            ich = chans.pop()
+            co = int(mc * mult)
+            blk = [dict(kind="res", name=f"output_blocks.{oidx}.0", cin=ch + ich, cout=co, mode=0, split=ch)]
+            ch = co
+            sub = 1
+            if ds in cfg["attention_ds"]:
+                blk.append(dict(kind="attn", name=f"output_blocks.{oidx}.{sub}", ch=ch, heads=heads(ch, True)))
+                sub += 1
+            if level and i == nrb:
+                blk.append(dict(kind="res", name=f"output_blocks.{oidx}.{sub}", cin=ch, cout=ch, mode=ops.RESAMPLE_UP))
+                ds //= 2
+            out.append(blk)
+            oidx += 1
+    return dict(inp=inp, mid=mid, out=out, final_ch=ch)
+
+
+def _res_shapes(r, emb_dim):
+    n, ci, co = r["name"], r["cin"], r["cout"]
+    sh = OrderedDict()
+    sh[f"{n}.in_layers.0.weight"] = (ci,)
+    sh[f"{n}.in_layers.0.bias"] = (ci,)
+    sh[f"{n}.in_layers.2.weight"] = (co, ci, 3, 3)
+    sh[f"{n}.in_layers.2.bias"] = (co,)
+    sh[f"{n}.emb_layers.1.weight"] = (2 * co, emb_dim)
+    sh[f"{n}.emb_layers.1.bias"] = (2 * co,)
+    sh[f"{n}.out_layers.0.weight"] = (co,)
+    sh[f"{n}.out_layers.0.bias"] = (co,)
+    sh[f"{n}.out_layers.3.weight"] = (co, co, 3, 3)
+    sh[f"{n}.out_layers.3.bias"] = (co,)
+    if ci != co:
+        sh[f"{n}.skip_connection.weight"] = (co, ci, 1, 1)
+        sh[f"{n}.skip_connection.bias"] = (co,)
+    return sh
+
+
+def param_shapes(cfg):
+    """state_dict key -> shape, in the reference's registration order (unet.py:475-624)."""
+    mc = cfg["model_channels"]
+    ed = 4 * mc
+    plan = _plan(cfg)
+    sh = OrderedDict()
+    sh["time_embed.0.weight"] = (ed, mc)
+    sh["time_embed.0.bias"] = (ed,)
+    sh["time_embed.2.weight"] = (ed, ed)
+    sh["time_embed.2.bias"] = (ed,)
+    for blk in [r for b in plan["inp"] for r in b] + plan["mid"] + [r for b in plan["out"] for r in b]:
+        n = blk["name"]
+        if blk["kind"] == "stem":
+            sh[f"{n}.weight"] = (blk["cout"], blk["cin"], 3, 3)
+            sh[f"{n}.bias"] = (blk["cout"],)
+        elif blk["kind"] == "res":
+            sh.update(_res_shapes(blk, ed))
+        else:
+            c = blk["ch"]
+            sh[f"{n}.norm.weight"] = (c,)
+            sh[f"{n}.norm.bias"] = (c,)
+            sh[f"{n}.qkv.weight"] = (3 * c, c, 1)
+            sh[f"{n}.qkv.bias"] = (3 * c,)
+            sh[f"{n}.proj_out.weight"] = (c, c, 1)
+            sh[f"{n}.proj_out.bias"] = (c,)
+    fc = plan["final_ch"]
+    sh["out.0.weight"] = (fc,)
+    sh["out.0.bias"] = (fc,)
+    sh["out.2.weight"] = (cfg["out_channels"], fc, 3, 3)
+    sh["out.2.bias"] = (cfg["out_channels"],)
+    return sh
+
+
+class GuidedUNet:
+    """score network eps_theta(x, t): NHWC in, NHWC out ([B, H, W, out_channels])."""
+
+    GN_GROUPS = 32   # nn.py:101-108 normalization(): GroupNorm32(32, C)
+    GN_EPS = 1e-5
+
+    def __init__(self, cfg, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.plan = _plan(cfg)
+        self.p = {}
+        mc = cfg["model_channels"]
+        half = mc // 2
+        # nn.py:121-123, evaluated on the host exactly as the reference does, then kept resident
+        self.freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(self.device)
+        self.emb_cols = 0
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        want = param_shapes(self.cfg)
+        missing = [k for k in want if k not in sd]
+        if missing:
+            raise KeyError(f"state_dict is missing {len(missing)} keys, e.g. {missing[:3]}")
+        for k, shp in want.items():
+            if tuple(sd[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: expected {shp}, got {tuple(sd[k].shape)}")
+        dev = self.device
+        P = {}
+
+        def vec(k):
+            return sd[k].detach().float().contiguous().to(dev)
+
+        P["te0.w"] = ops.pack_linear_weight(sd["time_embed.0.weight"].detach()).to(dev)
+        P["te0.b"] = vec("time_embed.0.bias")
+        P["te2.w"] = ops.pack_linear_weight(sd["time_embed.2.weight"].detach()).to(dev)
+        P["te2.b"] = vec("time_embed.2.bias")
+        emb_w, emb_b, off = [], [], 0
+        blocks = [r for b in self.plan["inp"] for r in b] + self.plan["mid"] + [r for b in self.plan["out"] for r in b]
+        for r in blocks:
+            n = r["name"]
+            if r["kind"] == "stem":
+                P[n + ".w"] = ops.pack_conv_weight(sd[n + ".weight"].detach()).to(dev)
+                P[n + ".b"] = vec(n + ".bias")
+            elif r["kind"] == "res":
+                P[n + ".g1"], P[n + ".b1"] = vec(n + ".in_layers.0.weight"), vec(n + ".in_layers.0.bias")
+                P[n + ".w1"] = ops.pack_conv_weight(sd[n + ".in_layers.2.weight"].detach()).to(dev)
+                P[n + ".c1"] = vec(n + ".in_layers.2.bias")
+                P[n + ".g2"], P[n + ".b2"] = vec(n + ".out_layers.0.weight"), vec(n + ".out_layers.0.bias")
+                P[n + ".w2"] = ops.pack_conv_weight(sd[n + ".out_layers.3.weight"].detach()).to(dev)
+                P[n + ".c2"] = vec(n + ".out_layers.3.bias")
+                if r["cin"] != r["cout"]:
+                    P[n + ".ws"] = ops.pack_conv_weight(sd[n + ".skip_connection.weight"].detach()).to(dev)
+                    P[n + ".cs"] = vec(n + ".skip_connection.bias")
+                emb_w.append(sd[n + ".emb_layers.1.weight"].detach().float())
+                emb_b.append(sd[n + ".emb_layers.1.bias"].detach().float())
+                r["emb_off"] = off
+                off += 2 * r["cout"]
+            else:
+                P[n + ".g"], P[n + ".b"] = vec(n + ".norm.weight"), vec(n + ".norm.bias")
+                P[n + ".wqkv"] = ops.pack_conv_weight(sd[n + ".qkv.weight"].detach()).to(dev)
+                P[n + ".cqkv"] = vec(n + ".qkv.bias")
+                P[n + ".wproj"] = ops.pack_conv_weight(sd[n + ".proj_out.weight"].detach()).to(dev)
+                P[n + ".cproj"] = vec(n + ".proj_out.bias")
+        # one packed [emb_dim, sum(2*cout)] panel for every block's emb_layers Linear
+        P["emb.w"] = ops.pack_linear_weight(torch.cat(emb_w, dim=0)).to(dev)
+        P["emb.b"] = torch.cat(emb_b, dim=0).contiguous().to(dev)
+        self.emb_cols = off
+        P["out.g"], P["out.b"] = vec("out.0.weight"), vec("out.0.bias")
+        P["out.w"] = ops.pack_conv_weight(sd["out.2.weight"].detach()).to(dev)
+        P["out.c"] = vec("out.2.bias")
+        self.p = P
+        return self
+
+    # -- blocks ----------------------------------------------------------------------------------
+    def _res(self, r, x, x2, film_table):
+        P, n, co = self.p, r["name"], r["cout"]
+        G, eps = self.GN_GROUPS, self.GN_EPS
+        mode = r["mode"]
+        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode)
+        h = ops.conv2d(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"])
+        off = r["emb_off"]
+        film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
+        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True)
+        if mode:
+            skip = ops.resample(x, mode)
+        elif r["cin"] != co:
+            skip = ops.conv2d(x, P[n + ".ws"], co, 1, bias=P[n + ".cs"], x2=x2)
+        else:
+            skip = x if x2 is None else torch.cat([x, x2], dim=3)
+        return ops.conv2d(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip)
+
+    def _attn(self, r, x):
+        P, n, c = self.p, r["name"], r["ch"]
+        b, hh, ww, _ = x.shape
+        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"])
+        qkv = ops.conv2d(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
+        a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
+        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x)
+
+    def _run(self, blk, h, h2, film):
+        for r in blk:
+            if r["kind"] == "res":
+                h = self._res(r, h, h2, film)
+                h2 = None
+            else:
+                h = self._attn(r, h)
+        return h
+
+    # -- forward ---------------------------------------------------------------------------------
+    def time_table(self, timesteps):
+        """timesteps: float32 GPU tensor [R] (R = 1 for a batch-uniform step, else B).
+        -> FiLM table [R, sum(2*cout)]: (scale | shift) rows of every ResBlock."""
+        P = self.p
+        e = ops.timestep_embedding(timesteps, self.freqs, cos_first=True)
+        ed = 4 * self.cfg["model_channels"]
+        e = ops.linear(e, P["te0.w"], ed, P["te0.b"])
+        e = ops.linear(ops.silu(e), P["te2.w"], ed, P["te2.b"])
+        return ops.linear(ops.silu(e), P["emb.w"], self.emb_cols, P["emb.b"])
+
+    def forward(self, x, timesteps=None, table_row=None):
+        """x: [B, H, W, 3] NHWC fp32 on the GPU; timesteps: [1] or [B] float32 (integer-valued for
+        the SDE path, unet.py:642-671 receives `(s*1000).long()`), or `table_row` = precomputed
+        rows of `time_table` ([1, cols] broadcast over the batch, or [B, cols])."""
+        if not self.p:
+            raise RuntimeError("GuidedUNet: weights not loaded")
+        film = table_row if table_row is not None else self.time_table(timesteps)
+        P = self.p
+        hs = []
+        stem = self.plan["inp"][0][0]
+        h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"])
+        hs.append(h)
+        for blk in self.plan["inp"][1:]:
+            h = self._run(blk, h, None, film)
+            hs.append(h)
+        h = self._run(self.plan["mid"], h, None, film)
+        for blk in self.plan["out"]:
+            h = self._run(blk, h, hs.pop(), film)
+        h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True)
+        return ops.conv2d(h, P["out.w"], self.cfg["out_channels"], 3, bias=P["out.c"])
+
+    __call__ = forward

@@ -1,0 +1,258 @@
+"""MI355X engine for the score_sde NCSN++ score network (CIFAR-10 32x32, "ddpmpp deep").
+
+Same function as score_sde.models.ncsnpp.NCSNpp.forward (/root/reference/score_sde/models/
+ncsnpp.py:232-381, topology :139-230) for the configuration DiffPure ships (configs/cifar10.yml:
+BigGAN ResBlocks, fir False, progressive none, positional embedding); loads the reference's
+`all_modules.N.*` state_dict keys (and therefore the EMA parameter list in the same order).
+
+  ResnetBlockBigGANpp (layerspp.py:242-274) = gn_stats -> gn_apply(+SiLU, +2x up/down)
+        -> conv3x3(+bias, + Dense_0(SiLU(temb)) row per sample)
+        -> gn_stats -> gn_apply(+SiLU) -> conv3x3(+bias, + [x | conv1x1(x)] residual, * 1/sqrt2)
+  AttnBlockpp (layerspp.py:75-91) = gn -> ONE 1x1 GEMM for NIN_0|NIN_1|NIN_2 -> QK^T -> softmax
+        -> PV -> NIN_3 GEMM (+residual, * 1/sqrt2)
+  All Dense_0 layers of the 76 ResBlocks are one packed GEMM per forward.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+INV_SQRT2 = 1.0 / math.sqrt(2.0)
+
+
+def parse_config(cfg):
+    """cfg: dict with 'model' and 'data' sections (configs/cifar10.yml)."""
+    m, d = cfg["model"], cfg["data"]
+    ok = (
+        m["name"] == "ncsnpp" and m["resblock_type"].lower() == "biggan" and not m["fir"]
+        and m["progressive"].lower() == "none" and m["progressive_input"].lower() == "none"
+        and m["embedding_type"].lower() == "positional" and m["conditional"]
+        and m["nonlinearity"].lower() == "swish" and not m["scale_by_sigma"] and d["centered"] and m["skip_rescale"]
+    )
+    if not ok:
+        raise NotImplementedError("engine covers the DiffPure CIFAR-10 NCSN++ family (configs/cifar10.yml)")
+    return dict(
+        nf=int(m["nf"]),
+        ch_mult=tuple(m["ch_mult"]),
+        num_res_blocks=int(m["num_res_blocks"]),
+        attn_resolutions=tuple(m["attn_resolutions"]),
+        image_size=int(d["image_size"]),
+        channels=int(d["num_channels"]),
+        sigma_min=float(m["sigma_min"]),
+        sigma_max=float(m["sigma_max"]),
+        num_scales=int(m["num_scales"]),
+    )
+
+
+def _plan(cfg):
+    nf, nrb, mults = cfg["nf"], cfg["num_res_blocks"], cfg["ch_mult"]
+    nres = len(mults)
+    res = [cfg["image_size"] // (2 ** i) for i in range(nres)]
+    down, up = [], []
+    i = 2
+    stem = dict(kind="stem", idx=i, cin=cfg["channels"], cout=nf)
+    i += 1
+    hs_c = [nf]
+    ch = nf
+    for lvl in range(nres):
+        for _ in range(nrb):
+            co = nf * mults[lvl]
+            blk = [dict(kind="res", idx=i, cin=ch, cout=co, mode=0)]
+            i += 1
+            ch = co
+            if res[lvl] in cfg["attn_resolutions"]:
+                blk.append(dict(kind="attn", idx=i, ch=ch))
+                i += 1
+            down.append(blk)
+            hs_c.append(ch)
+        if lvl != nres - 1:
+            down.append([dict(kind="res", idx=i, cin=ch, cout=ch, mode=ops.RESAMPLE_DOWN)])
+            i += 1
+            hs_c.append(ch)
+    mid = [dict(kind="res", idx=i, cin=ch, cout=ch, mode=0), dict(kind="attn", idx=i + 1, ch=ch),
+           dict(kind="res", idx=i + 2, cin=ch, cout=ch, mode=0)]
+    i += 3
+    for lvl in reversed(range(nres)):
+        for _ in range(nrb + 1):
+            co = nf * mults[lvl]
+            sk = hs_c.pop()
+            up.append(dict(kind="res", idx=i, cin=ch + sk, cout=co, mode=0, pop=True))
+            i += 1
+            ch = co
+        if res[lvl] in cfg["attn_resolutions"]:
+            up.append(dict(kind="attn", idx=i, ch=ch))
+            i += 1
+        if lvl != 0:
+            up.append(dict(kind="res", idx=i, cin=ch, cout=ch, mode=ops.RESAMPLE_UP))
+            i += 1
+    assert not hs_c
+    return dict(stem=stem, down=down, mid=mid, up=up, gn_idx=i, conv_idx=i + 1, final_ch=ch)
+
+
+def param_shapes(cfg):
+    """state_dict key -> shape in all_modules order (= the EMA shadow-parameter order)."""
+    nf = cfg["nf"]
+    plan = _plan(cfg)
+    sh = OrderedDict()
+    sh["sigmas"] = (cfg["num_scales"],)
+    M = "all_modules."
+    sh[M + "0.weight"], sh[M + "0.bias"] = (4 * nf, nf), (4 * nf,)
+    sh[M + "1.weight"], sh[M + "1.bias"] = (4 * nf, 4 * nf), (4 * nf,)
+    st = plan["stem"]
+    sh[M + f"{st['idx']}.weight"], sh[M + f"{st['idx']}.bias"] = (st["cout"], st["cin"], 3, 3), (st["cout"],)
+    recs = [r for b in plan["down"] for r in b] + plan["mid"] + plan["up"]
+    for r in recs:
+        p = M + str(r["idx"])
+        if r["kind"] == "res":
+            ci, co = r["cin"], r["cout"]
+            sh[p + ".GroupNorm_0.weight"], sh[p + ".GroupNorm_0.bias"] = (ci,), (ci,)
+            sh[p + ".Conv_0.weight"], sh[p + ".Conv_0.bias"] = (co, ci, 3, 3), (co,)
+            sh[p + ".Dense_0.weight"], sh[p + ".Dense_0.bias"] = (co, 4 * nf), (co,)
+            sh[p + ".GroupNorm_1.weight"], sh[p + ".GroupNorm_1.bias"] = (co,), (co,)
+            sh[p + ".Conv_1.weight"], sh[p + ".Conv_1.bias"] = (co, co, 3, 3), (co,)
+            if ci != co or r["mode"]:
+                sh[p + ".Conv_2.weight"], sh[p + ".Conv_2.bias"] = (co, ci, 1, 1), (co,)
+        else:
+            c = r["ch"]
+            sh[p + ".GroupNorm_0.weight"], sh[p + ".GroupNorm_0.bias"] = (c,), (c,)
+            for j in range(4):
+                sh[p + f".NIN_{j}.W"], sh[p + f".NIN_{j}.b"] = (c, c), (c,)
+    fc = plan["final_ch"]
+    sh[M + f"{plan['gn_idx']}.weight"], sh[M + f"{plan['gn_idx']}.bias"] = (fc,), (fc,)
+    sh[M + f"{plan['conv_idx']}.weight"] = (cfg["channels"], fc, 3, 3)
+    sh[M + f"{plan['conv_idx']}.bias"] = (cfg["channels"],)
+    return sh
+
+
+class NCSNpp:
+    """score network: NHWC in, NHWC out ([B, H, W, channels]); `labels` = 999*s float."""
+
+    GN_EPS = 1e-6
+
+    def __init__(self, cfg, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.plan = _plan(cfg)
+        self.p = {}
+        half = cfg["nf"] // 2
+        # layers.py:518-521 on the host, as the reference evaluates it
+        e = math.log(10000) / (half - 1)
+        self.freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -e).to(self.device)
+        self.dense_cols = 0
+
+    @staticmethod
+    def _groups(c):
+        return min(c // 4, 32)
+
+    def load_state_dict(self, sd):
+        want = param_shapes(self.cfg)
+        for k, shp in want.items():
+            if k == "sigmas":
+                continue
+            if k not in sd:
+                raise KeyError(f"state_dict is missing {k}")
+            if tuple(sd[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: expected {shp}, got {tuple(sd[k].shape)}")
+        dev = self.device
+        P = {}
+        M = "all_modules."
+
+        def vec(k):
+            return sd[k].detach().float().contiguous().to(dev)
+
+        P["t0.w"], P["t0.b"] = ops.pack_linear_weight(sd[M + "0.weight"].detach()).to(dev), vec(M + "0.bias")
+        P["t1.w"], P["t1.b"] = ops.pack_linear_weight(sd[M + "1.weight"].detach()).to(dev), vec(M + "1.bias")
+        si = self.plan["stem"]["idx"]
+        P["stem.w"], P["stem.b"] = ops.pack_conv_weight(sd[M + f"{si}.weight"].detach()).to(dev), vec(M + f"{si}.bias")
+        dw, db, off = [], [], 0
+        recs = [r for b in self.plan["down"] for r in b] + self.plan["mid"] + self.plan["up"]
+        for r in recs:
+            p = M + str(r["idx"])
+            n = str(r["idx"])
+            if r["kind"] == "res":
+                P[n + ".g0"], P[n + ".b0"] = vec(p + ".GroupNorm_0.weight"), vec(p + ".GroupNorm_0.bias")
+                P[n + ".w0"], P[n + ".c0"] = ops.pack_conv_weight(sd[p + ".Conv_0.weight"].detach()).to(dev), vec(p + ".Conv_0.bias")
+                P[n + ".g1"], P[n + ".b1"] = vec(p + ".GroupNorm_1.weight"), vec(p + ".GroupNorm_1.bias")
+                P[n + ".w1"], P[n + ".c1"] = ops.pack_conv_weight(sd[p + ".Conv_1.weight"].detach()).to(dev), vec(p + ".Conv_1.bias")
+                if r["cin"] != r["cout"] or r["mode"]:
+                    P[n + ".w2"], P[n + ".c2"] = ops.pack_conv_weight(sd[p + ".Conv_2.weight"].detach()).to(dev), vec(p + ".Conv_2.bias")
+                dw.append(sd[p + ".Dense_0.weight"].detach().float())
+                db.append(sd[p + ".Dense_0.bias"].detach().float())
+                r["dense_off"] = off
+                off += r["cout"]
+            else:
+                P[n + ".g"], P[n + ".b"] = vec(p + ".GroupNorm_0.weight"), vec(p + ".GroupNorm_0.bias")
+                wq = torch.cat([sd[p + f".NIN_{j}.W"].detach().float() for j in range(3)], dim=1)
+                P[n + ".wqkv"] = ops.pack_nin_weight(wq).to(dev)
+                P[n + ".cqkv"] = torch.cat([sd[p + f".NIN_{j}.b"].detach().float() for j in range(3)]).contiguous().to(dev)
+                P[n + ".w3"], P[n + ".c3"] = ops.pack_nin_weight(sd[p + ".NIN_3.W"].detach()).to(dev), vec(p + ".NIN_3.b")
+        P["dense.w"] = ops.pack_linear_weight(torch.cat(dw, dim=0)).to(dev)
+        P["dense.b"] = torch.cat(db, dim=0).contiguous().to(dev)
+        self.dense_cols = off
+        gi, ci = self.plan["gn_idx"], self.plan["conv_idx"]
+        P["out.g"], P["out.b"] = vec(M + f"{gi}.weight"), vec(M + f"{gi}.bias")
+        P["out.w"], P["out.c"] = ops.pack_conv_weight(sd[M + f"{ci}.weight"].detach()).to(dev), vec(M + f"{ci}.bias")
+        self.p = P
+        return self
+
+    def _res(self, r, x, x2, dense):
+        P, n, co = self.p, str(r["idx"]), r["cout"]
+        mode = r["mode"]
+        h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True, resample=mode)
+        off = r["dense_off"]
+        h = ops.conv2d(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co])
+        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True)
+        if mode:
+            xs = ops.resample(x, mode)
+            skip = ops.conv2d(xs, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+        elif r["cin"] != co:
+            skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
+        else:
+            skip = x if x2 is None else torch.cat([x, x2], dim=3)
+        return ops.conv2d(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2)
+
+    def _attn(self, r, x):
+        P, n, c = self.p, str(r["idx"]), r["ch"]
+        b, hh, ww, _ = x.shape
+        hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"])
+        qkv = ops.conv2d(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
+        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2)
+
+    def time_table(self, labels):
+        """labels: float32 GPU tensor [R] (= 999*s). -> Dense_0 rows of every ResBlock [R, sum(cout)]."""
+        P, nf = self.p, self.cfg["nf"]
+        e = ops.timestep_embedding(labels, self.freqs, cos_first=False)
+        e = ops.linear(e, P["t0.w"], 4 * nf, P["t0.b"])
+        e = ops.linear(ops.silu(e), P["t1.w"], 4 * nf, P["t1.b"])
+        return ops.linear(ops.silu(e), P["dense.w"], self.dense_cols, P["dense.b"])
+
+    def forward(self, x, labels=None, table_row=None):
+        if not self.p:
+            raise RuntimeError("NCSNpp: weights not loaded")
+        P = self.p
+        dense = table_row if table_row is not None else self.time_table(labels)
+        st = self.plan["stem"]
+        hs = [ops.conv2d(x, P["stem.w"], st["cout"], 3, bias=P["stem.b"])]
+        for blk in self.plan["down"]:
+            h = hs[-1]
+            for r in blk:
+                h = self._res(r, h, None, dense) if r["kind"] == "res" else self._attn(r, h)
+            hs.append(h)
+        h = hs[-1]
+        for r in self.plan["mid"]:
+            h = self._res(r, h, None, dense) if r["kind"] == "res" else self._attn(r, h)
+        for r in self.plan["up"]:
+            if r["kind"] == "attn":
+                h = self._attn(r, h)
+            elif r.get("pop"):
+                h = self._res(r, h, hs.pop(), dense)
+            else:
+                h = self._res(r, h, None, dense)
+        assert not hs
+        h = ops.group_norm(h, self._groups(self.plan["final_ch"]), self.GN_EPS, P["out.g"], P["out.b"], act=True)
+        return ops.conv2d(h, P["out.w"], self.cfg["channels"], 3, bias=P["out.c"])
+
+    __call__ = forward

@@ -1,0 +1,286 @@
+"""Tensor-level operators of the purification engine: thin wrappers that validate shapes, allocate
+outputs with torch's caching allocator and launch libdiffpure_hip.so kernels on torch's current
+HIP stream.  PyTorch is plumbing here (device memory + streams); every FLOP runs in the HIP library.
+
+Layout: activations are NHWC fp32 `[B, H, W, C]`; "rows" tensors are `[M, K]`.
+No CPU path exists: tensors must live on a GPU and the library must be built.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, ndim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.DiffpureHipError(f"{name}: expected a GPU tensor (the HIP engine has no CPU fallback)")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.DiffpureHipError(f"{name}: expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+    if ndim is not None and t.dim() != ndim:
+        raise _lib.DiffpureHipError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing (host-side, once at load)
+# ---------------------------------------------------------------------------------------------
+def _pad_cols(w2d):
+    k, n = w2d.shape
+    ldw = (n + 3) // 4 * 4
+    if ldw == n:
+        return w2d.contiguous()
+    out = w2d.new_zeros(k, ldw)
+    out[:, :n] = w2d
+    return out
+
+
+def pack_conv_weight(w):
+    """OIHW (or OI for 1x1 / OIk for Conv1d k=1) -> [KH*KW*I, ldw] with k = (ky*KW+kx)*I + ci."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, :, None]
+    o, i, kh, kw = w.shape
+    return _pad_cols(w.permute(2, 3, 1, 0).reshape(kh * kw * i, o).float())
+
+
+def pack_linear_weight(w):
+    """nn.Linear weight [out, in] -> [in, ldw]."""
+    return _pad_cols(w.t().float())
+
+
+def pack_nin_weight(w):
+    """score_sde NIN.W [in, out] -> [in, ldw]."""
+    return _pad_cols(w.float())
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution / linear
+# ---------------------------------------------------------------------------------------------
+def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None):
+    """out = scale * (res + bias + temb[b] + conv_{ksize x ksize, same}(cat(x, x2)))   (NHWC)."""
+    _chk(x, "conv2d.x", 4)
+    b, h, w, c1 = x.shape
+    c2 = 0
+    if x2 is not None:
+        _chk(x2, "conv2d.x2", 4)
+        assert x2.shape[:3] == x.shape[:3], (x.shape, x2.shape)
+        c2 = x2.shape[3]
+    _chk(wp, "conv2d.w", 2)
+    assert wp.shape[0] == ksize * ksize * (c1 + c2), (wp.shape, ksize, c1, c2)
+    assert wp.shape[1] >= n_out
+    if bias is not None:
+        _chk(bias, "conv2d.bias", 1)
+    ts = 0
+    if temb is not None:
+        # temb: [R, >=n_out] rows, R in {1, B}; may be a column view of a wider table (row stride kept)
+        assert temb.is_cuda and temb.dtype == torch.float32 and temb.dim() == 2 and temb.stride(1) == 1
+        assert temb.shape[0] in (1, b) and temb.shape[1] >= n_out
+        ts = 0 if temb.shape[0] == 1 else temb.stride(0)
+    if out is None:
+        out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float32)
+    ldr = 0
+    if res is not None:
+        _chk(res, "conv2d.res", 4)
+        assert res.shape == out.shape, (res.shape, out.shape)
+        ldr = n_out
+    _lib.call("dp_conv2d_nhwc", _ptr(x), c1, _ptr(x2), c2, b, h, w, ksize, ksize, _ptr(wp), wp.shape[1], n_out,
+              _ptr(bias), _ptr(temb), ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, 0, _stream())
+    return out
+
+
+def linear(x, wp, n_out, bias=None):
+    """[M, K] @ [K, N] + bias."""
+    _chk(x, "linear.x", 2)
+    m, k = x.shape
+    return conv2d(x.view(m, 1, 1, k), wp, n_out, 1, bias=bias).view(m, n_out)
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupNorm (+FiLM) (+SiLU) (+resample)
+# ---------------------------------------------------------------------------------------------
+RESAMPLE_NONE, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
+
+
+def _nsplit(hw):
+    # pixel slabs per sample for the statistics pass. A function of the image size ONLY: the slab
+    # partition fixes the summation order, and results must not depend on how a batch is sharded.
+    return max(1, min(hw // 256, 128))
+
+
+def group_norm_stats(x, groups, eps, x2=None):
+    """-> stats [B, G, 2] = (mean, rstd) of cat(x, x2) per (sample, group)."""
+    _chk(x, "gn.x", 4)
+    b, h, w, c1 = x.shape
+    c2 = 0 if x2 is None else _chk(x2, "gn.x2", 4).shape[3]
+    hw = h * w
+    ns = _nsplit(hw)
+    partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
+    stats = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
+    s = _stream()
+    _lib.call("dp_gn_stats", _ptr(x), c1, _ptr(x2), c2, b, hw, groups, ns, _ptr(partial), s)
+    _lib.call("dp_gn_finalize", _ptr(partial), b, ns, groups, hw * ((c1 + c2) // groups), float(eps), _ptr(stats), s)
+    return stats
+
+
+def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None):
+    """y = resample(act(FiLM(GroupNorm(cat(x, x2))))).  film = (scale [R,C], shift [R,C]) with R in
+    {1, B}; the two may be column views of one [R, 2C] tensor (row stride is taken from them)."""
+    _chk(x, "gn.x", 4)
+    b, h, w, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    c = c1 + c2
+    if stats is None:
+        stats = group_norm_stats(x, groups, eps, x2)
+    fs = fh = None
+    fstride = 0
+    if film is not None:
+        fs, fh = film
+        assert fs.is_cuda and fs.dtype == torch.float32 and fs.shape[-1] == c and fs.stride(-1) == 1
+        assert fh.shape == fs.shape and fh.stride() == fs.stride()
+        assert fs.shape[0] in (1, b)
+        fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
+    ho, wo = (h * 2, w * 2) if resample == RESAMPLE_UP else ((h // 2, w // 2) if resample == RESAMPLE_DOWN else (h, w))
+    y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
+              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, _ptr(y), _stream())
+    return y
+
+
+def resample(x, mode):
+    """Nearest x2 up (mode 1) or 2x2 mean down (mode 2) of an NHWC tensor, no normalisation."""
+    _chk(x, "resample.x", 4)
+    b, h, w, c = x.shape
+    ho, wo = (h * 2, w * 2) if mode == RESAMPLE_UP else (h // 2, w // 2)
+    y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, _ptr(y), _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# attention core
+# ---------------------------------------------------------------------------------------------
+def attention(qkv, n_heads, layout):
+    """softmax(q k^T / sqrt(d)) v for qkv [B, T, 3C] -> [B, T, C].
+    layout 'legacy': channels = heads x [q(d) | k(d) | v(d)]   (QKVAttentionLegacy, unet.py:345-362)
+    layout 'split' : channels = [Q(all heads) | K | V]         (QKVAttention unet.py:377-397; NCSN++ q,k,v NINs)"""
+    _chk(qkv, "attention.qkv", 3)
+    b, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // n_heads
+    if layout == "legacy":
+        oq, ok, ov, sh = 0, d, 2 * d, 3 * d
+    elif layout == "split":
+        oq, ok, ov, sh = 0, c, 2 * c, d
+    else:
+        raise ValueError(layout)
+    s = _stream()
+    scores = torch.empty((b * n_heads, t, t), device=qkv.device, dtype=torch.float32)
+    out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    el = 4
+    # scores[z] = (1/sqrt(d)) * Q K^T
+    _lib.call("dp_gemm_strided", base + oq * el, c3, t * c3, sh, base + ok * el, c3, t * c3, sh, 1,
+              _ptr(scores), t, n_heads * t * t, t * t, t, t, d, b, n_heads, 1.0 / math.sqrt(d), s)
+    _lib.call("dp_softmax_rows", _ptr(scores), b * n_heads * t, t, s)
+    # out[z] = P V
+    _lib.call("dp_gemm_strided", _ptr(scores), t, n_heads * t * t, t * t, base + ov * el, c3, t * c3, sh, 0,
+              _ptr(out), c, t * c, d, t, d, t, b, n_heads, 1.0, s)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# small pieces
+# ---------------------------------------------------------------------------------------------
+def silu(x):
+    _chk(x, "silu.x")
+    y = torch.empty_like(x)
+    _lib.call("dp_silu", _ptr(x), _ptr(y), x.numel(), _stream())
+    return y
+
+
+def axpby(x, a, y, b):
+    _chk(x, "axpby.x")
+    _chk(y, "axpby.y")
+    assert x.shape == y.shape
+    out = torch.empty_like(x)
+    _lib.call("dp_axpby", _ptr(x), float(a), _ptr(y), float(b), _ptr(out), x.numel(), _stream())
+    return out
+
+
+def timestep_embedding(t, freqs, cos_first):
+    _chk(t, "temb.t", 1)
+    _chk(freqs, "temb.freqs", 1)
+    n, half = t.shape[0], freqs.shape[0]
+    emb = torch.empty((n, 2 * half), device=t.device, dtype=torch.float32)
+    _lib.call("dp_timestep_embedding", _ptr(t), n, _ptr(freqs), half, 1 if cos_first else 0, _ptr(emb), _stream())
+    return emb
+
+
+def philox_normal(shape, seed, sample0, step, device):
+    """Standard normals [B, ...] keyed by (seed, sample0 + b, step, element)."""
+    b = shape[0]
+    per = 1
+    for s_ in shape[1:]:
+        per *= s_
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    _lib.call("dp_philox_normal", _ptr(out), b, per, int(seed), int(sample0), int(step), _stream())
+    return out
+
+
+def em_step(x, eps, neg_half_beta, gg, score_coef, score_div, h, g, sqrt_h, noise=None, seed=0, sample0=0, step=0,
+            out=None):
+    """x: [B,H,W,C] state; eps: [B,H,W,Ce] network output (first C channels used)."""
+    _chk(x, "em_step.x", 4)
+    _chk(eps, "em_step.eps", 4)
+    b, hh, ww, c = x.shape
+    assert eps.shape[:3] == x.shape[:3] and eps.shape[3] >= c
+    if noise is not None:
+        _chk(noise, "em_step.noise", 4)
+        assert noise.shape == x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("dp_em_step", _ptr(x), _ptr(eps), eps.shape[3], b, hh * ww, c, float(neg_half_beta), float(gg),
+              float(score_coef), 1 if score_div else 0, float(h), float(g), float(sqrt_h), _ptr(noise), int(seed),
+              int(sample0), int(step), _ptr(out), _stream())
+    return out
+
+
+def ddpm_step(x, out6, sr, srm1, c1, c2, min_log, max_log, nonzero, noise=None, seed=0, sample0=0, step=0, out=None):
+    _chk(x, "ddpm_step.x", 4)
+    _chk(out6, "ddpm_step.out6", 4)
+    b, hh, ww, c = x.shape
+    assert out6.shape == (b, hh, ww, 2 * c)
+    if noise is not None:
+        _chk(noise, "ddpm_step.noise", 4)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("dp_ddpm_step", _ptr(x), _ptr(out6), b, hh * ww, c, float(sr), float(srm1), float(c1), float(c2),
+              float(min_log), float(max_log), 1 if nonzero else 0, _ptr(noise), int(seed), int(sample0), int(step),
+              _ptr(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# profiling hooks (bench.py roofline leg)
+# ---------------------------------------------------------------------------------------------
+def prof_enable(on=True):
+    _lib.call("dp_prof_enable", 1 if on else 0)
+
+
+def prof_collect():
+    import ctypes as C
+    ms3, ms1, f3, f1 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    n3, n1 = C.c_longlong(), C.c_longlong()
+    _lib.call("dp_prof_collect", C.addressof(ms3), C.addressof(n3), C.addressof(f3), C.addressof(ms1), C.addressof(n1),
+              C.addressof(f1))
+    return dict(ms3x3=ms3.value, n3x3=n3.value, flop3x3=f3.value, ms1x1=ms1.value, n1x1=n1.value, flop1x1=f1.value)

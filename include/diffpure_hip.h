@@ -1,0 +1,143 @@
+/*
+ * diffpure_hip.h - C ABI of libdiffpure_hip.so, the MI355X (gfx950) kernels behind the DiffPure
+ * purification hot path.
+ *
+ * The reference has no FFI of its own for this path: its device work is `torch.nn` calls that end
+ * in cuDNN / cuBLAS / ATen kernels.  Each entry point below therefore replaces one *call site* of
+ * the reference (cited as file:line under /root/reference) and is what a maintainer would bind
+ * (ctypes / pybind / TORCH_LIBRARY - see INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory, plain sizes; no torch types.
+ *   - activations are NHWC fp32 ("pixel-major": [B][H][W][C]); weights are pre-packed by the host
+ *     (see each function).  All float4-vectorised paths need the channel counts named below to be
+ *     multiples of 4 and the base pointers 16-byte aligned.
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  Nothing synchronises.
+ *   - return 0 on success, non-zero on error; dp_last_error() gives the message (thread-local).
+ *   - no hidden allocations: scratch is passed in by the caller.
+ */
+#ifndef DIFFPURE_HIP_H
+#define DIFFPURE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------ */
+int dp_abi_version(void);
+const char* dp_last_error(void);
+
+/* Per-launch timing of the convolution kernels with hipEvents recorded on the launch stream
+ * (bench.py's roofline leg).  dp_prof_enable(1) starts recording; dp_prof_collect() synchronises
+ * the recorded events and returns totals since enable: milliseconds, launches and algorithmic
+ * FLOPs (2*M*N*K) separately for 3x3 and for 1x1/linear launches. */
+int dp_prof_enable(int on);
+int dp_prof_collect(double* ms3x3, long long* n3x3, double* flop3x3,
+                    double* ms1x1, long long* n1x1, double* flop1x1);
+
+/* ---- convolution / linear: implicit GEMM on MFMA -------------------------------------------
+ * Replaces nn.Conv2d / nn.Conv1d(k=1) / nn.Linear / NIN at
+ *   guided_diffusion/unet.py:196 (in_layers conv), :224 (out_layers conv), :229-234 (skip),
+ *   :295 (qkv), :302 (proj_out), :478-484, :623 (stem / head), :213-216 (emb linear),
+ *   score_sde/models/layerspp.py:224,233,235 (Conv_0/1/2), :226 (Dense_0),
+ *   score_sde/models/layers.py:552-555 (NIN), score_sde/models/ncsnpp.py:87-92 (temb MLP).
+ *
+ * out[m][n] = scale * ( res[m][n] + bias[n] + temb[b(m)][n] + sum_k A[m][k] * w[k][n] )
+ *   m = (b, oy, ox) over B*H*W output pixels (stride 1, "same" zero padding, KH=KW in {1,3});
+ *   k = ((ky*KW + kx) * Cin + ci), Cin = C1 + C2: the input is the channel concatenation of x1
+ *   (C1 channels) and optional x2 (C2 channels) - the th.cat of unet.py:667 / ncsnpp.py:325 is
+ *   never materialised;  w is [K][ldw] row-major (ldw >= N, ldw % 4 == 0, pad columns zero);
+ *   bias [N] or NULL; temb [B][temb_stride] or NULL (temb_stride 0 broadcasts one row);
+ *   res [M][ldr] or NULL; out [M][ldo].
+ * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation).
+ */
+int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
+                   int B, int H, int W, int KH, int KW,
+                   const float* w, int ldw, int N,
+                   const float* bias, const float* temb, int temb_stride,
+                   const float* res, int ldr, float scale,
+                   float* out, int ldo, int precision, void* stream);
+
+/* ---- strided batched GEMM (attention cores) -------------------------------------------------
+ * Replaces the einsums at unet.py:355-359 / :389-396 and layerspp.py:82,86.
+ * C[z][m][n] = alpha * sum_k A[z][m][k] * Bop[z][k][n];  z = zb*ZH + zh, and each operand's batch
+ * offset is zb*s?b + zh*s?h (elements).  transB = 0: B stored [K][ldb]; 1: B stored [N][ldb].
+ * K % 4 == 0, lda/ldb % 4 == 0, (transB ? 1 : N % 4 == 0). */
+int dp_gemm_strided(const float* A, int lda, long long sAb, long long sAh,
+                    const float* B, int ldb, long long sBb, long long sBh, int transB,
+                    float* C, int ldc, long long sCb, long long sCh,
+                    int M, int N, int K, int ZB, int ZH, float alpha, void* stream);
+
+/* Row softmax in place, rows x cols fp32 (unet.py:358 `th.softmax(weight.float(), -1)`,
+ * layerspp.py:84). */
+int dp_softmax_rows(float* x, long long rows, int cols, void* stream);
+
+/* ---- GroupNorm (+FiLM) (+SiLU) (+2x resample) -----------------------------------------------
+ * Replaces GroupNorm32 + SiLU + Upsample/Downsample at unet.py:193-195, :218-221, :245-250,
+ * :258-261, :293, :621-622 and nn.GroupNorm + act + naive_{up,down}sample_2d at
+ * layerspp.py:217,230,243-258,268, :66,77, ncsnpp.py:225-227,372.
+ *
+ * Step 1  dp_gn_stats:   partial[b][s][g] = (sum, sumsq) over pixel slab s of (x1|x2) (float2)
+ * Step 2  dp_gn_finalize: stats[b][g] = (mean, rstd) in float, combined in double
+ * Step 3  dp_gn_apply:   y = resample( act( ((x-mean)*rstd*gamma+beta) * (1+fscale) + fshift ) )
+ *   C = C1 + C2, C % (4*G) == 0; nsplit chosen by the caller (scratch = B*nsplit*G*2 floats).
+ *   fscale/fshift: [B][film_stride] rows or NULL (film_stride 0 broadcasts one row).
+ *   gamma == NULL skips the normalisation (pure act/resample of x: the x-branch of a
+ *   resampling ResBlock, unet.py:249 / layerspp.py:249,256).
+ *   act: 0 none, 1 SiLU.  resample: 0 none, 1 nearest x2 (out 2H x 2W), 2 mean 2x2 (out H/2 x W/2).
+ */
+int dp_gn_stats(const float* x1, int C1, const float* x2, int C2, int B, int HW, int G,
+                int nsplit, float* partial, void* stream);
+int dp_gn_finalize(const float* partial, int B, int nsplit, int G, long long count, float eps,
+                   float* stats, void* stream);
+int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+                const float* stats, const float* gamma, const float* beta,
+                const float* fscale, const float* fshift, int film_stride,
+                int act, int resample, float* y, void* stream);
+
+/* ---- small elementwise pieces ----------------------------------------------------------------*/
+/* y = x * sigmoid(x)   (nn.SiLU on the embedding vector, unet.py:211, layerspp.py:265) */
+int dp_silu(const float* x, float* y, long long n, void* stream);
+/* out = a*x + b*y      (forward diffusion, runners/diffpure_sde.py:223) */
+int dp_axpby(const float* x, float a, const float* y, float b, float* out, long long n, void* stream);
+/* emb[i][:] = sinusoid(t[i] * freqs[:half]); cos_first=1: [cos|sin] (guided nn.py:111-129),
+ * 0: [sin|cos] (score_sde layers.py:515-529).  freqs is the host-computed table. */
+int dp_timestep_embedding(const float* t, int n, const float* freqs, int half, int cos_first,
+                          float* emb, void* stream);
+
+/* ---- solver steps -----------------------------------------------------------------------------
+ * One fixed step of the reverse VP-SDE (Euler-Maruyama) or of the probability-flow ODE (Euler),
+ * fused over all pixels.  Replaces RevVPSDE.f/.g (runners/diffpure_sde.py:86-147) + torchsde's
+ * Euler.step, and VPODE.ode_fn (runners/diffpure_ode.py:90-122) + torchdiffeq's Euler step:
+ *   score = score_div ? (-eps)/score_coef : score_coef*eps
+ *   drift = neg_half_beta*x - gg*score          (gg = g^2 for the SDE, 0.5*g^2 for the ODE)
+ *   x_new = x + (-drift)*h + g*(z*sqrt_h)       (g = 0: no noise is drawn or read)
+ * x: [B][HW][C] state; eps: network output [B][HW][eps_ld], first C channels used; x_out may alias
+ * x.  Noise z: read from `noise` ([B][HW][C]) if non-NULL, else Philox4x32-10 + Box-Muller keyed
+ * by (seed, global sample index = sample0 + b, step, element) so that any sharding of the batch
+ * over GPUs draws the same stream.  All scalars are computed by the host in float32 exactly as the
+ * reference computes them. */
+int dp_em_step(const float* x, const float* eps, int eps_ld, int B, int HW, int C,
+               float neg_half_beta, float gg, float score_coef, int score_div,
+               float h, float g, float sqrt_h,
+               const float* noise, unsigned long long seed, long long sample0, int step,
+               float* x_out, void* stream);
+/* Standard normals from the same Philox stream (used for the forward-diffusion noise `e`,
+ * diffpure_sde.py:217; step = -1 by convention). out: [B][per_sample]. per_sample % 4 == 0. */
+int dp_philox_normal(float* out, int B, long long per_sample, unsigned long long seed,
+                     long long sample0, int step, void* stream);
+/* DDPM ancestral step with learned-range variance and clipped x0
+ * (gaussian_diffusion.py:266-334, :438-446). out6: [B][HW][2C] (eps | v). z as in dp_em_step. */
+int dp_ddpm_step(const float* x, const float* out6, int B, int HW, int C,
+                 float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1, float coef2,
+                 float min_log, float max_log, int nonzero,
+                 const float* noise, unsigned long long seed, long long sample0, int step,
+                 float* x_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFPURE_HIP_H */

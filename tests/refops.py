@@ -1,0 +1,197 @@
+"""TEST INFRASTRUCTURE: plain-PyTorch fp32 statements of every `diffpure_amd.ops` contract.
+
+Two uses:
+  * `-m gpu` tests compare each HIP operator against the function of the same name here;
+  * `-m "not gpu"` tests monkeypatch `diffpure_amd.ops` with these (see `patch_ops`) so that the
+    HOST logic of the engine - block wiring, weight packing, channel-split loaders, time tables,
+    schedules - is checked on CPU against the oracle / the reference's golden vectors.
+The product never imports this module.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+RESAMPLE_NONE, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
+
+
+def _cat(x, x2):
+    return x if x2 is None else torch.cat([x, x2], dim=3)
+
+
+def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None):
+    xin = _cat(x, x2)
+    b, h, w, cin = xin.shape
+    wt = wp[:, :n_out].reshape(ksize, ksize, cin, n_out).permute(3, 2, 0, 1).contiguous()
+    y = F.conv2d(xin.permute(0, 3, 1, 2), wt, None, padding=ksize // 2).permute(0, 2, 3, 1)
+    if bias is not None:
+        y = y + bias[:n_out]
+    if temb is not None:
+        y = y + temb[:, :n_out].reshape(-1, 1, 1, n_out)
+    if res is not None:
+        y = y + res
+    y = (y * scale).contiguous()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def linear(x, wp, n_out, bias=None):
+    m, k = x.shape
+    return conv2d(x.view(m, 1, 1, k), wp, n_out, 1, bias=bias).view(m, n_out)
+
+
+def group_norm_stats(x, groups, eps, x2=None):
+    xin = _cat(x, x2)
+    b, h, w, c = xin.shape
+    v = xin.reshape(b, h * w, groups, c // groups).double()
+    mean = v.mean(dim=(1, 3))
+    var = v.var(dim=(1, 3), unbiased=False)
+    return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).float()
+
+
+def _resample(y, mode):
+    if mode == RESAMPLE_UP:
+        return y.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    if mode == RESAMPLE_DOWN:
+        b, h, w, c = y.shape
+        return y.reshape(b, h // 2, 2, w // 2, 2, c).mean(dim=(2, 4))
+    return y
+
+
+def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None):
+    xin = _cat(x, x2)
+    y = F.group_norm(xin.permute(0, 3, 1, 2), groups, gamma, beta, eps).permute(0, 2, 3, 1)
+    if film is not None:
+        fs, fh = film
+        y = y * (1 + fs.reshape(-1, 1, 1, fs.shape[-1])) + fh.reshape(-1, 1, 1, fh.shape[-1])
+    if act:
+        y = F.silu(y)
+    return _resample(y, resample).contiguous()
+
+
+def resample(x, mode):
+    return _resample(x, mode).contiguous()
+
+
+def attention(qkv, n_heads, layout):
+    b, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // n_heads
+    if layout == "legacy":
+        v = qkv.reshape(b, t, n_heads, 3, d)
+        q, k, vv = v[:, :, :, 0], v[:, :, :, 1], v[:, :, :, 2]
+    else:
+        v = qkv.reshape(b, t, 3, n_heads, d)
+        q, k, vv = v[:, :, 0], v[:, :, 1], v[:, :, 2]
+    w = torch.einsum("bthd,bshd->bhts", q, k) / math.sqrt(d)
+    w = torch.softmax(w, dim=-1)
+    return torch.einsum("bhts,bshd->bthd", w, vv).reshape(b, t, c).contiguous()
+
+
+def silu(x):
+    return F.silu(x)
+
+
+def axpby(x, a, y, b):
+    return x * a + y * b
+
+
+def timestep_embedding(t, freqs, cos_first):
+    a = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(a), torch.sin(a)] if cos_first else [torch.sin(a), torch.cos(a)], dim=-1)
+
+
+# ---- Philox4x32-10 + Box-Muller, numpy restatement of csrc/elementwise.hip ----------------------
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) for v in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(_M0) * c0
+        p1 = np.uint64(_M1) * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & mask, lo1, (hi0 ^ c3 ^ k1) & mask, lo0
+        k0 = (k0 + np.uint64(_W0)) & mask
+        k1 = (k1 + np.uint64(_W1)) & mask
+    return c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32)
+
+
+def philox_normal(shape, seed, sample0, step, device=None):
+    b = shape[0]
+    per = int(np.prod(shape[1:]))
+    assert per % 4 == 0
+    nq = per // 4
+    out = np.empty((b, nq, 4), dtype=np.float32)
+    q = np.arange(nq, dtype=np.uint64)
+    for i in range(b):
+        smp = (sample0 + i) & 0xFFFFFFFFFFFFFFFF
+        r = philox4x32_10(q, np.full(nq, (step + 1) & 0xFFFFFFFF, dtype=np.uint64),
+                          np.full(nq, smp & 0xFFFFFFFF, dtype=np.uint64), np.full(nq, smp >> 32, dtype=np.uint64),
+                          seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        u = [((v >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0) for v in r]
+        r0 = np.sqrt(np.float32(-2.0) * np.log(u[0]))
+        r1 = np.sqrt(np.float32(-2.0) * np.log(u[2]))
+        a0 = np.float32(6.283185307179586) * u[1]
+        a1 = np.float32(6.283185307179586) * u[3]
+        out[i, :, 0], out[i, :, 1] = r0 * np.cos(a0), r0 * np.sin(a0)
+        out[i, :, 2], out[i, :, 3] = r1 * np.cos(a1), r1 * np.sin(a1)
+    t = torch.from_numpy(out.reshape(shape))
+    return t if device is None else t.to(device)
+
+
+def em_step(x, eps, neg_half_beta, gg, score_coef, score_div, h, g, sqrt_h, noise=None, seed=0, sample0=0, step=0,
+            out=None):
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+    c = x.shape[3]
+    e = eps[..., :c]
+    score = (-e) / f32(score_coef) if score_div else f32(score_coef) * e
+    drift = f32(neg_half_beta) * x - f32(gg) * score
+    if g != 0.0:
+        z = noise if noise is not None else philox_normal(tuple(x.shape), seed, sample0, step)
+        y = x + (-drift) * f32(h) + f32(g) * (z * f32(sqrt_h))
+    else:
+        y = x + (-drift) * f32(h)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def ddpm_step(x, out6, sr, srm1, c1, c2, min_log, max_log, nonzero, noise=None, seed=0, sample0=0, step=0, out=None):
+    c = x.shape[3]
+    eps, v = out6[..., :c], out6[..., c:]
+    frac = (v + 1) / 2
+    logvar = frac * max_log + (1 - frac) * min_log
+    x0 = (sr * x - srm1 * eps).clamp(-1, 1)
+    mean = c1 * x0 + c2 * x
+    if nonzero:
+        z = noise if noise is not None else philox_normal(tuple(x.shape), seed, sample0, step)
+        y = mean + torch.exp(0.5 * logvar) * z
+    else:
+        y = mean
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+PATCHED = ["conv2d", "linear", "group_norm_stats", "group_norm", "resample", "attention", "silu", "axpby",
+           "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
+
+
+def patch_ops(monkeypatch):
+    """Route diffpure_amd.ops through the torch-CPU statements above (host-logic tests only)."""
+    import sys
+
+    from diffpure_amd import ops
+
+    me = sys.modules[__name__]
+    for name in PATCHED:
+        monkeypatch.setattr(ops, name, getattr(me, name))

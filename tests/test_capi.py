@@ -1,0 +1,45 @@
+"""The C-ABI library loads and exports every symbol include/diffpure_hip.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "diffpure_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diffpure_amd import _lib
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/diffpure_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.dp_abi_version() == 1
+
+
+def test_argument_validation_reports_errors_without_a_gpu():
+    from diffpure_amd import _lib
+    lib = _lib.load()
+    # null pointers are rejected before any launch
+    rc = lib.dp_silu(None, None, 4, None)
+    assert rc != 0 and b"dp_silu" in lib.dp_last_error()
+    rc = lib.dp_conv2d_nhwc(None, 4, None, 0, 1, 1, 1, 3, 3, None, 4, 4, None, None, 0, None, 0, 1.0, None, 4, 0, None)
+    assert rc != 0 and b"null" in lib.dp_last_error()
+
+
+def test_product_does_not_import_oracle_or_reference():
+    bad = re.compile(r"^\s*(from|import)\s+(oracle|refops)\b|/root/reference/|sys\.path.*reference", re.M)
+    for pkg in ("diffpure_amd", "runners"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dirpath, f)).read()
+                    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("#", '"""')))
+                    m = re.search(r"^\s*(from|import)\s+(oracle|refops|tests)\b", code, re.M)
+                    assert m is None, f"{pkg}/{f} imports test infrastructure: {m.group(0)}"

@@ -1,0 +1,185 @@
+"""-m gpu: the HIP engine end to end against (a) golden vectors produced by the reference's own
+modules and (b) the CPU oracle on the same seeded inputs, weights and injected noise.
+
+Tolerances (fp32 MFMA path; stated per SURVEY.md section 8c / north_star):
+  single UNet forward            max-abs 1e-3 relative to outputs of O(1) (observed ~1e-5)
+  purified pixels, full loop     max-abs 1e-3   (BASELINE.json north_star)
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from diffpure_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def make_ncsnpp(name):
+    from diffpure_amd import ncsnpp as pn
+    g = load_golden(name)
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    return g, pn.NCSNpp(cfg, DEV).load_state_dict(sd), sd
+
+
+def make_guided(name):
+    from diffpure_amd import guided_unet as pg
+    g = load_golden(name)
+    cfg = pg.parse_config(g["cfg"])
+    sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
+    return g, pg.GuidedUNet(cfg, DEV).load_state_dict(sd), sd
+
+
+def maxabs(a, b):
+    return (a - b).abs().max().item()
+
+
+def test_ncsnpp_small_forward_vs_reference_golden():
+    g, net, _ = make_ncsnpp("ncsnpp_small.pt")
+    out = nchw(net.forward(nhwc(g["x"]).to(DEV), g["labels"].to(DEV))).cpu()
+    assert maxabs(out, g["out"]) < 1e-4, maxabs(out, g["out"])
+
+
+def test_guided_small_forward_vs_reference_golden():
+    g, net, _ = make_guided("guided_small.pt")
+    out = nchw(net.forward(nhwc(g["x"]).to(DEV), g["t"].float().to(DEV))).cpu()
+    assert maxabs(out, g["out"]) < 1e-4, maxabs(out, g["out"])
+
+
+def test_ncsnpp_full_forward_vs_reference_golden():
+    g, net, _ = make_ncsnpp("ncsnpp_full.pt")
+    out = nchw(net.forward(nhwc(g["x"]).to(DEV), g["labels"].to(DEV))).cpu()
+    assert maxabs(out, g["out"]) < 5e-4, maxabs(out, g["out"])
+
+
+def test_guided_full_forward_vs_reference_golden():
+    g, net, _ = make_guided("guided_full.pt")
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(g["x_seed"])) * 2 - 1
+    out = nchw(net.forward(nhwc(x).to(DEV), g["t"].float().to(DEV))).cpu()
+    assert maxabs(out[:, :, ::16, ::16], g["out_crop"]) < 1e-3, maxabs(out[:, :, ::16, ::16], g["out_crop"])
+    assert abs(out.abs().mean().item() - g["out_absmean"]) < 1e-4
+
+
+def test_batch_uniform_time_row_equals_per_sample_rows():
+    g, net, _ = make_ncsnpp("ncsnpp_small.pt")
+    x = nhwc(g["x"]).to(DEV)
+    lab = torch.tensor([123.0, 123.0], device=DEV)
+    a = net.forward(x, lab)
+    b = net.forward(x, table_row=net.time_table(lab[:1]))
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
+def test_sde_loop_small_vs_oracle(kind):
+    from diffpure_amd.sde import Purifier
+    from oracle import guided_unet as og, ncsnpp as on, solvers as osol
+    if kind == "ncsnpp":
+        g, net, sd = make_ncsnpp("ncsnpp_small.pt")
+        score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    else:
+        g, net, sd = make_guided("guided_small.pt")
+        score = osol.make_score_fn("guided", sd, og.parse_guided_config(g["cfg"]))
+    x0 = g["x"]
+    gen = torch.Generator().manual_seed(7)
+    t_int, dt = 100, 5e-3   # 20 steps
+    n = len(osol.sde_time_grid(t_int, dt)) - 1
+    e = torch.randn(x0.shape, generator=gen)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(n)]
+    with torch.no_grad():
+        ref = osol.sde_purify(score, x0, e, zs, t_int, dt)
+    out = Purifier(net, kind, DEV).sde(x0, t_int, dt, noise=dict(e=e, z=zs)).cpu()
+    assert maxabs(out, ref) < 1e-3, maxabs(out, ref)
+
+
+def test_config1_cifar_b4_20steps_vs_oracle():
+    """BASELINE.json configs[0]: CIFAR-10 NCSN++ (full size), B=4, t*=0.1, 20 EM steps, vs the CPU path."""
+    from diffpure_amd.sde import Purifier
+    from oracle import ncsnpp as on, solvers as osol
+    g, net, sd = make_ncsnpp("ncsnpp_full.pt")
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    gen = torch.Generator().manual_seed(1234)
+    x0 = torch.rand(4, 3, 32, 32, generator=gen) * 2 - 1
+    e = torch.randn(x0.shape, generator=gen)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(20)]
+    with torch.no_grad():
+        ref = osol.sde_purify(score, x0, e, zs, 100, 5e-3)
+    out = Purifier(net, "ncsnpp", DEV).sde(x0, 100, 5e-3, noise=dict(e=e, z=zs)).cpu()
+    assert maxabs(out, ref) < 1e-3, maxabs(out, ref)
+
+
+def test_ode_and_ddpm_loops_small_vs_oracle():
+    from diffpure_amd.sde import Purifier
+    from oracle import guided_unet as og, ncsnpp as on, solvers as osol
+    g, net, sd = make_ncsnpp("ncsnpp_small.pt")
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    x0 = g["x"]
+    e = torch.randn(x0.shape, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = osol.ode_purify(score, x0, e, 100, step=5e-3)
+    out = Purifier(net, "ncsnpp", DEV).ode(x0, 100, step=5e-3, noise=dict(e=e, z=[])).cpu()
+    assert maxabs(out, ref) < 1e-3, maxabs(out, ref)
+
+    g, net, sd = make_guided("guided_small.pt")
+    cfg = og.parse_guided_config(g["cfg"])
+    unet = lambda x, ts: og.guided_unet_forward(sd, cfg, x, ts)
+    gen = torch.Generator().manual_seed(5)
+    x0 = g["x"]
+    e = torch.randn(x0.shape, generator=gen)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(8)]
+    with torch.no_grad():
+        ref = osol.ddpm_purify(unet, x0, e, zs, 8)
+    out = Purifier(net, "guided", DEV).ddpm(x0, 8, noise=dict(e=e, z=zs)).cpu()
+    assert maxabs(out, ref) < 1e-3, maxabs(out, ref)
+
+
+def test_shard_invariance_bitwise():
+    """Philox noise is keyed by the global sample index and no kernel mixes samples: purifying a
+    batch of 4 at once or as two shards of 2 (as two GPUs would) gives identical bits."""
+    from diffpure_amd.sde import Purifier
+    g, net, _ = make_ncsnpp("ncsnpp_small.pt")
+    x0 = torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(11)) * 2 - 1
+    pur = Purifier(net, "ncsnpp", DEV)
+    full = pur.sde(x0, 100, 1e-2, seed=77, sample0=0)
+    a = pur.sde(x0[:2], 100, 1e-2, seed=77, sample0=0)
+    b = pur.sde(x0[2:], 100, 1e-2, seed=77, sample0=2)
+    assert torch.equal(full, torch.cat([a, b]))
+    again = pur.sde(x0, 100, 1e-2, seed=77, sample0=0)
+    assert torch.equal(full, again)          # run-to-run deterministic (no float atomics anywhere)
+    other = pur.sde(x0, 100, 1e-2, seed=78, sample0=0)
+    assert not torch.equal(full, other)
+    assert torch.isfinite(full).all()
+
+
+def test_drop_in_runner_boundary(tmp_path):
+    """The reference's constructor/method surface: Runner(args, config, device).image_editing_sample."""
+    import argparse
+    from runners.diffpure_sde import RevGuidedDiffusion
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device(DEV)
+    args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=2, log_dir=str(tmp_path),
+                              score_type="score_sde", seed=1234, synthetic_weights=True, dt=1e-2)
+    runner = RevGuidedDiffusion(args, config, device=config.device)
+    assert isinstance(runner, torch.nn.Module)
+    x = torch.rand(3, 3, 16, 16) * 2 - 1
+    out = runner.image_editing_sample(x, bs_id=0, tag="t")
+    assert out.shape == (6, 3, 16, 16) and out.device.type == "cuda" and torch.isfinite(out).all()
+    assert (tmp_path / "bs0_t").is_dir()
+    with pytest.raises(NotImplementedError):
+        runner.image_editing_sample(x.clone().requires_grad_(True), bs_id=5)

@@ -1,0 +1,199 @@
+"""-m gpu: every HIP operator (through the C ABI) against its plain-PyTorch fp32 statement
+(tests/refops.py, evaluated on CPU in fp32/fp64)."""
+import math
+
+import pytest
+import torch
+
+import refops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from diffpure_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(got, ref, rtol, atol):
+    torch.testing.assert_close(got.cpu(), ref, rtol=rtol, atol=atol)
+
+
+CONV_CASES = [
+    # B, H, W, C1, C2, N, k, bias, temb(rows), res, scale
+    (2, 16, 16, 128, 0, 256, 3, True, 0, False, 1.0),       # main 128x128 tile path
+    (2, 16, 16, 128, 64, 128, 3, True, 2, True, 0.70710678),  # channel-split input + temb per sample + residual
+    (1, 5, 7, 132, 0, 72, 3, True, 1, False, 1.0),          # ragged M, Cin % 16 != 0 (k-cursor crosses taps mid-tile)
+    (3, 8, 8, 20, 12, 40, 3, False, 0, True, 1.0),           # small Cin, C1 % 16 != 0 split
+    (2, 32, 32, 3, 0, 128, 3, True, 0, False, 1.0),          # stem: Cin = 3 scalar loader
+    (2, 16, 16, 128, 0, 6, 3, True, 0, False, 1.0),          # head: N = 6 (ldw 8), 128x32 tile
+    (2, 16, 16, 128, 0, 3, 3, True, 0, False, 1.0),          # head: N = 3 (ldw 4)
+    (4, 4, 4, 256, 256, 256, 3, True, 1, True, 0.70710678),  # low resolution, few tiles -> 64x64 tiles
+    (2, 16, 16, 256, 0, 768, 1, True, 0, False, 1.0),        # 1x1 (qkv)
+    (2, 8, 8, 384, 128, 256, 1, True, 0, False, 1.0),        # 1x1 skip over a split input
+    (1, 1, 1, 512, 0, 1000, 1, True, 0, False, 1.0),         # linear with M = 1 (time table)
+    (2, 64, 64, 64, 0, 64, 3, False, 0, False, 1.0),         # larger M
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv2d(dev, case):
+    from diffpure_amd import ops
+    B, H, W, C1, C2, N, k, has_bias, temb_rows, has_res, scale = case
+    x = rnd(B, H, W, C1, seed=1)
+    x2 = rnd(B, H, W, C2, seed=2) if C2 else None
+    w = rnd(N, C1 + C2, k, k, seed=3, scale=1.0 / math.sqrt((C1 + C2) * k * k))
+    wp = ops.pack_conv_weight(w)
+    bias = rnd(N, seed=4) if has_bias else None
+    temb = None
+    if temb_rows:
+        table = rnd(B if temb_rows == 2 else 1, N + 8, seed=5)
+        temb = table[:, 4:4 + N]  # column view of a wider table, as the engines pass it
+    res = rnd(B, H, W, N, seed=6) if has_res else None
+    ref = refops.conv2d(x.double(), wp.double(), N, k, None if bias is None else bias.double(),
+                        None if x2 is None else x2.double(), None if temb is None else temb.double(),
+                        None if res is None else res.double(), scale).float()
+    d = lambda t: None if t is None else t.to(dev)
+    table_d = None if temb is None else table.to(dev)
+    temb_d = None if temb is None else table_d[:, 4:4 + N]
+    got = ops.conv2d(d(x), d(wp), N, k, bias=d(bias), x2=d(x2), temb=temb_d, res=d(res), scale=scale)
+    close(got, ref, rtol=1e-4, atol=2e-5)
+
+
+def test_conv_is_an_exact_fp32_fma_chain(dev):
+    """A = I check with an asymmetric weight panel: catches any transposed MFMA fragment mapping."""
+    from diffpure_amd import ops
+    C = 64
+    x = torch.zeros(1, 8, 8, C)
+    for p in range(64):
+        x[0, p // 8, p % 8, p] = 1.0          # pixel p carries unit vector e_p
+    w = torch.arange(C * C, dtype=torch.float32).reshape(C, C) / 7.0   # w[out, in], asymmetric
+    got = ops.conv2d(x.to(dev), ops.pack_conv_weight(w).to(dev), C, 1).cpu()
+    assert torch.equal(got.reshape(64, C), w.t().contiguous())  # out[p, n] = w[n, p] exactly
+
+
+GN_CASES = [
+    # B, H, W, C1, C2, G, film_rows, act, resample
+    (2, 16, 16, 128, 0, 32, 0, True, 0),
+    (2, 8, 8, 256, 128, 32, 0, True, 0),      # split input, groups straddle nothing (384/32 = 12)
+    (2, 8, 8, 1024, 512, 32, 0, True, 0),     # C4 = 384 threads, group of 48 straddles the split
+    (1, 4, 4, 2048, 0, 32, 1, True, 0),       # 512 threads, broadcast FiLM
+    (3, 8, 8, 256, 0, 32, 2, True, 0),        # per-sample FiLM
+    (2, 8, 8, 128, 0, 32, 0, True, 1),        # + nearest x2
+    (2, 8, 8, 128, 0, 32, 0, True, 2),        # + mean 2x2
+    (2, 16, 16, 32, 0, 8, 0, False, 0),       # tiny C (NCSN++ small), no activation
+    (1, 64, 64, 256, 0, 32, 0, True, 0),      # many pixel slabs
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES, ids=[str(c) for c in GN_CASES])
+def test_group_norm(dev, case):
+    from diffpure_amd import ops
+    B, H, W, C1, C2, G, film_rows, act, rs = case
+    C = C1 + C2
+    x = rnd(B, H, W, C1, seed=1) * 2 + 0.5
+    x2 = (rnd(B, H, W, C2, seed=2) - 1.0) if C2 else None
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    film = None
+    if film_rows:
+        tab = 0.3 * rnd(B if film_rows == 2 else 1, 2 * C, seed=5)
+        film = (tab[:, :C], tab[:, C:])
+    eps = 1e-5
+    ref = refops.group_norm(x.double(), G, eps, gamma.double(), beta.double(), None if x2 is None else x2.double(),
+                            None if film is None else (film[0].double(), film[1].double()), act, rs).float()
+    d = lambda t: None if t is None else t.to(dev)
+    film_d = None
+    if film is not None:
+        tab_d = tab.to(dev)
+        film_d = (tab_d[:, :C], tab_d[:, C:])
+    got = ops.group_norm(d(x), G, eps, d(gamma), d(beta), x2=d(x2), film=film_d, act=act, resample=rs)
+    close(got, ref, rtol=2e-5, atol=2e-5)
+    st = ops.group_norm_stats(d(x), G, eps, d(x2))
+    close(st, refops.group_norm_stats(x, G, eps, x2), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_resample(dev, mode):
+    from diffpure_amd import ops
+    x = rnd(2, 8, 8, 64, seed=9)
+    close(ops.resample(x.to(dev), mode), refops.resample(x, mode), rtol=0, atol=1e-7)
+
+
+ATT_CASES = [(2, 16, 256, 1, "split"), (2, 256, 256, 1, "split"), (2, 64, 128, 2, "legacy"), (1, 1024, 128, 2, "legacy"),
+             (2, 64, 128, 2, "split"), (3, 256, 256, 4, "legacy")]
+
+
+@pytest.mark.parametrize("case", ATT_CASES, ids=[str(c) for c in ATT_CASES])
+def test_attention(dev, case):
+    from diffpure_amd import ops
+    B, T, C, heads, layout = case
+    qkv = rnd(B, T, 3 * C, seed=11)
+    ref = refops.attention(qkv.double(), heads, layout).float()
+    close(ops.attention(qkv.to(dev), heads, layout), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_softmax_forced_large_logits(dev):
+    from diffpure_amd import _lib
+    x = rnd(37, 200, seed=12) * 30
+    x[5, 17] = 500.0  # one dominating logit
+    xd = x.to(dev).contiguous()
+    _lib.call("dp_softmax_rows", xd.data_ptr(), 37, 200, torch.cuda.current_stream().cuda_stream)
+    close(xd, torch.softmax(x.double(), -1).float(), rtol=1e-5, atol=1e-7)
+
+
+def test_small_elementwise(dev):
+    from diffpure_amd import ops
+    x, y = rnd(5, 333, seed=13) * 4, rnd(5, 333, seed=14)
+    close(ops.silu(x.to(dev)), refops.silu(x.double()).float(), rtol=1e-6, atol=1e-7)
+    close(ops.axpby(x.to(dev), 0.9, y.to(dev), -0.3), x * 0.9 + y * -0.3, rtol=1e-6, atol=1e-6)
+    freqs = torch.exp(-math.log(10000) * torch.arange(128, dtype=torch.float32) / 128)
+    t = torch.tensor([0.0, 1.0, 37.0, 99.0, 999.0])
+    for cf in (True, False):
+        close(ops.timestep_embedding(t.to(dev), freqs.to(dev), cf), refops.timestep_embedding(t, freqs, cf), rtol=0, atol=2e-5)
+
+
+def test_philox_matches_numpy_restatement_and_is_shard_invariant(dev):
+    from diffpure_amd import ops
+    shape = (3, 8, 8, 3)
+    got = ops.philox_normal(shape, seed=0x1234ABCD5678, sample0=5, step=17, device=dev).cpu()
+    ref = refops.philox_normal(shape, 0x1234ABCD5678, 5, 17)
+    torch.testing.assert_close(got, ref, rtol=0, atol=3e-5)
+    part = ops.philox_normal((1, 8, 8, 3), seed=0x1234ABCD5678, sample0=7, step=17, device=dev).cpu()
+    assert torch.equal(part[0], got[2])
+    big = ops.philox_normal((64, 32, 32, 3), seed=1, sample0=0, step=0, device=dev)
+    assert abs(big.mean().item()) < 5e-3 and abs(big.std().item() - 1) < 5e-3
+
+
+def test_em_step_injected_and_philox(dev):
+    from diffpure_amd import ops
+    x, eps6, z = rnd(2, 8, 8, 3, seed=20), rnd(2, 8, 8, 6, seed=21), rnd(2, 8, 8, 3, seed=22)
+    args = dict(neg_half_beta=-1.045, gg=2.09, score_coef=-3.1, score_div=0, h=1e-3, g=1.4457, sqrt_h=0.0316228)
+    ref = refops.em_step(x, eps6, noise=z, **args)
+    close(ops.em_step(x.to(dev), eps6.to(dev), noise=z.to(dev), **args), ref, rtol=1e-6, atol=1e-6)
+    args["score_div"], args["score_coef"] = 1, 0.322
+    ref = refops.em_step(x, eps6, seed=99, sample0=4, step=3, **args)
+    close(ops.em_step(x.to(dev), eps6.to(dev), seed=99, sample0=4, step=3, **args), ref, rtol=1e-5, atol=2e-6)
+    args["g"] = 0.0
+    close(ops.em_step(x.to(dev), eps6.to(dev), **args), refops.em_step(x, eps6, **args), rtol=1e-6, atol=1e-6)
+
+
+def test_ddpm_step(dev):
+    from diffpure_amd import ops
+    x, o6, z = rnd(2, 8, 8, 3, seed=30), rnd(2, 8, 8, 6, seed=31), rnd(2, 8, 8, 3, seed=32)
+    a = dict(sr=1.02, srm1=0.2, c1=0.3, c2=0.69, min_log=-9.0, max_log=-6.0)
+    for nz in (True, False):
+        ref = refops.ddpm_step(x, o6, nonzero=nz, noise=z, **a)
+        close(ops.ddpm_step(x.to(dev), o6.to(dev), nonzero=nz, noise=z.to(dev), **a), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_ops_refuse_cpu_tensors(dev):
+    from diffpure_amd import _lib, ops
+    with pytest.raises(_lib.DiffpureHipError):
+        ops.silu(torch.zeros(4))

@@ -1,0 +1,94 @@
+"""Pin the CPU oracle against vectors produced by the reference's own modules (tests/golden/)."""
+import pytest
+import torch
+
+from conftest import load_golden
+from diffpure_amd.synth import synth_state_dict
+from oracle import guided_unet as og
+from oracle import ncsnpp as on
+from oracle import solvers as osol
+
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def _ncsnpp(name):
+    g = load_golden(name)
+    cfg = on.parse_ncsnpp_config(g["cfg"])
+    import diffpure_amd.ncsnpp as pn
+    sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), g["seed"])
+    return g, cfg, sd
+
+
+def _guided(name):
+    g = load_golden(name)
+    cfg = og.parse_guided_config(g["cfg"])
+    import diffpure_amd.guided_unet as pg
+    sd = synth_state_dict(pg.param_shapes(pg.parse_config(g["cfg"])), g["seed"])
+    return g, cfg, sd
+
+
+def test_ncsnpp_small_matches_reference():
+    g, cfg, sd = _ncsnpp("ncsnpp_small.pt")
+    out = on.ncsnpp_forward(sd, cfg, g["x"], g["labels"])
+    assert g["out"].abs().mean() > 0.05  # non-vacuous weights
+    torch.testing.assert_close(out, g["out"], **TOL)
+
+
+def test_guided_small_matches_reference():
+    g, cfg, sd = _guided("guided_small.pt")
+    out = og.guided_unet_forward(sd, cfg, g["x"], g["t"])
+    assert g["out"].abs().mean() > 0.05
+    torch.testing.assert_close(out, g["out"], **TOL)
+
+
+def test_ncsnpp_full_matches_reference():
+    g, cfg, sd = _ncsnpp("ncsnpp_full.pt")
+    out = on.ncsnpp_forward(sd, cfg, g["x"], g["labels"])
+    torch.testing.assert_close(out, g["out"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.slow
+def test_guided_full_matches_reference():
+    g, cfg, sd = _guided("guided_full.pt")
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(g["x_seed"])) * 2 - 1
+    out = og.guided_unet_forward(sd, cfg, x, g["t"])
+    torch.testing.assert_close(out[:, :, ::16, ::16], g["out_crop"], rtol=1e-3, atol=2e-4)
+    assert abs(out.abs().mean().item() - g["out_absmean"]) < 1e-4
+
+
+def test_sde_drift_diffusion_and_ode_rhs_match_reference():
+    g = load_golden("sde_fg.pt")
+    gn, cfgn, sdn = _ncsnpp("ncsnpp_small.pt")
+    gg, cfgg, sdg = _guided("guided_small.pt")
+    cases = (("score_sde", osol.make_score_fn("ncsnpp", sdn, cfgn), g["xn"]),
+             ("guided_diffusion", osol.make_score_fn("guided", sdg, cfgg), g["xg"]))
+    for name, score, x in cases:
+        for tp in (0.9, 0.9635, 0.99999):
+            t = torch.tensor(tp, dtype=torch.float32)
+            torch.testing.assert_close(osol.rev_sde_f(score, t, x), g["rec"][(name, "f", tp)], rtol=5e-4, atol=5e-4)
+            torch.testing.assert_close(osol.rev_sde_g(t, 2), g["rec"][(name, "g", tp)], rtol=1e-6, atol=0)
+        for s in (0.1, 0.0365, 1e-5):
+            t = torch.tensor(s, dtype=torch.float32)
+            torch.testing.assert_close(osol.ode_rhs(score, t, x), g["rec"][(name, "ode", s)], rtol=5e-4, atol=5e-4)
+
+
+def test_ddpm_p_sample_matches_reference():
+    g = load_golden("ddpm_psample.pt")
+    gg, cfgg, sdg = _guided("guided_small.pt")
+    sched = osol.DdpmSchedule(1000)
+    unet = lambda x, ts: og.guided_unet_forward(sdg, cfgg, x, ts)
+    for i, ref in g["outs"].items():
+        out = osol.ddpm_p_sample(unet, sched, gg["x"], i, g["z"])
+        torch.testing.assert_close(out, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_solver_clocks():
+    # exactly 100 steps for t=100 and 150 for t=150 at dt=1e-3, short last step
+    for t_int in (100, 150):
+        grid = osol.sde_time_grid(t_int)
+        assert len(grid) - 1 == t_int
+        assert abs(float(grid[-1] - grid[-2]) - 9.9e-4) < 2e-5
+    assert len(osol.sde_time_grid(100, 5e-3)) - 1 == 20
+    ts = torch.linspace(0.1, 1e-5, 2)
+    tau = osol.ode_grid(-ts, 1e-3)
+    assert len(tau) == 101 and tau[0] == -ts[0] and tau[-1] == -ts[1]
