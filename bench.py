@@ -64,7 +64,9 @@ def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
     for the full n_steps-step purification (the UNet call is >99.9 % of a step)."""
     from oracle import guided_unet as og
     from oracle import ncsnpp as on
-    cores = os.cpu_count() or 1
+    # usable cores = the affinity mask (os.cpu_count() over-reports inside a cgroup / container);
+    # oneDNN convolutions at batch 1-4 peak at ~16 threads on the MI355X host (probe: 8t 0.152 s, 16t 0.112 s, 32t 0.199 s, 64t 0.409 s, 256t >100 s).
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("DIFFPURE_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     if workload == "imagenet256_guided":
         cfg = og.parse_guided_config(IMAGENET_CFG)

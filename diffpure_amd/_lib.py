@@ -54,6 +54,15 @@ def load():
             f"{LIB_PATH} not found: the HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (needs hipcc). There is no CPU fallback for the purification engine."
         )
+    # The library's HIP calls must bind to the SAME HIP runtime torch uses (streams and device
+    # pointers are shared).  PyTorch-ROCm bundles its own libamdhip64; load it first so that the
+    # dynamic loader reuses it for our NEEDED entry instead of pulling a second copy from /opt/rocm
+    # (two runtimes in one process => "no ROCm-capable device is detected" on the first launch).
+    import torch
+
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
