@@ -27,7 +27,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"f32": 157.3}   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+# MI355X_MICROARCH.md: fp32-input MFMA = 157.3 TF; dense fp16 MFMA ~2.5 PF (the f16x3 path spends
+# three fp16 MFMA passes per algorithmic MAC, so its matrix ceiling in ALGORITHMIC flops is 2500/3).
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
 WORKLOADS = {
     # name: (kind, config file section, image size, algorithmic GFLOP / image / UNet call, 3x3 share)
     "imagenet256_guided": dict(kind="guided", hw=256, gflop=2239.67, gflop3x3=2115.44),
@@ -47,15 +49,15 @@ CIFAR_CFG = dict(
                embedding_type="positional", fourier_scale=16, conv_size=3))   # configs/cifar10.yml
 
 
-def build_engine(workload, device, seed):
+def build_engine(workload, device, seed, precision):
     from diffpure_amd import guided_unet, ncsnpp, synth
     if workload == "imagenet256_guided":
         cfg = guided_unet.parse_config(IMAGENET_CFG)
         sd = synth.synth_state_dict(guided_unet.param_shapes(cfg), seed)
-        return guided_unet.GuidedUNet(cfg, device).load_state_dict(sd), sd, cfg
+        return guided_unet.GuidedUNet(cfg, device, precision).load_state_dict(sd), sd, cfg
     cfg = ncsnpp.parse_config(CIFAR_CFG)
     sd = synth.synth_state_dict(ncsnpp.param_shapes(cfg), seed)
-    return ncsnpp.NCSNpp(cfg, device).load_state_dict(sd), sd, cfg
+    return ncsnpp.NCSNpp(cfg, device, precision).load_state_dict(sd), sd, cfg
 
 
 def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
@@ -102,6 +104,8 @@ def main():
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="f32: fp32-input MFMA; f16x3: split-fp16 3-pass MFMA (fp32-class accuracy)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,7 +125,7 @@ def main():
 
     wl = WORKLOADS[a.workload]
     B = a.batch or (16 if a.workload == "imagenet256_guided" else 256)
-    net, sd, _ = build_engine(a.workload, dev, a.seed)
+    net, sd, _ = build_engine(a.workload, dev, a.seed, a.precision)
     pur = Purifier(net, wl["kind"], dev)
     n_steps = len(sde_schedule(wl["kind"], a.t, a.dt))
     hw = wl["hw"]
@@ -163,7 +167,7 @@ def main():
     out = None
     if rank == 0:
         ach = prof["flop3x3"] / (prof["ms3x3"] * 1e-3) / 1e12 if prof["ms3x3"] > 0 else None
-        peak = PEAK_TFLOPS["f32"]
+        peak = PEAK_TFLOPS[a.precision]
         unet_tflops = value / world * wl["gflop"] * n_steps / 1e3
         out = {
             "metric": "purified images/sec (whole node), 256x256 GuidedDiff VP-SDE t*=0.1 100-step"
@@ -178,14 +182,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": a.precision,
             "data": "synthetic (seeded uniform images in [-1,1]; seeded non-trivial random weights of the named "
                     "architecture; Philox noise)",
             "config": {"workload": f"{a.workload}: reverse VP-SDE purification, t*={a.t / 1000:g}, dt={a.dt:g}, "
                                    f"{n_steps} Euler-Maruyama steps, one UNet call per step",
                        "per_gpu_batch": B, "global_batch": world * B, "image": f"3x{hw}x{hw}",
                        "parallelism": f"batch-sharded x{world}, one all_gather of outputs"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
+                                   "conv_igemm_h2 (3x3 implicit GEMM, 3 x v_mfma_f32_32x32x16_f16 per product; "
+                                   "executed MFMA flops = 3 x achieved)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": None if ach is None else ach / peak,
                          "traffic": None, "launches": prof["n3x3"],
                          "avg_launch_ms": prof["ms3x3"] / max(1, prof["n3x3"]),

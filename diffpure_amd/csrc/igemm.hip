@@ -403,6 +403,20 @@ ProfRec* g_prof = nullptr;
 
 }  // namespace
 
+void dp_prof_begin(int kind, double flop, hipStream_t s, void** rec_out) {
+    *rec_out = nullptr;
+    if (g_prof_on && g_prof_n < PROF_MAX) {
+        ProfRec* rec = &g_prof[g_prof_n++];
+        rec->flop = flop;
+        rec->kind = kind;
+        (void)hipEventRecord(rec->e0, s);
+        *rec_out = rec;
+    }
+}
+void dp_prof_end(void* rec, hipStream_t s) {
+    if (rec) (void)hipEventRecord(static_cast<ProfRec*>(rec)->e1, s);
+}
+
 extern "C" int dp_prof_enable(int on) {
     if (on && !g_prof) {
         g_prof = new ProfRec[PROF_MAX];
@@ -462,13 +476,8 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
     const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2));
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    ProfRec* rec = nullptr;
-    if (g_prof_on && g_prof_n < PROF_MAX) {
-        rec = &g_prof[g_prof_n++];
-        rec->flop = 2.0 * p.M * (double)p.N * p.K;
-        rec->kind = KH == 3 ? 0 : 1;
-        hipEventRecord(rec->e0, s);
-    }
+    void* rec = nullptr;
+    dp_prof_begin(KH == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (!vec) {
         p.tiles_n = (N + 127) / 128;
@@ -483,7 +492,7 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
         p.tiles_n = (N + 127) / 128;
         hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, 4>), dim3((unsigned)tiles(128, 128)), dim3(NT), 0, s, p);
     }
-    if (rec) hipEventRecord(rec->e1, s);
+    dp_prof_end(rec, s);
     DP_LAUNCH_CHECK("conv_igemm_f32");
     return 0;
 }

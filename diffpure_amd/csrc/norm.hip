@@ -88,65 +88,87 @@ struct ApplyArgs {
     int C4, cpg, Ho, Wo;
 };
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) {
     const float* src = (c < p.C1) ? (p.x1 + pix * p.C1 + c) : (p.x2 + pix * p.C2 + (c - p.C1));
     return *reinterpret_cast<const f32x4*>(src);
 }
 
+// One work item = VEC channels of one OUTPUT pixel: VEC = 4 (fp32 out, one float4) or 8 (h2 out:
+// 8 fp16 hi | 8 fp16 lo = 32 bytes, the operand format of csrc/igemm_h2.hip).
+template <bool H2>
 __global__ void gn_apply_kernel(ApplyArgs p) {
-    const long long total = (long long)p.B * p.Ho * p.Wo * p.C4;
+    constexpr int VEC = H2 ? 8 : 4, NQ = VEC / 4;
+    const int CV = p.C4 * 4 / VEC;
+    const long long total = (long long)p.B * p.Ho * p.Wo * CV;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % p.C4);
-        const long long opix = i / p.C4;
+        const int cv = (int)(i % CV);
+        const long long opix = i / CV;
         const int ox = (int)(opix % p.Wo);
         const long long t2 = opix / p.Wo;
         const int oy = (int)(t2 % p.Ho), b = (int)(t2 / p.Ho);
-        const int c = cq * 4;
-
-        f32x4 a = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};  // y = x*a + d before act
-        if (p.gamma) {
-            const int g = c / p.cpg;
-            const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+        f32x4 o[NQ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a[j] = rstd * ga[j];
-                d[j] = be[j] - mean * a[j];
+        for (int qd = 0; qd < NQ; ++qd) {
+            const int c = cv * VEC + qd * 4;
+            f32x4 a = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};  // y = x*a + d before act
+            if (p.gamma) {
+                const int g = c / p.cpg;
+                const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = rstd * ga[j];
+                    d[j] = be[j] - mean * a[j];
+                }
+            }
+            if (p.fscale) {
+                const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
+                const f32x4 fh = *reinterpret_cast<const f32x4*>(p.fshift + (size_t)b * p.film_stride + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float m = 1.f + fs[j];
+                    a[j] *= m;
+                    d[j] = d[j] * m + fh[j];
+                }
+            }
+            auto xf = [&](size_t pix) {
+                f32x4 v = gn_load(p, pix, c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float u = v[j] * a[j] + d[j];
+                    v[j] = p.act ? dp_silu_f(u) : u;
+                }
+                return v;
+            };
+            if (p.resample == 0) {
+                o[qd] = xf(((size_t)b * p.H + oy) * p.W + ox);
+            } else if (p.resample == 1) {
+                o[qd] = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
+            } else {
+                const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
+                const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[qd][j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
             }
         }
-        if (p.fscale) {
-            const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
-            const f32x4 fh = *reinterpret_cast<const f32x4*>(p.fshift + (size_t)b * p.film_stride + c);
+        if constexpr (H2) {
+            half8 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float m = 1.f + fs[j];
-                a[j] *= m;
-                d[j] = d[j] * m + fh[j];
+            for (int j = 0; j < 8; ++j) {
+                const float v = o[j >> 2][j & 3];
+                hi[j] = (_Float16)v;
+                lo[j] = (_Float16)(v - (float)hi[j]);
             }
-        }
-        auto xf = [&](size_t pix) {
-            f32x4 v = gn_load(p, pix, c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = v[j] * a[j] + d[j];
-                v[j] = p.act ? dp_silu_f(u) : u;
-            }
-            return v;
-        };
-        f32x4 o;
-        if (p.resample == 0) {
-            o = xf(((size_t)b * p.H + oy) * p.W + ox);
-        } else if (p.resample == 1) {
-            o = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
+            half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + ((size_t)opix * CV + cv) * 32);
+            dst[0] = hi;
+            dst[1] = lo;
         } else {
-            const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
-            const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+            *reinterpret_cast<f32x4*>(p.y + (size_t)opix * (p.C4 * 4) + cv * 4) = o[0];
         }
-        *reinterpret_cast<f32x4*>(p.y + (size_t)opix * (p.C4 * 4) + c) = o;
     }
 }
 
@@ -187,7 +209,8 @@ extern "C" int dp_gn_finalize(const float* partial, int B, int nsplit, int G, lo
 
 extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                            const float* stats, const float* gamma, const float* beta, const float* fscale,
-                           const float* fshift, int film_stride, int act, int resample, float* y, void* stream) {
+                           const float* fshift, int film_stride, int act, int resample, int out_fmt, void* y,
+                           void* stream) {
     const int C = C1 + C2;
     DP_REQUIRE(x1 && y && B > 0 && H > 0 && W > 0, "dp_gn_apply: bad args");
     DP_REQUIRE(C2 == 0 || x2, "dp_gn_apply: x2 missing");
@@ -198,11 +221,13 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     DP_REQUIRE(resample != 2 || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply: 2x2 mean needs even H, W");
     DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(y), "dp_gn_apply: misaligned tensor");
     DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply: misaligned FiLM rows");
-    ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, y,
+    DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && C % 8 == 0 && C1 % 8 == 0), "dp_gn_apply: out_fmt %d needs channel counts that are multiples of 8", out_fmt);
+    ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
                 C / 4, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
                 resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W)};
-    const long long total = (long long)B * p.Ho * p.Wo * p.C4;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    const long long total = (long long)B * p.Ho * p.Wo * p.C4 / (out_fmt ? 2 : 1);
+    if (out_fmt) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     DP_LAUNCH_CHECK("gn_apply");
     return 0;
 }

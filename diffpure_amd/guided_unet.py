@@ -171,8 +171,15 @@ class GuidedUNet:
     GN_GROUPS = 32   # nn.py:101-108 normalization(): GroupNorm32(32, C)
     GN_EPS = 1e-5
 
-    def __init__(self, cfg, device):
+    def __init__(self, cfg, device, precision="f32"):
+        """precision: "f32"  = exact fp32-input MFMA everywhere;
+                      "f16x3" = split-fp16 three-pass MFMA for every convolution whose input is a
+                      GroupNorm output (all 3x3 convolutions but the stem, and the qkv 1x1):
+                      fp32-class accuracy, ~5x the matrix ceiling (csrc/igemm_h2.hip)."""
+        if precision not in ("f32", "f16x3"):
+            raise ValueError(f"unknown precision {precision!r}")
         self.cfg = cfg
+        self.precision = precision
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -197,6 +204,12 @@ class GuidedUNet:
         def vec(k):
             return sd[k].detach().float().contiguous().to(dev)
 
+        def conv_w(k, cin):
+            """-> (packed weight, is_h2)"""
+            if self.precision == "f16x3" and cin % 32 == 0:
+                return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
+            return ops.pack_conv_weight(sd[k].detach()).to(dev), False
+
         P["te0.w"] = ops.pack_linear_weight(sd["time_embed.0.weight"].detach()).to(dev)
         P["te0.b"] = vec("time_embed.0.bias")
         P["te2.w"] = ops.pack_linear_weight(sd["time_embed.2.weight"].detach()).to(dev)
@@ -210,10 +223,10 @@ class GuidedUNet:
                 P[n + ".b"] = vec(n + ".bias")
             elif r["kind"] == "res":
                 P[n + ".g1"], P[n + ".b1"] = vec(n + ".in_layers.0.weight"), vec(n + ".in_layers.0.bias")
-                P[n + ".w1"] = ops.pack_conv_weight(sd[n + ".in_layers.2.weight"].detach()).to(dev)
+                P[n + ".w1"], r["h2_1"] = conv_w(n + ".in_layers.2.weight", r["cin"])
                 P[n + ".c1"] = vec(n + ".in_layers.2.bias")
                 P[n + ".g2"], P[n + ".b2"] = vec(n + ".out_layers.0.weight"), vec(n + ".out_layers.0.bias")
-                P[n + ".w2"] = ops.pack_conv_weight(sd[n + ".out_layers.3.weight"].detach()).to(dev)
+                P[n + ".w2"], r["h2_2"] = conv_w(n + ".out_layers.3.weight", r["cout"])
                 P[n + ".c2"] = vec(n + ".out_layers.3.bias")
                 if r["cin"] != r["cout"]:
                     P[n + ".ws"] = ops.pack_conv_weight(sd[n + ".skip_connection.weight"].detach()).to(dev)
@@ -224,7 +237,7 @@ class GuidedUNet:
                 off += 2 * r["cout"]
             else:
                 P[n + ".g"], P[n + ".b"] = vec(n + ".norm.weight"), vec(n + ".norm.bias")
-                P[n + ".wqkv"] = ops.pack_conv_weight(sd[n + ".qkv.weight"].detach()).to(dev)
+                P[n + ".wqkv"], r["h2"] = conv_w(n + ".qkv.weight", r["ch"])
                 P[n + ".cqkv"] = vec(n + ".qkv.bias")
                 P[n + ".wproj"] = ops.pack_conv_weight(sd[n + ".proj_out.weight"].detach()).to(dev)
                 P[n + ".cproj"] = vec(n + ".proj_out.bias")
@@ -233,7 +246,7 @@ class GuidedUNet:
         P["emb.b"] = torch.cat(emb_b, dim=0).contiguous().to(dev)
         self.emb_cols = off
         P["out.g"], P["out.b"] = vec("out.0.weight"), vec("out.0.bias")
-        P["out.w"] = ops.pack_conv_weight(sd["out.2.weight"].detach()).to(dev)
+        P["out.w"], self._out_h2 = conv_w("out.2.weight", self.plan["final_ch"])
         P["out.c"] = vec("out.2.bias")
         self.p = P
         return self
@@ -243,24 +256,26 @@ class GuidedUNet:
         P, n, co = self.p, r["name"], r["cout"]
         G, eps = self.GN_GROUPS, self.GN_EPS
         mode = r["mode"]
-        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode)
-        h = ops.conv2d(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"])
+        conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
+        conv2 = ops.conv2d_h2 if r["h2_2"] else ops.conv2d
+        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"])
+        h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"])
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
-        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True)
+        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"])
         if mode:
             skip = ops.resample(x, mode)
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".ws"], co, 1, bias=P[n + ".cs"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return ops.conv2d(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip)
+        return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip)
 
     def _attn(self, r, x):
         P, n, c = self.p, r["name"], r["ch"]
         b, hh, ww, _ = x.shape
-        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"])
-        qkv = ops.conv2d(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"])
+        qkv = (ops.conv2d_h2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x)
@@ -303,7 +318,7 @@ class GuidedUNet:
         h = self._run(self.plan["mid"], h, None, film)
         for blk in self.plan["out"]:
             h = self._run(blk, h, hs.pop(), film)
-        h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True)
-        return ops.conv2d(h, P["out.w"], self.cfg["out_channels"], 3, bias=P["out.c"])
+        h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2)
+        return (ops.conv2d_h2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["out_channels"], 3, bias=P["out.c"])
 
     __call__ = forward

@@ -131,8 +131,13 @@ class NCSNpp:
 
     GN_EPS = 1e-6
 
-    def __init__(self, cfg, device):
+    def __init__(self, cfg, device, precision="f32"):
+        """precision: "f32" exact fp32-input MFMA; "f16x3" split-fp16 three-pass MFMA for every
+        convolution fed by a GroupNorm (see GuidedUNet / csrc/igemm_h2.hip)."""
+        if precision not in ("f32", "f16x3"):
+            raise ValueError(f"unknown precision {precision!r}")
         self.cfg = cfg
+        self.precision = precision
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -162,6 +167,11 @@ class NCSNpp:
         def vec(k):
             return sd[k].detach().float().contiguous().to(dev)
 
+        def conv_w(k, cin):
+            if self.precision == "f16x3" and cin % 32 == 0:
+                return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
+            return ops.pack_conv_weight(sd[k].detach()).to(dev), False
+
         P["t0.w"], P["t0.b"] = ops.pack_linear_weight(sd[M + "0.weight"].detach()).to(dev), vec(M + "0.bias")
         P["t1.w"], P["t1.b"] = ops.pack_linear_weight(sd[M + "1.weight"].detach()).to(dev), vec(M + "1.bias")
         si = self.plan["stem"]["idx"]
@@ -173,9 +183,9 @@ class NCSNpp:
             n = str(r["idx"])
             if r["kind"] == "res":
                 P[n + ".g0"], P[n + ".b0"] = vec(p + ".GroupNorm_0.weight"), vec(p + ".GroupNorm_0.bias")
-                P[n + ".w0"], P[n + ".c0"] = ops.pack_conv_weight(sd[p + ".Conv_0.weight"].detach()).to(dev), vec(p + ".Conv_0.bias")
+                (P[n + ".w0"], r["h2_0"]), P[n + ".c0"] = conv_w(p + ".Conv_0.weight", r["cin"]), vec(p + ".Conv_0.bias")
                 P[n + ".g1"], P[n + ".b1"] = vec(p + ".GroupNorm_1.weight"), vec(p + ".GroupNorm_1.bias")
-                P[n + ".w1"], P[n + ".c1"] = ops.pack_conv_weight(sd[p + ".Conv_1.weight"].detach()).to(dev), vec(p + ".Conv_1.bias")
+                (P[n + ".w1"], r["h2_1"]), P[n + ".c1"] = conv_w(p + ".Conv_1.weight", r["cout"]), vec(p + ".Conv_1.bias")
                 if r["cin"] != r["cout"] or r["mode"]:
                     P[n + ".w2"], P[n + ".c2"] = ops.pack_conv_weight(sd[p + ".Conv_2.weight"].detach()).to(dev), vec(p + ".Conv_2.bias")
                 dw.append(sd[p + ".Dense_0.weight"].detach().float())
@@ -185,7 +195,9 @@ class NCSNpp:
             else:
                 P[n + ".g"], P[n + ".b"] = vec(p + ".GroupNorm_0.weight"), vec(p + ".GroupNorm_0.bias")
                 wq = torch.cat([sd[p + f".NIN_{j}.W"].detach().float() for j in range(3)], dim=1)
-                P[n + ".wqkv"] = ops.pack_nin_weight(wq).to(dev)
+                r["h2"] = self.precision == "f16x3" and r["ch"] % 32 == 0
+                # NIN W is [in, out]; the h2 packer wants [out, in] (conv OI layout)
+                P[n + ".wqkv"] = ops.pack_conv_weight_h2(wq.t().contiguous(), dev) if r["h2"] else ops.pack_nin_weight(wq).to(dev)
                 P[n + ".cqkv"] = torch.cat([sd[p + f".NIN_{j}.b"].detach().float() for j in range(3)]).contiguous().to(dev)
                 P[n + ".w3"], P[n + ".c3"] = ops.pack_nin_weight(sd[p + ".NIN_3.W"].detach()).to(dev), vec(p + ".NIN_3.b")
         P["dense.w"] = ops.pack_linear_weight(torch.cat(dw, dim=0)).to(dev)
@@ -193,17 +205,20 @@ class NCSNpp:
         self.dense_cols = off
         gi, ci = self.plan["gn_idx"], self.plan["conv_idx"]
         P["out.g"], P["out.b"] = vec(M + f"{gi}.weight"), vec(M + f"{gi}.bias")
-        P["out.w"], P["out.c"] = ops.pack_conv_weight(sd[M + f"{ci}.weight"].detach()).to(dev), vec(M + f"{ci}.bias")
+        (P["out.w"], self._out_h2), P["out.c"] = conv_w(M + f"{ci}.weight", self.plan["final_ch"]), vec(M + f"{ci}.bias")
         self.p = P
         return self
 
     def _res(self, r, x, x2, dense):
         P, n, co = self.p, str(r["idx"]), r["cout"]
         mode = r["mode"]
-        h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True, resample=mode)
+        conv0 = ops.conv2d_h2 if r["h2_0"] else ops.conv2d
+        conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
+        h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
+                           resample=mode, split=r["h2_0"])
         off = r["dense_off"]
-        h = ops.conv2d(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co])
-        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True)
+        h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co])
+        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"])
         if mode:
             xs = ops.resample(x, mode)
             skip = ops.conv2d(xs, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
@@ -211,13 +226,13 @@ class NCSNpp:
             skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return ops.conv2d(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2)
+        return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2)
 
     def _attn(self, r, x):
         P, n, c = self.p, str(r["idx"]), r["ch"]
         b, hh, ww, _ = x.shape
-        hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"])
-        qkv = ops.conv2d(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"])
+        qkv = (ops.conv2d_h2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2)
 
@@ -252,7 +267,8 @@ class NCSNpp:
             else:
                 h = self._res(r, h, None, dense)
         assert not hs
-        h = ops.group_norm(h, self._groups(self.plan["final_ch"]), self.GN_EPS, P["out.g"], P["out.b"], act=True)
-        return ops.conv2d(h, P["out.w"], self.cfg["channels"], 3, bias=P["out.c"])
+        h = ops.group_norm(h, self._groups(self.plan["final_ch"]), self.GN_EPS, P["out.g"], P["out.b"], act=True,
+                           split=self._out_h2)
+        return (ops.conv2d_h2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["channels"], 3, bias=P["out.c"])
 
     __call__ = forward

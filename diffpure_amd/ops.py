@@ -63,9 +63,66 @@ def pack_nin_weight(w):
     return _pad_cols(w.float())
 
 
+def pack_h2(t):
+    """fp32 GPU tensor [rows, cols] (cols % 8 == 0) -> "h2" split-fp16 tensor [rows, 2*cols] (fp16):
+    per 8 columns, 8 x hi then 8 x lo with hi = fp16(v), lo = fp16(v - hi)."""
+    _chk(t, "pack_h2.t", 2)
+    rows, cols = t.shape
+    out = torch.empty((rows, 2 * cols), device=t.device, dtype=torch.float16)
+    _lib.call("dp_pack_h2", _ptr(t), rows, cols, cols, _ptr(out), _stream())
+    return out
+
+
+def pack_conv_weight_h2(w, device):
+    """OIHW / OI / OIk weight -> h2 panel [N, 2*K] on `device`, k = (ky*KW+kx)*I + ci (for conv2d on
+    h2 activations)."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, :, None]
+    o, i, kh, kw = w.shape
+    return pack_h2(w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).float().contiguous().to(device))
+
+
+def _chk_h2(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+        raise _lib.DiffpureHipError(f"{name}: expected a contiguous fp16 (h2 split format) GPU tensor")
+    return t
+
+
 # ---------------------------------------------------------------------------------------------
 # convolution / linear
 # ---------------------------------------------------------------------------------------------
+def conv2d_h2(x, wh, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0):
+    """conv2d on h2 (split-fp16) activations/weights with three fp16 MFMA passes per product; same
+    epilogue contract as conv2d.  x: [B,H,W,2*C1] fp16 (h2), wh: [N, 2*K] fp16 (h2)."""
+    _chk_h2(x, "conv2d_h2.x")
+    b, h, w, c1 = x.shape[0], x.shape[1], x.shape[2], x.shape[3] // 2
+    c2 = 0
+    if x2 is not None:
+        _chk_h2(x2, "conv2d_h2.x2")
+        assert x2.shape[:3] == x.shape[:3]
+        c2 = x2.shape[3] // 2
+    _chk_h2(wh, "conv2d_h2.w")
+    assert wh.shape == (n_out, 2 * ksize * ksize * (c1 + c2)), (wh.shape, n_out, ksize, c1, c2)
+    if bias is not None:
+        _chk(bias, "conv2d_h2.bias", 1)
+    ts = 0
+    if temb is not None:
+        assert temb.is_cuda and temb.dtype == torch.float32 and temb.dim() == 2 and temb.stride(1) == 1
+        assert temb.shape[0] in (1, b) and temb.shape[1] >= n_out
+        ts = 0 if temb.shape[0] == 1 else temb.stride(0)
+    out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float32)
+    ldr = 0
+    if res is not None:
+        _chk(res, "conv2d_h2.res", 4)
+        assert res.shape == out.shape
+        ldr = n_out
+    _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c1, _ptr(x2), c2, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb),
+              ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, _stream())
+    return out
+
+
 def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None):
     """out = scale * (res + bias + temb[b] + conv_{ksize x ksize, same}(cat(x, x2)))   (NHWC)."""
     _chk(x, "conv2d.x", 4)
@@ -132,9 +189,11 @@ def group_norm_stats(x, groups, eps, x2=None):
     return stats
 
 
-def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None):
+def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
+               split=False):
     """y = resample(act(FiLM(GroupNorm(cat(x, x2))))).  film = (scale [R,C], shift [R,C]) with R in
-    {1, B}; the two may be column views of one [R, 2C] tensor (row stride is taken from them)."""
+    {1, B}; the two may be column views of one [R, 2C] tensor (row stride is taken from them).
+    split=True writes the "h2" split-fp16 operand format of conv2d_h2 ([B,Ho,Wo,2C] fp16)."""
     _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
@@ -150,9 +209,12 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         assert fs.shape[0] in (1, b)
         fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
     ho, wo = (h * 2, w * 2) if resample == RESAMPLE_UP else ((h // 2, w // 2) if resample == RESAMPLE_DOWN else (h, w))
-    y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    if split:
+        y = torch.empty((b, ho, wo, 2 * c), device=x.device, dtype=torch.float16)
+    else:
+        y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, _ptr(y), _stream())
+              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, 1 if split else 0, _ptr(y), _stream())
     return y
 
 
@@ -162,7 +224,7 @@ def resample(x, mode):
     b, h, w, c = x.shape
     ho, wo = (h * 2, w * 2) if mode == RESAMPLE_UP else (h // 2, w // 2)
     y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, _ptr(y), _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), _stream())
     return y
 
 

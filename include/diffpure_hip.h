@@ -61,6 +61,22 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
                    const float* res, int ldr, float scale,
                    float* out, int ldo, int precision, void* stream);
 
+/* Same contract on the fp16 matrix cores with fp32-class accuracy ("f16x3"): every operand is a
+ * (hi, lo) pair of fp16 numbers and every product is three v_mfma_f32_32x32x16_f16 passes
+ * (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi) into one fp32 accumulator.
+ * "h2" format: channels in blocks of 8, each block = 8 fp16 hi followed by 8 fp16 lo (32 bytes):
+ *   activations x1/x2: [B][H][W][C/8][2][8] fp16, produced by dp_gn_apply(out_fmt=1) or dp_pack_h2;
+ *   weights w: [N][K/8][2][8] fp16 with k = (ky*KS+kx)*Cin + ci, produced by dp_pack_h2 from the
+ *   [N][K] fp32 panel.  C1 % 32 == 0 and C2 % 32 == 0.  bias/temb/res/out are fp32 as above. */
+int dp_conv2d_nhwc_h2(const void* x1, int C1, const void* x2, int C2,
+                      int B, int H, int W, int KS,
+                      const void* w, int N,
+                      const float* bias, const float* temb, int temb_stride,
+                      const float* res, int ldr, float scale,
+                      float* out, int ldo, void* stream);
+/* fp32 [rows][ld] (first `cols` columns, cols % 8 == 0) -> h2 [rows][cols/8][2][8] fp16. */
+int dp_pack_h2(const float* src, long long rows, int cols, int ld, void* dst, void* stream);
+
 /* ---- strided batched GEMM (attention cores) -------------------------------------------------
  * Replaces the einsums at unet.py:355-359 / :389-396 and layerspp.py:82,86.
  * C[z][m][n] = alpha * sum_k A[z][m][k] * Bop[z][k][n];  z = zb*ZH + zh, and each operand's batch
@@ -88,6 +104,7 @@ int dp_softmax_rows(float* x, long long rows, int cols, void* stream);
  *   gamma == NULL skips the normalisation (pure act/resample of x: the x-branch of a
  *   resampling ResBlock, unet.py:249 / layerspp.py:249,256).
  *   act: 0 none, 1 SiLU.  resample: 0 none, 1 nearest x2 (out 2H x 2W), 2 mean 2x2 (out H/2 x W/2).
+ *   out_fmt: 0 = fp32 NHWC; 1 = "h2" split-fp16 NHWC (see dp_conv2d_nhwc_h2), same byte size.
  */
 int dp_gn_stats(const float* x1, int C1, const float* x2, int C2, int B, int HW, int G,
                 int nsplit, float* partial, void* stream);
@@ -96,7 +113,7 @@ int dp_gn_finalize(const float* partial, int B, int nsplit, int G, long long cou
 int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta,
                 const float* fscale, const float* fshift, int film_stride,
-                int act, int resample, float* y, void* stream);
+                int act, int resample, int out_fmt, void* y, void* stream);
 
 /* ---- small elementwise pieces ----------------------------------------------------------------*/
 /* y = x * sigmoid(x)   (nn.SiLU on the embedding vector, unet.py:211, layerspp.py:265) */

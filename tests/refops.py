@@ -20,6 +20,51 @@ def _cat(x, x2):
     return x if x2 is None else torch.cat([x, x2], dim=3)
 
 
+def h2_encode(t):
+    """fp32 [..., C] -> h2 [..., 2C] fp16: per 8 channels, 8 hi then 8 lo."""
+    shp = t.shape
+    v = t.reshape(-1, shp[-1] // 8, 8).float()
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    return torch.stack([hi, lo], dim=2).reshape(*shp[:-1], 2 * shp[-1])
+
+
+def h2_decode(t):
+    shp = t.shape
+    v = t.reshape(-1, shp[-1] // 16, 2, 8).double()
+    return (v[:, :, 0] + v[:, :, 1]).reshape(*shp[:-1], shp[-1] // 2)
+
+
+def pack_h2(t):
+    return h2_encode(t)
+
+
+def pack_conv_weight_h2(w, device=None):
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, :, None]
+    o, i, kh, kw = w.shape
+    return h2_encode(w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).float())
+
+
+def conv2d_h2(x, wh, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0):
+    """Statement of the f16x3 contract: exact products of the (hi+lo) operands (the dropped
+    lo*lo term is ~2^-22 relative, below the test tolerance)."""
+    xin = h2_decode(x) if x2 is None else torch.cat([h2_decode(x), h2_decode(x2)], dim=3)
+    wf = h2_decode(wh)                                   # [N, K]
+    cin = xin.shape[3]
+    wt = wf.reshape(n_out, ksize, ksize, cin).permute(0, 3, 1, 2).contiguous()
+    y = F.conv2d(xin.permute(0, 3, 1, 2), wt, None, padding=ksize // 2).permute(0, 2, 3, 1)
+    if bias is not None:
+        y = y + bias[:n_out]
+    if temb is not None:
+        y = y + temb[:, :n_out].reshape(-1, 1, 1, n_out)
+    if res is not None:
+        y = y + res
+    return (y * scale).float().contiguous()
+
+
 def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None):
     xin = _cat(x, x2)
     b, h, w, cin = xin.shape
@@ -61,7 +106,8 @@ def _resample(y, mode):
     return y
 
 
-def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None):
+def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
+               split=False):
     xin = _cat(x, x2)
     y = F.group_norm(xin.permute(0, 3, 1, 2), groups, gamma, beta, eps).permute(0, 2, 3, 1)
     if film is not None:
@@ -69,7 +115,8 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         y = y * (1 + fs.reshape(-1, 1, 1, fs.shape[-1])) + fh.reshape(-1, 1, 1, fh.shape[-1])
     if act:
         y = F.silu(y)
-    return _resample(y, resample).contiguous()
+    y = _resample(y, resample).contiguous()
+    return h2_encode(y) if split else y
 
 
 def resample(x, mode):
@@ -182,7 +229,7 @@ def ddpm_step(x, out6, sr, srm1, c1, c2, min_log, max_log, nonzero, noise=None, 
     return y
 
 
-PATCHED = ["conv2d", "linear", "group_norm_stats", "group_norm", "resample", "attention", "silu", "axpby",
+PATCHED = ["conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "group_norm_stats", "group_norm", "resample", "attention", "silu", "axpby",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
 
 

@@ -140,3 +140,32 @@ def test_philox_reference_stream_is_shard_invariant():
     assert abs(full.mean()) < 0.15 and abs(full.std() - 1) < 0.15
     other = refops.philox_normal((4, 3, 8, 8), seed=1234, sample0=0, step=4)
     assert not torch.equal(full, other)
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
+def test_f16x3_mode_engine_wiring(kind):
+    """precision="f16x3": GroupNorm emits the split-fp16 operand format and the 3x3 / qkv convolutions
+    consume it with pre-split weights; on CPU the ops are the torch statements of the same contract."""
+    if kind == "ncsnpp":
+        g = load_golden("ncsnpp_small.pt")
+        cfg = pn.parse_config(g["cfg"])
+        net = pn.NCSNpp(cfg, "cpu", precision="f16x3").load_state_dict(synth_state_dict(pn.param_shapes(cfg), g["seed"]))
+        out = nchw(net.forward(nhwc(g["x"]), g["labels"]))
+        assert all(r["h2_0"] and r["h2_1"] for b in net.plan["down"] for r in b if r["kind"] == "res")
+    else:
+        g = load_golden("guided_small.pt")
+        cfg = pg.parse_config(g["cfg"])
+        net = pg.GuidedUNet(cfg, "cpu", precision="f16x3").load_state_dict(synth_state_dict(pg.param_shapes(cfg), g["seed"]))
+        out = nchw(net.forward(nhwc(g["x"]), g["t"].float()))
+        assert net._out_h2 and net.p["out.w"].dtype == torch.float16
+    torch.testing.assert_close(out, g["out"], rtol=2e-4, atol=3e-5)
+
+
+def test_h2_format_roundtrip():
+    x = torch.randn(3, 5, 64) * 3
+    enc = refops.h2_encode(x)
+    assert enc.dtype == torch.float16 and enc.shape == (3, 5, 128)
+    dec = refops.h2_decode(enc).float()
+    assert (dec - x).abs().max() < 3e-6 * x.abs().max()
+    # layout: first 8 halves of each 16-half block are fp16(x)
+    assert torch.equal(enc.reshape(3, 5, 8, 2, 8)[:, :, :, 0], x.reshape(3, 5, 8, 8).half())
