@@ -9,31 +9,47 @@
 // 2.4e-6 max-abs vs fp32 - against 8.8e-4 for single-pass fp16 and 7.1e-3 for bf16 - at a matrix
 // ceiling of 2.5 PFLOP/s / 3 = 833 TFLOP/s instead of the 157 TFLOP/s of fp32-input MFMA.
 //
-// "h2" tensor format (written by gn_apply, csrc/norm.hip, and by the host weight packer):
+// "h2" tensor format (written by gn_apply, csrc/norm.hip, and by dp_pack_h2):
 //   channels in blocks of 8:  [ 8 x fp16 hi | 8 x fp16 lo ]  = 32 bytes per 8 channels,
-//   i.e. 4 bytes per element like fp32, and a 32-channel k-tile of one pixel is 128 contiguous
-//   bytes.  Weights are stored [N][K] with the same blocking along k = (ky*KW+kx)*Cin + ci.
+//   i.e. 4 bytes per element like fp32, and a 32-channel slice of one pixel is 128 contiguous bytes.
+//
+// Reduction order: k' = (c32 * KS*KS + tap) * 32 + (ci % 32)  - channel-slice-major, the KS*KS
+// taps INNERMOST.  Consecutive k-tiles of a workgroup therefore re-read the same 3 x 130-pixel x
+// 128-byte halo strip nine times (reuse distance ~50 KB per workgroup, ~3 MB per XCD: the kx
+// shifts hit L1, the ky rows hit the XCD's 4 MB L2) instead of streaming a fresh 128 KB per tap
+// (reuse distance 8 MB per XCD with the tap-major order, which sent the whole A stream to the
+// fabric).  Weights are packed [N][K'] in the same order by the host (ops.pack_conv_weight_h2).
 //
 // Tile: 128x128x32 per 256-thread workgroup (4 waves as 2x2, each 2x2 MFMA tiles of 32x32).
-// LDS image per operand and stage: 128 rows x 128 B; the 16-byte slot s of row r lives at slot
-// s ^ ((r>>1)&7)  -> every ds_read_b128 lane group touches 16 distinct bank slots (conflict-free),
-// and every ds_write_b128 of a staged 16-byte piece likewise.  Per k16 sub-step a wave issues
-// 8 ds_read_b128 for 12 MFMAs (384 matrix-pipe cycles): the loop is matrix-bound, not LDS-bound.
+// Operands arrive by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The
+// DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle of the LDS image is
+// applied to the SOURCE address: lane l fills physical slot (l&7) of row (l>>3) with the LOGICAL
+// slot (l&7) ^ ((row>>1)&7); readers apply the same involution -> every ds_read_b128 lane group
+// touches 16 distinct bank slots.
+// The activation operand carries a ONE-PIXEL ZERO BORDER ([B][H+2][W+2][C] h2, written by
+// gn_apply): every tap of every output pixel is an in-range read, so the loader has no bounds
+// tests, no predication and no per-tap pointer selection - one 64-bit add per DMA piece (PMC on
+// the masked version: 28 % of wave cycles went to issuing ~210 non-MFMA instructions per k-tile).
+// Workgroups are mapped to tiles XCD-aware: the hardware places workgroup b on XCD b % 8, so tile
+// ids are dealt in contiguous chunks per XCD and the n-tiles / halo neighbours of an m-tile share
+// one L2.
+#include <mutex>
+#include <stdlib.h>
+
 #include "dp_common.h"
 
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NT = 256;
 constexpr int BKH = 32;          // k elements per tile
 constexpr int ROWB = 128;        // bytes per LDS row (32 k x (hi,lo) fp16)
+constexpr int NXCD = 8;
 
 struct ConvH2Args {
-    const char* x1;
-    const char* x2;
-    int C1, C2;
+    const char* x;      // [B][H+2][W+2][C] h2, zero border
+    int C;
     int B, H, W, KS, pad;
     const char* w;
     const float* bias;
@@ -45,7 +61,8 @@ struct ConvH2Args {
     int ldo;
     int M, N, K;
     float scale;
-    int tiles_n;
+    int tiles_n, tiles;
+    const char* zero;   // >= 128 zero bytes in device memory (weight rows n >= N)
 };
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
@@ -59,62 +76,58 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (TM * 32), wn0 = (wave & 1) * (TN * 32);
-    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    // XCD-aware bijective remap of the workgroup id to a tile id (speed only, any placement is correct)
+    int tile;
+    {
+        const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
+    }
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int Cin = p.C1 + p.C2, HW = p.H * p.W;
-    const int slot = tid & 7, r0 = tid >> 3;            // this thread stages slot `slot` of rows r0 + 32*it
+    const int HW = p.H * p.W;
+    const int r0 = tid >> 3;
+    const int ls = (tid & 7) ^ ((tid >> 4) & 7);       // logical slot this lane fetches (same for every it)
+    const int taps = p.KS * p.KS;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: LDS-DMA bases stay scalar
+    const int Wp = p.W + 2;
 
-    int a_oy[A_IT], a_ox[A_IT], a_bH[A_IT];
-    bool a_ok[A_IT];
+    // per staged A row: pointer to the CENTRE pixel inside the zero-bordered tensor
+    const char* ctr[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int m = m0 + r0 + it * 32;
-        a_ok[it] = m < p.M;
-        const int mm = a_ok[it] ? m : 0;
-        const int b = mm / HW, rem = mm - b * HW;
-        a_oy[it] = rem / p.W;
-        a_ox[it] = rem - a_oy[it] * p.W;
-        a_bH[it] = b * p.H;
+        const int m = min(m0 + r0 + it * 32, p.M - 1);   // tail rows re-read the last pixel; never stored
+        const int b = m / HW, rem = m - b * HW;
+        const int oy = rem / p.W, ox = rem - oy * p.W;
+        ctr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 + ls * 16;
     }
-    // workgroup-uniform k cursor: tap (ky,kx) and first channel of the current 32-channel tile
-    int ci0 = 0, ky = 0, kx = 0;
+    const char* bptr[B_IT];
+    int bstep[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int n = n0 + r0 + it * 32;
+        const bool ok = n < p.N;
+        bptr[it] = ok ? p.w + (size_t)n * p.K * 4 + ls * 16 : p.zero + ls * 16;
+        bstep[it] = ok ? ROWB : 0;
+    }
 
-    u32x4 ra[A_IT], rb[B_IT];
-    auto gload = [&](int t) {
-        const bool first = ci0 < p.C1;
-        const char* base = first ? p.x1 : p.x2;
-        const int Cs = first ? p.C1 : p.C2;
-        const int cs = first ? ci0 : ci0 - p.C1;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            const int iy = a_oy[it] + ky - p.pad, ix = a_ox[it] + kx - p.pad;
-            if (a_ok[it] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                const size_t pix = (size_t)(a_bH[it] + iy) * p.W + ix;
-                v = *reinterpret_cast<const u32x4*>(base + (pix * Cs + cs) * 4 + slot * 16);
-            }
-            ra[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            const int n = n0 + r0 + it * 32;
-            if (n < p.N) v = *reinterpret_cast<const u32x4*>(p.w + ((size_t)n * p.K + (size_t)t * BKH) * 4 + slot * 16);
-            rb[it] = v;
-        }
-        ci0 += BKH;
-        if (ci0 == Cin) {
-            ci0 = 0;
-            if (++kx == p.KS) { kx = 0; ++ky; }
-        }
-    };
-    auto sstore = [&](int stage) {
-        char* As = smem + stage * STAGE;
+    // workgroup-uniform cursor of the k-tile being staged: channel slice c32, tap
+    int cur_c = 0, cur_tap = 0;
+    auto issue = [&](int stage) {
+        const int ky = cur_tap / p.KS, kx = cur_tap - ky * p.KS;
+        const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)cur_c * ROWB;
+        char* As = smem + stage * STAGE + wave_u * 8 * ROWB;
         char* Bs = As + BM * ROWB;
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) *reinterpret_cast<u32x4*>(As + swz(r0 + it * 32, slot)) = ra[it];
+        for (int it = 0; it < A_IT; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ctr[it] + off),
+                                             (__attribute__((address_space(3))) void*)(As + it * 32 * ROWB), 16, 0, 0);
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) *reinterpret_cast<u32x4*>(Bs + swz(r0 + it * 32, slot)) = rb[it];
+        for (int it = 0; it < B_IT; ++it) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
+                                             (__attribute__((address_space(3))) void*)(Bs + it * 32 * ROWB), 16, 0, 0);
+            bptr[it] += bstep[it];
+        }
+        if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
     };
 
     f32x16 acc[TM][TN];
@@ -161,14 +174,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
     };
 
     const int nt = p.K / BKH;
-    gload(0);
-    sstore(0);
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) gload(t + 1);
+        if (t + 1 < nt) issue(cur ^ 1);      // DMA of tile t+1 flies under the MFMAs of tile t
         compute(cur);
-        if (t + 1 < nt) sstore(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
     }
 }
 
-// fp32 [rows][cols] (row-major, ld) -> h2 [rows][cols/8][2][8]; host-side weight / tensor packer
+// fp32 [rows][cols] (row-major, ld) -> h2 [rows][cols/8][2][8]
 __global__ void pack_h2_kernel(const float* src, long long rows, int cols, int ld, _Float16* dst) {
     const long long nblk = rows * (cols / 8);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nblk; i += (long long)gridDim.x * blockDim.x) {
@@ -212,33 +225,46 @@ __global__ void pack_h2_kernel(const float* src, long long rows, int cols, int l
     }
 }
 
+const char* zero_page() {
+    static void* z = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (hipMalloc(&z, 256) == hipSuccess) (void)hipMemset(z, 0, 256);
+        else z = nullptr;
+    });
+    return static_cast<const char*>(z);
+}
+
 }  // namespace
 
-extern "C" int dp_conv2d_nhwc_h2(const void* x1, int C1, const void* x2, int C2, int B, int H, int W, int KS,
-                                 const void* w, int N, const float* bias, const float* temb, int temb_stride,
-                                 const float* res, int ldr, float scale, float* out, int ldo, void* stream) {
-    DP_REQUIRE(x1 && w && out, "dp_conv2d_nhwc_h2: null pointer");
+extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
+                                 const float* bias, const float* temb, int temb_stride, const float* res, int ldr,
+                                 float scale, float* out, int ldo, void* stream) {
+    DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
     DP_REQUIRE(KS == 1 || KS == 3, "dp_conv2d_nhwc_h2: kernel size %d unsupported", KS);
-    DP_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "dp_conv2d_nhwc_h2: bad channel split %d+%d", C1, C2);
-    DP_REQUIRE(C1 % 32 == 0 && C2 % 32 == 0, "dp_conv2d_nhwc_h2: channel counts must be multiples of 32 (got %d+%d)", C1, C2);
-    DP_REQUIRE(dp_aligned16(x1) && dp_aligned16(w) && (C2 == 0 || dp_aligned16(x2)), "dp_conv2d_nhwc_h2: misaligned operand");
+    DP_REQUIRE(C > 0 && C % 32 == 0, "dp_conv2d_nhwc_h2: channel count must be a multiple of 32 (got %d)", C);
+    DP_REQUIRE(dp_aligned16(x) && dp_aligned16(w), "dp_conv2d_nhwc_h2: misaligned operand");
     DP_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && (long long)B * H * W < (1ll << 31), "dp_conv2d_nhwc_h2: bad shape");
     ConvH2Args p;
-    p.x1 = (const char*)x1; p.x2 = (const char*)x2; p.C1 = C1; p.C2 = C2;
+    p.x = (const char*)x; p.C = C;
     p.B = B; p.H = H; p.W = W; p.KS = KS; p.pad = KS / 2;
     p.w = (const char*)w; p.bias = bias; p.temb = temb; p.temb_stride = temb_stride;
     p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo;
-    p.M = B * H * W; p.N = N; p.K = KS * KS * (C1 + C2); p.scale = scale;
+    p.M = B * H * W; p.N = N; p.K = KS * KS * C; p.scale = scale;
+    p.zero = zero_page();
+    DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
     hipStream_t s = static_cast<hipStream_t>(stream);
     void* rec = nullptr;
     dp_prof_begin(KS == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (N <= 64 || tiles(128, 128) < 256) {
         p.tiles_n = (N + 63) / 64;
-        hipLaunchKernelGGL((conv_igemm_h2<64, 64>), dim3((unsigned)tiles(64, 64)), dim3(NT), 0, s, p);
+        p.tiles = (int)tiles(64, 64);
+        hipLaunchKernelGGL((conv_igemm_h2<64, 64>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
     } else {
         p.tiles_n = (N + 127) / 128;
-        hipLaunchKernelGGL((conv_igemm_h2<128, 128>), dim3((unsigned)tiles(128, 128)), dim3(NT), 0, s, p);
+        p.tiles = (int)tiles(128, 128);
+        hipLaunchKernelGGL((conv_igemm_h2<128, 128>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
     }
     dp_prof_end(rec, s);
     DP_LAUNCH_CHECK("conv_igemm_h2");

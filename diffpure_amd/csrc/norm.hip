@@ -97,18 +97,32 @@ __device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) 
 
 // One work item = VEC channels of one OUTPUT pixel: VEC = 4 (fp32 out, one float4) or 8 (h2 out:
 // 8 fp16 hi | 8 fp16 lo = 32 bytes, the operand format of csrc/igemm_h2.hip).
+// H2 output carries a one-pixel zero border ([B][Ho+2][Wo+2][C]): the operand format of
+// csrc/igemm_h2.hip, whose loader then needs no bounds tests.
 template <bool H2>
 __global__ void gn_apply_kernel(ApplyArgs p) {
     constexpr int VEC = H2 ? 8 : 4, NQ = VEC / 4;
+    constexpr int BORDER = H2 ? 1 : 0;
     const int CV = p.C4 * 4 / VEC;
-    const long long total = (long long)p.B * p.Ho * p.Wo * CV;
+    const int Hq = p.Ho + 2 * BORDER, Wq = p.Wo + 2 * BORDER;
+    const long long total = (long long)p.B * Hq * Wq * CV;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
-        const long long opix = i / CV;
-        const int ox = (int)(opix % p.Wo);
-        const long long t2 = opix / p.Wo;
-        const int oy = (int)(t2 % p.Ho), b = (int)(t2 / p.Ho);
+        const long long opix = i / CV;                  // index in the (bordered) output
+        const int qx = (int)(opix % Wq);
+        const long long t2 = opix / Wq;
+        const int qy = (int)(t2 % Hq), b = (int)(t2 / Hq);
+        const int ox = qx - BORDER, oy = qy - BORDER;
+        if (H2 && ((unsigned)ox >= (unsigned)p.Wo || (unsigned)oy >= (unsigned)p.Ho)) {
+            half8 z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+            half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + ((size_t)opix * CV + cv) * 32);
+            dst[0] = z;
+            dst[1] = z;
+            continue;
+        }
         f32x4 o[NQ];
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd) {
@@ -167,7 +181,7 @@ __global__ void gn_apply_kernel(ApplyArgs p) {
             dst[0] = hi;
             dst[1] = lo;
         } else {
-            *reinterpret_cast<f32x4*>(p.y + (size_t)opix * (p.C4 * 4) + cv * 4) = o[0];
+            *reinterpret_cast<f32x4*>(p.y + (size_t)opix * (p.C4 * 4) + cv * 4) = o[0];   // BORDER == 0: opix is the pixel
         }
     }
 }
@@ -225,7 +239,7 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
                 C / 4, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
                 resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W)};
-    const long long total = (long long)B * p.Ho * p.Wo * p.C4 / (out_fmt ? 2 : 1);
+    const long long total = out_fmt ? (long long)B * (p.Ho + 2) * (p.Wo + 2) * (p.C4 / 2) : (long long)B * p.Ho * p.Wo * p.C4;
     if (out_fmt) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     DP_LAUNCH_CHECK("gn_apply");

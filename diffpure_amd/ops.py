@@ -74,14 +74,17 @@ def pack_h2(t):
 
 
 def pack_conv_weight_h2(w, device):
-    """OIHW / OI / OIk weight -> h2 panel [N, 2*K] on `device`, k = (ky*KW+kx)*I + ci (for conv2d on
-    h2 activations)."""
+    """OIHW / OI / OIk weight -> h2 panel [N, 2*K] on `device` in the reduction order of
+    csrc/igemm_h2.hip: k' = (c32 * KH*KW + tap) * 32 + ci % 32 (32-channel slices outermost, the
+    taps innermost).  I % 32 == 0."""
     if w.dim() == 2:
         w = w[:, :, None, None]
     elif w.dim() == 3:
         w = w[:, :, :, None]
     o, i, kh, kw = w.shape
-    return pack_h2(w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).float().contiguous().to(device))
+    assert i % 32 == 0, i
+    wk = w.float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).reshape(o, kh * kw * i)
+    return pack_h2(wk.contiguous().to(device))
 
 
 def _chk_h2(t, name):
@@ -93,18 +96,14 @@ def _chk_h2(t, name):
 # ---------------------------------------------------------------------------------------------
 # convolution / linear
 # ---------------------------------------------------------------------------------------------
-def conv2d_h2(x, wh, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0):
     """conv2d on h2 (split-fp16) activations/weights with three fp16 MFMA passes per product; same
-    epilogue contract as conv2d.  x: [B,H,W,2*C1] fp16 (h2), wh: [N, 2*K] fp16 (h2)."""
+    epilogue contract as conv2d.  x: [B, H+2, W+2, 2*C] fp16 (h2 with a one-pixel zero border, as
+    group_norm(split=True) writes it), wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2)."""
     _chk_h2(x, "conv2d_h2.x")
-    b, h, w, c1 = x.shape[0], x.shape[1], x.shape[2], x.shape[3] // 2
-    c2 = 0
-    if x2 is not None:
-        _chk_h2(x2, "conv2d_h2.x2")
-        assert x2.shape[:3] == x.shape[:3]
-        c2 = x2.shape[3] // 2
+    b, h, w, c = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3] // 2
     _chk_h2(wh, "conv2d_h2.w")
-    assert wh.shape == (n_out, 2 * ksize * ksize * (c1 + c2)), (wh.shape, n_out, ksize, c1, c2)
+    assert wh.shape == (n_out, 2 * ksize * ksize * c), (wh.shape, n_out, ksize, c)
     if bias is not None:
         _chk(bias, "conv2d_h2.bias", 1)
     ts = 0
@@ -118,8 +117,8 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, x2=None, temb=None, res=None, scal
         _chk(res, "conv2d_h2.res", 4)
         assert res.shape == out.shape
         ldr = n_out
-    _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c1, _ptr(x2), c2, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb),
-              ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, _stream())
+    _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
+              ldr, float(scale), _ptr(out), n_out, _stream())
     return out
 
 
@@ -193,7 +192,8 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
                split=False):
     """y = resample(act(FiLM(GroupNorm(cat(x, x2))))).  film = (scale [R,C], shift [R,C]) with R in
     {1, B}; the two may be column views of one [R, 2C] tensor (row stride is taken from them).
-    split=True writes the "h2" split-fp16 operand format of conv2d_h2 ([B,Ho,Wo,2C] fp16)."""
+    split=True writes the "h2" split-fp16 operand format of conv2d_h2 with its one-pixel zero border
+    ([B, Ho+2, Wo+2, 2C] fp16)."""
     _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
@@ -210,7 +210,7 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
     ho, wo = (h * 2, w * 2) if resample == RESAMPLE_UP else ((h // 2, w // 2) if resample == RESAMPLE_DOWN else (h, w))
     if split:
-        y = torch.empty((b, ho, wo, 2 * c), device=x.device, dtype=torch.float16)
+        y = torch.empty((b, ho + 2, wo + 2, 2 * c), device=x.device, dtype=torch.float16)
     else:
         y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),

@@ -65,11 +65,14 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
  * (hi, lo) pair of fp16 numbers and every product is three v_mfma_f32_32x32x16_f16 passes
  * (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi) into one fp32 accumulator.
  * "h2" format: channels in blocks of 8, each block = 8 fp16 hi followed by 8 fp16 lo (32 bytes):
- *   activations x1/x2: [B][H][W][C/8][2][8] fp16, produced by dp_gn_apply(out_fmt=1) or dp_pack_h2;
- *   weights w: [N][K/8][2][8] fp16 with k = (ky*KS+kx)*Cin + ci, produced by dp_pack_h2 from the
- *   [N][K] fp32 panel.  C1 % 32 == 0 and C2 % 32 == 0.  bias/temb/res/out are fp32 as above. */
-int dp_conv2d_nhwc_h2(const void* x1, int C1, const void* x2, int C2,
-                      int B, int H, int W, int KS,
+ *   activations x: [B][H+2][W+2][C/8][2][8] fp16 WITH A ONE-PIXEL ZERO BORDER (so that the loader
+ *   has no bounds tests), produced by dp_gn_apply(out_fmt=1); C % 32 == 0;
+ *   weights w: [N][K/8][2][8] fp16 in the kernel's reduction order
+ *   k' = (c32*KS*KS + (ky*KS+kx))*32 + ci%32, c32 = ci/32 (channel slices outermost, taps innermost:
+ *   the 9 taps re-read the same halo strip from L1/L2), produced by dp_pack_h2 from the fp32 panel
+ *   [N][K'] (diffpure_amd/ops.py:pack_conv_weight_h2).
+ *   H, W are the OUTPUT (= interior) sizes; bias/temb/res/out are fp32 as above. */
+int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
                       const float* res, int ldr, float scale,
@@ -104,7 +107,8 @@ int dp_softmax_rows(float* x, long long rows, int cols, void* stream);
  *   gamma == NULL skips the normalisation (pure act/resample of x: the x-branch of a
  *   resampling ResBlock, unet.py:249 / layerspp.py:249,256).
  *   act: 0 none, 1 SiLU.  resample: 0 none, 1 nearest x2 (out 2H x 2W), 2 mean 2x2 (out H/2 x W/2).
- *   out_fmt: 0 = fp32 NHWC; 1 = "h2" split-fp16 NHWC (see dp_conv2d_nhwc_h2), same byte size.
+ *   out_fmt: 0 = fp32 NHWC [B][Ho][Wo][C]; 1 = "h2" split-fp16 with a one-pixel zero border,
+ *   [B][Ho+2][Wo+2][C] (see dp_conv2d_nhwc_h2).
  */
 int dp_gn_stats(const float* x1, int C1, const float* x2, int C2, int B, int HW, int G,
                 int nsplit, float* partial, void* stream);

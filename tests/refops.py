@@ -40,21 +40,22 @@ def pack_h2(t):
 
 
 def pack_conv_weight_h2(w, device=None):
+    """k' = (c32 * KH*KW + tap) * 32 + ci % 32 (see csrc/igemm_h2.hip)."""
     if w.dim() == 2:
         w = w[:, :, None, None]
     elif w.dim() == 3:
         w = w[:, :, :, None]
     o, i, kh, kw = w.shape
-    return h2_encode(w.permute(0, 2, 3, 1).reshape(o, kh * kw * i).float())
+    return h2_encode(w.float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).reshape(o, kh * kw * i))
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0):
     """Statement of the f16x3 contract: exact products of the (hi+lo) operands (the dropped
-    lo*lo term is ~2^-22 relative, below the test tolerance)."""
-    xin = h2_decode(x) if x2 is None else torch.cat([h2_decode(x), h2_decode(x2)], dim=3)
-    wf = h2_decode(wh)                                   # [N, K]
+    lo*lo term is ~2^-22 relative, below the test tolerance). x carries a one-pixel zero border."""
+    xin = h2_decode(x)[:, 1:-1, 1:-1, :]
     cin = xin.shape[3]
-    wt = wf.reshape(n_out, ksize, ksize, cin).permute(0, 3, 1, 2).contiguous()
+    wf = h2_decode(wh).reshape(n_out, cin // 32, ksize, ksize, 32)       # [N, c32, ky, kx, 32]
+    wt = wf.permute(0, 1, 4, 2, 3).reshape(n_out, cin, ksize, ksize).contiguous()
     y = F.conv2d(xin.permute(0, 3, 1, 2), wt, None, padding=ksize // 2).permute(0, 2, 3, 1)
     if bias is not None:
         y = y + bias[:n_out]
@@ -116,7 +117,7 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     if act:
         y = F.silu(y)
     y = _resample(y, resample).contiguous()
-    return h2_encode(y) if split else y
+    return h2_encode(F.pad(y, (0, 0, 1, 1, 1, 1))) if split else y
 
 
 def resample(x, mode):

@@ -200,47 +200,56 @@ def test_ops_refuse_cpu_tensors(dev):
 
 
 H2_CASES = [
-    # B, H, W, C1, C2, N, k, temb_rows, res, scale
-    (2, 16, 16, 128, 0, 256, 3, 0, False, 1.0),        # 128x128 tiles
-    (2, 16, 16, 256, 128, 128, 3, 2, True, 0.70710678),  # channel-split input, temb rows, residual, scale
-    (1, 5, 7, 64, 0, 96, 3, 1, False, 1.0),            # ragged M and N -> 64x64 tiles, masked rows/cols
-    (4, 4, 4, 256, 256, 256, 3, 0, True, 1.0),         # low resolution
-    (2, 16, 16, 128, 0, 6, 3, 0, False, 1.0),          # head: N = 6
-    (2, 16, 16, 256, 0, 768, 1, 0, False, 1.0),        # 1x1 qkv
-    (2, 32, 32, 32, 0, 32, 3, 0, False, 1.0),          # Cin = 32: one k-tile per tap
-    (1, 64, 64, 64, 0, 192, 3, 0, False, 1.0),         # larger M, 128x128 with N not a multiple of 128
+    # B, H, W, C, N, k, temb_rows, res, scale
+    (2, 16, 16, 128, 256, 3, 0, False, 1.0),           # 128x128 tiles
+    (2, 16, 16, 384, 128, 3, 2, True, 0.70710678),     # temb rows, residual, scale
+    (1, 5, 7, 64, 96, 3, 1, False, 1.0),               # ragged M and N -> 64x64 tiles, masked rows/cols
+    (4, 4, 4, 512, 256, 3, 0, True, 1.0),              # low resolution
+    (2, 16, 16, 128, 6, 3, 0, False, 1.0),             # head: N = 6
+    (2, 16, 16, 256, 768, 1, 0, False, 1.0),           # 1x1 qkv
+    (2, 32, 32, 32, 32, 3, 0, False, 1.0),             # Cin = 32: one channel slice
+    (1, 64, 64, 64, 192, 3, 0, False, 1.0),            # larger M, 128x128 with N not a multiple of 128
+    (3, 9, 9, 96, 160, 3, 0, False, 1.0),              # tile tail rows re-read the last pixel (M % 128 != 0)
 ]
+
+
+def _h2_bordered(x, dev):
+    """fp32 [B,H,W,C] -> zero-bordered h2 [B,H+2,W+2,2C] on the device via the device packer."""
+    from diffpure_amd import ops
+    B, H, W, C = x.shape
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1)).contiguous()
+    return ops.pack_h2(xp.reshape(-1, C).to(dev)).reshape(B, H + 2, W + 2, 2 * C)
 
 
 @pytest.mark.parametrize("case", H2_CASES, ids=[str(c) for c in H2_CASES])
 def test_conv2d_h2_split_fp16(dev, case):
     from diffpure_amd import ops
-    B, H, W, C1, C2, N, k, temb_rows, has_res, scale = case
-    x = rnd(B, H, W, C1, seed=1)
-    x2 = rnd(B, H, W, C2, seed=2) if C2 else None
-    w = rnd(N, C1 + C2, k, k, seed=3, scale=1.0 / math.sqrt((C1 + C2) * k * k))
+    B, H, W, C, N, k, temb_rows, has_res, scale = case
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(N, C, k, k, seed=3, scale=1.0 / math.sqrt(C * k * k))
     bias = rnd(N, seed=4)
     table = rnd(B if temb_rows == 2 else 1, N + 8, seed=5) if temb_rows else None
     res = rnd(B, H, W, N, seed=6) if has_res else None
     # exact fp64 convolution of the fp32 operands: the f16x3 path must be fp32-class accurate
-    xin = x if x2 is None else torch.cat([x, x2], dim=3)
-    ref = torch.nn.functional.conv2d(xin.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=k // 2).permute(0, 2, 3, 1)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=k // 2).permute(0, 2, 3, 1)
     if table is not None:
         ref = ref + table[:, 4:4 + N].double().reshape(-1, 1, 1, N)
     if res is not None:
         ref = ref + res.double()
     ref = (ref * scale).float()
-    xh = ops.pack_h2(x.reshape(-1, C1).to(dev)).reshape(B, H, W, 2 * C1)
-    x2h = ops.pack_h2(x2.reshape(-1, C2).to(dev)).reshape(B, H, W, 2 * C2) if C2 else None
+    xh = _h2_bordered(x, dev)
     wh = ops.pack_conv_weight_h2(w, dev)
-    assert torch.equal(xh.cpu(), refops.h2_encode(x))            # device packer == format statement
+    assert torch.equal(xh.cpu(), refops.h2_encode(torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))))   # packer == format statement
     table_d = None if table is None else table.to(dev)
-    got = ops.conv2d_h2(xh, wh, N, k, bias=bias.to(dev), x2=x2h, temb=None if table is None else table_d[:, 4:4 + N],
+    got = ops.conv2d_h2(xh, wh, N, k, bias=bias.to(dev), temb=None if table is None else table_d[:, 4:4 + N],
                         res=None if res is None else res.to(dev), scale=scale)
     close(got, ref, rtol=2e-5, atol=2e-5)
+    # and the torch statement of the same contract agrees with it
+    close(got, refops.conv2d_h2(xh.cpu(), wh.cpu(), N, k, bias, None if table is None else table[:, 4:4 + N], res, scale),
+          rtol=2e-5, atol=2e-5)
 
 
-def test_group_norm_split_output_is_h2_of_fp32_output(dev):
+def test_group_norm_split_output_is_bordered_h2_of_fp32_output(dev):
     from diffpure_amd import ops
     x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)
     x2 = rnd(2, 8, 8, 128, seed=2).to(dev)
@@ -248,5 +257,5 @@ def test_group_norm_split_output_is_h2_of_fp32_output(dev):
     for rs in (0, 1, 2):
         y32 = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, resample=rs)
         yh = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, resample=rs, split=True)
-        assert yh.dtype == torch.float16 and yh.shape[-1] == 768
-        assert torch.equal(yh.cpu(), refops.h2_encode(y32.cpu()))
+        assert yh.dtype == torch.float16 and yh.shape == (2, y32.shape[1] + 2, y32.shape[2] + 2, 768)
+        assert torch.equal(yh.cpu(), refops.h2_encode(torch.nn.functional.pad(y32.cpu(), (0, 0, 1, 1, 1, 1))))
