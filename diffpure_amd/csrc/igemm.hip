@@ -255,7 +255,7 @@ struct GemmArgs {
     int tiles_n, tiles_mn;
 };
 
-template <int BM, int BN, int WM, int WN, int TRANSB>
+template <int BM, int BN, int WM, int WN, int TRANSB, int TRANSA>
 __global__ __launch_bounds__(NT) void gemm_strided_f32(GemmArgs p) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -273,26 +273,54 @@ __global__ __launch_bounds__(NT) void gemm_strided_f32(GemmArgs p) {
     const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
     float* C = p.C + zb * p.sCb + zh * p.sCh;
 
-    constexpr int A_IT = BM * BK / 4 / NT;
+    // A tile: row-major [M][lda] (k contiguous, transposed into the k-major LDS image) or, with
+    // TRANSA, stored [K][lda] (m contiguous: already k-major, copied with float4 along m)
+    constexpr int AQ = BM / 4;
+    constexpr int A_IT = TRANSA ? ((BK * AQ + NT - 1) / NT) : (BM * BK / 4 / NT);
     f32x4 ra[A_IT];
     auto gload_A = [&](int t) {
-        const int k = t * BK + (tid & 3) * 4;
+        if constexpr (TRANSA) {
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int m = m0 + (tid >> 2) + it * (NT / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < p.M && k < p.K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + k);
-            ra[it] = v;
+            for (int it = 0; it < A_IT; ++it) {
+                const int idx = tid + it * NT;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (idx < BK * AQ) {
+                    const int kr = idx / AQ, mq = idx - kr * AQ;
+                    const int k = t * BK + kr, m = m0 + mq * 4;
+                    if (k < p.K && m < p.M) v = *reinterpret_cast<const f32x4*>(A + (size_t)k * p.lda + m);
+                }
+                ra[it] = v;
+            }
+        } else {
+            const int k = t * BK + (tid & 3) * 4;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int m = m0 + (tid >> 2) + it * (NT / 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < p.M && k < p.K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + k);
+                ra[it] = v;
+            }
         }
     };
     auto sstore_A = [&](int buf) {
         float* dst = As + buf * BK * LDA;
-        const int kq = tid & 3;
+        if constexpr (TRANSA) {
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int r = (tid >> 2) + it * (NT / 4);
+            for (int it = 0; it < A_IT; ++it) {
+                const int idx = tid + it * NT;
+                if (idx < BK * AQ) {
+                    const int kr = idx / AQ, mq = idx - kr * AQ;
+                    *reinterpret_cast<f32x4*>(dst + kr * LDA + mq * 4) = ra[it];
+                }
+            }
+        } else {
+            const int kq = tid & 3;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[(kq * 4 + j) * LDA + r] = ra[it][j];
+            for (int it = 0; it < A_IT; ++it) {
+                const int r = (tid >> 2) + it * (NT / 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(kq * 4 + j) * LDA + r] = ra[it][j];
+            }
         }
     };
 
@@ -497,12 +525,13 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
     return 0;
 }
 
-extern "C" int dp_gemm_strided(const float* A, int lda, long long sAb, long long sAh, const float* B, int ldb,
-                               long long sBb, long long sBh, int transB, float* C, int ldc, long long sCb,
+extern "C" int dp_gemm_strided(const float* A, int lda, long long sAb, long long sAh, int transA, const float* B,
+                               int ldb, long long sBb, long long sBh, int transB, float* C, int ldc, long long sCb,
                                long long sCh, int M, int N, int K, int ZB, int ZH, float alpha, void* stream) {
     DP_REQUIRE(A && B && C, "dp_gemm_strided: null pointer");
-    DP_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "dp_gemm_strided: K, lda, ldb must be multiples of 4");
-    DP_REQUIRE(transB || N % 4 == 0, "dp_gemm_strided: N must be a multiple of 4 when B is [K][N]");
+    DP_REQUIRE(lda % 4 == 0 && ldb % 4 == 0, "dp_gemm_strided: lda, ldb must be multiples of 4");
+    DP_REQUIRE(transA ? M % 4 == 0 : K % 4 == 0, "dp_gemm_strided: the contiguous extent of A must be a multiple of 4");
+    DP_REQUIRE(transB ? K % 4 == 0 : N % 4 == 0, "dp_gemm_strided: the contiguous extent of B must be a multiple of 4");
     DP_REQUIRE(sAb % 4 == 0 && sAh % 4 == 0 && sBb % 4 == 0 && sBh % 4 == 0, "dp_gemm_strided: batch strides must be multiples of 4");
     DP_REQUIRE(dp_aligned16(A) && dp_aligned16(B), "dp_gemm_strided: operands must be 16B aligned");
     GemmArgs p;
@@ -511,21 +540,22 @@ extern "C" int dp_gemm_strided(const float* A, int lda, long long sAb, long long
     p.M = M; p.N = N; p.K = K; p.ZH = ZH; p.alpha = alpha;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long Z = (long long)ZB * ZH;
-    if (M >= 128 && N >= 128) {
-        p.tiles_n = (N + 127) / 128;
-        p.tiles_mn = p.tiles_n * ((M + 127) / 128);
-        const long long grid = Z * p.tiles_mn;
-        DP_REQUIRE(grid < (1ll << 31), "dp_gemm_strided: grid too large");
-        if (transB) hipLaunchKernelGGL((gemm_strided_f32<128, 128, 2, 2, 1>), dim3((unsigned)grid), dim3(NT), 0, s, p);
-        else hipLaunchKernelGGL((gemm_strided_f32<128, 128, 2, 2, 0>), dim3((unsigned)grid), dim3(NT), 0, s, p);
+    const bool big = M >= 128 && N >= 128;
+    const int bm = big ? 128 : 64;
+    p.tiles_n = (N + bm - 1) / bm;
+    p.tiles_mn = p.tiles_n * ((M + bm - 1) / bm);
+    const long long grid = Z * p.tiles_mn;
+    DP_REQUIRE(grid < (1ll << 31), "dp_gemm_strided: grid too large");
+    const dim3 g((unsigned)grid), b(NT);
+#define DP_GEMM(BM_, TB_, TA_) hipLaunchKernelGGL((gemm_strided_f32<BM_, BM_, 2, 2, TB_, TA_>), g, b, 0, s, p)
+    if (big) {
+        if (transA) { if (transB) DP_GEMM(128, 1, 1); else DP_GEMM(128, 0, 1); }
+        else { if (transB) DP_GEMM(128, 1, 0); else DP_GEMM(128, 0, 0); }
     } else {
-        p.tiles_n = (N + 63) / 64;
-        p.tiles_mn = p.tiles_n * ((M + 63) / 64);
-        const long long grid = Z * p.tiles_mn;
-        DP_REQUIRE(grid < (1ll << 31), "dp_gemm_strided: grid too large");
-        if (transB) hipLaunchKernelGGL((gemm_strided_f32<64, 64, 2, 2, 1>), dim3((unsigned)grid), dim3(NT), 0, s, p);
-        else hipLaunchKernelGGL((gemm_strided_f32<64, 64, 2, 2, 0>), dim3((unsigned)grid), dim3(NT), 0, s, p);
+        if (transA) { if (transB) DP_GEMM(64, 1, 1); else DP_GEMM(64, 0, 1); }
+        else { if (transB) DP_GEMM(64, 1, 0); else DP_GEMM(64, 0, 0); }
     }
+#undef DP_GEMM
     DP_LAUNCH_CHECK("gemm_strided_f32");
     return 0;
 }

@@ -200,6 +200,8 @@ class GuidedUNet:
                 raise ValueError(f"{k}: expected {shp}, got {tuple(sd[k].shape)}")
         dev = self.device
         P = {}
+        self._sd = sd          # host copy: the input-gradient (dgrad) panels are packed lazily by enable_grad()
+        self._grad_ready = False
 
         def vec(k):
             return sd[k].detach().float().contiguous().to(dev)
@@ -252,17 +254,21 @@ class GuidedUNet:
         return self
 
     # -- blocks ----------------------------------------------------------------------------------
-    def _res(self, r, x, x2, film_table):
+    def _res(self, r, x, x2, film_table, tape=None):
         P, n, co = self.p, r["name"], r["cout"]
         G, eps = self.GN_GROUPS, self.GN_EPS
         mode = r["mode"]
         conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
         conv2 = ops.conv2d_h2 if r["h2_2"] else ops.conv2d
-        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"])
+        st1 = ops.group_norm_stats(x, G, eps, x2)
+        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"], stats=st1)
         h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"])
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
-        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"])
+        st2 = ops.group_norm_stats(h, G, eps)
+        if tape is not None:
+            tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
+        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"], stats=st2)
         if mode:
             skip = ops.resample(x, mode)
         elif r["cin"] != co:
@@ -271,22 +277,27 @@ class GuidedUNet:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
         return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip)
 
-    def _attn(self, r, x):
+    def _attn(self, r, x, tape=None):
         P, n, c = self.p, r["name"], r["ch"]
         b, hh, ww, _ = x.shape
-        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"])
+        st = ops.group_norm_stats(x, self.GN_GROUPS, self.GN_EPS)
+        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"], stats=st)
         qkv = (ops.conv2d_h2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
-        a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
+        if tape is None:
+            a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
+        else:
+            a, probs = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout, return_probs=True)
+            tape.append(dict(r=r, x=x, st=st, qkv=qkv, probs=probs, layout=layout))
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x)
 
-    def _run(self, blk, h, h2, film):
+    def _run(self, blk, h, h2, film, tape=None):
         for r in blk:
             if r["kind"] == "res":
-                h = self._res(r, h, h2, film)
+                h = self._res(r, h, h2, film, tape)
                 h2 = None
             else:
-                h = self._attn(r, h)
+                h = self._attn(r, h, tape)
         return h
 
     # -- forward ---------------------------------------------------------------------------------
@@ -300,7 +311,7 @@ class GuidedUNet:
         e = ops.linear(ops.silu(e), P["te2.w"], ed, P["te2.b"])
         return ops.linear(ops.silu(e), P["emb.w"], self.emb_cols, P["emb.b"])
 
-    def forward(self, x, timesteps=None, table_row=None):
+    def forward(self, x, timesteps=None, table_row=None, tape=None):
         """x: [B, H, W, 3] NHWC fp32 on the GPU; timesteps: [1] or [B] float32 (integer-valued for
         the SDE path, unet.py:642-671 receives `(s*1000).long()`), or `table_row` = precomputed
         rows of `time_table` ([1, cols] broadcast over the batch, or [B, cols])."""
@@ -313,12 +324,132 @@ class GuidedUNet:
         h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"])
         hs.append(h)
         for blk in self.plan["inp"][1:]:
-            h = self._run(blk, h, None, film)
+            h = self._run(blk, h, None, film, tape)
             hs.append(h)
-        h = self._run(self.plan["mid"], h, None, film)
+        h = self._run(self.plan["mid"], h, None, film, tape)
         for blk in self.plan["out"]:
-            h = self._run(blk, h, hs.pop(), film)
-        h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2)
+            h = self._run(blk, h, hs.pop(), film, tape)
+        st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS)
+        if tape is not None:
+            tape.append(dict(head=True, x=h, st=st))
+        h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2, stats=st)
         return (ops.conv2d_h2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["out_channels"], 3, bias=P["out.c"])
 
     __call__ = forward
+
+    # -- input gradient (vector-Jacobian product) ------------------------------------------------
+    # Only dL/dx is formed: parameter gradients are never needed by an attack, and the time-
+    # conditioning path does not depend on x.  Every convolution's input gradient is the SAME
+    # implicit-GEMM kernel run with a flipped/transposed weight panel (packed once, lazily).
+    def enable_grad(self):
+        if self._grad_ready:
+            return self
+        sd, dev, P = self._sd, self.device, self.p
+
+        def dg(key, n_in_dgrad, lo=None, hi=None, out_lo=None, out_hi=None):
+            """dgrad panel of conv `key`; [lo:hi) selects input channels of the forward conv (= output
+            columns of the dgrad), [out_lo:out_hi) output channels of the forward (= dgrad input)."""
+            w = sd[key].detach().float()
+            if out_lo is not None:
+                w = w[out_lo:out_hi]
+            wd = ops.dgrad_weight(w)                       # [I, O, kh, kw]
+            if lo is not None:
+                wd = wd[lo:hi]
+            if self.precision == "f16x3" and n_in_dgrad % 32 == 0:
+                return ops.pack_conv_weight_h2(wd, dev), True
+            return ops.pack_conv_weight(wd).to(dev), False
+
+        blocks = [r for b in self.plan["inp"] for r in b] + self.plan["mid"] + [r for b in self.plan["out"] for r in b]
+        for r in blocks:
+            n = r["name"]
+            if r["kind"] == "stem":
+                P[n + ".dw"], _ = dg(n + ".weight", -1)
+            elif r["kind"] == "res":
+                c1 = r.get("split", r["cin"])
+                P[n + ".dw2"], r["dh2_2"] = dg(n + ".out_layers.3.weight", r["cout"])
+                # conv1's dgrad writes the gradient of the (concatenated) normalised input: one panel
+                P[n + ".dw1"], r["dh2_1"] = dg(n + ".in_layers.2.weight", r["cout"])
+                if r["cin"] != r["cout"]:
+                    P[n + ".dws1"], _ = dg(n + ".skip_connection.weight", -1, 0, c1)
+                    if c1 != r["cin"]:
+                        P[n + ".dws2"], _ = dg(n + ".skip_connection.weight", -1, c1, r["cin"])
+            else:
+                P[n + ".dwqkv"], r["dh2"] = dg(n + ".qkv.weight", 3 * r["ch"])
+                P[n + ".dwproj"], _ = dg(n + ".proj_out.weight", -1)
+        self._grad_ready = True
+        return self
+
+    def _dconv(self, dy, key, is_h2, n_out, ksize, scale=1.0):
+        if is_h2:
+            if dy.dtype != torch.float16:
+                dy = ops.to_h2(dy)
+            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale)
+        return ops.conv2d(dy, self.p[key], n_out, ksize, scale=scale)
+
+    def _res_bwd(self, t, dout):
+        r, P = t["r"], self.p
+        n, co, ci, mode = r["name"], r["cout"], r["cin"], r["mode"]
+        G = self.GN_GROUPS
+        dh3 = self._dconv(dout, n + ".dw2", r["dh2_2"], co, 3)
+        dh2, _ = ops.group_norm_bwd(t["hmid"], G, P[n + ".g2"], P[n + ".b2"], t["st2"], dh3, film=t["film"], act=True,
+                                    split=r["dh2_1"])
+        dh1 = self._dconv(dh2, n + ".dw1", r["dh2_1"], ci, 3)
+        dx, dx2 = ops.group_norm_bwd(t["x"], G, P[n + ".g1"], P[n + ".b1"], t["st1"], dh1, x2=t["x2"], act=True, resample=mode)
+        if mode:
+            dx = ops.add(dx, ops.resample_bwd(dout, mode))
+        elif ci != co:
+            c1 = t["x"].shape[3]
+            dx = ops.add(dx, ops.conv2d(dout, P[n + ".dws1"], c1, 1))
+            if dx2 is not None:
+                dx2 = ops.add(dx2, ops.conv2d(dout, P[n + ".dws2"], ci - c1, 1))
+        else:
+            dx = ops.add(dx, dout)
+        return dx, dx2
+
+    def _attn_bwd(self, t, dout):
+        r, P = t["r"], self.p
+        n, c = r["name"], r["ch"]
+        b, hh, ww, _ = dout.shape
+        da = ops.conv2d(dout, P[n + ".dwproj"], c, 1)
+        dqkv = ops.attention_bwd(t["qkv"].view(b, hh * ww, 3 * c), t["probs"], da.view(b, hh * ww, c), r["heads"], t["layout"])
+        dxn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
+        dx, _ = ops.group_norm_bwd(t["x"], self.GN_GROUPS, P[n + ".g"], P[n + ".b"], t["st"], dxn)
+        return ops.add(dx, dout)
+
+    def vjp(self, tape, dout):
+        """(d eps / d x)^T dout for the forward that filled `tape`. dout: [B,H,W,Cd] fp32 cotangent on the
+        FIRST Cd output channels (Cd = 3: the eps half of a learn_sigma network; the rest is zero)."""
+        self.enable_grad()
+        P, sd = self.p, self._sd
+        cd = dout.shape[3]
+        key = f"out.dw{cd}"
+        if key not in P:       # head dgrad restricted to the first cd output channels
+            P[key] = ops.pack_conv_weight(ops.dgrad_weight(sd["out.2.weight"].detach().float()[:cd])).to(self.device)
+        tape = list(tape)
+        head = tape.pop()
+        dh = ops.conv2d(dout, P[key], self.plan["final_ch"], 3)
+        dh, _ = ops.group_norm_bwd(head["x"], self.GN_GROUPS, P["out.g"], P["out.b"], head["st"], dh, act=True)
+        skips = []             # gradients of the skip tensors, in the order the up path consumed them
+        for blk in reversed(self.plan["out"]):
+            for r in reversed(blk):
+                t = tape.pop()
+                assert t["r"] is r
+                if r["kind"] == "res":
+                    dh, d2 = self._res_bwd(t, dh)
+                    if d2 is not None:
+                        skips.append(d2)
+                else:
+                    dh = self._attn_bwd(t, dh)
+        # skips[0] belongs to the LAST out block = hs[0] (the stem output); skips[-1] to hs[-1]
+        for r in reversed(self.plan["mid"]):
+            t = tape.pop()
+            dh = self._res_bwd(t, dh)[0] if r["kind"] == "res" else self._attn_bwd(t, dh)
+        for blk in reversed(self.plan["inp"][1:]):
+            dh = ops.add(dh, skips.pop())
+            for r in reversed(blk):
+                t = tape.pop()
+                dh = self._res_bwd(t, dh)[0] if r["kind"] == "res" else self._attn_bwd(t, dh)
+        dh = ops.add(dh, skips.pop())
+        assert not skips and not tape
+        stem = self.plan["inp"][0][0]
+        return ops.conv2d(dh, P[stem["name"] + ".dw"], stem["cin"], 3)

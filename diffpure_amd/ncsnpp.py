@@ -78,7 +78,7 @@ def _plan(cfg):
         for _ in range(nrb + 1):
             co = nf * mults[lvl]
             sk = hs_c.pop()
-            up.append(dict(kind="res", idx=i, cin=ch + sk, cout=co, mode=0, pop=True))
+            up.append(dict(kind="res", idx=i, cin=ch + sk, cout=co, mode=0, pop=True, c1=ch))
             i += 1
             ch = co
         if res[lvl] in cfg["attn_resolutions"]:
@@ -163,6 +163,8 @@ class NCSNpp:
         dev = self.device
         P = {}
         M = "all_modules."
+        self._sd = sd          # host copy for the lazily packed input-gradient panels (enable_grad)
+        self._grad_ready = False
 
         def vec(k):
             return sd[k].detach().float().contiguous().to(dev)
@@ -209,16 +211,20 @@ class NCSNpp:
         self.p = P
         return self
 
-    def _res(self, r, x, x2, dense):
+    def _res(self, r, x, x2, dense, tape=None):
         P, n, co = self.p, str(r["idx"]), r["cout"]
         mode = r["mode"]
         conv0 = ops.conv2d_h2 if r["h2_0"] else ops.conv2d
         conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
+        st0 = ops.group_norm_stats(x, self._groups(r["cin"]), self.GN_EPS, x2)
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
-                           resample=mode, split=r["h2_0"])
+                           resample=mode, split=r["h2_0"], stats=st0)
         off = r["dense_off"]
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co])
-        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"])
+        st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
+        if tape is not None:
+            tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
+        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"], stats=st1)
         if mode:
             xs = ops.resample(x, mode)
             skip = ops.conv2d(xs, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
@@ -228,12 +234,17 @@ class NCSNpp:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
         return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2)
 
-    def _attn(self, r, x):
+    def _attn(self, r, x, tape=None):
         P, n, c = self.p, str(r["idx"]), r["ch"]
         b, hh, ww, _ = x.shape
-        hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"])
+        st = ops.group_norm_stats(x, self._groups(c), self.GN_EPS)
+        hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"], stats=st)
         qkv = (ops.conv2d_h2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
-        a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
+        if tape is None:
+            a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
+        else:
+            a, probs = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split", return_probs=True)
+            tape.append(dict(r=r, x=x, st=st, qkv=qkv, probs=probs))
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2)
 
     def time_table(self, labels):
@@ -244,7 +255,7 @@ class NCSNpp:
         e = ops.linear(ops.silu(e), P["t1.w"], 4 * nf, P["t1.b"])
         return ops.linear(ops.silu(e), P["dense.w"], self.dense_cols, P["dense.b"])
 
-    def forward(self, x, labels=None, table_row=None):
+    def forward(self, x, labels=None, table_row=None, tape=None):
         if not self.p:
             raise RuntimeError("NCSNpp: weights not loaded")
         P = self.p
@@ -254,21 +265,132 @@ class NCSNpp:
         for blk in self.plan["down"]:
             h = hs[-1]
             for r in blk:
-                h = self._res(r, h, None, dense) if r["kind"] == "res" else self._attn(r, h)
+                h = self._res(r, h, None, dense, tape) if r["kind"] == "res" else self._attn(r, h, tape)
             hs.append(h)
         h = hs[-1]
         for r in self.plan["mid"]:
-            h = self._res(r, h, None, dense) if r["kind"] == "res" else self._attn(r, h)
+            h = self._res(r, h, None, dense, tape) if r["kind"] == "res" else self._attn(r, h, tape)
         for r in self.plan["up"]:
             if r["kind"] == "attn":
-                h = self._attn(r, h)
+                h = self._attn(r, h, tape)
             elif r.get("pop"):
-                h = self._res(r, h, hs.pop(), dense)
+                h = self._res(r, h, hs.pop(), dense, tape)
             else:
-                h = self._res(r, h, None, dense)
+                h = self._res(r, h, None, dense, tape)
         assert not hs
-        h = ops.group_norm(h, self._groups(self.plan["final_ch"]), self.GN_EPS, P["out.g"], P["out.b"], act=True,
-                           split=self._out_h2)
+        g = self._groups(self.plan["final_ch"])
+        sth = ops.group_norm_stats(h, g, self.GN_EPS)
+        if tape is not None:
+            tape.append(dict(head=True, x=h, st=sth))
+        h = ops.group_norm(h, g, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2, stats=sth)
         return (ops.conv2d_h2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["channels"], 3, bias=P["out.c"])
 
     __call__ = forward
+
+    # -- input gradient (vector-Jacobian product); see GuidedUNet.vjp -------------------------------
+    def enable_grad(self):
+        if self._grad_ready:
+            return self
+        sd, dev, P = self._sd, self.device, self.p
+        M = "all_modules."
+
+        def dg(w, n_in_dgrad, lo=None, hi=None):
+            wd = ops.dgrad_weight(w.detach().float())
+            if lo is not None:
+                wd = wd[lo:hi]
+            if self.precision == "f16x3" and n_in_dgrad % 32 == 0:
+                return ops.pack_conv_weight_h2(wd, dev), True
+            return ops.pack_conv_weight(wd).to(dev), False
+
+        P["stem.dw"], _ = dg(sd[M + f"{self.plan['stem']['idx']}.weight"], -1)
+        recs = [r for b in self.plan["down"] for r in b] + self.plan["mid"] + self.plan["up"]
+        for r in recs:
+            p, n = M + str(r["idx"]), str(r["idx"])
+            if r["kind"] == "res":
+                P[n + ".dw1"], r["dh2_1"] = dg(sd[p + ".Conv_1.weight"], r["cout"])
+                P[n + ".dw0"], r["dh2_0"] = dg(sd[p + ".Conv_0.weight"], r["cout"])
+                if r["cin"] != r["cout"] or r["mode"]:
+                    c1 = r.get("c1", r["cin"])
+                    P[n + ".dw2a"], _ = dg(sd[p + ".Conv_2.weight"], -1, 0, c1)
+                    if c1 != r["cin"]:
+                        P[n + ".dw2b"], _ = dg(sd[p + ".Conv_2.weight"], -1, c1, r["cin"])
+            else:
+                c = r["ch"]
+                wq = torch.cat([sd[p + f".NIN_{j}.W"].detach().float() for j in range(3)], dim=1)   # [C, 3C] (in, out)
+                P[n + ".dwqkv"], r["dh2"] = dg(wq.t().contiguous(), 3 * c)                            # as OI conv weight
+                P[n + ".dw3"], _ = dg(sd[p + ".NIN_3.W"].detach().float().t().contiguous(), -1)
+        self._grad_ready = True
+        return self
+
+    def _dconv(self, dy, key, is_h2, n_out, ksize, scale=1.0):
+        if is_h2:
+            if dy.dtype != torch.float16:
+                dy = ops.to_h2(dy)
+            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale)
+        return ops.conv2d(dy, self.p[key], n_out, ksize, scale=scale)
+
+    def _res_bwd(self, t, dout):
+        r, P = t["r"], self.p
+        n, co, ci, mode = str(r["idx"]), r["cout"], r["cin"], r["mode"]
+        # out = (skip + conv1(h3)) * s
+        dh3 = self._dconv(dout, n + ".dw1", r["dh2_1"], co, 3, scale=INV_SQRT2)
+        dh2, _ = ops.group_norm_bwd(t["hmid"], self._groups(co), P[n + ".g1"], P[n + ".b1"], t["st1"], dh3, act=True,
+                                    split=r["dh2_0"])
+        dh1 = self._dconv(dh2, n + ".dw0", r["dh2_0"], ci, 3)
+        dx, dx2 = ops.group_norm_bwd(t["x"], self._groups(ci), P[n + ".g0"], P[n + ".b0"], t["st0"], dh1, x2=t["x2"], act=True,
+                                     resample=mode)
+        if mode:
+            ds = ops.conv2d(dout, P[n + ".dw2a"], ci, 1, scale=INV_SQRT2)
+            dx = ops.add(dx, ops.resample_bwd(ds, mode))
+        elif ci != co:
+            c1 = t["x"].shape[3]
+            dx = ops.add(dx, ops.conv2d(dout, P[n + ".dw2a"], c1, 1, scale=INV_SQRT2))
+            if dx2 is not None:
+                dx2 = ops.add(dx2, ops.conv2d(dout, P[n + ".dw2b"], ci - c1, 1, scale=INV_SQRT2))
+        else:
+            dx = ops.axpby(dx, 1.0, dout, INV_SQRT2)
+        return dx, dx2
+
+    def _attn_bwd(self, t, dout):
+        r, P = t["r"], self.p
+        n, c = str(r["idx"]), r["ch"]
+        b, hh, ww, _ = dout.shape
+        da = ops.conv2d(dout, P[n + ".dw3"], c, 1, scale=INV_SQRT2)
+        dqkv = ops.attention_bwd(t["qkv"].view(b, hh * ww, 3 * c), t["probs"], da.view(b, hh * ww, c), 1, "split")
+        dhn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
+        dx, _ = ops.group_norm_bwd(t["x"], self._groups(c), P[n + ".g"], P[n + ".b"], t["st"], dhn)
+        return ops.axpby(dx, 1.0, dout, INV_SQRT2)
+
+    def vjp(self, tape, dout):
+        """(d out / d x)^T dout for the forward that filled `tape`; dout [B,H,W,channels] fp32."""
+        self.enable_grad()
+        P = self.p
+        M = "all_modules."
+        if "out.dw" not in P:
+            P["out.dw"] = ops.pack_conv_weight(ops.dgrad_weight(self._sd[M + f"{self.plan['conv_idx']}.weight"].detach().float())).to(self.device)
+        tape = list(tape)
+        head = tape.pop()
+        fc = self.plan["final_ch"]
+        dh = ops.conv2d(dout, P["out.dw"], fc, 3)
+        dh, _ = ops.group_norm_bwd(head["x"], self._groups(fc), P["out.g"], P["out.b"], head["st"], dh, act=True)
+        skips = []
+        for r in reversed(self.plan["up"]):
+            t = tape.pop()
+            assert t["r"] is r
+            if r["kind"] == "attn":
+                dh = self._attn_bwd(t, dh)
+            else:
+                dh, d2 = self._res_bwd(t, dh)
+                if d2 is not None:
+                    skips.append(d2)
+        for r in reversed(self.plan["mid"]):
+            t = tape.pop()
+            dh = self._res_bwd(t, dh)[0] if r["kind"] == "res" else self._attn_bwd(t, dh)
+        for blk in reversed(self.plan["down"]):
+            dh = ops.add(dh, skips.pop())
+            for r in reversed(blk):
+                t = tape.pop()
+                dh = self._res_bwd(t, dh)[0] if r["kind"] == "res" else self._attn_bwd(t, dh)
+        dh = ops.add(dh, skips.pop())
+        assert not skips and not tape
+        return ops.conv2d(dh, P["stem.dw"], self.cfg["channels"], 3)

@@ -218,6 +218,79 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     return y
 
 
+def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False):
+    """Input gradient of `group_norm` (same arguments, `stats` from the forward, dy at the forward's
+    output resolution). -> (dx, dx2); with split=True (single source) dx is the zero-bordered h2
+    operand for the next dgrad convolution."""
+    _chk(x, "gn_bwd.x", 4)
+    _chk(dy, "gn_bwd.dy", 4)
+    b, h, w, c1 = x.shape
+    c2 = 0 if x2 is None else _chk(x2, "gn_bwd.x2", 4).shape[3]
+    c = c1 + c2
+    fs = fh = None
+    fstride = 0
+    if film is not None:
+        fs, fh = film
+        assert fs.shape[0] in (1, b) and fs.shape[-1] == c and fs.stride(-1) == 1 and fh.stride() == fs.stride()
+        fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
+    ho, wo = (h * 2, w * 2) if resample == RESAMPLE_UP else ((h // 2, w // 2) if resample == RESAMPLE_DOWN else (h, w))
+    assert dy.shape == (b, ho, wo, c), (dy.shape, (b, ho, wo, c))
+    ns = _nsplit(h * w)
+    partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
+    sums = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
+    s = _stream()
+    common = (_ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
+              fstride, 1 if act else 0, resample, _ptr(dy))
+    _lib.call("dp_gn_bwd_stats", *common, ns, _ptr(partial), _ptr(sums), s)
+    if split:
+        assert x2 is None
+        dx = torch.empty((b, h + 2, w + 2, 2 * c), device=x.device, dtype=torch.float16)
+        dx2 = None
+    else:
+        dx = torch.empty_like(x)
+        dx2 = None if x2 is None else torch.empty_like(x2)
+    _lib.call("dp_gn_bwd_apply", *common, _ptr(sums), 1 if split else 0, _ptr(dx), _ptr(dx2), s)
+    return dx, dx2
+
+
+def resample_bwd(dy, mode):
+    """Adjoint of `resample(x, mode)`; dy at the forward's output resolution."""
+    _chk(dy, "resample_bwd.dy", 4)
+    b, ho, wo, c = dy.shape
+    h, w = (ho // 2, wo // 2) if mode == RESAMPLE_UP else (ho * 2, wo * 2)
+    dx = torch.empty((b, h, w, c), device=dy.device, dtype=torch.float32)
+    _lib.call("dp_resample_bwd", _ptr(dy), b, ho, wo, c, mode, _ptr(dx), _stream())
+    return dx
+
+
+def add(a, b):
+    _chk(a, "add.a")
+    _chk(b, "add.b")
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.call("dp_add", _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream())
+    return out
+
+
+def to_h2(x):
+    """fp32 NHWC -> zero-bordered h2 operand ([B, H+2, W+2, 2C] fp16) without normalisation."""
+    _chk(x, "to_h2.x", 4)
+    b, h, w, c = x.shape
+    y = torch.empty((b, h + 2, w + 2, 2 * c), device=x.device, dtype=torch.float16)
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, 0, 1, _ptr(y), _stream())
+    return y
+
+
+def dgrad_weight(w):
+    """Weight of the input-gradient convolution: for y = conv(x, W) (stride 1, 'same'),
+    dx = conv(dy, Wd) with Wd[i, o, ky, kx] = W[o, i, KH-1-ky, KW-1-kx]."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, :, None]
+    return w.flip(2, 3).transpose(0, 1).contiguous()
+
+
 def resample(x, mode):
     """Nearest x2 up (mode 1) or 2x2 mean down (mode 2) of an NHWC tensor, no normalisation."""
     _chk(x, "resample.x", 4)
@@ -231,33 +304,69 @@ def resample(x, mode):
 # ---------------------------------------------------------------------------------------------
 # attention core
 # ---------------------------------------------------------------------------------------------
-def attention(qkv, n_heads, layout):
-    """softmax(q k^T / sqrt(d)) v for qkv [B, T, 3C] -> [B, T, C].
+def _attn_offsets(c, d, layout):
+    if layout == "legacy":
+        return 0, d, 2 * d, 3 * d
+    if layout == "split":
+        return 0, c, 2 * c, d
+    raise ValueError(layout)
+
+
+def attention(qkv, n_heads, layout, return_probs=False):
+    """softmax(q k^T / sqrt(d)) v for qkv [B, T, 3C] -> [B, T, C]  (, probs [B*heads, T, T]).
     layout 'legacy': channels = heads x [q(d) | k(d) | v(d)]   (QKVAttentionLegacy, unet.py:345-362)
     layout 'split' : channels = [Q(all heads) | K | V]         (QKVAttention unet.py:377-397; NCSN++ q,k,v NINs)"""
     _chk(qkv, "attention.qkv", 3)
     b, t, c3 = qkv.shape
     c = c3 // 3
     d = c // n_heads
-    if layout == "legacy":
-        oq, ok, ov, sh = 0, d, 2 * d, 3 * d
-    elif layout == "split":
-        oq, ok, ov, sh = 0, c, 2 * c, d
-    else:
-        raise ValueError(layout)
+    oq, ok, ov, sh = _attn_offsets(c, d, layout)
     s = _stream()
     scores = torch.empty((b * n_heads, t, t), device=qkv.device, dtype=torch.float32)
     out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
     base = qkv.data_ptr()
     el = 4
     # scores[z] = (1/sqrt(d)) * Q K^T
-    _lib.call("dp_gemm_strided", base + oq * el, c3, t * c3, sh, base + ok * el, c3, t * c3, sh, 1,
+    _lib.call("dp_gemm_strided", base + oq * el, c3, t * c3, sh, 0, base + ok * el, c3, t * c3, sh, 1,
               _ptr(scores), t, n_heads * t * t, t * t, t, t, d, b, n_heads, 1.0 / math.sqrt(d), s)
     _lib.call("dp_softmax_rows", _ptr(scores), b * n_heads * t, t, s)
     # out[z] = P V
-    _lib.call("dp_gemm_strided", _ptr(scores), t, n_heads * t * t, t * t, base + ov * el, c3, t * c3, sh, 0,
+    _lib.call("dp_gemm_strided", _ptr(scores), t, n_heads * t * t, t * t, 0, base + ov * el, c3, t * c3, sh, 0,
               _ptr(out), c, t * c, d, t, d, t, b, n_heads, 1.0, s)
-    return out
+    return (out, scores) if return_probs else out
+
+
+def attention_bwd(qkv, probs, dout, n_heads, layout):
+    """Gradient of `attention` w.r.t. qkv: dV = P^T dO, dP = dO V^T, dS = softmax'(P, dP),
+    dQ = dS K / sqrt(d), dK = dS^T Q / sqrt(d), written into dqkv [B, T, 3C] in the same layout."""
+    _chk(qkv, "attention_bwd.qkv", 3)
+    _chk(probs, "attention_bwd.probs", 3)
+    _chk(dout, "attention_bwd.dout", 3)
+    b, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // n_heads
+    oq, ok, ov, sh = _attn_offsets(c, d, layout)
+    s = _stream()
+    el = 4
+    dqkv = torch.empty_like(qkv)
+    dp = torch.empty_like(probs)
+    q0, g0, do0 = qkv.data_ptr(), dqkv.data_ptr(), dout.data_ptr()
+    sc = 1.0 / math.sqrt(d)
+    zb, zh = n_heads * t * t, t * t
+    # dV[s][c] = sum_t P[t][s] dO[t][c]                 (A = P stored [K=t][M=s] -> transA)
+    _lib.call("dp_gemm_strided", _ptr(probs), t, zb, zh, 1, do0, c, t * c, d, 0, g0 + ov * el, c3, t * c3, sh,
+              t, d, t, b, n_heads, 1.0, s)
+    # dP[t][s] = sum_c dO[t][c] V[s][c]                 (B = V stored [N=s][K=c] -> transB)
+    _lib.call("dp_gemm_strided", do0, c, t * c, d, 0, q0 + ov * el, c3, t * c3, sh, 1, _ptr(dp), t, zb, zh,
+              t, t, d, b, n_heads, 1.0, s)
+    _lib.call("dp_softmax_bwd_rows", _ptr(probs), _ptr(dp), b * n_heads * t, t, s)
+    # dQ[t][c] = sc * sum_s dS[t][s] K[s][c]
+    _lib.call("dp_gemm_strided", _ptr(dp), t, zb, zh, 0, q0 + ok * el, c3, t * c3, sh, 0, g0 + oq * el, c3, t * c3, sh,
+              t, d, t, b, n_heads, sc, s)
+    # dK[s][c] = sc * sum_t dS[t][s] Q[t][c]            (A = dS stored [K=t][M=s] -> transA)
+    _lib.call("dp_gemm_strided", _ptr(dp), t, zb, zh, 1, q0 + oq * el, c3, t * c3, sh, 0, g0 + ok * el, c3, t * c3, sh,
+              t, d, t, b, n_heads, sc, s)
+    return dqkv
 
 
 # ---------------------------------------------------------------------------------------------

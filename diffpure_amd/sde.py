@@ -193,6 +193,34 @@ class Purifier:
             x = ops.em_step(x, eps, st["nhb"], st["gg"], st["sc"], st["div"], st["h"], 0.0, 0.0, out=x)
         return to_nchw(x)
 
+    # -- adjoint of the probability-flow ODE: dL/dx for adaptive attacks ---------------------------
+    def ode_vjp(self, x_final_nchw, grad_out_nchw, t_int, step=1e-3):
+        """Continuous adjoint as torchdiffeq's odeint_adjoint integrates it (diffpure_ode.py:229-238):
+        the augmented state (y, a) starts at (x(1e-5), dL/dx(1e-5)) and is Euler-stepped on the grid
+        1e-5 + k*step up to t/1000;  da/ds = -a^T dF/dy,  F = -0.5*beta*y - 0.5*beta*score(y).
+        Per step: one UNet forward (taped) + one input-gradient pass.  The parameter adjoints the
+        reference also integrates (106.6 M values nobody reads) are not formed - dL/dx does not
+        depend on them.  -> dL/dx at s = t/1000 (before the forward-diffusion scaling), NCHW."""
+        y = to_nhwc(x_final_nchw.to(self.device, torch.float32))
+        a = to_nhwc(grad_out_nchw.to(self.device, torch.float32))
+        sched = ode_schedule(self.kind, t_int, step, reverse=True)
+        table = self._tables(("ode_rev", t_int, step), sched)
+        for k, st in enumerate(sched):
+            tape = []
+            eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
+            g = self.net.vjp(tape, a)                       # (d eps / d y)^T a
+            del tape
+            kk = (-1.0 / st["sc"]) if st["div"] else st["sc"]   # score = kk * eps
+            ds = st["h"]
+            a_new = ops.axpby(a, 1.0 - ds * st["nhb"], g, ds * st["gg"] * kk)
+            y = ops.em_step(y, eps, st["nhb"], st["gg"], st["sc"], st["div"], -ds, 0.0, 0.0, out=y)   # y + ds * F(y)
+            a = a_new
+        return to_nchw(a)
+
+    def diffuse_scale(self, t_int):
+        """d x(t) / d x0 of the forward diffusion x = x0*sqrt(abar) + e*sqrt(1-abar)."""
+        return diffusion_coeffs(t_int, self._abar)[0]
+
     # -- DDPM ancestral sampling (GuidedDiffusion.image_editing_sample) ---------------------------
     def ddpm(self, x_nchw, t_int, noise=None, seed=0, sample0=0, diffusion_steps=1000):
         assert self.kind == "guided"

@@ -80,12 +80,13 @@ int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
 /* fp32 [rows][ld] (first `cols` columns, cols % 8 == 0) -> h2 [rows][cols/8][2][8] fp16. */
 int dp_pack_h2(const float* src, long long rows, int cols, int ld, void* dst, void* stream);
 
-/* ---- strided batched GEMM (attention cores) -------------------------------------------------
- * Replaces the einsums at unet.py:355-359 / :389-396 and layerspp.py:82,86.
- * C[z][m][n] = alpha * sum_k A[z][m][k] * Bop[z][k][n];  z = zb*ZH + zh, and each operand's batch
- * offset is zb*s?b + zh*s?h (elements).  transB = 0: B stored [K][ldb]; 1: B stored [N][ldb].
- * K % 4 == 0, lda/ldb % 4 == 0, (transB ? 1 : N % 4 == 0). */
-int dp_gemm_strided(const float* A, int lda, long long sAb, long long sAh,
+/* ---- strided batched GEMM (attention cores, forward and backward) --------------------------------
+ * Replaces the einsums at unet.py:355-359 / :389-396 and layerspp.py:82,86 (and their autograd).
+ * C[z][m][n] = alpha * sum_k Aop[z][m][k] * Bop[z][k][n];  z = zb*ZH + zh, and each operand's batch
+ * offset is zb*s?b + zh*s?h (elements).
+ * transA = 0: A stored [M][lda]; 1: A stored [K][lda].  transB = 0: B stored [K][ldb]; 1: [N][ldb].
+ * The contiguous extent of each operand (K or M for A, N or K for B) and lda/ldb must be % 4 == 0. */
+int dp_gemm_strided(const float* A, int lda, long long sAb, long long sAh, int transA,
                     const float* B, int ldb, long long sBb, long long sBh, int transB,
                     float* C, int ldc, long long sCb, long long sCh,
                     int M, int N, int K, int ZB, int ZH, float alpha, void* stream);
@@ -157,6 +158,30 @@ int dp_ddpm_step(const float* x, const float* out6, int B, int HW, int C,
                  float min_log, float max_log, int nonzero,
                  const float* noise, unsigned long long seed, long long sample0, int step,
                  float* x_out, void* stream);
+
+/* ---- backward (adjoint-ODE, dL/dx only; runners/diffpure_ode.py:229-238 odeint_adjoint) ----------
+ * Input gradient of dp_gn_apply's operator (see there for the forward):
+ *   da = resample^T(dy); du = da*act'(u); dxh = du*(1+fscale)*gamma;
+ *   dx = rstd*(dxh - mean_g(dxh) - xh*mean_g(dxh*xh)).
+ * H, W = INPUT resolution of the forward; dy: [B][Ho][Wo][C] fp32 (Ho, Wo per `resample`).
+ * dp_gn_bwd_stats: slab partials [B][nsplit][G][2] -> sums [B][G][2] = the two group means.
+ * dp_gn_bwd_apply: dx1 [B][H][W][C1] (+ dx2 [B][H][W][C2]) fp32, or with out_fmt=1 (C2 == 0) dx1 in
+ * the zero-bordered h2 operand format, ready for the next dgrad convolution. */
+int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+                    const float* stats, const float* gamma, const float* beta,
+                    const float* fscale, const float* fshift, int film_stride, int act, int resample,
+                    const float* dy, int nsplit, float* partial, float* sums, void* stream);
+int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+                    const float* stats, const float* gamma, const float* beta,
+                    const float* fscale, const float* fshift, int film_stride, int act, int resample,
+                    const float* dy, const float* sums, int out_fmt, void* dx1, float* dx2, void* stream);
+/* Adjoint of the plain 2x resamplers: mode 1 (forward was nearest x2): dx[Ho/2][Wo/2] = sum of the
+ * 2x2 dy block; mode 2 (forward was mean 2x2): dx[2Ho][2Wo] = 0.25 * dy[y/2][x/2]. */
+int dp_resample_bwd(const float* dy, int B, int Ho, int Wo, int C, int mode, float* dx, void* stream);
+/* Softmax backward in place on dP given P: dS = P * (dP - sum_j dP_j P_j) per row. */
+int dp_softmax_bwd_rows(const float* p, float* dp, long long rows, int cols, void* stream);
+/* out = a + b (gradient accumulation at fan-out points). n % 4 == 0. */
+int dp_add(const float* a, const float* b, float* out, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,27 @@ from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC, Purifier
 from . import _common
 
 
+class _OdePurify(torch.autograd.Function):
+    """purified = ODE-solve(diffuse(img)); backward = the continuous adjoint on the HIP engine
+    (what torchdiffeq.odeint_adjoint provides upstream, runners/diffpure_ode.py:229-238)."""
+
+    @staticmethod
+    def forward(ctx, img, runner, t, step, noise, seed, sample0):
+        with torch.no_grad():
+            out = runner.purifier.ode(img, t, step, noise=noise, seed=seed, sample0=sample0)
+        ctx.runner, ctx.t, ctx.step = runner, t, step
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (out,) = ctx.saved_tensors
+        with torch.no_grad():
+            a = ctx.runner.purifier.ode_vjp(out, grad_out, ctx.t, ctx.step)
+            a = a * ctx.runner.purifier.diffuse_scale(ctx.t)
+        return a, None, None, None, None, None, None
+
+
 class OdeGuidedDiffusion(torch.nn.Module):
     def __init__(self, args, config, device=None):
         super().__init__()
@@ -41,10 +62,12 @@ class OdeGuidedDiffusion(torch.nn.Module):
     def image_editing_sample(self, img, bs_id=0, tag=None, noise=None):
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim
-        _common.check_no_grad_needed(img, "OdeGuidedDiffusion.image_editing_sample")
         out_dir = _common.out_dir_for(self.args, bs_id, tag)
         log = bs_id < 2 and out_dir is not None
-        with torch.no_grad():
+        need_grad = img.requires_grad and torch.is_grad_enabled()
+        if need_grad and getattr(self.args, "shard_batch", False):
+            raise NotImplementedError("gradients through a batch-sharded purification call: run the attack per rank")
+        with torch.set_grad_enabled(need_grad):
             x0 = img.to(self.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
@@ -64,6 +87,8 @@ class OdeGuidedDiffusion(torch.nn.Module):
 
                 def run(xl, sample0, inj=inj, call_seed=call_seed):
                     loc = inj if inj is None else dict(e=inj["e"][sample0:sample0 + xl.shape[0]], z=[])
+                    if need_grad:
+                        return _OdePurify.apply(xl, self, self.args.t, step, loc, call_seed, sample0)
                     return self.purifier.ode(xl, self.args.t, step, noise=loc, seed=call_seed, sample0=sample0)
 
                 x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)

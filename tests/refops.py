@@ -124,7 +124,7 @@ def resample(x, mode):
     return _resample(x, mode).contiguous()
 
 
-def attention(qkv, n_heads, layout):
+def attention(qkv, n_heads, layout, return_probs=False):
     b, t, c3 = qkv.shape
     c = c3 // 3
     d = c // n_heads
@@ -136,7 +136,62 @@ def attention(qkv, n_heads, layout):
         q, k, vv = v[:, :, 0], v[:, :, 1], v[:, :, 2]
     w = torch.einsum("bthd,bshd->bhts", q, k) / math.sqrt(d)
     w = torch.softmax(w, dim=-1)
-    return torch.einsum("bhts,bshd->bthd", w, vv).reshape(b, t, c).contiguous()
+    out = torch.einsum("bhts,bshd->bthd", w, vv).reshape(b, t, c).contiguous()
+    return (out, w.reshape(b * n_heads, t, t).contiguous()) if return_probs else out
+
+
+def attention_bwd(qkv, probs, dout, n_heads, layout):
+    with torch.enable_grad():
+        q = qkv.detach().clone().requires_grad_(True)
+        out = attention(q, n_heads, layout)
+        (g,) = torch.autograd.grad(out, q, dout)
+    return g
+
+
+def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False):
+    """autograd through the torch statement of the forward (eps folded back out of `stats`)."""
+    with torch.enable_grad():
+        a = x.detach().clone().requires_grad_(True)
+        b2 = None if x2 is None else x2.detach().clone().requires_grad_(True)
+        xin = _cat(a, b2)
+        bb, h, w, c = xin.shape
+        v = xin.reshape(bb, h * w, groups, c // groups)
+        mean = stats[..., 0].reshape(bb, 1, groups, 1)
+        rstd = stats[..., 1].reshape(bb, 1, groups, 1)
+        # mean/rstd are functions of x: rebuild them differentiably, using the forward's eps
+        mu = v.mean(dim=(1, 3), keepdim=True)
+        var = v.var(dim=(1, 3), unbiased=False, keepdim=True)
+        eps = (1.0 / rstd ** 2 - var.detach()).clamp_min(0)
+        y = ((v - mu) / torch.sqrt(var + eps)).reshape(bb, h, w, c) * gamma + beta
+        if film is not None:
+            fs, fh = film
+            y = y * (1 + fs.reshape(-1, 1, 1, c)) + fh.reshape(-1, 1, 1, c)
+        if act:
+            y = F.silu(y)
+        y = _resample(y, resample)
+        grads = torch.autograd.grad(y, [a] + ([] if b2 is None else [b2]), dy)
+    dx = grads[0]
+    dx2 = grads[1] if b2 is not None else None
+    if split:
+        return h2_encode(F.pad(dx, (0, 0, 1, 1, 1, 1))), None
+    return dx.contiguous(), None if dx2 is None else dx2.contiguous()
+
+
+def resample_bwd(dy, mode):
+    b, ho, wo, c = dy.shape
+    h, w = (ho // 2, wo // 2) if mode == RESAMPLE_UP else (ho * 2, wo * 2)
+    with torch.enable_grad():
+        x = torch.zeros(b, h, w, c, dtype=dy.dtype, requires_grad=True)
+        (g,) = torch.autograd.grad(_resample(x, mode), x, dy)
+    return g.contiguous()
+
+
+def add(a, b):
+    return a + b
+
+
+def to_h2(x):
+    return h2_encode(F.pad(x, (0, 0, 1, 1, 1, 1)))
 
 
 def silu(x):
@@ -230,7 +285,8 @@ def ddpm_step(x, out6, sr, srm1, c1, c2, min_log, max_log, nonzero, noise=None, 
     return y
 
 
-PATCHED = ["conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "group_norm_stats", "group_norm", "resample", "attention", "silu", "axpby",
+PATCHED = ["conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd",
+           "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "resample", "attention", "silu", "axpby",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
 
 

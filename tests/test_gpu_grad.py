@@ -1,0 +1,190 @@
+"""-m gpu: backward operators and the adjoint-ODE path (BASELINE.json configs[4]) on the HIP engine
+against torch.autograd (ops) and the CPU oracle (network VJP, adjoint integration)."""
+import argparse
+
+import pytest
+import torch
+
+import refops
+from conftest import load_golden
+from diffpure_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+GNB_CASES = [
+    # B, H, W, C1, C2, G, film_rows, act, resample
+    (2, 8, 8, 128, 0, 32, 0, True, 0),
+    (2, 8, 8, 256, 128, 32, 0, True, 0),     # split input -> two gradient tensors
+    (2, 4, 4, 1024, 512, 32, 0, True, 0),    # group of 48 straddles the split
+    (3, 8, 8, 256, 0, 32, 2, True, 0),       # per-sample FiLM
+    (1, 8, 8, 256, 0, 32, 1, True, 0),       # broadcast FiLM
+    (2, 8, 8, 128, 0, 32, 0, True, 1),       # forward nearest x2
+    (2, 8, 8, 128, 0, 32, 0, True, 2),       # forward mean 2x2
+    (2, 16, 16, 32, 0, 8, 0, False, 0),      # attention pre-norm (no activation)
+]
+
+
+@pytest.mark.parametrize("case", GNB_CASES, ids=[str(c) for c in GNB_CASES])
+def test_group_norm_bwd(case):
+    from diffpure_amd import ops
+    B, H, W, C1, C2, G, film_rows, act, rs = case
+    C = C1 + C2
+    x = rnd(B, H, W, C1, seed=1) * 2 + 0.5
+    x2 = (rnd(B, H, W, C2, seed=2) - 1.0) if C2 else None
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    film = None
+    if film_rows:
+        tab = 0.3 * rnd(B if film_rows == 2 else 1, 2 * C, seed=5)
+        film = (tab[:, :C], tab[:, C:])
+    eps = 1e-5
+    ho, wo = (2 * H, 2 * W) if rs == 1 else ((H // 2, W // 2) if rs == 2 else (H, W))
+    dy = rnd(B, ho, wo, C, seed=6)
+    d64 = lambda t: None if t is None else t.double()
+    st64 = refops.group_norm_stats(x.double(), G, eps, d64(x2)).double()
+    ref1, ref2 = refops.group_norm_bwd(x.double(), G, gamma.double(), beta.double(), st64, dy.double(), d64(x2),
+                                       None if film is None else (film[0].double(), film[1].double()), act, rs)
+    d = lambda t: None if t is None else t.to(DEV)
+    film_d = None
+    if film is not None:
+        tab_d = tab.to(DEV)
+        film_d = (tab_d[:, :C], tab_d[:, C:])
+    st = ops.group_norm_stats(d(x), G, eps, d(x2))
+    g1, g2 = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), x2=d(x2), film=film_d, act=act, resample=rs)
+    assert relerr(g1.cpu(), ref1.float()) < 2e-4
+    if C2:
+        assert relerr(g2.cpu(), ref2.float()) < 2e-4
+    else:
+        gh, _ = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), film=film_d, act=act, resample=rs, split=True)
+        assert torch.equal(gh.cpu(), refops.to_h2(g1.cpu()))     # h2 form of the same gradient
+
+
+@pytest.mark.parametrize("case", [(2, 16, 256, 1, "split"), (2, 64, 128, 2, "legacy"), (1, 256, 256, 4, "legacy"), (2, 64, 128, 2, "split")],
+                         ids=str)
+def test_attention_bwd(case):
+    from diffpure_amd import ops
+    B, T, C, heads, layout = case
+    qkv, dout = rnd(B, T, 3 * C, seed=11), rnd(B, T, C, seed=12)
+    ref = refops.attention_bwd(qkv.double(), None, dout.double(), heads, layout).float()
+    out, probs = ops.attention(qkv.to(DEV), heads, layout, return_probs=True)
+    got = ops.attention_bwd(qkv.to(DEV), probs, dout.to(DEV), heads, layout)
+    assert relerr(got.cpu(), ref) < 1e-4
+
+
+def test_small_backward_pieces():
+    from diffpure_amd import ops
+    for mode in (1, 2):
+        dy = rnd(2, 8, 8, 64, seed=20)
+        torch.testing.assert_close(ops.resample_bwd(dy.to(DEV), mode).cpu(), refops.resample_bwd(dy, mode), rtol=1e-6, atol=1e-6)
+    a, b = rnd(3, 5, 8, seed=21), rnd(3, 5, 8, seed=22)
+    assert torch.equal(ops.add(a.to(DEV), b.to(DEV)).cpu(), a + b)
+    x = rnd(2, 4, 4, 64, seed=23)
+    assert torch.equal(ops.to_h2(x.to(DEV)).cpu(), refops.to_h2(x))
+    # dgrad weight identity: <conv(x, W), dy> == <x, conv(dy, Wd)>
+    w = rnd(24, 16, 3, 3, seed=24)
+    xx, dy = rnd(2, 6, 6, 16, seed=25), rnd(2, 6, 6, 24, seed=26)
+    y = ops.conv2d(xx.to(DEV), ops.pack_conv_weight(w).to(DEV), 24, 3).cpu()
+    dx = ops.conv2d(dy.to(DEV), ops.pack_conv_weight(ops.dgrad_weight(w)).to(DEV), 16, 3).cpu()
+    assert abs((y * dy).sum() - (xx * dx).sum()) < 1e-3 * (y * dy).sum().abs()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_ncsnpp_full_vjp_vs_autograd(precision):
+    from diffpure_amd import ncsnpp as pn
+    from oracle import ncsnpp as on
+    g = load_golden("ncsnpp_full.pt")
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    net = pn.NCSNpp(cfg, DEV, precision).load_state_dict(sd)
+    x, lab = g["x"], g["labels"]
+    u = rnd(*x.shape, seed=1)
+    xr = x.clone().requires_grad_(True)
+    (ref,) = torch.autograd.grad(on.ncsnpp_forward(sd, on.parse_ncsnpp_config(g["cfg"]), xr, lab), xr, u)
+    tape = []
+    net.forward(nhwc(x).to(DEV), lab.to(DEV), tape=tape)
+    got = nchw(net.vjp(tape, nhwc(u).to(DEV))).cpu()
+    assert relerr(got, ref) < 2e-3, relerr(got, ref)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_guided_small_vjp_vs_autograd(precision):
+    from diffpure_amd import guided_unet as pg
+    from oracle import guided_unet as og
+    g = load_golden("guided_small.pt")
+    cfg = pg.parse_config(g["cfg"])
+    sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
+    net = pg.GuidedUNet(cfg, DEV, precision).load_state_dict(sd)
+    x, t = g["x"], g["t"]
+    u = rnd(*x.shape, seed=2)
+    xr = x.clone().requires_grad_(True)
+    (ref,) = torch.autograd.grad(og.guided_unet_forward(sd, og.parse_guided_config(g["cfg"]), xr, t)[:, :3], xr, u)
+    tape = []
+    net.forward(nhwc(x).to(DEV), t.float().to(DEV), tape=tape)
+    got = nchw(net.vjp(tape, nhwc(u).to(DEV))).cpu()
+    assert relerr(got, ref) < 2e-3, relerr(got, ref)
+
+
+def test_config5_adjoint_ode_vs_oracle():
+    """BASELINE.json configs[4] at test size: CIFAR-10 NCSN++ (full), adjoint-ODE dL/dx, B=2, 10 steps,
+    against the oracle's restated continuous adjoint on the same grid."""
+    from diffpure_amd import ncsnpp as pn
+    from diffpure_amd.sde import Purifier
+    from oracle import ncsnpp as on, solvers as osol
+    g = load_golden("ncsnpp_full.pt")
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    gen = torch.Generator().manual_seed(9)
+    x0 = g["x"]
+    e = torch.randn(x0.shape, generator=gen)
+    cot = torch.randn(x0.shape, generator=gen)
+    step = 1e-2
+    for precision in ("f32", "f16x3"):
+        net = pn.NCSNpp(cfg, DEV, precision).load_state_dict(sd)
+        pur = Purifier(net, "ncsnpp", DEV)
+        xf = pur.ode(x0, 100, step, noise=dict(e=e, z=[]))
+        with torch.no_grad():
+            xf_ref = osol.ode_purify(score, x0, e, 100, step)
+        assert (xf.cpu() - xf_ref).abs().max() < 1e-3
+        ref = osol.ode_diffuse_grad(osol.ode_adjoint_grad(score, xf_ref, cot, 100, step), 100)
+        got = (pur.ode_vjp(xf, cot, 100, step) * pur.diffuse_scale(100)).cpu()
+        assert relerr(got, ref) < 5e-3, (precision, relerr(got, ref))
+
+
+def test_ode_runner_autograd_on_gpu(tmp_path):
+    from runners.diffpure_ode import OdeGuidedDiffusion
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device(DEV)
+    args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path),
+                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=1e-2)
+    runner = OdeGuidedDiffusion(args, config, device=config.device)
+    x = (torch.rand(3, 3, 16, 16) * 2 - 1).to(DEV).requires_grad_(True)
+    out = runner.image_editing_sample(x, bs_id=9)
+    loss = (out ** 2).sum()
+    (gx,) = torch.autograd.grad(loss, x)
+    assert gx.shape == x.shape and torch.isfinite(gx).all() and gx.abs().max() > 0

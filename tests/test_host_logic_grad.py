@@ -1,0 +1,132 @@
+"""CPU checks of the input-gradient (VJP / adjoint-ODE) HOST logic with the HIP operators replaced
+by their torch statements: tape bookkeeping, dgrad weight panels, skip-gradient routing, adjoint
+stepping.  Oracle: torch.autograd through the CPU oracle network, and oracle.solvers.ode_adjoint_grad."""
+import argparse
+
+import pytest
+import torch
+
+import refops
+from conftest import load_golden
+from diffpure_amd import guided_unet as pg
+from diffpure_amd import ncsnpp as pn
+from diffpure_amd import sde as psde
+from diffpure_amd.synth import synth_state_dict
+from oracle import guided_unet as og
+from oracle import ncsnpp as on
+from oracle import solvers as osol
+
+
+@pytest.fixture(autouse=True)
+def _cpu_ops(monkeypatch):
+    refops.patch_ops(monkeypatch)
+    yield
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_ncsnpp_vjp_matches_autograd(precision):
+    g = load_golden("ncsnpp_small.pt")
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    net = pn.NCSNpp(cfg, "cpu", precision).load_state_dict(sd)
+    x, lab = g["x"], g["labels"]
+    u = torch.randn(x.shape, generator=torch.Generator().manual_seed(1))
+    xr = x.clone().requires_grad_(True)
+    out = on.ncsnpp_forward(sd, on.parse_ncsnpp_config(g["cfg"]), xr, lab)
+    (ref,) = torch.autograd.grad(out, xr, u)
+    tape = []
+    net.forward(nhwc(x), lab, tape=tape)
+    got = nchw(net.vjp(tape, nhwc(u)))
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_guided_vjp_matches_autograd(precision):
+    g = load_golden("guided_small.pt")
+    cfg = pg.parse_config(g["cfg"])
+    sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
+    net = pg.GuidedUNet(cfg, "cpu", precision).load_state_dict(sd)
+    x, t = g["x"], g["t"]
+    u = torch.randn(x.shape, generator=torch.Generator().manual_seed(2))      # cotangent on the eps half only
+    xr = x.clone().requires_grad_(True)
+    out = og.guided_unet_forward(sd, og.parse_guided_config(g["cfg"]), xr, t)
+    (ref,) = torch.autograd.grad(out[:, :3], xr, u)
+    tape = []
+    net.forward(nhwc(x), t.float(), tape=tape)
+    got = nchw(net.vjp(tape, nhwc(u)))
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+
+
+def test_ode_adjoint_matches_oracle():
+    g = load_golden("ncsnpp_small.pt")
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    net = pn.NCSNpp(cfg, "cpu").load_state_dict(sd)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    gen = torch.Generator().manual_seed(9)
+    x0 = g["x"]
+    e = torch.randn(x0.shape, generator=gen)
+    cot = torch.randn(x0.shape, generator=gen)
+    step = 2e-2
+    with torch.no_grad():
+        xf = osol.ode_purify(score, x0, e, 100, step)
+    ref = osol.ode_diffuse_grad(osol.ode_adjoint_grad(score, xf, cot, 100, step), 100)
+    pur = psde.Purifier(net, "ncsnpp", "cpu")
+    got = pur.ode_vjp(xf, cot, 100, step) * pur.diffuse_scale(100)
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+
+
+def test_ode_runner_is_differentiable():
+    """The drop-in OdeGuidedDiffusion returns a tensor autograd can differentiate w.r.t. the input
+    (what an adaptive attack does upstream through torchdiffeq.odeint_adjoint)."""
+    from runners.diffpure_ode import OdeGuidedDiffusion
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device("cpu")
+    args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=None, score_type="score_sde",
+                              seed=1234, synthetic_weights=True, step_size=2e-2)
+    runner = OdeGuidedDiffusion(args, config, device="cpu")
+    x0 = g["x"].clone().requires_grad_(True)
+    e = torch.randn(x0.shape, generator=torch.Generator().manual_seed(9))
+    cot = torch.randn(x0.shape, generator=torch.Generator().manual_seed(10))
+    out = runner.image_editing_sample(x0, bs_id=7, noise=dict(e=e, z=[]))
+    (out * cot).sum().backward()
+    sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    ref = osol.ode_diffuse_grad(osol.ode_adjoint_grad(score, out.detach(), cot, 100, 2e-2), 100)
+    torch.testing.assert_close(x0.grad, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+
+
+def test_oracle_adjoint_converges_to_unrolled_autograd():
+    """Pins the restated continuous adjoint (oracle/solvers.py) to ground truth: as the step shrinks it
+    converges to torch.autograd through the unrolled Euler loop (measured cosine 0.80 / 0.977 / 0.996 at
+    step 2e-2 / 5e-3 / 2e-3 on this network) - optimise-then-discretise vs discretise-then-optimise."""
+    g = load_golden("ncsnpp_small.pt")
+    sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    e = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(9))
+    cot = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(10))
+    cos = []
+    for step in (2e-2, 5e-3):
+        xr = g["x"].clone().requires_grad_(True)
+        with torch.enable_grad():
+            o2 = osol.ode_purify(score, xr, e, 100, step)
+            (g2,) = torch.autograd.grad(o2, xr, cot)
+        ref = osol.ode_diffuse_grad(osol.ode_adjoint_grad(score, o2.detach(), cot, 100, step), 100)
+        cos.append(torch.nn.functional.cosine_similarity(ref.flatten(), g2.flatten(), dim=0).item())
+    assert cos[1] > 0.95 and cos[1] > cos[0], cos
