@@ -34,6 +34,9 @@ WORKLOADS = {
     # name: (kind, config file section, image size, algorithmic GFLOP / image / UNet call, 3x3 share)
     "imagenet256_guided": dict(kind="guided", hw=256, gflop=2239.67, gflop3x3=2115.44),
     "cifar32_ncsnpp": dict(kind="ncsnpp", hw=32, gflop=37.094, gflop3x3=33.629),
+    # BASELINE.json configs[4]: probability-flow ODE forward + continuous-adjoint backward (dL/dx only):
+    # 100 forward UNet calls + 100 x (forward + input-gradient pass) = 300 F of convolution work
+    "cifar32_ncsnpp_adjoint": dict(kind="ncsnpp", hw=32, gflop=3 * 37.094, gflop3x3=3 * 33.629),
 }
 IMAGENET_CFG = dict(attention_resolutions="32,16,8", class_cond=False, diffusion_steps=1000, rescale_timesteps=True,
                     timestep_respacing="1000", image_size=256, learn_sigma=True, noise_schedule="linear",
@@ -55,7 +58,7 @@ def build_engine(workload, device, seed, precision):
         cfg = guided_unet.parse_config(IMAGENET_CFG)
         sd = synth.synth_state_dict(guided_unet.param_shapes(cfg), seed)
         return guided_unet.GuidedUNet(cfg, device, precision).load_state_dict(sd), sd, cfg
-    cfg = ncsnpp.parse_config(CIFAR_CFG)
+    cfg = ncsnpp.parse_config(CIFAR_CFG)   # cifar32_ncsnpp and cifar32_ncsnpp_adjoint
     sd = synth.synth_state_dict(ncsnpp.param_shapes(cfg), seed)
     return ncsnpp.NCSNpp(cfg, device, precision).load_state_dict(sd), sd, cfg
 
@@ -80,15 +83,29 @@ def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
         b = 4
         x = torch.rand(b, 3, 32, 32) * 2 - 1
         fn = lambda: on.ncsnpp_forward(sd, cfg, x, torch.full((b,), 99.9))
-    with torch.no_grad():
-        fn()  # warm-up (oneDNN primitive creation)
+
+    def timed(f):
+        f()  # warm-up (oneDNN primitive creation)
         calls, t0 = 0, time.time()
         while calls < 1 or (time.time() - t0 < budget_s and calls < 64):
-            fn()
+            f()
             calls += 1
-        el = time.time() - t0
-    s_per_img_step = el / (calls * b)
-    return dict(value=1.0 / (s_per_img_step * n_steps), unit="images/s", cores=cores, kind="port",
+        return (time.time() - t0) / (calls * b), calls, time.time() - t0
+
+    with torch.no_grad():
+        s_fwd, calls, el = timed(fn)
+    if workload.endswith("_adjoint"):
+        # the adjoint solve costs one forward + one input-gradient pass per step (autograd on the CPU)
+        def fb():
+            xr = x.clone().requires_grad_(True)
+            out = on.ncsnpp_forward(sd, cfg, xr, torch.full((b,), 99.9))
+            torch.autograd.grad(out, xr, torch.ones_like(out))
+        s_fb, calls2, el2 = timed(fb)
+        per_image = n_steps * s_fwd + n_steps * s_fb
+        return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
+                    sample=f"{calls} forward(s) + {calls2} forward+input-gradient pass(es) at batch {b} ({el + el2:.1f} s of CPU "
+                           f"work); {n_steps} ODE steps + {n_steps} adjoint steps extrapolated; torch-CPU oracle")
+    return dict(value=1.0 / (s_fwd * n_steps), unit="images/s", cores=cores, kind="port",
                 sample=f"{calls} UNet forward(s) at batch {b} ({el:.1f} s of CPU work), x{n_steps} steps extrapolated; "
                        "oracle = torch-CPU fp32 restatement of the reference modules (pinned to them by tests/golden)")
 
@@ -104,7 +121,7 @@ def main():
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="f32: fp32-input MFMA; f16x3: split-fp16 3-pass MFMA (fp32-class accuracy)")
     a = ap.parse_args()
 
@@ -124,7 +141,8 @@ def main():
     from diffpure_amd.sde import Purifier, sde_schedule
 
     wl = WORKLOADS[a.workload]
-    B = a.batch or (16 if a.workload == "imagenet256_guided" else 256)
+    adjoint = a.workload.endswith("_adjoint")
+    B = a.batch or (16 if a.workload == "imagenet256_guided" else (128 if adjoint else 256))
     net, sd, _ = build_engine(a.workload, dev, a.seed, a.precision)
     pur = Purifier(net, wl["kind"], dev)
     n_steps = len(sde_schedule(wl["kind"], a.t, a.dt))
@@ -133,8 +151,16 @@ def main():
     x = (torch.rand(B, 3, hw, hw, generator=gen) * 2 - 1).to(dev)      # resident in HBM before timing
     gathered = torch.empty((world * B, 3, hw, hw), device=dev) if world > 1 else None
 
+    cot = torch.randn(B, 3, hw, hw, generator=gen).to(dev) if adjoint else None
+    if adjoint:
+        net.enable_grad()
+
     def one_call(i):
-        y = pur.sde(x, a.t, a.dt, seed=a.seed + 1000003 * i, sample0=rank * B)
+        if adjoint:   # forward ODE solve, then the adjoint solve for dL/dx with a fixed cotangent
+            xf = pur.ode(x, a.t, a.dt, seed=a.seed + 1000003 * i, sample0=rank * B)
+            y = pur.ode_vjp(xf, cot, a.t, a.dt) * pur.diffuse_scale(a.t)
+        else:
+            y = pur.sde(x, a.t, a.dt, seed=a.seed + 1000003 * i, sample0=rank * B)
         if world > 1:
             dist.all_gather_into_tensor(gathered, y)
         return y
@@ -172,7 +198,9 @@ def main():
         out = {
             "metric": "purified images/sec (whole node), 256x256 GuidedDiff VP-SDE t*=0.1 100-step"
             if a.workload == "imagenet256_guided" and a.t == 100 and n_steps == 100
-            else f"purified images/sec (whole node), {a.workload} VP-SDE t={a.t} {n_steps}-step",
+            else (f"images/sec with input gradient (whole node), {a.workload}: ODE purification + adjoint dL/dx, t={a.t} "
+                  f"{n_steps}-step" if adjoint else
+                  f"purified images/sec (whole node), {a.workload} VP-SDE t={a.t} {n_steps}-step"),
             "value": value,
             "unit": "images/s",
             "n_gpus": world,

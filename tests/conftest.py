@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The oracle runs on the host: oneDNN convolutions at batch 1-4 are fastest with ~16 threads on the
+# MI355X box (256 hardware threads; the default of 128 is 4-10x slower, measured in tests/probes).
+torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
