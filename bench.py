@@ -213,8 +213,11 @@ def main():
             "dtype": a.precision,
             "data": "synthetic (seeded uniform images in [-1,1]; seeded non-trivial random weights of the named "
                     "architecture; Philox noise)",
-            "config": {"workload": f"{a.workload}: reverse VP-SDE purification, t*={a.t / 1000:g}, dt={a.dt:g}, "
-                                   f"{n_steps} Euler-Maruyama steps, one UNet call per step",
+            "config": {"workload": (f"{a.workload}: probability-flow ODE purification ({n_steps} Euler steps) + continuous-adjoint "
+                                    f"backward for dL/dx ({n_steps} steps, each one UNet forward + one input-gradient pass), "
+                                    f"t*={a.t / 1000:g}, step={a.dt:g}") if adjoint else
+                                   (f"{a.workload}: reverse VP-SDE purification, t*={a.t / 1000:g}, dt={a.dt:g}, "
+                                    f"{n_steps} Euler-Maruyama steps, one UNet call per step"),
                        "per_gpu_batch": B, "global_batch": world * B, "image": f"3x{hw}x{hw}",
                        "parallelism": f"batch-sharded x{world}, one all_gather of outputs"},
             "roofline": {"bound": "mfma",

@@ -30,6 +30,11 @@ def guided_model_defaults():
                 rescale_learned_sigmas=False)
 
 
+def precision_of(args):
+    """args.precision: "f16x3" (default; split-fp16 three-pass MFMA, fp32-class accuracy) | "f32"."""
+    return getattr(args, "precision", None) or os.environ.get("DIFFPURE_PRECISION", "f16x3")
+
+
 def want_synthetic(args):
     return bool(getattr(args, "synthetic_weights", False)) or os.environ.get("DIFFPURE_SYNTH_WEIGHTS", "0") == "1"
 
@@ -53,7 +58,7 @@ def build_guided(args, config, device, model_dir="pretrained/guided_diffusion"):
     if mc.get("class_cond"):
         raise NotImplementedError("class-conditional guided diffusion is outside the purification path")
     cfg = guided_unet.parse_config(mc)
-    net = guided_unet.GuidedUNet(cfg, device)
+    net = guided_unet.GuidedUNet(cfg, device, precision_of(args))
     path = f"{model_dir}/256x256_diffusion_uncond.pt"
     if os.path.exists(path):
         sd = torch.load(path, map_location="cpu")
@@ -70,7 +75,7 @@ def build_guided(args, config, device, model_dir="pretrained/guided_diffusion"):
 
 def build_ncsnpp(args, config, device, model_dir="pretrained/score_sde"):
     cfg = ncsnpp.parse_config(_ns_to_dict(config))
-    net = ncsnpp.NCSNpp(cfg, device)
+    net = ncsnpp.NCSNpp(cfg, device, precision_of(args))
     path = f"{model_dir}/checkpoint_8.pth"
     if os.path.exists(path):
         sd = ncsnpp_state_from_checkpoint(torch.load(path, map_location="cpu"), cfg)
