@@ -86,6 +86,7 @@ struct ApplyArgs {
     int film_stride, act, resample;
     float* y;
     int C4, cpg, Ho, Wo;
+    char* y_raw;     // optional second output (H2 kernels, resample == 0): the UN-normalised input in bordered h2 form
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -121,9 +122,15 @@ __global__ void gn_apply_kernel(ApplyArgs p) {
             half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + ((size_t)opix * CV + cv) * 32);
             dst[0] = z;
             dst[1] = z;
+            if (p.y_raw) {
+                half8* dr = reinterpret_cast<half8*>(p.y_raw + ((size_t)opix * CV + cv) * 32);
+                dr[0] = z;
+                dr[1] = z;
+            }
             continue;
         }
         f32x4 o[NQ];
+        f32x4 raw[NQ];
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd) {
             const int c = cv * VEC + qd * 4;
@@ -151,6 +158,7 @@ __global__ void gn_apply_kernel(ApplyArgs p) {
             }
             auto xf = [&](size_t pix) {
                 f32x4 v = gn_load(p, pix, c);
+                raw[qd] = v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float u = v[j] * a[j] + d[j];
@@ -180,6 +188,17 @@ __global__ void gn_apply_kernel(ApplyArgs p) {
             half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + ((size_t)opix * CV + cv) * 32);
             dst[0] = hi;
             dst[1] = lo;
+            if (p.y_raw) {       // resample == 0 here: raw[] holds this very pixel
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = raw[j >> 2][j & 3];
+                    hi[j] = (_Float16)v;
+                    lo[j] = (_Float16)(v - (float)hi[j]);
+                }
+                half8* dr = reinterpret_cast<half8*>(p.y_raw + ((size_t)opix * CV + cv) * 32);
+                dr[0] = hi;
+                dr[1] = lo;
+            }
         } else {
             *reinterpret_cast<f32x4*>(p.y + (size_t)opix * (p.C4 * 4) + cv * 4) = o[0];   // BORDER == 0: opix is the pixel
         }
@@ -224,7 +243,7 @@ extern "C" int dp_gn_finalize(const float* partial, int B, int nsplit, int G, lo
 extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                            const float* stats, const float* gamma, const float* beta, const float* fscale,
                            const float* fshift, int film_stride, int act, int resample, int out_fmt, void* y,
-                           void* stream) {
+                           void* y_raw, void* stream) {
     const int C = C1 + C2;
     DP_REQUIRE(x1 && y && B > 0 && H > 0 && W > 0, "dp_gn_apply: bad args");
     DP_REQUIRE(C2 == 0 || x2, "dp_gn_apply: x2 missing");
@@ -236,9 +255,10 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(y), "dp_gn_apply: misaligned tensor");
     DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply: misaligned FiLM rows");
     DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && C % 8 == 0 && C1 % 8 == 0), "dp_gn_apply: out_fmt %d needs channel counts that are multiples of 8", out_fmt);
+    DP_REQUIRE(!y_raw || (out_fmt == 1 && resample == 0), "dp_gn_apply: the raw h2 output needs out_fmt=1 and no resampling");
     ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
                 C / 4, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
-                resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W)};
+                resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W), (char*)y_raw};
     const long long total = out_fmt ? (long long)B * (p.Ho + 2) * (p.Wo + 2) * (p.C4 / 2) : (long long)B * p.Ho * p.Wo * p.C4;
     if (out_fmt) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);

@@ -231,7 +231,14 @@ class GuidedUNet:
                 P[n + ".w2"], r["h2_2"] = conv_w(n + ".out_layers.3.weight", r["cout"])
                 P[n + ".c2"] = vec(n + ".out_layers.3.bias")
                 if r["cin"] != r["cout"]:
-                    P[n + ".ws"] = ops.pack_conv_weight(sd[n + ".skip_connection.weight"].detach()).to(dev)
+                    # the 1x1 skip reads the RAW block input; with f16x3, GroupNorm-apply emits that input in
+                    # operand form in the same pass, so the skip runs on the fp16 matrix path too
+                    c1 = r.get("split", r["cin"])
+                    r["h2_s"] = r["h2_1"] and c1 % 8 == 0
+                    if r["h2_s"]:
+                        P[n + ".ws"] = ops.pack_conv_weight_h2(sd[n + ".skip_connection.weight"].detach(), dev)
+                    else:
+                        P[n + ".ws"] = ops.pack_conv_weight(sd[n + ".skip_connection.weight"].detach()).to(dev)
                     P[n + ".cs"] = vec(n + ".skip_connection.bias")
                 emb_w.append(sd[n + ".emb_layers.1.weight"].detach().float())
                 emb_b.append(sd[n + ".emb_layers.1.bias"].detach().float())
@@ -261,7 +268,11 @@ class GuidedUNet:
         conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
         conv2 = ops.conv2d_h2 if r["h2_2"] else ops.conv2d
         st1 = ops.group_norm_stats(x, G, eps, x2)
-        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"], stats=st1)
+        want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False)
+        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"], stats=st1,
+                           raw=want_raw)
+        if want_raw:
+            h, xraw = h
         h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"])
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
@@ -271,6 +282,8 @@ class GuidedUNet:
         h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"], stats=st2)
         if mode:
             skip = ops.resample(x, mode)
+        elif want_raw:
+            skip = ops.conv2d_h2(xraw, P[n + ".ws"], co, 1, bias=P[n + ".cs"])
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".ws"], co, 1, bias=P[n + ".cs"], x2=x2)
         else:

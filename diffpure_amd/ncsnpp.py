@@ -189,7 +189,14 @@ class NCSNpp:
                 P[n + ".g1"], P[n + ".b1"] = vec(p + ".GroupNorm_1.weight"), vec(p + ".GroupNorm_1.bias")
                 (P[n + ".w1"], r["h2_1"]), P[n + ".c1"] = conv_w(p + ".Conv_1.weight", r["cout"]), vec(p + ".Conv_1.bias")
                 if r["cin"] != r["cout"] or r["mode"]:
-                    P[n + ".w2"], P[n + ".c2"] = ops.pack_conv_weight(sd[p + ".Conv_2.weight"].detach()).to(dev), vec(p + ".Conv_2.bias")
+                    # Conv_2 reads the RAW (possibly resampled) block input: on the f16x3 path GroupNorm-apply /
+                    # the resampler emit it in operand form, so the 1x1 runs on the fp16 matrix path too
+                    r["h2_s"] = r["h2_0"] and r.get("c1", r["cin"]) % 8 == 0
+                    if r["h2_s"]:
+                        P[n + ".w2"] = ops.pack_conv_weight_h2(sd[p + ".Conv_2.weight"].detach(), dev)
+                    else:
+                        P[n + ".w2"] = ops.pack_conv_weight(sd[p + ".Conv_2.weight"].detach()).to(dev)
+                    P[n + ".c2"] = vec(p + ".Conv_2.bias")
                 dw.append(sd[p + ".Dense_0.weight"].detach().float())
                 db.append(sd[p + ".Dense_0.bias"].detach().float())
                 r["dense_off"] = off
@@ -217,8 +224,12 @@ class NCSNpp:
         conv0 = ops.conv2d_h2 if r["h2_0"] else ops.conv2d
         conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
         st0 = ops.group_norm_stats(x, self._groups(r["cin"]), self.GN_EPS, x2)
+        h2s = r.get("h2_s", False)
+        want_raw = h2s and not mode
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
-                           resample=mode, split=r["h2_0"], stats=st0)
+                           resample=mode, split=r["h2_0"], stats=st0, raw=want_raw)
+        if want_raw:
+            h, xraw = h
         off = r["dense_off"]
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co])
         st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
@@ -226,8 +237,12 @@ class NCSNpp:
             tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
         h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"], stats=st1)
         if mode:
-            xs = ops.resample(x, mode)
-            skip = ops.conv2d(xs, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+            if h2s:
+                skip = ops.conv2d_h2(ops.to_h2(x, mode), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+            else:
+                skip = ops.conv2d(ops.resample(x, mode), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+        elif want_raw:
+            skip = ops.conv2d_h2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
         else:

@@ -189,11 +189,12 @@ def group_norm_stats(x, groups, eps, x2=None):
 
 
 def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
-               split=False):
+               split=False, raw=False):
     """y = resample(act(FiLM(GroupNorm(cat(x, x2))))).  film = (scale [R,C], shift [R,C]) with R in
     {1, B}; the two may be column views of one [R, 2C] tensor (row stride is taken from them).
     split=True writes the "h2" split-fp16 operand format of conv2d_h2 with its one-pixel zero border
-    ([B, Ho+2, Wo+2, 2C] fp16)."""
+    ([B, Ho+2, Wo+2, 2C] fp16).  raw=True (with split, no resampling) additionally returns the
+    un-normalised cat(x, x2) in the same operand format (input of a 1x1 skip convolution)."""
     _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
@@ -213,9 +214,13 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         y = torch.empty((b, ho + 2, wo + 2, 2 * c), device=x.device, dtype=torch.float16)
     else:
         y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    yr = None
+    if raw:
+        assert split and resample == RESAMPLE_NONE
+        yr = torch.empty_like(y)
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, 1 if split else 0, _ptr(y), _stream())
-    return y
+              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, 1 if split else 0, _ptr(y), _ptr(yr), _stream())
+    return (y, yr) if raw else y
 
 
 def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False):
@@ -272,12 +277,14 @@ def add(a, b):
     return out
 
 
-def to_h2(x):
-    """fp32 NHWC -> zero-bordered h2 operand ([B, H+2, W+2, 2C] fp16) without normalisation."""
+def to_h2(x, mode=RESAMPLE_NONE):
+    """fp32 NHWC -> zero-bordered h2 operand ([B, H'+2, W'+2, 2C] fp16) without normalisation,
+    optionally through the 2x resampler (`mode`)."""
     _chk(x, "to_h2.x", 4)
     b, h, w, c = x.shape
-    y = torch.empty((b, h + 2, w + 2, 2 * c), device=x.device, dtype=torch.float16)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, 0, 1, _ptr(y), _stream())
+    ho, wo = (h * 2, w * 2) if mode == RESAMPLE_UP else ((h // 2, w // 2) if mode == RESAMPLE_DOWN else (h, w))
+    y = torch.empty((b, ho + 2, wo + 2, 2 * c), device=x.device, dtype=torch.float16)
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 1, _ptr(y), None, _stream())
     return y
 
 
@@ -297,7 +304,7 @@ def resample(x, mode):
     b, h, w, c = x.shape
     ho, wo = (h * 2, w * 2) if mode == RESAMPLE_UP else (h // 2, w // 2)
     y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), None, _stream())
     return y
 
 

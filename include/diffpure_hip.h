@@ -110,6 +110,9 @@ int dp_softmax_rows(float* x, long long rows, int cols, void* stream);
  *   act: 0 none, 1 SiLU.  resample: 0 none, 1 nearest x2 (out 2H x 2W), 2 mean 2x2 (out H/2 x W/2).
  *   out_fmt: 0 = fp32 NHWC [B][Ho][Wo][C]; 1 = "h2" split-fp16 with a one-pixel zero border,
  *   [B][Ho+2][Wo+2][C] (see dp_conv2d_nhwc_h2).
+ *   y_raw (optional, out_fmt=1 and resample=0 only): second output = the UN-normalised input
+ *   cat(x1, x2) in the same bordered h2 form, the operand of a 1x1 skip convolution
+ *   (unet.py:229-234 / layerspp.py:235) - written in the same pass that reads it.
  */
 int dp_gn_stats(const float* x1, int C1, const float* x2, int C2, int B, int HW, int G,
                 int nsplit, float* partial, void* stream);
@@ -118,7 +121,7 @@ int dp_gn_finalize(const float* partial, int B, int nsplit, int G, long long cou
 int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta,
                 const float* fscale, const float* fshift, int film_stride,
-                int act, int resample, int out_fmt, void* y, void* stream);
+                int act, int resample, int out_fmt, void* y, void* y_raw, void* stream);
 
 /* ---- small elementwise pieces ----------------------------------------------------------------*/
 /* y = x * sigmoid(x)   (nn.SiLU on the embedding vector, unet.py:211, layerspp.py:265) */

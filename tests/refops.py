@@ -108,7 +108,7 @@ def _resample(y, mode):
 
 
 def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
-               split=False):
+               split=False, raw=False):
     xin = _cat(x, x2)
     y = F.group_norm(xin.permute(0, 3, 1, 2), groups, gamma, beta, eps).permute(0, 2, 3, 1)
     if film is not None:
@@ -117,6 +117,8 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     if act:
         y = F.silu(y)
     y = _resample(y, resample).contiguous()
+    if raw:
+        return h2_encode(F.pad(y, (0, 0, 1, 1, 1, 1))), h2_encode(F.pad(xin, (0, 0, 1, 1, 1, 1)))
     return h2_encode(F.pad(y, (0, 0, 1, 1, 1, 1))) if split else y
 
 
@@ -190,8 +192,8 @@ def add(a, b):
     return a + b
 
 
-def to_h2(x):
-    return h2_encode(F.pad(x, (0, 0, 1, 1, 1, 1)))
+def to_h2(x, mode=RESAMPLE_NONE):
+    return h2_encode(F.pad(_resample(x, mode), (0, 0, 1, 1, 1, 1)))
 
 
 def silu(x):

@@ -259,3 +259,17 @@ def test_group_norm_split_output_is_bordered_h2_of_fp32_output(dev):
         yh = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, resample=rs, split=True)
         assert yh.dtype == torch.float16 and yh.shape == (2, y32.shape[1] + 2, y32.shape[2] + 2, 768)
         assert torch.equal(yh.cpu(), refops.h2_encode(torch.nn.functional.pad(y32.cpu(), (0, 0, 1, 1, 1, 1))))
+
+
+def test_group_norm_raw_second_output(dev):
+    """GroupNorm-apply also emits the un-normalised cat(x, x2) in operand form (input of the 1x1 skip)."""
+    from diffpure_amd import ops
+    x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)
+    x2 = rnd(2, 8, 8, 128, seed=2).to(dev)
+    gamma, beta = (1 + 0.1 * rnd(384, seed=3)).to(dev), (0.1 * rnd(384, seed=4)).to(dev)
+    y, yr = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, split=True, raw=True)
+    y0 = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, split=True)
+    assert torch.equal(y, y0)
+    assert torch.equal(yr.cpu(), refops.to_h2(torch.cat([x, x2], dim=3).cpu()))
+    for mode in (1, 2):
+        assert torch.equal(ops.to_h2(x, mode).cpu(), refops.to_h2(x.cpu(), mode))
