@@ -22,7 +22,8 @@ SIGNATURES = {
     "dp_last_error": [],
     "dp_prof_enable": [_i],
     "dp_prof_collect": [_p, _p, _p, _p, _p, _p],
-    "dp_conv2d_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _p],
+    "dp_conv2d_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _p, _p, _p],
+    "dp_gn_finalize_cols": [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p],
     "dp_gemm_strided": [_p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _p],
     "dp_gn_bwd_stats": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p],
     "dp_gn_bwd_apply": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p],
@@ -33,7 +34,7 @@ SIGNATURES = {
     "dp_gn_stats": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p],
     "dp_gn_finalize": [_p, _i, _i, _i, _ll, _f, _p, _p],
     "dp_gn_apply": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p],
-    "dp_conv2d_nhwc_h2": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _p],
+    "dp_conv2d_nhwc_h2": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _p, _p, _p],
     "dp_pack_h2": [_p, _ll, _i, _i, _p, _p],
     "dp_silu": [_p, _p, _ll, _p],
     "dp_axpby": [_p, _f, _p, _f, _p, _ll, _p],

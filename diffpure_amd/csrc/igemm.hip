@@ -38,6 +38,7 @@ struct ConvArgs {
     int M, N, K;
     float scale;
     int tiles_n;
+    float* colstats;   // optional [tiles_m][2][N]: per output column, sum and sum of squares over the tile's rows
 };
 
 template <int TM, int TN, int LDA, int LDB>
@@ -220,23 +221,55 @@ __global__ __launch_bounds__(NT) void conv_igemm_f32(ConvArgs p) {
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Optionally also reduces, per output column, sum and sum-of-squares of the FINAL values over the
+    // tile's rows (fixed order: registers -> half-wave swap -> wave rows through LDS): the statistics
+    // pass of the GroupNorm that consumes this tensor then never re-reads it.
     const int lr = lane & 31, lk = lane >> 5;
+    float* cs_lds = smem;     // [WM][BN][2] floats; the k-loop's last barrier has released the tiles
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + lr;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const bool cok = col < p.N;
+        const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
+        float cs = 0.f, cq = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row >= p.M) continue;
+                if (row >= p.M || !cok) continue;
                 float v = acc[i][j][r] + bv;
                 if (p.temb) v += p.temb[(size_t)(row / HW) * p.temb_stride + col];
                 if (p.res) v += p.res[(size_t)row * p.ldr + col];
-                p.out[(size_t)row * p.ldo + col] = v * p.scale;
+                v *= p.scale;
+                p.out[(size_t)row * p.ldo + col] = v;
+                cs += v;
+                cq += v * v;
             }
+        }
+        if (p.colstats) {
+            cs += __shfl_xor(cs, 32, 64);
+            cq += __shfl_xor(cq, 32, 64);
+            if (lk == 0) {
+                float* d = cs_lds + (((wave / WN) * BN) + wn0 + j * 32 + lr) * 2;
+                d[0] = cs;
+                d[1] = cq;
+            }
+        }
+    }
+    if (p.colstats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            if (n0 + c >= p.N) continue;
+            float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+            for (int wr = 0; wr < WM; ++wr) {
+                s0 += cs_lds[(wr * BN + c) * 2];
+                q0 += cs_lds[(wr * BN + c) * 2 + 1];
+            }
+            float* d = p.colstats + (size_t)tile_m * 2 * p.N + n0 + c;
+            d[0] = s0;
+            d[p.N] = q0;
         }
     }
 }
@@ -486,7 +519,7 @@ extern "C" int dp_prof_collect(double* ms3, long long* n3, double* f3, double* m
 extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int KH,
                               int KW, const float* w, int ldw, int N, const float* bias, const float* temb,
                               int temb_stride, const float* res, int ldr, float scale, float* out, int ldo,
-                              int precision, void* stream) {
+                              int precision, float* colstats, int* tile_rows, void* stream) {
     DP_REQUIRE(precision == 0, "dp_conv2d_nhwc: precision %d not built (0 = fp32 MFMA)", precision);
     DP_REQUIRE(x1 && w && out, "dp_conv2d_nhwc: null pointer");
     DP_REQUIRE(KH == KW && (KH == 1 || KH == 3), "dp_conv2d_nhwc: kernel %dx%d unsupported", KH, KW);
@@ -501,12 +534,15 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
     p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo;
     p.M = B * H * W; p.N = N; p.K = KH * KW * (C1 + C2);
     p.scale = scale;
+    p.colstats = colstats;
+    DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc: colstats needs tile_rows");
     const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2));
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     void* rec = nullptr;
     dp_prof_begin(KH == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    int bm = 128;
     if (!vec) {
         p.tiles_n = (N + 127) / 128;
         hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, 1>), dim3((unsigned)tiles(128, 128)), dim3(NT), 0, s, p);
@@ -515,11 +551,13 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
         hipLaunchKernelGGL((conv_igemm_f32<128, 32, 4, 1, 4>), dim3((unsigned)tiles(128, 32)), dim3(NT), 0, s, p);
     } else if (N <= 64 || tiles(128, 128) < 384) {
         p.tiles_n = (N + 63) / 64;
+        bm = 64;
         hipLaunchKernelGGL((conv_igemm_f32<64, 64, 2, 2, 4>), dim3((unsigned)tiles(64, 64)), dim3(NT), 0, s, p);
     } else {
         p.tiles_n = (N + 127) / 128;
         hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, 4>), dim3((unsigned)tiles(128, 128)), dim3(NT), 0, s, p);
     }
+    if (tile_rows) *tile_rows = bm;
     dp_prof_end(rec, s);
     DP_LAUNCH_CHECK("conv_igemm_f32");
     return 0;

@@ -63,6 +63,7 @@ struct ConvH2Args {
     float scale;
     int tiles_n, tiles;
     const char* zero;   // >= 128 zero bytes in device memory (weight rows n >= N)
+    float* colstats;    // optional [tiles_m][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
 };
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
@@ -185,22 +186,47 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
         __syncthreads();
     }
 
+    float* cs_lds = reinterpret_cast<float*>(smem);     // [2][BN][2] floats, tiles released by the last barrier
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + lr;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const bool cok = col < p.N;
+        const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
+        float cs = 0.f, cq = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row >= p.M) continue;
+                if (row >= p.M || !cok) continue;
                 float v = acc[i][j][r] + bv;
                 if (p.temb) v += p.temb[(size_t)(row / HW) * p.temb_stride + col];
                 if (p.res) v += p.res[(size_t)row * p.ldr + col];
-                p.out[(size_t)row * p.ldo + col] = v * p.scale;
+                v *= p.scale;
+                p.out[(size_t)row * p.ldo + col] = v;
+                cs += v;
+                cq += v * v;
             }
+        }
+        if (p.colstats) {
+            cs += __shfl_xor(cs, 32, 64);
+            cq += __shfl_xor(cq, 32, 64);
+            if (lk == 0) {
+                float* d = cs_lds + (((wave >> 1) * BN) + wn0 + j * 32 + lr) * 2;
+                d[0] = cs;
+                d[1] = cq;
+            }
+        }
+    }
+    if (p.colstats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            if (n0 + c >= p.N) continue;
+            const float s0 = cs_lds[c * 2] + cs_lds[(BN + c) * 2];
+            const float q0 = cs_lds[c * 2 + 1] + cs_lds[(BN + c) * 2 + 1];
+            float* d = p.colstats + (size_t)tile_m * 2 * p.N + n0 + c;
+            d[0] = s0;
+            d[p.N] = q0;
         }
     }
 }
@@ -239,7 +265,7 @@ const char* zero_page() {
 
 extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
                                  const float* bias, const float* temb, int temb_stride, const float* res, int ldr,
-                                 float scale, float* out, int ldo, void* stream) {
+                                 float scale, float* out, int ldo, float* colstats, int* tile_rows, void* stream) {
     DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
     DP_REQUIRE(KS == 1 || KS == 3, "dp_conv2d_nhwc_h2: kernel size %d unsupported", KS);
     DP_REQUIRE(C > 0 && C % 32 == 0, "dp_conv2d_nhwc_h2: channel count must be a multiple of 32 (got %d)", C);
@@ -253,6 +279,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.M = B * H * W; p.N = N; p.K = KS * KS * C; p.scale = scale;
     p.zero = zero_page();
     DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
+    p.colstats = colstats;
+    DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc_h2: colstats needs tile_rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     void* rec = nullptr;
     dp_prof_begin(KS == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
@@ -260,8 +288,10 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     if (N <= 64 || tiles(128, 128) < 256) {
         p.tiles_n = (N + 63) / 64;
         p.tiles = (int)tiles(64, 64);
+        if (tile_rows) *tile_rows = 64;
         hipLaunchKernelGGL((conv_igemm_h2<64, 64>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
     } else {
+        if (tile_rows) *tile_rows = 128;
         p.tiles_n = (N + 127) / 128;
         p.tiles = (int)tiles(128, 128);
         hipLaunchKernelGGL((conv_igemm_h2<128, 128>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);

@@ -74,6 +74,47 @@ __global__ void gn_finalize_kernel(const float* partial, int B, int nsplit, int 
     stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// (mean, rstd) per (sample, group) from the per-column (sum, sumsq) partials the convolution epilogues
+// leave behind: source s has C_s channels and one [2][C_s] record per tile of tr_s output rows;
+// a sample owns HW / tr_s consecutive tiles.  One workgroup per (sample, group); fixed-order tree.
+__global__ void gn_finalize_cols_kernel(const float* cs1, int C1, int tr1, const float* cs2, int C2, int tr2, int HW,
+                                        int G, float eps, float* stats) {
+    __shared__ double rs[256];
+    __shared__ double rq[256];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int C = C1 + C2, cpg = C / G;
+    double s = 0.0, q = 0.0;
+    for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
+        const bool first = ch < C1;
+        const float* base = first ? cs1 : cs2;
+        const int Cs = first ? C1 : C2, c = first ? ch : ch - C1, tr = first ? tr1 : tr2;
+        const int tps = HW / tr;
+        for (int t = threadIdx.x; t < tps; t += blockDim.x) {
+            const float* rec = base + (size_t)(b * tps + t) * 2 * Cs;
+            s += rec[c];
+            q += rec[Cs + c];
+        }
+    }
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            rs[threadIdx.x] += rs[threadIdx.x + o];
+            rq[threadIdx.x] += rq[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double inv = 1.0 / ((double)HW * cpg);
+        const double mean = rs[0] * inv;
+        double var = rq[0] * inv - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[(b * G + g) * 2] = (float)mean;
+        stats[(b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 struct ApplyArgs {
     const float* x1;
     const float* x2;
@@ -237,6 +278,18 @@ extern "C" int dp_gn_finalize(const float* partial, int B, int nsplit, int G, lo
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, B,
                        nsplit, G, 1.0 / (double)count, eps, stats);
     DP_LAUNCH_CHECK("gn_finalize");
+    return 0;
+}
+
+extern "C" int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, const float* cs2, int C2, int tile_rows2, int B,
+                                   int HW, int G, float eps, float* stats, void* stream) {
+    DP_REQUIRE(cs1 && stats && B > 0 && HW > 0 && G > 0 && C1 > 0 && C2 >= 0 && (C2 == 0 || cs2), "dp_gn_finalize_cols: bad args");
+    DP_REQUIRE((C1 + C2) % G == 0, "dp_gn_finalize_cols: C must be a multiple of G");
+    DP_REQUIRE(tile_rows1 > 0 && HW % tile_rows1 == 0 && (C2 == 0 || (tile_rows2 > 0 && HW % tile_rows2 == 0)),
+               "dp_gn_finalize_cols: a convolution tile must not straddle two samples (HW %% tile_rows != 0)");
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3((unsigned)(B * G)), dim3(256), 0, (hipStream_t)stream, cs1, C1, tile_rows1,
+                       cs2, C2, C2 ? tile_rows2 : 1, HW, G, eps, stats);
+    DP_LAUNCH_CHECK("gn_finalize_cols");
     return 0;
 }
 

@@ -273,7 +273,7 @@ class GuidedUNet:
                            raw=want_raw)
         if want_raw:
             h, xraw = h
-        h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"])
+        h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True)
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
         st2 = ops.group_norm_stats(h, G, eps)
@@ -288,7 +288,7 @@ class GuidedUNet:
             skip = ops.conv2d(x, P[n + ".ws"], co, 1, bias=P[n + ".cs"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip)
+        return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip, colstats=True)
 
     def _attn(self, r, x, tape=None):
         P, n, c = self.p, r["name"], r["ch"]
@@ -302,7 +302,7 @@ class GuidedUNet:
         else:
             a, probs = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout, return_probs=True)
             tape.append(dict(r=r, x=x, st=st, qkv=qkv, probs=probs, layout=layout))
-        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x)
+        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True)
 
     def _run(self, blk, h, h2, film, tape=None):
         for r in blk:
@@ -334,7 +334,7 @@ class GuidedUNet:
         P = self.p
         hs = []
         stem = self.plan["inp"][0][0]
-        h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"])
+        h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"], colstats=True)
         hs.append(h)
         for blk in self.plan["inp"][1:]:
             h = self._run(blk, h, None, film, tape)

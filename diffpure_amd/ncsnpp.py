@@ -231,7 +231,7 @@ class NCSNpp:
         if want_raw:
             h, xraw = h
         off = r["dense_off"]
-        h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co])
+        h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True)
         st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
@@ -247,7 +247,7 @@ class NCSNpp:
             skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2)
+        return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2, colstats=True)
 
     def _attn(self, r, x, tape=None):
         P, n, c = self.p, str(r["idx"]), r["ch"]
@@ -260,7 +260,7 @@ class NCSNpp:
         else:
             a, probs = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split", return_probs=True)
             tape.append(dict(r=r, x=x, st=st, qkv=qkv, probs=probs))
-        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2)
+        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True)
 
     def time_table(self, labels):
         """labels: float32 GPU tensor [R] (= 999*s). -> Dense_0 rows of every ResBlock [R, sum(cout)]."""
@@ -276,7 +276,7 @@ class NCSNpp:
         P = self.p
         dense = table_row if table_row is not None else self.time_table(labels)
         st = self.plan["stem"]
-        hs = [ops.conv2d(x, P["stem.w"], st["cout"], 3, bias=P["stem.b"])]
+        hs = [ops.conv2d(x, P["stem.w"], st["cout"], 3, bias=P["stem.b"], colstats=True)]
         for blk in self.plan["down"]:
             h = hs[-1]
             for r in blk:

@@ -5,6 +5,7 @@ HIP stream.  PyTorch is plumbing here (device memory + streams); every FLOP runs
 Layout: activations are NHWC fp32 `[B, H, W, C]`; "rows" tensors are `[M, K]`.
 No CPU path exists: tensors must live on a GPU and the library must be built.
 """
+import ctypes
 import math
 
 import torch
@@ -96,7 +97,20 @@ def _chk_h2(t, name):
 # ---------------------------------------------------------------------------------------------
 # convolution / linear
 # ---------------------------------------------------------------------------------------------
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0):
+class ColStats:
+    """Per-column (sum, sumsq) partials a convolution epilogue left behind for the GroupNorm that
+    consumes its output: `buf` [tiles][2][N] for tiles of `tile_rows` output rows."""
+    __slots__ = ("buf", "tile_rows", "n")
+
+    def __init__(self, buf, tile_rows, n):
+        self.buf, self.tile_rows, self.n = buf, tile_rows, n
+
+
+def _colstats_alloc(m, n, device):
+    return torch.empty(((m + 63) // 64, 2, n), device=device, dtype=torch.float32), ctypes.c_int(0)
+
+
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False):
     """conv2d on h2 (split-fp16) activations/weights with three fp16 MFMA passes per product; same
     epilogue contract as conv2d.  x: [B, H+2, W+2, 2*C] fp16 (h2 with a one-pixel zero border, as
     group_norm(split=True) writes it), wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2)."""
@@ -117,13 +131,18 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0):
         _chk(res, "conv2d_h2.res", 4)
         assert res.shape == out.shape
         ldr = n_out
+    cs, tr = _colstats_alloc(b * h * w, n_out, x.device) if colstats else (None, None)
     _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
-              ldr, float(scale), _ptr(out), n_out, _stream())
+              ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _stream())
+    if colstats:
+        out._dp_cols = ColStats(cs, tr.value, n_out)
     return out
 
 
-def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None):
-    """out = scale * (res + bias + temb[b] + conv_{ksize x ksize, same}(cat(x, x2)))   (NHWC)."""
+def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False):
+    """out = scale * (res + bias + temb[b] + conv_{ksize x ksize, same}(cat(x, x2)))   (NHWC).
+    colstats=True: the epilogue also leaves per-column partial sums on the result (`out._dp_cols`), which
+    `group_norm_stats` turns into GroupNorm statistics without reading the tensor again."""
     _chk(x, "conv2d.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0
@@ -149,8 +168,12 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
         _chk(res, "conv2d.res", 4)
         assert res.shape == out.shape, (res.shape, out.shape)
         ldr = n_out
+    cs, tr = _colstats_alloc(b * h * w, n_out, x.device) if colstats else (None, None)
     _lib.call("dp_conv2d_nhwc", _ptr(x), c1, _ptr(x2), c2, b, h, w, ksize, ksize, _ptr(wp), wp.shape[1], n_out,
-              _ptr(bias), _ptr(temb), ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, 0, _stream())
+              _ptr(bias), _ptr(temb), ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, 0, _ptr(cs),
+              None if tr is None else ctypes.addressof(tr), _stream())
+    if colstats:
+        out._dp_cols = ColStats(cs, tr.value, n_out)
     return out
 
 
@@ -179,10 +202,17 @@ def group_norm_stats(x, groups, eps, x2=None):
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else _chk(x2, "gn.x2", 4).shape[3]
     hw = h * w
-    ns = _nsplit(hw)
-    partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
     stats = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
     s = _stream()
+    k1 = getattr(x, "_dp_cols", None)
+    k2 = getattr(x2, "_dp_cols", None) if x2 is not None else None
+    if k1 is not None and hw % k1.tile_rows == 0 and (x2 is None or (k2 is not None and hw % k2.tile_rows == 0)):
+        # the producing convolutions already reduced this tensor per column: no pass over the data
+        _lib.call("dp_gn_finalize_cols", _ptr(k1.buf), c1, k1.tile_rows, None if k2 is None else _ptr(k2.buf), c2,
+                  0 if k2 is None else k2.tile_rows, b, hw, groups, float(eps), _ptr(stats), s)
+        return stats
+    ns = _nsplit(hw)
+    partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
     _lib.call("dp_gn_stats", _ptr(x), c1, _ptr(x2), c2, b, hw, groups, ns, _ptr(partial), s)
     _lib.call("dp_gn_finalize", _ptr(partial), b, ns, groups, hw * ((c1 + c2) // groups), float(eps), _ptr(stats), s)
     return stats

@@ -53,13 +53,18 @@ int dp_prof_collect(double* ms3x3, long long* n3x3, double* flop3x3,
  *   bias [N] or NULL; temb [B][temb_stride] or NULL (temb_stride 0 broadcasts one row);
  *   res [M][ldr] or NULL; out [M][ldo].
  * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation).
+ * colstats (optional): [ceil(M/tile_rows)][2][N] floats; for every tile of `*tile_rows` consecutive output
+ *   rows (the value is returned through tile_rows: 64 or 128) the per-column sum and sum of squares of the
+ *   FINAL values, reduced in a fixed order inside the epilogue.  dp_gn_finalize_cols turns them into the
+ *   GroupNorm statistics of the tensor without re-reading it (the caller sizes the buffer for 64-row tiles).
  */
 int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
                    int B, int H, int W, int KH, int KW,
                    const float* w, int ldw, int N,
                    const float* bias, const float* temb, int temb_stride,
                    const float* res, int ldr, float scale,
-                   float* out, int ldo, int precision, void* stream);
+                   float* out, int ldo, int precision,
+                   float* colstats, int* tile_rows, void* stream);
 
 /* Same contract on the fp16 matrix cores with fp32-class accuracy ("f16x3"): every operand is a
  * (hi, lo) pair of fp16 numbers and every product is three v_mfma_f32_32x32x16_f16 passes
@@ -76,7 +81,7 @@ int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
                       const float* res, int ldr, float scale,
-                      float* out, int ldo, void* stream);
+                      float* out, int ldo, float* colstats, int* tile_rows, void* stream);
 /* fp32 [rows][ld] (first `cols` columns, cols % 8 == 0) -> h2 [rows][cols/8][2][8] fp16. */
 int dp_pack_h2(const float* src, long long rows, int cols, int ld, void* dst, void* stream);
 
@@ -118,6 +123,10 @@ int dp_gn_stats(const float* x1, int C1, const float* x2, int C2, int B, int HW,
                 int nsplit, float* partial, void* stream);
 int dp_gn_finalize(const float* partial, int B, int nsplit, int G, long long count, float eps,
                    float* stats, void* stream);
+/* Step 1+2 without reading the tensor: statistics of cat(x1, x2) from the column partials the producing
+ * convolutions wrote (dp_conv2d_nhwc[_h2] colstats).  HW % tile_rows == 0 for every source. */
+int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, const float* cs2, int C2, int tile_rows2,
+                        int B, int HW, int G, float eps, float* stats, void* stream);
 int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta,
                 const float* fscale, const float* fshift, int film_stride,

@@ -49,7 +49,7 @@ def pack_conv_weight_h2(w, device=None):
     return h2_encode(w.float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).reshape(o, kh * kw * i))
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False):
     """Statement of the f16x3 contract: exact products of the (hi+lo) operands (the dropped
     lo*lo term is ~2^-22 relative, below the test tolerance). x carries a one-pixel zero border."""
     xin = h2_decode(x)[:, 1:-1, 1:-1, :]
@@ -66,7 +66,7 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0):
     return (y * scale).float().contiguous()
 
 
-def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None):
+def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False):
     xin = _cat(x, x2)
     b, h, w, cin = xin.shape
     wt = wp[:, :n_out].reshape(ksize, ksize, cin, n_out).permute(3, 2, 0, 1).contiguous()

@@ -29,7 +29,7 @@ def test_argument_validation_reports_errors_without_a_gpu():
     # null pointers are rejected before any launch
     rc = lib.dp_silu(None, None, 4, None)
     assert rc != 0 and b"dp_silu" in lib.dp_last_error()
-    rc = lib.dp_conv2d_nhwc(None, 4, None, 0, 1, 1, 1, 3, 3, None, 4, 4, None, None, 0, None, 0, 1.0, None, 4, 0, None)
+    rc = lib.dp_conv2d_nhwc(None, 4, None, 0, 1, 1, 1, 3, 3, None, 4, 4, None, None, 0, None, 0, 1.0, None, 4, 0, None, None, None)
     assert rc != 0 and b"null" in lib.dp_last_error()
 
 
