@@ -225,15 +225,18 @@ __global__ __launch_bounds__(NT) void conv_igemm_f32(ConvArgs p) {
     // tile's rows (fixed order: registers -> half-wave swap -> wave rows through LDS): the statistics
     // pass of the GroupNorm that consumes this tensor then never re-reads it.
     const int lr = lane & 31, lk = lane >> 5;
-    float* cs_lds = smem;     // [WM][BN][2] floats; the k-loop's last barrier has released the tiles
+    // Column partials are formed in a tile-shape-independent order - 16 register values per lane, the two
+    // half-waves, then the two 32-row sub-tiles of a 64-row record - so that every kernel variant (and any
+    // sharding of the batch, which changes the variant chosen) produces bit-identical GroupNorm statistics.
+    float* cs_lds = smem;     // [BM/32][BN][2] floats; the k-loop's last barrier has released the tiles
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + lr;
         const bool cok = col < p.N;
         const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
-        float cs = 0.f, cq = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float cs = 0.f, cq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -246,28 +249,26 @@ __global__ __launch_bounds__(NT) void conv_igemm_f32(ConvArgs p) {
                 cs += v;
                 cq += v * v;
             }
-        }
-        if (p.colstats) {
-            cs += __shfl_xor(cs, 32, 64);
-            cq += __shfl_xor(cq, 32, 64);
-            if (lk == 0) {
-                float* d = cs_lds + (((wave / WN) * BN) + wn0 + j * 32 + lr) * 2;
-                d[0] = cs;
-                d[1] = cq;
+            if (p.colstats) {
+                cs += __shfl_xor(cs, 32, 64);
+                cq += __shfl_xor(cq, 32, 64);
+                if (lk == 0) {
+                    float* d = cs_lds + ((((wave / WN) * TM + i) * BN) + wn0 + j * 32 + lr) * 2;
+                    d[0] = cs;
+                    d[1] = cq;
+                }
             }
         }
     }
     if (p.colstats) {
         __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            if (n0 + c >= p.N) continue;
-            float s0 = 0.f, q0 = 0.f;
-#pragma unroll
-            for (int wr = 0; wr < WM; ++wr) {
-                s0 += cs_lds[(wr * BN + c) * 2];
-                q0 += cs_lds[(wr * BN + c) * 2 + 1];
-            }
-            float* d = p.colstats + (size_t)tile_m * 2 * p.N + n0 + c;
+        constexpr int REC = BM / 64;
+        for (int c = tid; c < BN * REC; c += NT) {
+            const int rec = c / BN, cc = c - rec * BN;
+            if (n0 + cc >= p.N) continue;
+            const float s0 = cs_lds[((2 * rec) * BN + cc) * 2] + cs_lds[((2 * rec + 1) * BN + cc) * 2];
+            const float q0 = cs_lds[((2 * rec) * BN + cc) * 2 + 1] + cs_lds[((2 * rec + 1) * BN + cc) * 2 + 1];
+            float* d = p.colstats + (size_t)(tile_m * REC + rec) * 2 * p.N + n0 + cc;
             d[0] = s0;
             d[p.N] = q0;
         }
@@ -557,7 +558,8 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
         p.tiles_n = (N + 127) / 128;
         hipLaunchKernelGGL((conv_igemm_f32<128, 128, 2, 2, 4>), dim3((unsigned)tiles(128, 128)), dim3(NT), 0, s, p);
     }
-    if (tile_rows) *tile_rows = bm;
+    (void)bm;
+    if (tile_rows) *tile_rows = 64;   // records are always per 64 output rows, whatever the tile
     dp_prof_end(rec, s);
     DP_LAUNCH_CHECK("conv_igemm_f32");
     return 0;

@@ -186,15 +186,16 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
         __syncthreads();
     }
 
-    float* cs_lds = reinterpret_cast<float*>(smem);     // [2][BN][2] floats, tiles released by the last barrier
+    // column partials in the tile-shape-independent order of igemm.hip (32-row sub-sums -> 64-row records)
+    float* cs_lds = reinterpret_cast<float*>(smem);     // [BM/32][BN][2] floats, tiles released by the last barrier
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + lr;
         const bool cok = col < p.N;
         const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
-        float cs = 0.f, cq = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float cs = 0.f, cq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -207,24 +208,26 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
                 cs += v;
                 cq += v * v;
             }
-        }
-        if (p.colstats) {
-            cs += __shfl_xor(cs, 32, 64);
-            cq += __shfl_xor(cq, 32, 64);
-            if (lk == 0) {
-                float* d = cs_lds + (((wave >> 1) * BN) + wn0 + j * 32 + lr) * 2;
-                d[0] = cs;
-                d[1] = cq;
+            if (p.colstats) {
+                cs += __shfl_xor(cs, 32, 64);
+                cq += __shfl_xor(cq, 32, 64);
+                if (lk == 0) {
+                    float* d = cs_lds + ((((wave >> 1) * TM + i) * BN) + wn0 + j * 32 + lr) * 2;
+                    d[0] = cs;
+                    d[1] = cq;
+                }
             }
         }
     }
     if (p.colstats) {
         __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            if (n0 + c >= p.N) continue;
-            const float s0 = cs_lds[c * 2] + cs_lds[(BN + c) * 2];
-            const float q0 = cs_lds[c * 2 + 1] + cs_lds[(BN + c) * 2 + 1];
-            float* d = p.colstats + (size_t)tile_m * 2 * p.N + n0 + c;
+        constexpr int REC = BM / 64;
+        for (int c = tid; c < BN * REC; c += NT) {
+            const int rec = c / BN, cc = c - rec * BN;
+            if (n0 + cc >= p.N) continue;
+            const float s0 = cs_lds[((2 * rec) * BN + cc) * 2] + cs_lds[((2 * rec + 1) * BN + cc) * 2];
+            const float q0 = cs_lds[((2 * rec) * BN + cc) * 2 + 1] + cs_lds[((2 * rec + 1) * BN + cc) * 2 + 1];
+            float* d = p.colstats + (size_t)(tile_m * REC + rec) * 2 * p.N + n0 + cc;
             d[0] = s0;
             d[p.N] = q0;
         }
@@ -291,7 +294,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         if (tile_rows) *tile_rows = 64;
         hipLaunchKernelGGL((conv_igemm_h2<64, 64>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
     } else {
-        if (tile_rows) *tile_rows = 128;
+        if (tile_rows) *tile_rows = 64;   // records are per 64 output rows in every variant
         p.tiles_n = (N + 127) / 128;
         p.tiles = (int)tiles(128, 128);
         hipLaunchKernelGGL((conv_igemm_h2<128, 128>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);

@@ -53,10 +53,11 @@ int dp_prof_collect(double* ms3x3, long long* n3x3, double* flop3x3,
  *   bias [N] or NULL; temb [B][temb_stride] or NULL (temb_stride 0 broadcasts one row);
  *   res [M][ldr] or NULL; out [M][ldo].
  * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation).
- * colstats (optional): [ceil(M/tile_rows)][2][N] floats; for every tile of `*tile_rows` consecutive output
- *   rows (the value is returned through tile_rows: 64 or 128) the per-column sum and sum of squares of the
- *   FINAL values, reduced in a fixed order inside the epilogue.  dp_gn_finalize_cols turns them into the
- *   GroupNorm statistics of the tensor without re-reading it (the caller sizes the buffer for 64-row tiles).
+ * colstats (optional): [ceil(M/64)][2][N] floats; for every record of 64 consecutive output rows the
+ *   per-column sum and sum of squares of the FINAL values, reduced inside the epilogue in an order that
+ *   does not depend on the tile shape the dispatcher picks (bit-identical for any batch sharding).
+ *   *tile_rows returns the record size (64).  dp_gn_finalize_cols turns the records into the GroupNorm
+ *   statistics of the tensor without re-reading it.
  */
 int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
                    int B, int H, int W, int KH, int KW,

@@ -233,3 +233,20 @@ def test_f16x3_config1_cifar_b4_20steps_vs_oracle():
     a = pur.sde(x0[:2], 100, 5e-3, seed=5, sample0=0)
     b = pur.sde(x0[2:], 100, 5e-3, seed=5, sample0=2)
     assert torch.equal(pur.sde(x0, 100, 5e-3, seed=5, sample0=0), torch.cat([a, b]))
+
+
+def test_shard_invariance_across_kernel_variants():
+    """A batch of 160 and its two shards of 80 pick different convolution tile shapes (128- vs 64-row
+    tiles); results - including the GroupNorm statistics taken from the convolution epilogues - must still
+    be bit-identical."""
+    from diffpure_amd import ncsnpp as pn
+    from diffpure_amd.sde import Purifier
+    g = load_golden("ncsnpp_small.pt")
+    cfg = pn.parse_config(g["cfg"])
+    net = pn.NCSNpp(cfg, DEV, precision="f16x3").load_state_dict(synth_state_dict(pn.param_shapes(cfg), g["seed"]))
+    x0 = torch.rand(160, 3, 16, 16, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    pur = Purifier(net, "ncsnpp", DEV)
+    full = pur.sde(x0, 100, 2.5e-2, seed=5, sample0=0)
+    a = pur.sde(x0[:80], 100, 2.5e-2, seed=5, sample0=0)
+    b = pur.sde(x0[80:], 100, 2.5e-2, seed=5, sample0=80)
+    assert torch.equal(full, torch.cat([a, b]))
