@@ -84,6 +84,20 @@ def sde_schedule(kind, t_int, dt=1e-3):
     return steps
 
 
+def sde_schedule_at_ends(kind, t_int, dt=1e-3):
+    """Coefficients of the reverse SDE evaluated at the END t'_{k+1} of every step k (the stochastic adjoint
+    walks the forward clock backwards and evaluates f, g at the point it is leaving)."""
+    grid = sde_clock(t_int, dt)
+    out = []
+    for k in range(len(grid) - 1):
+        s = 1 - grid[k + 1]
+        beta = BETA_MIN + s * (BETA_MAX - BETA_MIN)
+        g = torch.sqrt(beta)
+        coef, div, mt = _score_scalars(kind, s)
+        out.append(dict(nhb=(-0.5 * beta).item(), gg=(g ** 2).item(), sc=coef, div=div, g=g.item(), model_time=mt, s=s.item()))
+    return out
+
+
 def ode_schedule(kind, t_int, step=1e-3, reverse=False):
     grid = ode_clock(t_int, step, reverse)
     steps = []
@@ -177,6 +191,39 @@ class Purifier:
             x = ops.em_step(x, eps, st["nhb"], st["gg"], st["sc"], st["div"], st["h"], st["g"], st["sqrt_h"], noise=z,
                             seed=seed, sample0=sample0, step=k, out=x)
         return to_nchw(x)
+
+    def sde_vjp(self, x_final_nchw, grad_out_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0):
+        """Stochastic adjoint of `sde` (upstream: torchsde.sdeint_adjoint behind
+        runners/diffpure_sde.py:236-238).  g(t) is state-independent, so the adjoint has no noise term:
+        da = -a^T df/dy dt, while the state is re-integrated backward from x_final along the SAME Brownian
+        path - free here, because the Philox increments are a pure function of (seed, sample, step) and are
+        simply regenerated (torchsde has to keep a BrownianInterval tree for this).  Euler on the forward
+        clock in reverse:  y_k = y_{k+1} - f(t_{k+1}, y_{k+1}) h_k - g(t_{k+1}) dW_k,
+                           a_k = a_{k+1} + h_k (df/dy)^T a_{k+1}.
+        -> dL/dx at t'_0 (before the forward-diffusion scaling), NCHW."""
+        y = to_nhwc(x_final_nchw.to(self.device, torch.float32))
+        a = to_nhwc(grad_out_nchw.to(self.device, torch.float32))
+        sched = sde_schedule(self.kind, t_int, dt)
+        # coefficients at the END point t_{k+1} of every interval: the schedule entry of step k+1, plus one
+        # more entry for the final time t'_end
+        ends = sde_schedule_at_ends(self.kind, t_int, dt)
+        table = self._tables(("sde_rev", t_int, dt), ends)
+        for k in reversed(range(len(sched))):
+            st, en = sched[k], ends[k]
+            tape = []
+            eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
+            gj = self.net.vjp(tape, a)                      # (d eps / d y)^T a
+            del tape
+            kk = (-1.0 / en["sc"]) if en["div"] else en["sc"]   # score = kk * eps
+            h = st["h"]
+            # f = -(nhb*y - gg*score)  =>  (df/dy)^T a = -nhb*a + gg*kk*J^T a
+            a_new = ops.axpby(a, 1.0 - h * en["nhb"], gj, h * en["gg"] * kk)
+            z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
+            # y - f*h - g*dW  ==  em_step with (h -> -h, g -> -g): x + (-drift)*(-h) + (-g)*(z*sqrt_h)
+            y = ops.em_step(y, eps, en["nhb"], en["gg"], en["sc"], en["div"], -h, -en["g"], st["sqrt_h"], noise=z, seed=seed,
+                            sample0=sample0, step=k, out=y)
+            a = a_new
+        return to_nchw(a)
 
     # -- probability-flow ODE forward (OdeGuidedDiffusion.image_editing_sample) -------------------
     def ode(self, x_nchw, t_int, step=1e-3, noise=None, seed=0, sample0=0, e_nhwc=None):

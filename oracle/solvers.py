@@ -135,6 +135,34 @@ def sde_purify(score_fn, x0, e, noises, t_int, dt=1e-3):
     return x
 
 
+def sde_adjoint_grad(score_fn, x_final, grad_out, noises, t_int, dt=1e-3):
+    """Stochastic adjoint of the reverse VP-SDE solve (what torchsde.sdeint_adjoint provides for
+    runners/diffpure_sde.py:236-238; torchsde itself is absent, so this restates the published scheme,
+    Li et al. 2020, for this SDE): the diffusion g(t) does not depend on the state, so the adjoint process
+    has no noise term and no Ito correction,
+        da = -a^T (df/dy) dt ,
+    and the state is re-integrated BACKWARD from x_final along the SAME Brownian path.  Discretisation:
+    Euler on the forward clock walked in reverse, with the forward increments dW_k = sqrt(h_k) z_k reused:
+        y_k = y_{k+1} - f(t_{k+1}, y_{k+1}) h_k - g(t_{k+1}) dW_k
+        a_k = a_{k+1} + h_k (df/dy (t_{k+1}, y_{k+1}))^T a_{k+1}
+    ("parity unpinned" against torchsde, which walks its own grid from the far end and queries its
+    BrownianInterval there; pinned instead to torch.autograd through the unrolled forward loop, to which it
+    converges as dt -> 0: tests/test_host_logic_grad.py).  -> dL/dx at t'_0 (before the diffusion scaling)."""
+    grid = sde_time_grid(t_int, dt)
+    y, a = x_final.clone(), grad_out.clone()
+    for k in reversed(range(len(grid) - 1)):
+        tk, tn = grid[k], grid[k + 1]
+        h = tn - tk
+        with torch.enable_grad():
+            yy = y.detach().requires_grad_(True)
+            f = rev_sde_f(score_fn, tn, yy)
+            (vjp,) = torch.autograd.grad(f, yy, a)
+        g = rev_sde_g(tn, y.shape[0])[:, None, None, None]
+        y = y - f.detach() * h - g * (noises[k] * torch.sqrt(h))
+        a = a + h * vjp
+    return a
+
+
 # ----------------------------------------------------------------------------------------------
 # probability-flow ODE (diffpure_ode.py) + adjoint
 # ----------------------------------------------------------------------------------------------

@@ -21,6 +21,28 @@ from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC, Purifier
 from . import _common
 
 
+class _SdePurify(torch.autograd.Function):
+    """purified = EM-solve(diffuse(img)); backward = the stochastic adjoint on the HIP engine with the SAME
+    (regenerated) Brownian path - what torchsde.sdeint_adjoint provides upstream (reference :236-238)."""
+
+    @staticmethod
+    def forward(ctx, img, runner, t, dt, noise, seed, sample0):
+        with torch.no_grad():
+            out = runner.purifier.sde(img, t, dt, noise=noise, seed=seed, sample0=sample0)
+        ctx.runner, ctx.cfg = runner, (t, dt, noise, seed, sample0)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (out,) = ctx.saved_tensors
+        t, dt, noise, seed, sample0 = ctx.cfg
+        with torch.no_grad():
+            a = ctx.runner.purifier.sde_vjp(out, grad_out, t, dt, noise=noise, seed=seed, sample0=sample0)
+            a = a * ctx.runner.purifier.diffuse_scale(t)
+        return a, None, None, None, None, None, None
+
+
 class RevGuidedDiffusion(torch.nn.Module):
     def __init__(self, args, config, device=None):
         super().__init__()
@@ -47,10 +69,12 @@ class RevGuidedDiffusion(torch.nn.Module):
     def image_editing_sample(self, img, bs_id=0, tag=None, noise=None):
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim
-        _common.check_no_grad_needed(img, "RevGuidedDiffusion.image_editing_sample")
         out_dir = _common.out_dir_for(self.args, bs_id, tag)
         log = bs_id < 2 and out_dir is not None
-        with torch.no_grad():
+        need_grad = img.requires_grad and torch.is_grad_enabled()
+        if need_grad and getattr(self.args, "shard_batch", False):
+            raise NotImplementedError("gradients through a batch-sharded purification call: run the attack per rank")
+        with torch.set_grad_enabled(need_grad):
             x0 = img.to(self.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
@@ -67,6 +91,8 @@ class RevGuidedDiffusion(torch.nn.Module):
                 self._calls += 1
 
                 def run(xl, sample0, t=t, call_seed=call_seed):
+                    if need_grad:
+                        return _SdePurify.apply(xl, self, t, dt, noise, call_seed, sample0)
                     return self.purifier.sde(xl, t, dt, noise=noise, seed=call_seed, sample0=sample0)
 
                 x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)

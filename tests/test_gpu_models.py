@@ -181,8 +181,12 @@ def test_drop_in_runner_boundary(tmp_path):
     out = runner.image_editing_sample(x, bs_id=0, tag="t")
     assert out.shape == (6, 3, 16, 16) and out.device.type == "cuda" and torch.isfinite(out).all()
     assert (tmp_path / "bs0_t").is_dir()
-    with pytest.raises(NotImplementedError):
-        runner.image_editing_sample(x.clone().requires_grad_(True), bs_id=5)
+    # differentiable w.r.t. the input (stochastic adjoint with the regenerated Philox path)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    args.sample_step = 1
+    o = runner.image_editing_sample(xg, bs_id=5)
+    (gx,) = torch.autograd.grad((o ** 2).sum(), xg)
+    assert gx.shape == xg.shape and torch.isfinite(gx).all() and gx.abs().max() > 0
 
 
 # ---- precision="f16x3": split-fp16 three-pass MFMA path, same tolerances as fp32 -----------------

@@ -130,3 +130,82 @@ def test_oracle_adjoint_converges_to_unrolled_autograd():
         ref = osol.ode_diffuse_grad(osol.ode_adjoint_grad(score, o2.detach(), cot, 100, step), 100)
         cos.append(torch.nn.functional.cosine_similarity(ref.flatten(), g2.flatten(), dim=0).item())
     assert cos[1] > 0.95 and cos[1] > cos[0], cos
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
+def test_sde_stochastic_adjoint_matches_oracle(kind):
+    if kind == "ncsnpp":
+        g = load_golden("ncsnpp_small.pt")
+        cfg = pn.parse_config(g["cfg"])
+        sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+        net = pn.NCSNpp(cfg, "cpu").load_state_dict(sd)
+        score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    else:
+        g = load_golden("guided_small.pt")
+        cfg = pg.parse_config(g["cfg"])
+        sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
+        net = pg.GuidedUNet(cfg, "cpu").load_state_dict(sd)
+        score = osol.make_score_fn("guided", sd, og.parse_guided_config(g["cfg"]))
+    gen = torch.Generator().manual_seed(4)
+    x0 = g["x"]
+    dt = 2e-2
+    n = len(osol.sde_time_grid(100, dt)) - 1
+    e = torch.randn(x0.shape, generator=gen)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(n)]
+    cot = torch.randn(x0.shape, generator=gen)
+    with torch.no_grad():
+        xf = osol.sde_purify(score, x0, e, zs, 100, dt)
+    ref = osol.ode_diffuse_grad(osol.sde_adjoint_grad(score, xf, cot, zs, 100, dt), 100)
+    pur = psde.Purifier(net, kind, "cpu")
+    got = pur.sde_vjp(xf, cot, 100, dt, noise=dict(e=e, z=zs)) * pur.diffuse_scale(100)
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+
+
+def test_oracle_sde_adjoint_converges_to_unrolled_autograd():
+    """The restated stochastic adjoint approaches torch.autograd through the unrolled Euler-Maruyama loop
+    (same injected noise) as dt shrinks."""
+    g = load_golden("ncsnpp_small.pt")
+    sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    gen = torch.Generator().manual_seed(9)
+    e = torch.randn(g["x"].shape, generator=gen)
+    cot = torch.randn(g["x"].shape, generator=gen)
+    cos = []
+    for dt in (2e-2, 5e-3):
+        n = len(osol.sde_time_grid(100, dt)) - 1
+        zs = [torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(100 + i)) for i in range(n)]
+        xr = g["x"].clone().requires_grad_(True)
+        with torch.enable_grad():
+            o2 = osol.sde_purify(score, xr, e, zs, 100, dt)
+            (g2,) = torch.autograd.grad(o2, xr, cot)
+        ref = osol.ode_diffuse_grad(osol.sde_adjoint_grad(score, o2.detach(), cot, zs, 100, dt), 100)
+        cos.append(torch.nn.functional.cosine_similarity(ref.flatten(), g2.flatten(), dim=0).item())
+    assert cos[1] > 0.93 and cos[1] > cos[0], cos   # measured 0.69 / 0.947 / 0.988 / 0.997 at dt 2e-2 / 5e-3 / 2e-3 / 1e-3
+
+
+def test_sde_runner_is_differentiable():
+    from runners.diffpure_sde import RevGuidedDiffusion
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device("cpu")
+    args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=None, score_type="score_sde",
+                              seed=1234, synthetic_weights=True, dt=2e-2, precision="f32")
+    runner = RevGuidedDiffusion(args, config, device="cpu")
+    gen = torch.Generator().manual_seed(4)
+    x0 = g["x"].clone().requires_grad_(True)
+    e = torch.randn(x0.shape, generator=gen)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(5)]
+    cot = torch.randn(x0.shape, generator=gen)
+    out = runner.image_editing_sample(x0, bs_id=7, noise=dict(e=e, z=zs))
+    (out * cot).sum().backward()
+    sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    ref = osol.ode_diffuse_grad(osol.sde_adjoint_grad(score, out.detach(), cot, zs, 100, 2e-2), 100)
+    torch.testing.assert_close(x0.grad, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
