@@ -43,8 +43,6 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int NT = 256;
-constexpr int BKH = 32;          // k elements per tile
-constexpr int ROWB = 128;        // bytes per LDS row (32 k x (hi,lo) fp16)
 constexpr int NXCD = 8;
 
 struct ConvH2Args {
@@ -63,15 +61,35 @@ struct ConvH2Args {
     float scale;
     int tiles_n, tiles;
     const char* zero;   // >= 128 zero bytes in device memory (weight rows n >= N)
-    float* colstats;    // optional [tiles_m][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
+    float* colstats;    // optional [M/64][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
 };
 
-__device__ __forceinline__ int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+// Tile variants (all: 256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS
+// stages, two workgroups per CU):
+//   <128,128,32>  TM=TN=2   64 KB LDS   8 DMA + 16 ds_read per 24 MFMA per wave   (general)
+//   <64,64,32>    TM=TN=1   32 KB LDS                                              (few tiles)
+//   <128,256,16>, <256,128,16>  TM x TN = 2x4 / 4x2, 48 KB LDS, 6 DMA + 12 ds_read per 24 MFMA: built and
+//                 tested, but NOT faster (342 vs 344 TFLOP/s on 256^2 x 256->256): their 64-byte DMA rows are
+//                 half cache lines, so line transactions per MFMA rise 1.5x.  Only used with DP_H2_PRIO=11.
+// Timing ablations on <128,128,32> (256^2 x 256->256, B=8): as is 337 TFLOP/s; without the per-tile
+// wait+barrier 338 (synchronisation is NOT the cost); without any operand DMA 445 = 1.33 PFLOP/s of executed
+// fp16 MFMA, the rate the best plain-HIP GEMM reaches on random data under this chip's DVFS.
+// BKH = k elements per LDS stage (32 or 16); an LDS row holds BKH (hi,lo) pairs = BKH*4 bytes = SPR 16-byte
+// slots.  XOR swizzle of the slot index with row bits chosen so that 16 consecutive rows at one logical slot
+// cover 16 distinct 16-byte bank positions: (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows.
+template <int BKH>
+__device__ __forceinline__ int swz(int row, int slot) {
+    if constexpr (BKH == 32) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    else return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+}
 
-template <int BM, int BN>
-__global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
+template <int BM, int BN, int BKH, int ABL>
+__global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     constexpr int TM = BM / 64, TN = BN / 64;           // 2x2 waves, 32x32 MFMA tiles
-    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+    constexpr int ROWB = BKH * 4, SPR = BKH / 4;        // bytes / 16-byte slots per LDS row
+    constexpr int RPP = NT / SPR, RPI = 64 / SPR;       // rows staged per pass of the workgroup / per DMA instruction
+    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+    constexpr int NS = BKH / 16, NSUB = 32 / BKH;       // k16 sub-steps per stage; stages per 32-channel slice
     constexpr int STAGE = (BM + BN) * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -86,8 +104,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W;
-    const int r0 = tid >> 3;
-    const int ls = (tid & 7) ^ ((tid >> 4) & 7);       // logical slot this lane fetches (same for every it)
+    const int r0 = tid / SPR;
+    // logical slot this lane fetches: physical slot (tid % SPR) un-swizzled with the row key, which is the
+    // same for every pass because RPP is a multiple of 16
+    const int ls = (BKH == 32) ? ((tid & 7) ^ ((r0 >> 1) & 7)) : ((tid & 3) ^ ((r0 >> 2) & 3));
     const int taps = p.KS * p.KS;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: LDS-DMA bases stay scalar
     const int Wp = p.W + 2;
@@ -96,7 +116,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
     const char* ctr[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int m = min(m0 + r0 + it * 32, p.M - 1);   // tail rows re-read the last pixel; never stored
+        const int m = min(m0 + r0 + it * RPP, p.M - 1);   // tail rows re-read the last pixel; never stored
         const int b = m / HW, rem = m - b * HW;
         const int oy = rem / p.W, ox = rem - oy * p.W;
         ctr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 + ls * 16;
@@ -105,30 +125,34 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
     int bstep[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int n = n0 + r0 + it * 32;
+        const int n = n0 + r0 + it * RPP;
         const bool ok = n < p.N;
         bptr[it] = ok ? p.w + (size_t)n * p.K * 4 + ls * 16 : p.zero + ls * 16;
         bstep[it] = ok ? ROWB : 0;
     }
 
-    // workgroup-uniform cursor of the k-tile being staged: channel slice c32, tap
-    int cur_c = 0, cur_tap = 0;
+    // workgroup-uniform cursor of the k-stage being staged, in weight order: 32-channel slice c32 outermost,
+    // then the tap, then (BKH == 16) the half of the slice
+    int cur_c = 0, cur_tap = 0, cur_h = 0;
     auto issue = [&](int stage) {
         const int ky = cur_tap / p.KS, kx = cur_tap - ky * p.KS;
-        const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)cur_c * ROWB;
-        char* As = smem + stage * STAGE + wave_u * 8 * ROWB;
+        const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)cur_c * 128 + cur_h * ROWB;
+        char* As = smem + stage * STAGE + wave_u * RPI * ROWB;
         char* Bs = As + BM * ROWB;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ctr[it] + off),
-                                             (__attribute__((address_space(3))) void*)(As + it * 32 * ROWB), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(As + it * RPP * ROWB), 16, 0, 0);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
-                                             (__attribute__((address_space(3))) void*)(Bs + it * 32 * ROWB), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(Bs + it * RPP * ROWB), 16, 0, 0);
             bptr[it] += bstep[it];
         }
-        if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+        if (NSUB == 1 || ++cur_h == NSUB) {
+            cur_h = 0;
+            if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -144,21 +168,22 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
         const char* As = smem + stage * STAGE;
         const char* Bs = As + BM * ROWB;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             half8 ah[TM], al[TM], bh[TN], bl[TN];
             const int sl = s * 4 + lk * 2;  // hi slot; lo slot = sl + 1
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm0 + i * 32 + lr;
-                ah[i] = *reinterpret_cast<const half8*>(As + swz(row, sl));
-                al[i] = *reinterpret_cast<const half8*>(As + swz(row, sl + 1));
+                ah[i] = *reinterpret_cast<const half8*>(As + swz<BKH>(row, sl));
+                al[i] = *reinterpret_cast<const half8*>(As + swz<BKH>(row, sl + 1));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lr;
-                bh[j] = *reinterpret_cast<const half8*>(Bs + swz(row, sl));
-                bl[j] = *reinterpret_cast<const half8*>(Bs + swz(row, sl + 1));
+                bh[j] = *reinterpret_cast<const half8*>(Bs + swz<BKH>(row, sl));
+                bl[j] = *reinterpret_cast<const half8*>(Bs + swz<BKH>(row, sl + 1));
             }
+            if constexpr (ABL == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -171,6 +196,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            if constexpr (ABL == 1) __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -180,8 +206,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2(ConvH2Args p) {
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) issue(cur ^ 1);      // DMA of tile t+1 flies under the MFMAs of tile t
+        if constexpr (ABL == 2) {            // TIMING ABLATION ONLY (wrong results): no DMA after the prologue
+            compute(cur);
+            __syncthreads();
+            continue;
+        }
+        if (t + 1 < nt) issue(cur ^ 1);      // DMA of stage t+1 flies under the MFMAs of stage t
         compute(cur);
+        if constexpr (ABL == 3) continue;    // TIMING ABLATION ONLY (wrong results): no wait, no barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -285,20 +317,28 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.colstats = colstats;
     DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc_h2: colstats needs tile_rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // tuning switch: 0 = heuristic below; 1 = s_setprio around the MFMA clusters (measured: no gain);
+    // 2 / 3 = timing ablations (WRONG RESULTS); 10 = force <128,128,32>; 11 = force the wide variants
+    static const int sw = [] { const char* e = getenv("DP_H2_PRIO"); return e ? atoi(e) : 0; }();
     void* rec = nullptr;
     dp_prof_begin(KS == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (N <= 64 || tiles(128, 128) < 256) {
-        p.tiles_n = (N + 63) / 64;
-        p.tiles = (int)tiles(64, 64);
-        if (tile_rows) *tile_rows = 64;
-        hipLaunchKernelGGL((conv_igemm_h2<64, 64>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
-    } else {
-        if (tile_rows) *tile_rows = 64;   // records are per 64 output rows in every variant
-        p.tiles_n = (N + 127) / 128;
-        p.tiles = (int)tiles(128, 128);
-        hipLaunchKernelGGL((conv_igemm_h2<128, 128>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
-    }
+#define DP_H2_LAUNCH(BM_, BN_, BK_, ABL_)                                                                  \
+    do {                                                                                                   \
+        p.tiles_n = (N + BN_ - 1) / BN_;                                                                   \
+        p.tiles = (int)tiles(BM_, BN_);                                                                    \
+        hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p); \
+    } while (0)
+    const bool wide_ok = sw == 11 && tiles(128, 256) >= 384;      // wide variants: experiment only (see above)
+    if (N <= 64 || tiles(128, 128) < 256) DP_H2_LAUNCH(64, 64, 32, 0);
+    else if (wide_ok && N % 256 == 0) DP_H2_LAUNCH(128, 256, 16, 0);
+    else if (wide_ok && N <= 128) DP_H2_LAUNCH(256, 128, 16, 0);
+    else if (sw == 1) DP_H2_LAUNCH(128, 128, 32, 1);
+    else if (sw == 2) DP_H2_LAUNCH(128, 128, 32, 2);
+    else if (sw == 3) DP_H2_LAUNCH(128, 128, 32, 3);
+    else DP_H2_LAUNCH(128, 128, 32, 0);
+#undef DP_H2_LAUNCH
+    if (tile_rows) *tile_rows = 64;   // column-sum records are per 64 output rows in every variant
     dp_prof_end(rec, s);
     DP_LAUNCH_CHECK("conv_igemm_h2");
     return 0;
