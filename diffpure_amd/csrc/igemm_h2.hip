@@ -286,14 +286,20 @@ __global__ void pack_h2_kernel(const float* src, long long rows, int cols, int l
     }
 }
 
+// 256 zero bytes on the CURRENT device (one page per device: a process may drive several GPUs from several
+// threads); allocated on first use, which must therefore happen outside any stream capture.
 const char* zero_page() {
-    static void* z = nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        if (hipMalloc(&z, 256) == hipSuccess) (void)hipMemset(z, 0, 256);
-        else z = nullptr;
-    });
-    return static_cast<const char*>(z);
+    constexpr int MAXDEV = 64;
+    static void* z[MAXDEV] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!z[dev]) {
+        if (hipMalloc(&z[dev], 256) != hipSuccess) return nullptr;
+        if (hipMemset(z[dev], 0, 256) != hipSuccess) return nullptr;
+    }
+    return static_cast<const char*>(z[dev]);
 }
 
 }  // namespace
@@ -330,6 +336,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p); \
     } while (0)
     const bool wide_ok = sw == 11 && tiles(128, 256) >= 384;      // wide variants: experiment only (see above)
+    // (thresholds 256 / 512 / 1024 and a <128,64,32> middle variant were tried on the low-resolution shapes:
+    //  all within run-to-run noise)
     if (N <= 64 || tiles(128, 128) < 256) DP_H2_LAUNCH(64, 64, 32, 0);
     else if (wide_ok && N % 256 == 0) DP_H2_LAUNCH(128, 256, 16, 0);
     else if (wide_ok && N <= 128) DP_H2_LAUNCH(256, 128, 16, 0);
