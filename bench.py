@@ -226,6 +226,9 @@ def main():
                                    "executed MFMA flops = 3 x achieved)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": None if ach is None else ach / peak,
                          "traffic": None, "launches": prof["n3x3"],
+                         # f16x3 spends 3 fp16 MFMA passes per algorithmic MAC: the matrix pipe executes 3x `achieved`
+                         "mfma_passes": 3 if a.precision == "f16x3" else 1,
+                         "executed_frac": None if ach is None else ach * (3 if a.precision == "f16x3" else 1) / peak,
                          "avg_launch_ms": prof["ms3x3"] / max(1, prof["n3x3"]),
                          "time_share_of_step": prof["ms3x3"] * 1e-3 / el,
                          "end_to_end_unet_tflops_per_gpu": unet_tflops},
