@@ -83,14 +83,20 @@ __global__ void gn_finalize_cols_kernel(const float* cs1, int C1, int tr1, const
     __shared__ double rq[256];
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int C = C1 + C2, cpg = C / G;
+    const int ch0 = g * cpg, ch1 = ch0 + cpg;
     double s = 0.0, q = 0.0;
-    for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
-        const bool first = ch < C1;
-        const float* base = first ? cs1 : cs2;
-        const int Cs = first ? C1 : C2, c = first ? ch : ch - C1, tr = first ? tr1 : tr2;
-        const int tps = HW / tr;
-        for (int t = threadIdx.x; t < tps; t += blockDim.x) {
-            const float* rec = base + (size_t)(b * tps + t) * 2 * Cs;
+    // the group's channels are contiguous inside a record: threads sweep (record, channel) pairs so that
+    // consecutive lanes read consecutive floats (a group may straddle the two sources)
+    for (int src = 0; src < 2; ++src) {
+        const float* base = src ? cs2 : cs1;
+        const int Cs = src ? C2 : C1, tr = src ? tr2 : tr1, coff = src ? C1 : 0;
+        const int lo = max(ch0, coff) - coff, hi = min(ch1, coff + Cs) - coff;   // channel range inside this source
+        if (!base || hi <= lo) continue;
+        const int n = hi - lo, tps = HW / tr;
+        const float* rec0 = base + (size_t)b * tps * 2 * Cs + lo;
+        for (int idx = threadIdx.x; idx < tps * n; idx += blockDim.x) {
+            const int t = idx / n, c = idx - t * n;
+            const float* rec = rec0 + (size_t)t * 2 * Cs;
             s += rec[c];
             q += rec[Cs + c];
         }
