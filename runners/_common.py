@@ -21,11 +21,3 @@ def save_image(x, path):
     except Exception:
         return
     tvu.save_image((x + 1) * 0.5, path)
-
-
-def check_no_grad_needed(img, what):
-    if img.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError(
-            f"{what}: gradients w.r.t. the input are not available on this runner yet (the stochastic adjoint of the "
-            "reverse SDE is listed as 'next' in SURVEY.md section 8f); use diffusion_type='ode' for adaptive-attack "
-            "gradients, or call under torch.no_grad().")

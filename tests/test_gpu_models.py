@@ -1,7 +1,7 @@
 """-m gpu: the HIP engine end to end against (a) golden vectors produced by the reference's own
 modules and (b) the CPU oracle on the same seeded inputs, weights and injected noise.
 
-Tolerances (fp32 MFMA path; stated per SURVEY.md section 8c / north_star):
+Tolerances (identical for precision="f32" and the default "f16x3"; stated per SURVEY.md section 8c / north_star):
   single UNet forward            max-abs 1e-3 relative to outputs of O(1) (observed ~1e-5)
   purified pixels, full loop     max-abs 1e-3   (BASELINE.json north_star)
 """
