@@ -1,0 +1,26 @@
+// Argument block shared by the f16x3 implicit-GEMM convolution kernels (igemm_h2.hip, igemm_h2_pp.hip).
+#pragma once
+#include "dp_common.h"
+
+struct ConvH2Args {
+    const char* x;      // [B][H+2][W+2][C] h2, zero border
+    int C;
+    int B, H, W, KS, pad;
+    const char* w;
+    const float* bias;
+    const float* temb;
+    int temb_stride;
+    const float* res;
+    int ldr;
+    float* out;
+    int ldo;
+    int M, N, K;
+    float scale;
+    int tiles_n, tiles;
+    const char* zero;   // >= 128 zero bytes in device memory (weight rows n >= N)
+    float* colstats;    // optional [M/64][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
+};
+
+// 256x256-tile, 8-wave "ping-pong" variant (igemm_h2_pp.hip).  Preconditions (checked by the caller):
+// M % 256 == 0, N % 256 == 0, C % 32 == 0.  Fills p.tiles / p.tiles_n itself.
+void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s);

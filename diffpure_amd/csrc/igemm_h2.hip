@@ -36,7 +36,7 @@
 #include <mutex>
 #include <stdlib.h>
 
-#include "dp_common.h"
+#include "igemm_h2.h"
 
 namespace {
 
@@ -44,25 +44,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int NT = 256;
 constexpr int NXCD = 8;
+constexpr int DP_H2_PP_DEFAULT = 0;   // see the dispatcher
 
-struct ConvH2Args {
-    const char* x;      // [B][H+2][W+2][C] h2, zero border
-    int C;
-    int B, H, W, KS, pad;
-    const char* w;
-    const float* bias;
-    const float* temb;
-    int temb_stride;
-    const float* res;
-    int ldr;
-    float* out;
-    int ldo;
-    int M, N, K;
-    float scale;
-    int tiles_n, tiles;
-    const char* zero;   // >= 128 zero bytes in device memory (weight rows n >= N)
-    float* colstats;    // optional [M/64][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
-};
 
 // Tile variants (all: 256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS
 // stages, two workgroups per CU):
@@ -335,6 +318,21 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         p.tiles = (int)tiles(BM_, BN_);                                                                    \
         hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p); \
     } while (0)
+    // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
+    // also fills the chip (>= one tile per CU); unset = DP_H2_PP_DEFAULT.  Read per call so that a probe can
+    // flip it inside one process.
+    {
+        const char* e = getenv("DP_H2_PP");
+        const int pp = e ? atoi(e) : DP_H2_PP_DEFAULT;
+        const bool shape_ok = p.M % 256 == 0 && N % 256 == 0;
+        if (shape_ok && pp != 0 && (pp == 1 || tiles(256, 256) >= 256)) {
+            dp_launch_conv_h2_pp(p, s);
+            if (tile_rows) *tile_rows = 64;
+            dp_prof_end(rec, s);
+            DP_LAUNCH_CHECK("conv_igemm_h2_pp");
+            return 0;
+        }
+    }
     const bool wide_ok = sw == 11 && tiles(128, 256) >= 384;      // wide variants: experiment only (see above)
     // (thresholds 256 / 512 / 1024 and a <128,64,32> middle variant were tried on the low-resolution shapes:
     //  all within run-to-run noise)

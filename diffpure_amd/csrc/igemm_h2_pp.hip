@@ -1,0 +1,268 @@
+// f16x3 implicit-GEMM convolution, 256x256 tile, 8 waves in two "ping-pong" groups.
+//
+// Same arithmetic, operand formats and per-element accumulation order as conv_igemm_h2 (igemm_h2.hip):
+// results are bit-identical to the other tile variants.  What changes is the schedule.  The 128x128
+// kernel drains its LDS-DMA queue (vmcnt(0)) and meets a barrier once per k-tile, and each wave stalls
+// four times per k-tile on a full ds_read round trip; PMC showed the matrix pipe 55 % busy, and the
+// ablations put a quarter of the time on operand staging.  Here
+//
+//   * one workgroup = 8 waves = 2 groups (wr = 0, 1) x 4 (wc); wave tile 128 x 64 (4 x 2 MFMA tiles of
+//     32x32); LDS = 2 k-tile buffers x (A 256 rows + B 256 rows) x 128 B = 128 KB -> one workgroup per CU,
+//     two waves per SIMD, one from each group (waves 0-3 / 4-7 land on distinct SIMDs);
+//   * a k-tile (one 32-channel slice of one tap) is computed in FOUR phases, one 64x32 quadrant of the
+//     wave tile each (Q00, Q01, Q11, Q10: only the operand that changes is re-read from LDS);
+//     a phase is  { ds_read fragments | issue 2 LDS-DMA loads | s_waitcnt vmcnt(6) } barrier
+//     { 12 MFMA } barrier;
+//   * group 1 runs ONE BARRIER LATE: while one wave of a SIMD issues its 12 MFMAs (384 cycles) the
+//     other one does its ds_reads and DMA issue, then they swap - the matrix pipe always has a wave in
+//     its MFMA phase and the loads are spread evenly over time instead of arriving in bursts;
+//   * the DMA queue is never drained in the steady state: every phase stages one 16 KB "unit" (2 loads
+//     per thread) that is read FOUR phases later, and waits only until at most three units are in flight.
+//
+// Hazard bookkeeping (phase numbers j = 4 t + ph; interval = time between two consecutive barriers;
+// group 0 does the load part of phase j in interval 2j and its MFMA part in 2j+1, group 1 one later):
+//   units of k-tile t, buffer t & 1:   A0 = A rows {0..63, 128..191}   read in phase (t,0)
+//                                      B0 = B rows {64 wc + 0..31}      read in phase (t,0), KEPT IN REGISTERS for (t,3)
+//                                      B1 = B rows {64 wc + 32..63}     read in phase (t,1)
+//                                      A1 = A rows {64..127, 192..255}  read in phase (t,2)
+//   staged:  A0(t+1) in (t,0), B1(t+1) in (t,1), A1(t+1) in (t,2)  -> other buffer, last read 4 phases ago
+//            B0(t+2) in (t,3)  -> the buffer being computed, whose B0 was last read 3 phases ago
+//   RAW: a unit staged in phase s is retired by every wave's vmcnt(6) of phase s+3 (in-order return; 2 loads
+//        per phase), which sits BEFORE that phase's first barrier; the earliest reader (group 0, phase s+4,
+//        interval 2s+8) has passed the barrier that closes interval 2s+7, in which group 1 did that wait.
+//   WAR: the last reads of a unit are complete (lgkmcnt(0) after the first barrier of their phase) by
+//        interval 2d+2; the earliest restaging DMA is issued in interval 2(d+3).
+//   The last three k-tiles use vmcnt(0) (fewer than three units follow them).
+// The barriers are inline asm with a memory clobber so that no LDS read is hoisted across them;
+// sched_barrier(0) keeps each MFMA cluster inside its interval.
+#include "igemm_h2.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int NT = 512;
+constexpr int NXCD = 8;
+constexpr int BM = 256, BN = 256;
+constexpr int ROWB = 128;               // bytes per LDS row: 32 channels as (hi, lo) fp16 octets
+constexpr int TILE_B = 256 * ROWB;      // one operand tile of one k-tile
+constexpr int BUF = 2 * TILE_B;         // A tile, then B tile
+
+#define PP_GLDS(src, dst)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),     \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define PP_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+__global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int tile;
+    {   // XCD-aware bijective remap (speed only)
+        const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
+    }
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
+    const int nt = p.K / 32;
+
+    // ---- staging geometry: a unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7
+    const int u = tid >> 3;
+    const int ls = (tid & 7) ^ ((u >> 1) & 7);     // logical slot fetched (XOR swizzle applied on the source side)
+    const char* actr[2][2];                        // [unit][piece]: centre pixel of A row m0 + piece*128 + unit*64 + u
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + i * 128 + a * 64 + u;
+            const int b = m / HW, rem = m - b * HW;
+            const int oy = rem / p.W, ox = rem - oy * p.W;
+            actr[a][i] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 + ls * 16;
+        }
+    const char* bsrc[2][2];                        // [unit][piece]: weight row n0 + piece*128 + (u>>5)*64 + unit*32 + (u&31)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + i * 128 + (u >> 5) * 64 + b * 32 + (u & 31);
+            bsrc[b][i] = p.w + (size_t)n * p.K * 4 + ls * 16;
+        }
+    const int u0 = wave * 8;                       // first row of this wave inside a piece (wave-uniform)
+    const int adst = u0 * ROWB;                                            // + (piece*128 + unit*64) * ROWB
+    const int bdst = TILE_B + ((u0 >> 5) * 64 + (u0 & 31)) * ROWB;         // + (piece*128 + unit*32) * ROWB
+
+    auto tap_off = [&](int c32, int tap) -> long long {
+        const int ky = tap / p.KS, kx = tap - ky * p.KS;
+        return ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)c32 * 128;
+    };
+    auto stage_a = [&](char* buf, int a, long long off) {
+        PP_GLDS(actr[a][0] + off, buf + adst + (a * 64) * ROWB);
+        PP_GLDS(actr[a][1] + off, buf + adst + (128 + a * 64) * ROWB);
+    };
+    auto stage_b = [&](char* buf, int b, long long off) {
+        PP_GLDS(bsrc[b][0] + off, buf + bdst + (b * 32) * ROWB);
+        PP_GLDS(bsrc[b][1] + off, buf + bdst + (128 + b * 32) * ROWB);
+    };
+
+    // ---- fragment addressing: lane -> row lr of a 32-row MFMA tile, k-half lk; slot (s*4 + lk*2 + h) ^ key
+    const int lr = lane & 31, lk = lane >> 5, key = (lr >> 1) & 7;
+    const int arow = (wr * 128 + lr) * ROWB;                 // + (sub*64 + i*32) * ROWB
+    const int brow = TILE_B + (wc * 64 + lr) * ROWB;         // + (sub*32) * ROWB
+    int soff[2][2];                                          // [s][h] byte offset of the fragment inside its row
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) soff[s][h] = ((s * 4 + lk * 2 + h) ^ key) << 4;
+
+    half8 fah[2][2], fal[2][2];     // A fragments of the current 64-row half: [m-tile i][k16 step s]
+    half8 fb0h[2], fb0l[2];         // B fragments, column sub-block 0 (kept from phase 0 to phase 3)
+    half8 fb1h[2], fb1l[2];         // B fragments, column sub-block 1
+    auto read_a = [&](const char* buf, int sub) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const char* r = buf + arow + (sub * 64 + i * 32) * ROWB;
+                fah[i][s] = *reinterpret_cast<const half8*>(r + soff[s][0]);
+                fal[i][s] = *reinterpret_cast<const half8*>(r + soff[s][1]);
+            }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // quadrant (asub, bsub): 2 m-tiles x 1 n-tile x 2 k16 steps x 3 passes, per-element order
+    // (a_lo w_hi, a_hi w_lo, a_hi w_hi) per k16 step - identical to conv_igemm_h2
+#define PP_MFMA(ASUB, BSUB, BH, BL)                                                                              \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                              \
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i][s], BH[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                              \
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], BL[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                              \
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], BH[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);     \
+        }                                                                                                        \
+    } while (0)
+    // end of a phase's load part .. MFMA part .. end of phase
+#define PP_SYNC_THEN_MFMA(COUNTED, ASUB, BSUB, BH, BL)                             \
+    do {                                                                           \
+        if (COUNTED) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+        PP_BARRIER();                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        __builtin_amdgcn_s_setprio(1);                                             \
+        PP_MFMA(ASUB, BSUB, BH, BL);                                               \
+        __builtin_amdgcn_s_setprio(0);                                             \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        PP_BARRIER();                                                              \
+    } while (0)
+
+    // ---- prologue: all of k-tile 0 and B0 of k-tile 1, drained
+    stage_a(smem, 0, tap_off(0, 0));
+    stage_b(smem, 0, 0);
+    stage_b(smem, 1, 0);
+    stage_a(smem, 1, tap_off(0, 0));
+    if (nt > 1) stage_b(smem + BUF, 0, 128);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if (wr == 1) PP_BARRIER();          // group 1 runs one interval behind group 0
+
+    int c1 = 0, tap1 = 1;               // (slice, tap) of k-tile t+1
+    if (tap1 == taps) { tap1 = 0; c1 = 1; }
+    for (int t = 0; t < nt; ++t) {
+        const char* cur = smem + (t & 1) * BUF;
+        char* nxt = smem + ((t + 1) & 1) * BUF;
+        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+        const long long offa = tap_off(c1, tap1);
+        const long long offb1 = (long long)(t + 1) * 128;
+
+        // phase 0: Q00
+        read_a(cur, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            fb0h[s] = *reinterpret_cast<const half8*>(cur + brow + soff[s][0]);
+            fb0l[s] = *reinterpret_cast<const half8*>(cur + brow + soff[s][1]);
+        }
+        if (more1) stage_a(nxt, 0, offa);
+        PP_SYNC_THEN_MFMA(more1, 0, 0, fb0h, fb0l);
+
+        // phase 1: Q01
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            fb1h[s] = *reinterpret_cast<const half8*>(cur + brow + 32 * ROWB + soff[s][0]);
+            fb1l[s] = *reinterpret_cast<const half8*>(cur + brow + 32 * ROWB + soff[s][1]);
+        }
+        if (more1) stage_b(nxt, 1, offb1);
+        PP_SYNC_THEN_MFMA(more1, 0, 1, fb1h, fb1l);
+
+        // phase 2: Q11
+        read_a(cur, 1);
+        if (more1) stage_a(nxt, 1, offa);
+        PP_SYNC_THEN_MFMA(more1, 1, 1, fb1h, fb1l);
+
+        // phase 3: Q10 (B sub-block 0 still in registers); B0 of k-tile t+2 goes into the buffer being computed
+        if (more2) stage_b(const_cast<char*>(cur), 0, offb1 + 128);
+        PP_SYNC_THEN_MFMA(more2, 1, 0, fb0h, fb0l);
+
+        if (++tap1 == taps) { tap1 = 0; ++c1; }
+    }
+    if (wr == 0) PP_BARRIER();          // re-align the two groups (barrier counts must match)
+#undef PP_SYNC_THEN_MFMA
+#undef PP_MFMA
+
+    // ---- epilogue: bias / temb / residual / scale, store, per-column (sum, sumsq) of every 64 output rows.
+    // 32-row sub-sums (16 values per lane in r order, then the partner half-wave) paired even+odd: the
+    // tile-shape-independent order of igemm.hip.  Both sub-sums of a record live in this wave: no LDS.
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + lr;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        float cs[4], cq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cs[i] = 0.f;
+            cq[i] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float v = acc[i][j][r] + bv;
+                if (p.temb) v += p.temb[(size_t)(row / HW) * p.temb_stride + col];
+                if (p.res) v += p.res[(size_t)row * p.ldr + col];
+                v *= p.scale;
+                p.out[(size_t)row * p.ldo + col] = v;
+                cs[i] += v;
+                cq[i] += v * v;
+            }
+            if (p.colstats) {
+                cs[i] += __shfl_xor(cs[i], 32, 64);
+                cq[i] += __shfl_xor(cq[i], 32, 64);
+            }
+        }
+        if (p.colstats && lk == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col;
+                d[0] = cs[2 * q] + cs[2 * q + 1];
+                d[p.N] = cq[2 * q] + cq[2 * q + 1];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s) {
+    p.tiles_n = p.N / BN;
+    p.tiles = (p.M / BM) * p.tiles_n;
+    hipLaunchKernelGGL(conv_igemm_h2_pp, dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
+}

@@ -255,6 +255,51 @@ def test_conv2d_h2_split_fp16(dev, case):
           rtol=2e-5, atol=2e-5)
 
 
+PP_CASES = [
+    # B, H, W, C, N, k, temb_rows, res, scale      (M % 256 == 0 and N % 256 == 0: the 256x256 ping-pong variant applies)
+    (2, 16, 16, 128, 256, 3, 2, True, 0.70710678),     # 2 tiles, 36 k-tiles, every epilogue term
+    (1, 16, 16, 32, 256, 3, 0, False, 1.0),            # 9 k-tiles (one channel slice)
+    (1, 16, 16, 64, 512, 1, 0, False, 1.0),            # 1x1: 2 k-tiles, two n-tiles
+    (1, 16, 16, 32, 256, 1, 1, False, 1.0),            # a single k-tile (prologue only)
+    (1, 16, 16, 96, 256, 1, 0, True, 1.0),             # 3 k-tiles (all of them in the drained tail)
+    (4, 32, 32, 256, 512, 3, 2, True, 1.0),            # 32 tiles, several tiles per sample, 72 k-tiles
+]
+
+
+@pytest.mark.parametrize("case", PP_CASES, ids=[str(c) for c in PP_CASES])
+def test_conv2d_h2_pingpong_variant_is_bit_identical(dev, case, monkeypatch):
+    """The 8-wave 256x256 variant (igemm_h2_pp.hip) against the fp64 convolution AND bit-for-bit against the
+    128x128 / 64x64 variants, column-sum records included; repeated launches screen for LDS-DMA races."""
+    from diffpure_amd import ops
+    B, H, W, C, N, k, temb_rows, has_res, scale = case
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(N, C, k, k, seed=3, scale=1.0 / math.sqrt(C * k * k))
+    bias = rnd(N, seed=4).to(dev)
+    table = rnd(B if temb_rows == 2 else 1, N + 8, seed=5).to(dev) if temb_rows else None
+    res = rnd(B, H, W, N, seed=6).to(dev) if has_res else None
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.cpu().double(), padding=k // 2).permute(0, 2, 3, 1)
+    if table is not None:
+        ref = ref + table.cpu()[:, 4:4 + N].double().reshape(-1, 1, 1, N)
+    if res is not None:
+        ref = ref + res.cpu().double()
+    ref = (ref * scale).float()
+    xh, wh = _h2_bordered(x, dev), ops.pack_conv_weight_h2(w, dev)
+
+    def run():
+        y = ops.conv2d_h2(xh, wh, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale,
+                          colstats=True)
+        return y, y._dp_cols.buf.clone()
+
+    monkeypatch.setenv("DP_H2_PP", "0")
+    base, base_cs = run()
+    monkeypatch.setenv("DP_H2_PP", "1")
+    for _ in range(6):
+        got, got_cs = run()
+        assert torch.equal(got, base)
+        assert torch.equal(got_cs, base_cs)
+    close(got, ref, rtol=2e-5, atol=2e-5)
+
+
 def test_group_norm_split_output_is_bordered_h2_of_fp32_output(dev):
     from diffpure_amd import ops
     x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)
