@@ -229,11 +229,31 @@ __global__ __launch_bounds__(NT) void conv_igemm_f32(ConvArgs p) {
     // half-waves, then the two 32-row sub-tiles of a 64-row record - so that every kernel variant (and any
     // sharding of the batch, which changes the variant chosen) produces bit-identical GroupNorm statistics.
     float* cs_lds = smem;     // [BM/32][BN][2] floats; the k-loop's last barrier has released the tiles
+    // residual reads of a column block issued together (TM x 16 loads in flight per lane), temb one value per
+    // 32-row block when a block cannot straddle two samples - same value order as every other variant
+    const float* __restrict__ resp = p.res;
+    const float* __restrict__ tembp = p.temb;
+    float* __restrict__ outp = p.out;
+    const bool hw32 = HW % 32 == 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + lr;
         const bool cok = col < p.N;
         const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
+        float rv[TM][16];
+        float tv[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rowb = m0 + wm0 + i * 32 + 4 * lk;
+            if (resp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rowb + (r & 3) + 8 * (r >> 2);
+                    rv[i][r] = (cok && row < p.M) ? resp[(size_t)row * p.ldr + col] : 0.f;
+                }
+            }
+            tv[i] = (tembp && hw32 && cok && rowb < p.M) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float cs = 0.f, cq = 0.f;
@@ -242,10 +262,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_f32(ConvArgs p) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row >= p.M || !cok) continue;
                 float v = acc[i][j][r] + bv;
-                if (p.temb) v += p.temb[(size_t)(row / HW) * p.temb_stride + col];
-                if (p.res) v += p.res[(size_t)row * p.ldr + col];
+                if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
+                if (resp) v += rv[i][r];
                 v *= p.scale;
-                p.out[(size_t)row * p.ldo + col] = v;
+                outp[(size_t)row * p.ldo + col] = v;
                 cs += v;
                 cq += v * v;
             }

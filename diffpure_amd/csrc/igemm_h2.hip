@@ -203,11 +203,32 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
 
     // column partials in the tile-shape-independent order of igemm.hip (32-row sub-sums -> 64-row records)
     float* cs_lds = reinterpret_cast<float*>(smem);     // [BM/32][BN][2] floats, tiles released by the last barrier
+    // The residual reads of one column block are all issued before their first use (TM x 16 loads in flight per
+    // lane) instead of one dependent round trip per element; temb is one value per 32-row block when a block
+    // cannot straddle two samples.  Value order (bias, temb, residual, scale) is the same in every variant.
+    const float* __restrict__ resp = p.res;
+    const float* __restrict__ tembp = p.temb;
+    float* __restrict__ outp = p.out;
+    const bool hw32 = HW % 32 == 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + lr;
         const bool cok = col < p.N;
         const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
+        float rv[TM][16];
+        float tv[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rowb = m0 + wm0 + i * 32 + 4 * lk;
+            if (resp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rowb + (r & 3) + 8 * (r >> 2);
+                    rv[i][r] = (cok && row < p.M) ? resp[(size_t)row * p.ldr + col] : 0.f;
+                }
+            }
+            tv[i] = (tembp && hw32 && cok && rowb < p.M) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float cs = 0.f, cq = 0.f;
@@ -216,10 +237,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row >= p.M || !cok) continue;
                 float v = acc[i][j][r] + bv;
-                if (p.temb) v += p.temb[(size_t)(row / HW) * p.temb_stride + col];
-                if (p.res) v += p.res[(size_t)row * p.ldr + col];
+                if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
+                if (resp) v += rv[i][r];
                 v *= p.scale;
-                p.out[(size_t)row * p.ldo + col] = v;
+                outp[(size_t)row * p.ldo + col] = v;
                 cs += v;
                 cq += v * v;
             }
@@ -304,6 +325,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.zero = zero_page();
     DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
     p.colstats = colstats;
+    p.stagger = 0;
     DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc_h2: colstats needs tile_rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // tuning switch: 0 = heuristic below; 1 = s_setprio around the MFMA clusters (measured: no gain);
@@ -330,6 +352,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         const long long t256 = tiles(256, 256), rounds = (t256 + 255) / 256;
         const bool fills = t256 >= 256 && t256 * 5 >= rounds * 256 * 4;
         if (shape_ok && pp != 0 && (pp == 1 || fills)) {
+            const char* sg = getenv("DP_H2_STAGGER");
+            p.stagger = sg ? atoi(sg) : 0;
             dp_launch_conv_h2_pp(p, s);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);

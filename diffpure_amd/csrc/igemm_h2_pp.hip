@@ -69,6 +69,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
 
+    // EXPERIMENT: de-correlate the epilogue store bursts of the CUs (first round only; later workgroups inherit
+    // the offsets because a CU takes its next workgroup when it finishes the previous one)
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        for (int n = (int)blockIdx.x * p.stagger / 256; n > 0; n -= 16) __builtin_amdgcn_s_sleep(16);
+    }
+
     // ---- staging geometry: a unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7
     const int u = tid >> 3;
     const int ls = (tid & 7) ^ ((u >> 1) & 7);     // logical slot fetched (XOR swizzle applied on the source side)
@@ -223,10 +229,27 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     // ---- epilogue: bias / temb / residual / scale, store, per-column (sum, sumsq) of every 64 output rows.
     // 32-row sub-sums (16 values per lane in r order, then the partner half-wave) paired even+odd: the
     // tile-shape-independent order of igemm.hip.  Both sub-sums of a record live in this wave: no LDS.
+    // The residual reads of one column block (4 m-tiles x 16 rows) are all issued before the first use: 64
+    // loads in flight per lane (the fragment registers are free now) instead of one round trip per element.
+    const float* __restrict__ resp = p.res;
+    const float* __restrict__ tembp = p.temb;
+    float* __restrict__ outp = p.out;
+    const bool hw32 = HW % 32 == 0;          // a 32-row block lies inside one sample: one temb value per block
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wc * 64 + j * 32 + lr;
         const float bv = p.bias ? p.bias[col] : 0.f;
+        float rv[4][16];
+        float tv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
+            if (resp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[i][r] = resp[(size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col];
+            }
+            tv[i] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col] : 0.f;
+        }
         float cs[4], cq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -236,10 +259,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 float v = acc[i][j][r] + bv;
-                if (p.temb) v += p.temb[(size_t)(row / HW) * p.temb_stride + col];
-                if (p.res) v += p.res[(size_t)row * p.ldr + col];
+                if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
+                if (resp) v += rv[i][r];
                 v *= p.scale;
-                p.out[(size_t)row * p.ldo + col] = v;
+                if (p.stagger != -1 || v == 12345.678f) outp[(size_t)row * p.ldo + col] = v;   // -1: timing ablation without stores
                 cs[i] += v;
                 cq[i] += v * v;
             }

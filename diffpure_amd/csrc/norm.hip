@@ -147,41 +147,28 @@ __device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) 
 // 8 fp16 hi | 8 fp16 lo = 32 bytes, the operand format of csrc/igemm_h2.hip).
 // H2 output carries a one-pixel zero border ([B][Ho+2][Wo+2][C]): the operand format of
 // csrc/igemm_h2.hip, whose loader then needs no bounds tests.
+// One workgroup = one (bordered) output row of one sample; a thread owns ONE channel vector (its
+// normalisation / FiLM coefficients are formed once, not per pixel) and walks the row's pixels in
+// steps of `slots`, so the inner loop has no integer division: load, fma, SiLU, convert, store.
+// Lanes run along the channels: a wave touches 64 * VEC * 4 contiguous bytes per step.
 template <bool H2>
-__global__ void gn_apply_kernel(ApplyArgs p) {
+__global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
     constexpr int VEC = H2 ? 8 : 4, NQ = VEC / 4;
     constexpr int BORDER = H2 ? 1 : 0;
     const int CV = p.C4 * 4 / VEC;
     const int Hq = p.Ho + 2 * BORDER, Wq = p.Wo + 2 * BORDER;
-    const long long total = (long long)p.B * Hq * Wq * CV;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        const long long opix = i / CV;                  // index in the (bordered) output
-        const int qx = (int)(opix % Wq);
-        const long long t2 = opix / Wq;
-        const int qy = (int)(t2 % Hq), b = (int)(t2 / Hq);
-        const int ox = qx - BORDER, oy = qy - BORDER;
-        if (H2 && ((unsigned)ox >= (unsigned)p.Wo || (unsigned)oy >= (unsigned)p.Ho)) {
-            half8 z;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
-            half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + ((size_t)opix * CV + cv) * 32);
-            dst[0] = z;
-            dst[1] = z;
-            if (p.y_raw) {
-                half8* dr = reinterpret_cast<half8*>(p.y_raw + ((size_t)opix * CV + cv) * 32);
-                dr[0] = z;
-                dr[1] = z;
-            }
-            continue;
-        }
-        f32x4 o[NQ];
-        f32x4 raw[NQ];
+    const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
+    const int oy = qy - BORDER;
+    const bool zrow = H2 && (unsigned)oy >= (unsigned)p.Ho;
+    const int slot = threadIdx.x / CVT;
+    const size_t orow = ((size_t)b * Hq + qy) * Wq;     // first pixel of this row in the (bordered) output
+    for (int cv = threadIdx.x - slot * CVT; cv < CV; cv += CVT) {
+        f32x4 a[NQ], d[NQ];                             // y = x*a + d before act
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd) {
             const int c = cv * VEC + qd * 4;
-            f32x4 a = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};  // y = x*a + d before act
+            a[qd] = f32x4{1.f, 1.f, 1.f, 1.f};
+            d[qd] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.gamma) {
                 const int g = c / p.cpg;
                 const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
@@ -189,8 +176,8 @@ __global__ void gn_apply_kernel(ApplyArgs p) {
                 const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a[j] = rstd * ga[j];
-                    d[j] = be[j] - mean * a[j];
+                    a[qd][j] = rstd * ga[j];
+                    d[qd][j] = be[j] - mean * a[qd][j];
                 }
             }
             if (p.fscale) {
@@ -199,64 +186,81 @@ __global__ void gn_apply_kernel(ApplyArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float m = 1.f + fs[j];
-                    a[j] *= m;
-                    d[j] = d[j] * m + fh[j];
+                    a[qd][j] *= m;
+                    d[qd][j] = d[qd][j] * m + fh[j];
                 }
-            }
-            auto xf = [&](size_t pix) {
-                f32x4 v = gn_load(p, pix, c);
-                raw[qd] = v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float u = v[j] * a[j] + d[j];
-                    v[j] = p.act ? dp_silu_f(u) : u;
-                }
-                return v;
-            };
-            if (p.resample == 0) {
-                o[qd] = xf(((size_t)b * p.H + oy) * p.W + ox);
-            } else if (p.resample == 1) {
-                o[qd] = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
-            } else {
-                const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
-                const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[qd][j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
             }
         }
-        if constexpr (H2) {
-            half8 hi, lo;
+        for (int qx = slot; qx < Wq; qx += slots) {
+            const int ox = qx - BORDER;
+            const size_t opix = orow + qx;
+            if (H2 && (zrow || (unsigned)ox >= (unsigned)p.Wo)) {
+                half8 z;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = o[j >> 2][j & 3];
-                hi[j] = (_Float16)v;
-                lo[j] = (_Float16)(v - (float)hi[j]);
+                for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+                half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CV + cv) * 32);
+                dst[0] = z;
+                dst[1] = z;
+                if (p.y_raw) {
+                    half8* dr = reinterpret_cast<half8*>(p.y_raw + (opix * CV + cv) * 32);
+                    dr[0] = z;
+                    dr[1] = z;
+                }
+                continue;
             }
-            half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + ((size_t)opix * CV + cv) * 32);
-            dst[0] = hi;
-            dst[1] = lo;
-            if (p.y_raw) {       // resample == 0 here: raw[] holds this very pixel
+            f32x4 o[NQ];
+            f32x4 raw[NQ];
+#pragma unroll
+            for (int qd = 0; qd < NQ; ++qd) {
+                const int c = cv * VEC + qd * 4;
+                auto xf = [&](size_t pix) {
+                    f32x4 v = gn_load(p, pix, c);
+                    raw[qd] = v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float u = v[j] * a[qd][j] + d[qd][j];
+                        v[j] = p.act ? dp_silu_f(u) : u;
+                    }
+                    return v;
+                };
+                if (p.resample == 0) {
+                    o[qd] = xf(((size_t)b * p.H + oy) * p.W + ox);
+                } else if (p.resample == 1) {
+                    o[qd] = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
+                } else {
+                    const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
+                    const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[qd][j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+                }
+            }
+            if constexpr (H2) {
+                half8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float v = raw[j >> 2][j & 3];
+                    const float v = o[j >> 2][j & 3];
                     hi[j] = (_Float16)v;
                     lo[j] = (_Float16)(v - (float)hi[j]);
                 }
-                half8* dr = reinterpret_cast<half8*>(p.y_raw + ((size_t)opix * CV + cv) * 32);
-                dr[0] = hi;
-                dr[1] = lo;
+                half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CV + cv) * 32);
+                dst[0] = hi;
+                dst[1] = lo;
+                if (p.y_raw) {       // resample == 0 here: raw[] holds this very pixel
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = raw[j >> 2][j & 3];
+                        hi[j] = (_Float16)v;
+                        lo[j] = (_Float16)(v - (float)hi[j]);
+                    }
+                    half8* dr = reinterpret_cast<half8*>(p.y_raw + (opix * CV + cv) * 32);
+                    dr[0] = hi;
+                    dr[1] = lo;
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(p.y + opix * (p.C4 * 4) + cv * 4) = o[0];   // BORDER == 0: opix is the pixel
             }
-        } else {
-            *reinterpret_cast<f32x4*>(p.y + (size_t)opix * (p.C4 * 4) + cv * 4) = o[0];   // BORDER == 0: opix is the pixel
         }
     }
-}
-
-inline unsigned grid_cap(long long items, int block, int cap) {
-    long long g = (items + block - 1) / block;
-    if (g < 1) g = 1;
-    if (g > cap) g = cap;
-    return (unsigned)g;
 }
 
 }  // namespace
@@ -318,9 +322,11 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
                 C / 4, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
                 resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W), (char*)y_raw};
-    const long long total = out_fmt ? (long long)B * (p.Ho + 2) * (p.Wo + 2) * (p.C4 / 2) : (long long)B * p.Ho * p.Wo * p.C4;
-    if (out_fmt) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    const int CV = out_fmt ? C / 8 : C / 4;
+    const int CVT = CV < 256 ? CV : 256, slots = 256 / CVT;
+    const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));
+    if (out_fmt) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots);
     DP_LAUNCH_CHECK("gn_apply");
     return 0;
 }
