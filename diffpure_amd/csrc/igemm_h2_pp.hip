@@ -35,6 +35,8 @@
 //   The last three k-tiles use vmcnt(0) (fewer than three units follow them).
 // The barriers are inline asm with a memory clobber so that no LDS read is hoisted across them;
 // sched_barrier(0) keeps each MFMA cluster inside its interval.
+#include <stdlib.h>
+
 #include "igemm_h2.h"
 
 namespace {
@@ -48,11 +50,27 @@ constexpr int ROWB = 128;               // bytes per LDS row: 32 channels as (hi
 constexpr int TILE_B = 256 * ROWB;      // one operand tile of one k-tile
 constexpr int BUF = 2 * TILE_B;         // A tile, then B tile
 
-#define PP_GLDS(src, dst)                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),     \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// LDS-DMA with (scalar base + 32-bit lane offset) addressing, spelled in asm: the builtin lets the
+// compiler strength-reduce the k-loop addresses back into 64-bit VGPR pointers (two VALU adds and two
+// address VGPRs per DMA).  M0 = LDS destination of lane 0 (wave-uniform); lane l lands at M0 + 16 l.
+// make a wave-uniform 64-bit value provably scalar for the compiler
+__device__ __forceinline__ long long pp_uniform(long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const char* lds_dst) {
+    const unsigned m0v = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(m0v)
+                 : "memory");
+}
 #define PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// MODE (timing experiments, DP_H2_PP_MODE): bit 0 = no s_setprio; bit 1 = no operand traffic after k-tile 0 (WRONG
+// RESULTS); bit 2 = no barriers in the k-loop (WRONG RESULTS); bit 3 = no ds_reads / bit 4 = no DMA after k-tile 0 / bit 5 = no vmcnt waits (WRONG RESULTS)
+template <int MODE>
 __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
 
@@ -78,7 +96,18 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     // ---- staging geometry: a unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7
     const int u = tid >> 3;
     const int ls = (tid & 7) ^ ((u >> 1) & 7);     // logical slot fetched (XOR swizzle applied on the source side)
-    const char* actr[2][2];                        // [unit][piece]: centre pixel of A row m0 + piece*128 + unit*64 + u
+    // Sources are addressed as (scalar 64-bit base) + (32-bit lane offset): the lane offsets are loop
+    // invariant and the per-k-tile part (tap shift, channel slice, weight column block) lives in the
+    // scalar base, so a DMA issue costs no vector ALU work and reads one address VGPR per lane.
+    // Activation lane offsets are relative to the centre pixel of the tile's first row (always < 2^31:
+    // a tile spans 256 consecutive output pixels).
+    unsigned aoff[2][2];                           // [unit][piece]: A row m0 + piece*128 + unit*64 + u
+    long long aorg;                                // centre pixel of row m0, in bytes from p.x
+    {
+        const int b = m0 / HW, rem = m0 - b * HW;
+        const int oy = rem / p.W, ox = rem - oy * p.W;
+        aorg = ((long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -86,16 +115,16 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             const int m = m0 + i * 128 + a * 64 + u;
             const int b = m / HW, rem = m - b * HW;
             const int oy = rem / p.W, ox = rem - oy * p.W;
-            actr[a][i] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 + ls * 16;
+            aoff[a][i] = (unsigned)(((long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 - aorg) + ls * 16;
         }
-    const char* bsrc[2][2];                        // [unit][piece]: weight row n0 + piece*128 + (u>>5)*64 + unit*32 + (u&31)
+    unsigned boff[2][2];                           // [unit][piece]: weight row n0 + piece*128 + (u>>5)*64 + unit*32 + (u&31)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int n = n0 + i * 128 + (u >> 5) * 64 + b * 32 + (u & 31);
-            bsrc[b][i] = p.w + (size_t)n * p.K * 4 + ls * 16;
-        }
+        for (int i = 0; i < 2; ++i)
+            boff[b][i] = (unsigned)(i * 128 + (u >> 5) * 64 + b * 32 + (u & 31)) * (unsigned)(p.K * 4) + ls * 16;
+    const char* const abase = p.x + pp_uniform(aorg);              // uniform
+    const char* const bbase = p.w + pp_uniform((long long)n0 * p.K * 4);   // uniform
     const int u0 = wave * 8;                       // first row of this wave inside a piece (wave-uniform)
     const int adst = u0 * ROWB;                                            // + (piece*128 + unit*64) * ROWB
     const int bdst = TILE_B + ((u0 >> 5) * 64 + (u0 & 31)) * ROWB;         // + (piece*128 + unit*32) * ROWB
@@ -105,12 +134,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         return ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)c32 * 128;
     };
     auto stage_a = [&](char* buf, int a, long long off) {
-        PP_GLDS(actr[a][0] + off, buf + adst + (a * 64) * ROWB);
-        PP_GLDS(actr[a][1] + off, buf + adst + (128 + a * 64) * ROWB);
+        const char* sb = abase + pp_uniform(off);
+        pp_glds(aoff[a][0], sb, buf + adst + (a * 64) * ROWB);
+        pp_glds(aoff[a][1], sb, buf + adst + (128 + a * 64) * ROWB);
     };
     auto stage_b = [&](char* buf, int b, long long off) {
-        PP_GLDS(bsrc[b][0] + off, buf + bdst + (b * 32) * ROWB);
-        PP_GLDS(bsrc[b][1] + off, buf + bdst + (128 + b * 32) * ROWB);
+        const char* sb = bbase + pp_uniform(off);
+        pp_glds(boff[b][0], sb, buf + bdst + (b * 32) * ROWB);
+        pp_glds(boff[b][1], sb, buf + bdst + (128 + b * 32) * ROWB);
     };
 
     // ---- fragment addressing: lane -> row lr of a 32-row MFMA tile, k-half lk; slot (s*4 + lk*2 + h) ^ key
@@ -161,16 +192,18 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     // end of a phase's load part .. MFMA part .. end of phase
 #define PP_SYNC_THEN_MFMA(COUNTED, ASUB, BSUB, BH, BL)                             \
     do {                                                                           \
-        if (COUNTED) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
-        PP_BARRIER();                                                              \
+        if constexpr (!(MODE & 32)) {                                              \
+            if (COUNTED) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
+        }                                                                          \
+        if constexpr (!(MODE & 4)) PP_BARRIER();                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         \
         __builtin_amdgcn_sched_barrier(0);                                         \
-        __builtin_amdgcn_s_setprio(1);                                             \
+        if constexpr (!(MODE & 1)) __builtin_amdgcn_s_setprio(1);                  \
         PP_MFMA(ASUB, BSUB, BH, BL);                                               \
-        __builtin_amdgcn_s_setprio(0);                                             \
+        if constexpr (!(MODE & 1)) __builtin_amdgcn_s_setprio(0);                  \
         __builtin_amdgcn_sched_barrier(0);                                         \
-        PP_BARRIER();                                                              \
+        if constexpr (!(MODE & 4)) PP_BARRIER();                                   \
     } while (0)
 
     // ---- prologue: all of k-tile 0 and B0 of k-tile 1, drained
@@ -188,14 +221,16 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     for (int t = 0; t < nt; ++t) {
         const char* cur = smem + (t & 1) * BUF;
         char* nxt = smem + ((t + 1) & 1) * BUF;
-        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+        const bool traffic = !(MODE & (2 | 8)) || t == 0;                   // ds_reads
+        const bool dma = !(MODE & (2 | 16)) || t == 0;
+        const bool more1 = dma && t + 1 < nt, more2 = dma && t + 2 < nt;
         const long long offa = tap_off(c1, tap1);
         const long long offb1 = (long long)(t + 1) * 128;
 
         // phase 0: Q00
-        read_a(cur, 0);
+        if (traffic) read_a(cur, 0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 2 && traffic; ++s) {
             fb0h[s] = *reinterpret_cast<const half8*>(cur + brow + soff[s][0]);
             fb0l[s] = *reinterpret_cast<const half8*>(cur + brow + soff[s][1]);
         }
@@ -204,7 +239,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 
         // phase 1: Q01
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 2 && traffic; ++s) {
             fb1h[s] = *reinterpret_cast<const half8*>(cur + brow + 32 * ROWB + soff[s][0]);
             fb1l[s] = *reinterpret_cast<const half8*>(cur + brow + 32 * ROWB + soff[s][1]);
         }
@@ -212,7 +247,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         PP_SYNC_THEN_MFMA(more1, 0, 1, fb1h, fb1l);
 
         // phase 2: Q11
-        read_a(cur, 1);
+        if (traffic) read_a(cur, 1);
         if (more1) stage_a(nxt, 1, offa);
         PP_SYNC_THEN_MFMA(more1, 1, 1, fb1h, fb1l);
 
@@ -287,5 +322,17 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s) {
     p.tiles_n = p.N / BN;
     p.tiles = (p.M / BM) * p.tiles_n;
-    hipLaunchKernelGGL(conv_igemm_h2_pp, dim3((unsigned)p.tiles), dim3(NT), 0, s, p);
+    const char* e = getenv("DP_H2_PP_MODE");
+    const int mode = e ? atoi(e) : 0;
+#define PP_LAUNCH(M_) hipLaunchKernelGGL(conv_igemm_h2_pp<M_>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
+    switch (mode) {
+        case 1: PP_LAUNCH(1); break;
+        case 2: PP_LAUNCH(2); break;
+        case 6: PP_LAUNCH(6); break;
+        case 8: PP_LAUNCH(8); break;
+        case 16: PP_LAUNCH(16); break;
+        case 32: PP_LAUNCH(32); break;
+        default: PP_LAUNCH(0); break;
+    }
+#undef PP_LAUNCH
 }
