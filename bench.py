@@ -142,7 +142,9 @@ def main():
 
     wl = WORKLOADS[a.workload]
     adjoint = a.workload.endswith("_adjoint")
-    B = a.batch or (16 if a.workload == "imagenet256_guided" else (128 if adjoint else 256))
+    # per-GPU batches of BASELINE.json's configs: ImageNet 64 (configs[2], and 512 sharded 8 ways in configs[3]),
+    # CIFAR 256 (configs[1]), CIFAR adjoint 128 (configs[4])
+    B = a.batch or (64 if a.workload == "imagenet256_guided" else (128 if adjoint else 256))
     net, sd, _ = build_engine(a.workload, dev, a.seed, a.precision)
     pur = Purifier(net, wl["kind"], dev)
     n_steps = len(sde_schedule(wl["kind"], a.t, a.dt))

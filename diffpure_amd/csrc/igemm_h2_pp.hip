@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             fb0h[s] = *reinterpret_cast<const half8*>(cur + brow + soff[s][0]);
             fb0l[s] = *reinterpret_cast<const half8*>(cur + brow + soff[s][1]);
         }
-        if (more1) stage_a(nxt, 0, offa);
+        if (more1 && !(MODE & 64)) stage_a(nxt, 0, offa);
         PP_SYNC_THEN_MFMA(more1, 0, 0, fb0h, fb0l);
 
         // phase 1: Q01
@@ -243,16 +243,16 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             fb1h[s] = *reinterpret_cast<const half8*>(cur + brow + 32 * ROWB + soff[s][0]);
             fb1l[s] = *reinterpret_cast<const half8*>(cur + brow + 32 * ROWB + soff[s][1]);
         }
-        if (more1) stage_b(nxt, 1, offb1);
+        if (more1 && !(MODE & 128)) stage_b(nxt, 1, offb1);
         PP_SYNC_THEN_MFMA(more1, 0, 1, fb1h, fb1l);
 
         // phase 2: Q11
         if (traffic) read_a(cur, 1);
-        if (more1) stage_a(nxt, 1, offa);
+        if (more1 && !(MODE & 64)) stage_a(nxt, 1, offa);
         PP_SYNC_THEN_MFMA(more1, 1, 1, fb1h, fb1l);
 
         // phase 3: Q10 (B sub-block 0 still in registers); B0 of k-tile t+2 goes into the buffer being computed
-        if (more2) stage_b(const_cast<char*>(cur), 0, offb1 + 128);
+        if (more2 && !(MODE & 128)) stage_b(const_cast<char*>(cur), 0, offb1 + 128);
         PP_SYNC_THEN_MFMA(more2, 1, 0, fb0h, fb0l);
 
         if (++tap1 == taps) { tap1 = 0; ++c1; }
@@ -332,6 +332,8 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s) {
         case 8: PP_LAUNCH(8); break;
         case 16: PP_LAUNCH(16); break;
         case 32: PP_LAUNCH(32); break;
+        case 96: PP_LAUNCH(96); break;
+        case 160: PP_LAUNCH(160); break;
         default: PP_LAUNCH(0); break;
     }
 #undef PP_LAUNCH
