@@ -266,6 +266,13 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     // tile-shape-independent order of igemm.hip.  Both sub-sums of a record live in this wave: no LDS.
     // The residual reads of one column block (4 m-tiles x 16 rows) are all issued before the first use: 64
     // loads in flight per lane (the fragment registers are free now) instead of one round trip per element.
+    if constexpr (MODE & 256) {      // timing ablation: no epilogue at all (accumulators kept alive)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     const float* __restrict__ resp = p.res;
     const float* __restrict__ tembp = p.temb;
     float* __restrict__ outp = p.out;
@@ -332,6 +339,7 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s) {
         case 8: PP_LAUNCH(8); break;
         case 16: PP_LAUNCH(16); break;
         case 32: PP_LAUNCH(32); break;
+        case 256: PP_LAUNCH(256); break;
         case 96: PP_LAUNCH(96); break;
         case 160: PP_LAUNCH(160); break;
         default: PP_LAUNCH(0); break;

@@ -307,6 +307,32 @@ def add(a, b):
     return out
 
 
+def _img_dims(shape, nhwc):
+    return (shape[0], shape[3], shape[1], shape[2]) if nhwc else tuple(shape)
+
+
+def resize_affine(x, size, shift, scale, in_nhwc=False, out_nhwc=False):
+    """y = (F.interpolate(x, size, mode='bilinear', align_corners=False) + shift) * scale with a free choice
+    of layouts - the steps either side of the purifier in SDE_Adv_Model.forward (eval_sde_adv.py:74-89)."""
+    _chk(x, "resize_affine.x", 4)
+    b, c, hi, wi = _img_dims(x.shape, in_nhwc)
+    ho, wo = size
+    y = torch.empty((b, ho, wo, c) if out_nhwc else (b, c, ho, wo), device=x.device, dtype=torch.float32)
+    _lib.call("dp_resize_affine", _ptr(x), b, c, hi, wi, int(in_nhwc), float(shift), float(scale), _ptr(y), ho, wo, int(out_nhwc),
+              _stream())
+    return y
+
+
+def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
+    """Adjoint of `resize_affine`: dy in the forward's output layout -> dx [.., in_size ..] in its input layout."""
+    _chk(dy, "resize_affine_bwd.dy", 4)
+    b, c, ho, wo = _img_dims(dy.shape, out_nhwc)
+    hi, wi = in_size
+    dx = torch.empty((b, hi, wi, c) if in_nhwc else (b, c, hi, wi), device=dy.device, dtype=torch.float32)
+    _lib.call("dp_resize_affine_bwd", _ptr(dy), b, c, ho, wo, int(out_nhwc), float(scale), _ptr(dx), hi, wi, int(in_nhwc), _stream())
+    return dx
+
+
 def to_h2(x, mode=RESAMPLE_NONE):
     """fp32 NHWC -> zero-bordered h2 operand ([B, H'+2, W'+2, 2C] fp16) without normalisation,
     optionally through the 2x resampler (`mode`)."""

@@ -145,6 +145,16 @@ def to_nchw(x):
     return x.permute(0, 3, 1, 2).contiguous()
 
 
+def _state_in(x, device, nhwc):
+    """boundary of the loops: NCHW (the reference's layout) unless the caller already holds the NHWC state"""
+    x = x.to(device, torch.float32)
+    return x.contiguous() if nhwc else to_nhwc(x)
+
+
+def _state_out(x, nhwc):
+    return x if nhwc else to_nchw(x)
+
+
 class Purifier:
     """Runs the purification loops for one score network on one GPU.
 
@@ -180,8 +190,8 @@ class Purifier:
         return self.net.forward(x, table_row=table[k:k + 1])
 
     # -- reverse VP-SDE (RevGuidedDiffusion.image_editing_sample) ---------------------------------
-    def sde(self, x_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0):
-        x0 = to_nhwc(x_nchw.to(self.device, torch.float32))
+    def sde(self, x_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0, nhwc=False):
+        x0 = _state_in(x_nchw, self.device, nhwc)
         sched = sde_schedule(self.kind, t_int, dt)
         table = self._tables(("sde", t_int, dt), sched)
         x = self._diffuse(x0, t_int, noise, seed, sample0)
@@ -190,9 +200,9 @@ class Purifier:
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
             x = ops.em_step(x, eps, st["nhb"], st["gg"], st["sc"], st["div"], st["h"], st["g"], st["sqrt_h"], noise=z,
                             seed=seed, sample0=sample0, step=k, out=x)
-        return to_nchw(x)
+        return _state_out(x, nhwc)
 
-    def sde_vjp(self, x_final_nchw, grad_out_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0):
+    def sde_vjp(self, x_final_nchw, grad_out_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0, nhwc=False):
         """Stochastic adjoint of `sde` (upstream: torchsde.sdeint_adjoint behind
         runners/diffpure_sde.py:236-238).  g(t) is state-independent, so the adjoint has no noise term:
         da = -a^T df/dy dt, while the state is re-integrated backward from x_final along the SAME Brownian
@@ -201,8 +211,8 @@ class Purifier:
         clock in reverse:  y_k = y_{k+1} - f(t_{k+1}, y_{k+1}) h_k - g(t_{k+1}) dW_k,
                            a_k = a_{k+1} + h_k (df/dy)^T a_{k+1}.
         -> dL/dx at t'_0 (before the forward-diffusion scaling), NCHW."""
-        y = to_nhwc(x_final_nchw.to(self.device, torch.float32))
-        a = to_nhwc(grad_out_nchw.to(self.device, torch.float32))
+        y = _state_in(x_final_nchw, self.device, nhwc).clone()
+        a = _state_in(grad_out_nchw, self.device, nhwc)
         sched = sde_schedule(self.kind, t_int, dt)
         # coefficients at the END point t_{k+1} of every interval: the schedule entry of step k+1, plus one
         # more entry for the final time t'_end
@@ -223,11 +233,11 @@ class Purifier:
             y = ops.em_step(y, eps, en["nhb"], en["gg"], en["sc"], en["div"], -h, -en["g"], st["sqrt_h"], noise=z, seed=seed,
                             sample0=sample0, step=k, out=y)
             a = a_new
-        return to_nchw(a)
+        return _state_out(a, nhwc)
 
     # -- probability-flow ODE forward (OdeGuidedDiffusion.image_editing_sample) -------------------
-    def ode(self, x_nchw, t_int, step=1e-3, noise=None, seed=0, sample0=0, e_nhwc=None):
-        x0 = to_nhwc(x_nchw.to(self.device, torch.float32))
+    def ode(self, x_nchw, t_int, step=1e-3, noise=None, seed=0, sample0=0, e_nhwc=None, nhwc=False):
+        x0 = _state_in(x_nchw, self.device, nhwc)
         sched = ode_schedule(self.kind, t_int, step)
         table = self._tables(("ode", t_int, step), sched)
         if e_nhwc is not None:
@@ -238,18 +248,18 @@ class Purifier:
         for k, st in enumerate(sched):
             eps = self._eps(x, table, k)
             x = ops.em_step(x, eps, st["nhb"], st["gg"], st["sc"], st["div"], st["h"], 0.0, 0.0, out=x)
-        return to_nchw(x)
+        return _state_out(x, nhwc)
 
     # -- adjoint of the probability-flow ODE: dL/dx for adaptive attacks ---------------------------
-    def ode_vjp(self, x_final_nchw, grad_out_nchw, t_int, step=1e-3):
+    def ode_vjp(self, x_final_nchw, grad_out_nchw, t_int, step=1e-3, nhwc=False):
         """Continuous adjoint as torchdiffeq's odeint_adjoint integrates it (diffpure_ode.py:229-238):
         the augmented state (y, a) starts at (x(1e-5), dL/dx(1e-5)) and is Euler-stepped on the grid
         1e-5 + k*step up to t/1000;  da/ds = -a^T dF/dy,  F = -0.5*beta*y - 0.5*beta*score(y).
         Per step: one UNet forward (taped) + one input-gradient pass.  The parameter adjoints the
         reference also integrates (106.6 M values nobody reads) are not formed - dL/dx does not
         depend on them.  -> dL/dx at s = t/1000 (before the forward-diffusion scaling), NCHW."""
-        y = to_nhwc(x_final_nchw.to(self.device, torch.float32))
-        a = to_nhwc(grad_out_nchw.to(self.device, torch.float32))
+        y = _state_in(x_final_nchw, self.device, nhwc).clone()
+        a = _state_in(grad_out_nchw, self.device, nhwc)
         sched = ode_schedule(self.kind, t_int, step, reverse=True)
         table = self._tables(("ode_rev", t_int, step), sched)
         for k, st in enumerate(sched):
@@ -262,16 +272,16 @@ class Purifier:
             a_new = ops.axpby(a, 1.0 - ds * st["nhb"], g, ds * st["gg"] * kk)
             y = ops.em_step(y, eps, st["nhb"], st["gg"], st["sc"], st["div"], -ds, 0.0, 0.0, out=y)   # y + ds * F(y)
             a = a_new
-        return to_nchw(a)
+        return _state_out(a, nhwc)
 
     def diffuse_scale(self, t_int):
         """d x(t) / d x0 of the forward diffusion x = x0*sqrt(abar) + e*sqrt(1-abar)."""
         return diffusion_coeffs(t_int, self._abar)[0]
 
     # -- DDPM ancestral sampling (GuidedDiffusion.image_editing_sample) ---------------------------
-    def ddpm(self, x_nchw, t_int, noise=None, seed=0, sample0=0, diffusion_steps=1000):
+    def ddpm(self, x_nchw, t_int, noise=None, seed=0, sample0=0, diffusion_steps=1000, nhwc=False):
         assert self.kind == "guided"
-        x0 = to_nhwc(x_nchw.to(self.device, torch.float32))
+        x0 = _state_in(x_nchw, self.device, nhwc)
         ds = DdpmSchedule(diffusion_steps)
         # diffpure_guided.py:39,62: betas cast to fp32, cumprod in fp32
         abar = (1 - torch.from_numpy(ds.betas).float()).cumprod(dim=0)
@@ -286,4 +296,4 @@ class Purifier:
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
             x = ops.ddpm_step(x, out6, c["sr"], c["srm1"], c["c1"], c["c2"], c["min_log"], c["max_log"], i != 0, noise=z,
                               seed=seed, sample0=sample0, step=k, out=x)
-        return to_nchw(x)
+        return _state_out(x, nhwc)

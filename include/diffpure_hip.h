@@ -196,6 +196,20 @@ int dp_softmax_bwd_rows(const float* p, float* dp, long long rows, int cols, voi
 /* out = a + b (gradient accumulation at fan-out points). n % 4 == 0. */
 int dp_add(const float* a, const float* b, float* out, long long n, void* stream);
 
+/* ---- the steps either side of the purifier ---------------------------------------
+ * y = (bilinear(x) + shift) * scale, PyTorch semantics of F.interpolate(mode='bilinear',
+ * align_corners=False), with a free choice of layouts (in_nhwc / out_nhwc: 0 = NCHW, 1 = NHWC).
+ * Replaces, in SDE_Adv_Model.forward (/root/reference/eval_sde_adv.py):
+ *   :74-75 interpolate 224->256 + :78 (x - 0.5) * 2 + the NCHW->NHWC repack   (shift -0.5, scale 2)
+ *   :81-82 interpolate 256->224 + :89 (x_re + 1) * 0.5 + the NHWC->NCHW repack (shift  1 , scale 0.5)
+ * x: [B,C,Hi,Wi] or [B,Hi,Wi,C] fp32; y: [B,C,Ho,Wo] or [B,Ho,Wo,C] fp32. */
+int dp_resize_affine(const float* x, int B, int C, int Hi, int Wi, int in_nhwc, float shift, float scale, float* y,
+                     int Ho, int Wo, int out_nhwc, void* stream);
+/* Its adjoint, dx = scale * bilinear^T(dy) (what autograd runs for those lines on the adaptive-attack path),
+ * gather form, deterministic. dy has the forward's OUTPUT shape/layout, dx the forward's INPUT shape/layout. */
+int dp_resize_affine_bwd(const float* dy, int B, int C, int Ho, int Wo, int out_nhwc, float scale, float* dx, int Hi,
+                         int Wi, int in_nhwc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

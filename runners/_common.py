@@ -21,3 +21,11 @@ def save_image(x, path):
     except Exception:
         return
     tvu.save_image((x + 1) * 0.5, path)
+
+
+def as_nchw(x, nhwc):
+    return x.permute(0, 3, 1, 2) if nhwc else x
+
+
+def as_nchw_shape(shape, nhwc):
+    return (shape[0], shape[3], shape[1], shape[2]) if nhwc else tuple(shape)

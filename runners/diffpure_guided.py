@@ -28,7 +28,8 @@ class GuidedDiffusion(torch.nn.Module):
         self.betas = torch.from_numpy(DdpmSchedule(self.diffusion_steps).betas).float().to(self.device)
         self._calls = 0
 
-    def image_editing_sample(self, img, bs_id=0, tag=None, noise=None):
+    def image_editing_sample(self, img, bs_id=0, tag=None, noise=None, nhwc=False):
+        """nhwc=True (extension): `img` and the result are the NHWC state of the loop (diffpure_amd.adv_model)."""
         with torch.no_grad():
             assert isinstance(img, torch.Tensor)
             assert img.ndim == 4, img.ndim
@@ -37,7 +38,7 @@ class GuidedDiffusion(torch.nn.Module):
             x0 = img.to(self.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
-                _common.save_image(x0, os.path.join(out_dir, "original_input.png"))
+                _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
             seed = int(getattr(self.args, "seed", 0) or 0)
             xs = []
             for it in range(self.args.sample_step):
@@ -46,10 +47,10 @@ class GuidedDiffusion(torch.nn.Module):
 
                 def run(xl, sample0, call_seed=call_seed):
                     return self.purifier.ddpm(xl, self.args.t, noise=noise, seed=call_seed, sample0=sample0,
-                                              diffusion_steps=self.diffusion_steps)
+                                              diffusion_steps=self.diffusion_steps, nhwc=nhwc)
 
                 x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
                 if log:
-                    _common.save_image(x0, os.path.join(out_dir, f"samples_{it}.png"))
+                    _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)
             return torch.cat(xs, dim=0)

@@ -20,10 +20,10 @@ class _OdePurify(torch.autograd.Function):
     (what torchdiffeq.odeint_adjoint provides upstream, runners/diffpure_ode.py:229-238)."""
 
     @staticmethod
-    def forward(ctx, img, runner, t, step, noise, seed, sample0):
+    def forward(ctx, img, runner, t, step, noise, seed, sample0, nhwc=False):
         with torch.no_grad():
-            out = runner.purifier.ode(img, t, step, noise=noise, seed=seed, sample0=sample0)
-        ctx.runner, ctx.t, ctx.step = runner, t, step
+            out = runner.purifier.ode(img, t, step, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc)
+        ctx.runner, ctx.t, ctx.step, ctx.nhwc = runner, t, step, nhwc
         ctx.save_for_backward(out)
         return out
 
@@ -31,9 +31,9 @@ class _OdePurify(torch.autograd.Function):
     def backward(ctx, grad_out):
         (out,) = ctx.saved_tensors
         with torch.no_grad():
-            a = ctx.runner.purifier.ode_vjp(out, grad_out, ctx.t, ctx.step)
+            a = ctx.runner.purifier.ode_vjp(out, grad_out, ctx.t, ctx.step, nhwc=ctx.nhwc)
             a = a * ctx.runner.purifier.diffuse_scale(ctx.t)
-        return a, None, None, None, None, None, None
+        return a, None, None, None, None, None, None, None
 
 
 class OdeGuidedDiffusion(torch.nn.Module):
@@ -59,7 +59,8 @@ class OdeGuidedDiffusion(torch.nn.Module):
         self._calls = 0
         print(f"method: {self.method}, atol: {self.atol}, rtol: {self.rtol}, step_size: {self.args.step_size}")
 
-    def image_editing_sample(self, img, bs_id=0, tag=None, noise=None):
+    def image_editing_sample(self, img, bs_id=0, tag=None, noise=None, nhwc=False):
+        """nhwc=True (extension): `img` and the result are the NHWC state of the loop (diffpure_amd.adv_model)."""
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim
         out_dir = _common.out_dir_for(self.args, bs_id, tag)
@@ -71,7 +72,7 @@ class OdeGuidedDiffusion(torch.nn.Module):
             x0 = img.to(self.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
-                _common.save_image(x0, os.path.join(out_dir, "original_input.png"))
+                _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
             seed = int(getattr(self.args, "seed", 0) or 0)
             step = float(self.args.step_size)
             xs = []
@@ -80,7 +81,7 @@ class OdeGuidedDiffusion(torch.nn.Module):
                 if inj is None and getattr(self.args, "fix_rand", False):
                     # one fixed noise image repeated over the batch (reference :202-207)
                     g = torch.Generator().manual_seed(int(self.args.seed))
-                    e1 = torch.randn((1,) + tuple(x0.shape[1:]), generator=g)
+                    e1 = torch.randn((1,) + tuple(_common.as_nchw_shape(x0.shape, nhwc)[1:]), generator=g)
                     inj = dict(e=e1.repeat(x0.shape[0], 1, 1, 1), z=[])
                 call_seed = seed + 1000003 * self._calls
                 self._calls += 1
@@ -88,11 +89,11 @@ class OdeGuidedDiffusion(torch.nn.Module):
                 def run(xl, sample0, inj=inj, call_seed=call_seed):
                     loc = inj if inj is None else dict(e=inj["e"][sample0:sample0 + xl.shape[0]], z=[])
                     if need_grad:
-                        return _OdePurify.apply(xl, self, self.args.t, step, loc, call_seed, sample0)
-                    return self.purifier.ode(xl, self.args.t, step, noise=loc, seed=call_seed, sample0=sample0)
+                        return _OdePurify.apply(xl, self, self.args.t, step, loc, call_seed, sample0, nhwc)
+                    return self.purifier.ode(xl, self.args.t, step, noise=loc, seed=call_seed, sample0=sample0, nhwc=nhwc)
 
                 x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
                 if log:
-                    _common.save_image(x0, os.path.join(out_dir, f"samples_{it}.png"))
+                    _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)
             return torch.cat(xs, dim=0)

@@ -26,21 +26,21 @@ class _SdePurify(torch.autograd.Function):
     (regenerated) Brownian path - what torchsde.sdeint_adjoint provides upstream (reference :236-238)."""
 
     @staticmethod
-    def forward(ctx, img, runner, t, dt, noise, seed, sample0):
+    def forward(ctx, img, runner, t, dt, noise, seed, sample0, nhwc=False):
         with torch.no_grad():
-            out = runner.purifier.sde(img, t, dt, noise=noise, seed=seed, sample0=sample0)
-        ctx.runner, ctx.cfg = runner, (t, dt, noise, seed, sample0)
+            out = runner.purifier.sde(img, t, dt, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc)
+        ctx.runner, ctx.cfg = runner, (t, dt, noise, seed, sample0, nhwc)
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (out,) = ctx.saved_tensors
-        t, dt, noise, seed, sample0 = ctx.cfg
+        t, dt, noise, seed, sample0, nhwc = ctx.cfg
         with torch.no_grad():
-            a = ctx.runner.purifier.sde_vjp(out, grad_out, t, dt, noise=noise, seed=seed, sample0=sample0)
+            a = ctx.runner.purifier.sde_vjp(out, grad_out, t, dt, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc)
             a = a * ctx.runner.purifier.diffuse_scale(t)
-        return a, None, None, None, None, None, None
+        return a, None, None, None, None, None, None, None
 
 
 class RevGuidedDiffusion(torch.nn.Module):
@@ -66,7 +66,9 @@ class RevGuidedDiffusion(torch.nn.Module):
         print(f"t: {args.t}, rand_t: {args.rand_t}, t_delta: {args.t_delta}")
         print(f"use_bm: {args.use_bm}")
 
-    def image_editing_sample(self, img, bs_id=0, tag=None, noise=None):
+    def image_editing_sample(self, img, bs_id=0, tag=None, noise=None, nhwc=False):
+        """nhwc=True (extension): `img` and the result are the NHWC state of the loop - used by
+        diffpure_amd.adv_model, whose fused resize kernels read/write that layout directly."""
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim
         out_dir = _common.out_dir_for(self.args, bs_id, tag)
@@ -78,7 +80,7 @@ class RevGuidedDiffusion(torch.nn.Module):
             x0 = img.to(self.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
-                _common.save_image(x0, os.path.join(out_dir, "original_input.png"))
+                _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
             seed = int(getattr(self.args, "seed", 0) or 0)
             dt = float(getattr(self.args, "dt", 1e-3) or 1e-3)
             xs = []
@@ -92,11 +94,11 @@ class RevGuidedDiffusion(torch.nn.Module):
 
                 def run(xl, sample0, t=t, call_seed=call_seed):
                     if need_grad:
-                        return _SdePurify.apply(xl, self, t, dt, noise, call_seed, sample0)
-                    return self.purifier.sde(xl, t, dt, noise=noise, seed=call_seed, sample0=sample0)
+                        return _SdePurify.apply(xl, self, t, dt, noise, call_seed, sample0, nhwc)
+                    return self.purifier.sde(xl, t, dt, noise=noise, seed=call_seed, sample0=sample0, nhwc=nhwc)
 
                 x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
                 if log:
-                    _common.save_image(x0, os.path.join(out_dir, f"samples_{it}.png"))
+                    _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)
             return torch.cat(xs, dim=0)

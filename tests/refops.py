@@ -287,7 +287,27 @@ def ddpm_step(x, out6, sr, srm1, c1, c2, min_log, max_log, nonzero, noise=None, 
     return y
 
 
-PATCHED = ["conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd",
+def _dims(shape, nhwc):
+    return (shape[0], shape[3], shape[1], shape[2]) if nhwc else tuple(shape)
+
+
+def resize_affine(x, size, shift, scale, in_nhwc=False, out_nhwc=False):
+    """(F.interpolate(x, size, bilinear, align_corners=False) + shift) * scale with layout choice."""
+    xc = x.permute(0, 3, 1, 2) if in_nhwc else x
+    y = (torch.nn.functional.interpolate(xc, size=tuple(size), mode="bilinear", align_corners=False) + shift) * scale
+    return y.permute(0, 2, 3, 1).contiguous() if out_nhwc else y.contiguous()
+
+
+def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
+    b, c, ho, wo = _dims(dy.shape, out_nhwc)
+    x = torch.zeros((b, c) + tuple(in_size), requires_grad=True)
+    with torch.enable_grad():
+        y = torch.nn.functional.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False) * scale
+        (dx,) = torch.autograd.grad(y, x, dy.permute(0, 3, 1, 2) if out_nhwc else dy)
+    return dx.permute(0, 2, 3, 1).contiguous() if in_nhwc else dx.contiguous()
+
+
+PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd",
            "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "resample", "attention", "silu", "axpby",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
 

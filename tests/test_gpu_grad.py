@@ -220,3 +220,96 @@ def test_sde_stochastic_adjoint_vs_oracle():
     g1 = pur.sde_vjp(xf2, cot, 100, dt, seed=3, sample0=0)
     g2 = pur.sde_vjp(xf2, cot, 100, dt, seed=3, sample0=0)
     assert torch.equal(g1, g2) and torch.isfinite(g1).all()
+
+
+# ---- the steps either side of the purifier --------------------------------------------
+RESIZE_CASES = [
+    # B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, shift, scale
+    (2, 3, 224, 224, 256, 256, False, True, -0.5, 2.0),     # eval_sde_adv.py:74-75,78
+    (2, 3, 256, 256, 224, 224, True, False, 1.0, 0.5),      # eval_sde_adv.py:81-82,89
+    (3, 3, 32, 32, 32, 32, False, True, -0.5, 2.0),         # CIFAR-10: identity resize, affine + repack only
+    (1, 5, 17, 23, 40, 9, False, False, 0.25, -1.5),        # odd sizes, up and down at once, NCHW -> NCHW
+    (2, 4, 9, 9, 31, 31, True, True, 0.0, 1.0),             # large up-scale factor
+]
+
+
+@pytest.mark.parametrize("case", RESIZE_CASES, ids=[str(c) for c in RESIZE_CASES])
+def test_resize_affine_and_its_adjoint_vs_torch(case):
+    """y = (F.interpolate(x, bilinear, align_corners=False) + shift) * scale and dL/dx, against torch on the CPU."""
+    from diffpure_amd import ops
+    B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, shift, scale = case
+    x = rnd(B, C, Hi, Wi, seed=1).requires_grad_(True)
+    ref = (torch.nn.functional.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False) + shift) * scale
+    cot = rnd(B, C, Ho, Wo, seed=2)
+    (gref,) = torch.autograd.grad((ref * cot).sum(), x)
+    xin = (nhwc(x.detach()) if in_nhwc else x.detach()).to(DEV)
+    y = ops.resize_affine(xin, (Ho, Wo), shift, scale, in_nhwc, out_nhwc)
+    y_nchw = nchw(y.cpu()) if out_nhwc else y.cpu()
+    assert (y_nchw - ref.detach()).abs().max() < 2e-6 * max(1.0, ref.abs().max().item())
+    dy = (nhwc(cot) if out_nhwc else cot).to(DEV)
+    dx = ops.resize_affine_bwd(dy, (Hi, Wi), scale, in_nhwc, out_nhwc)
+    dx_nchw = nchw(dx.cpu()) if in_nhwc else dx.cpu()
+    assert relerr(dx_nchw, gref) < 1e-5
+    # deterministic (gather form, no atomics)
+    assert torch.equal(dx, ops.resize_affine_bwd(dy, (Hi, Wi), scale, in_nhwc, out_nhwc))
+
+
+class _TinyClassifier(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(rnd(7, 3, seed=11))
+
+    def forward(self, x):
+        return x.mean(dim=(2, 3)) @ self.w.t()
+
+
+@pytest.mark.parametrize("diffusion_type", ["sde", "ode"])
+def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, diffusion_type):
+    """diffpure_amd.adv_model.SDE_Adv_Model (fused resize/affine/repack kernels, NHWC in and out of the runner)
+    against the upstream composition of eval_sde_adv.py:73-89 spelled with torch ops around the same runner:
+    logits, and dL/dx of the whole defence (adjoint resize o adjoint purifier o adjoint resize)."""
+    from diffpure_amd.adv_model import SDE_Adv_Model
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device(DEV)
+    args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path),
+                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=2e-2, dt=2e-2,
+                              diffusion_type=diffusion_type, domain="cifar10", classifier_name="none", diffusion_size=(16, 16))
+    model = SDE_Adv_Model(args, config, classifier=_TinyClassifier())
+    runner = model.runner
+    F = torch.nn.functional
+    x = torch.rand(3, 3, 14, 14, generator=torch.Generator().manual_seed(5)).to(DEV)
+    cot = rnd(3, 7, seed=6).to(DEV)
+
+    def composition(xin):
+        up = F.interpolate(xin, size=(16, 16), mode="bilinear", align_corners=False)
+        pur = runner.image_editing_sample((up - 0.5) * 2, bs_id=9)
+        return model.classifier((F.interpolate(pur, size=(14, 14), mode="bilinear", align_corners=False) + 1) * 0.5)
+
+    x1 = x.clone().requires_grad_(True)
+    runner._calls = 0
+    model.counter.fill_(9)
+    out = model(x1)
+    (g1,) = torch.autograd.grad((out * cot).sum(), x1)
+    x2 = x.clone().requires_grad_(True)
+    runner._calls = 0
+    ref = composition(x2)
+    (g2,) = torch.autograd.grad((ref * cot).sum(), x2)
+    assert out.shape == (3, 7)
+    assert (out - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert relerr(g1.cpu(), g2.cpu()) < 1e-3
+    # EOT replicas as one batch == separate purifications with the matching global sample indices
+    with torch.no_grad():
+        runner._calls = 0
+        eot = model.forward_eot(x, 2)
+        runner._calls = 0
+        both = model(x.repeat(2, 1, 1, 1))
+    assert eot.shape == (2, 3, 7) and torch.equal(eot.reshape(6, 7), both)
+    assert (eot[0] - eot[1]).abs().max() > 0 if diffusion_type == "sde" else True

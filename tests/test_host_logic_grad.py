@@ -209,3 +209,48 @@ def test_sde_runner_is_differentiable():
     score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
     ref = osol.ode_diffuse_grad(osol.sde_adjoint_grad(score, out.detach(), cot, zs, 100, 2e-2), 100)
     torch.testing.assert_close(x0.grad, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+
+
+def test_adv_model_host_logic_vs_oracle(monkeypatch):
+    """SURVEY.md section 8f-2 on the CPU (ops routed through their torch statements): the NHWC-in / NHWC-out
+    path of the runners and the fused resize/affine steps of diffpure_amd.adv_model.SDE_Adv_Model reproduce
+    oracle/adv.py (= eval_sde_adv.py:73-89) around the same runner, forward and dL/dx."""
+    import refops
+    from diffpure_amd import adv_model
+    from oracle import adv as oadv
+    refops.patch_ops(monkeypatch)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device("cpu")
+    args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=None, score_type="score_sde",
+                              seed=1234, synthetic_weights=True, step_size=5e-2, dt=5e-2, diffusion_type="ode", domain="cifar10",
+                              classifier_name="none", diffusion_size=(16, 16), precision="f32")
+    w = torch.randn(5, 3, generator=torch.Generator().manual_seed(3))
+
+    class Clf(torch.nn.Module):
+        def forward(self, x):
+            return x.mean(dim=(2, 3)) @ w.t()
+
+    model = adv_model.SDE_Adv_Model(args, config, classifier=Clf())
+    runner = model.runner
+    x = torch.rand(2, 3, 12, 12, generator=torch.Generator().manual_seed(4))
+    cot = torch.randn(2, 5, generator=torch.Generator().manual_seed(5))
+    x1 = x.clone().requires_grad_(True)
+    model.counter.fill_(7)
+    runner._calls = 0
+    out = model(x1)
+    (g1,) = torch.autograd.grad((out * cot).sum(), x1)
+    x2 = x.clone().requires_grad_(True)
+    runner._calls = 0
+    ref = oadv.sde_adv_forward(lambda im: runner.image_editing_sample(im, bs_id=7), Clf(), x2, diffusion_size=(16, 16))
+    (g2,) = torch.autograd.grad((ref * cot).sum(), x2)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-6 * g2.abs().max().item())
