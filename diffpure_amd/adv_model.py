@@ -8,6 +8,9 @@ the engine needs, the purifier is entered and left in its native NHWC state (`nh
 whole thing stays differentiable w.r.t. `x` (adjoint resize kernel + the adjoint of the runner), which
 is what AutoAttack / BPDA+EOT differentiate through.
 
+`forward(x, mode=...)` also speaks the BPDA+EOT driver's dialect (SURVEY.md section 8f-3,
+eval_sde_adv_bpda.py:83-118: modes 'purify' / 'classify' / 'purify_and_classify', `.resnet`), whose
+`purify` calls arrive as `eot_defense_reps` (150) replicas per image in one batch.
 `forward_eot(x, reps)` serves the EOT repeats of an attack (`eot_iter`, eval_sde_adv.py:148-149) as one
 batch of reps*B independent purifications instead of `reps` sequential calls.
 
@@ -91,7 +94,20 @@ class SDE_Adv_Model(torch.nn.Module):
         state = self.runner.image_editing_sample(state, bs_id=bs_id, tag=self.tag, nhwc=True)
         return resize_affine(state, size_c, 1.0, 0.5, in_nhwc=True, out_nhwc=False)           # (x_re + 1) * 0.5, NCHW
 
-    def forward(self, x):
+    @property
+    def resnet(self):
+        """the classifier under the name eval_sde_adv_bpda.py uses (:57)"""
+        return self.classifier
+
+    def forward(self, x, mode="purify_and_classify"):
+        """eval_sde_adv.py:67-93 (`mode` left at its default) and the three modes of the BPDA+EOT driver's
+        model (eval_sde_adv_bpda.py:83-118): 'purify' -> purified images in [0,1] (what bpda_eot_attack.py:98-101
+        calls on `purify_reps` replicas of the batch at once), 'classify' -> classifier(x),
+        'purify_and_classify' -> classifier(purify(x))."""
+        if mode == "classify":
+            return self.classifier(x.to(self.device))
+        if mode not in ("purify", "purify_and_classify"):
+            raise NotImplementedError(f"unknown mode: {mode}")
         counter = int(self.counter.item())
         if counter % 5 == 0:
             print(f"diffusion times: {counter}")
@@ -103,9 +119,8 @@ class SDE_Adv_Model(torch.nn.Module):
             print(f"x shape (before diffusion models): {tuple(x.shape)}")
             print(f"x shape (before classifier): {tuple(x_re.shape)}")
             print("Sampling time per batch: {:0>2}:{:05.2f}".format(int(minutes), seconds))
-        out = self.classifier(x_re)
         self.counter += 1
-        return out
+        return x_re if mode == "purify" else self.classifier(x_re)
 
     def forward_eot(self, x, reps):
         """logits [reps, B, classes] of `reps` independent purifications of every image, as ONE batch

@@ -254,3 +254,14 @@ def test_adv_model_host_logic_vs_oracle(monkeypatch):
     (g2,) = torch.autograd.grad((ref * cot).sum(), x2)
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-6 * g2.abs().max().item())
+    # the BPDA+EOT driver's dialect (eval_sde_adv_bpda.py:83-118, bpda_eot_attack.py:98-101): replicas in one batch
+    with torch.no_grad():
+        runner._calls = 0
+        model.counter.fill_(7)
+        pur = model(x.repeat(3, 1, 1, 1), mode="purify")
+        assert pur.shape == (6, 3, 12, 12) and int(model.counter.item()) == 8
+        torch.testing.assert_close(model(pur, mode="classify"), model.resnet(pur))
+        runner._calls = 0
+        torch.testing.assert_close(model(x.repeat(3, 1, 1, 1), mode="purify_and_classify"), model.resnet(pur))
+    with pytest.raises(NotImplementedError):
+        model(x, mode="nonsense")
