@@ -22,6 +22,6 @@ struct ConvH2Args {
     float* colstats;    // optional [M/64][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
 };
 
-// 256x256-tile, 8-wave "ping-pong" variant (igemm_h2_pp.hip).  Preconditions (checked by the caller):
-// M % 256 == 0, N % 256 == 0, C % 32 == 0.  Fills p.tiles / p.tiles_n itself.
-void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s);
+// 8-wave "ping-pong" variants (igemm_h2_pp.hip): bn = 256 -> 256x256 tiles (needs M % 256 == 0, N % 256 == 0),
+// bn = 128 -> 512x128 tiles (M % 512 == 0, N % 128 == 0); C % 32 == 0.  Fills p.tiles / p.tiles_n itself.
+void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn);

@@ -346,15 +346,19 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     {
         const char* e = getenv("DP_H2_PP");
         const int pp = e ? atoi(e) : DP_H2_PP_DEFAULT;
-        const bool shape_ok = p.M % 256 == 0 && N % 256 == 0;
         // one workgroup per CU: the grid runs in rounds of 256 tiles; take the variant when the last round is not
         // mostly empty (measured at B=16: 407-450 TFLOP/s vs 326-375 on full rounds, 262 vs 350 on half a round)
-        const long long t256 = tiles(256, 256), rounds = (t256 + 255) / 256;
-        const bool fills = t256 >= 256 && t256 * 5 >= rounds * 256 * 4;
-        if (shape_ok && pp != 0 && (pp == 1 || fills)) {
+        auto fills = [&](int bm, int bn) {
+            const long long t = tiles(bm, bn), rounds = (t + 255) / 256;
+            return t >= 256 && t * 5 >= rounds * 256 * 4;
+        };
+        int bn = 0;
+        if (pp != 0 && p.M % 256 == 0 && N % 256 == 0 && (pp == 1 || fills(256, 256))) bn = 256;
+        else if (pp != 0 && p.M % 512 == 0 && N % 128 == 0 && (pp == 1 || fills(512, 128))) bn = 128;
+        if (bn) {
             const char* sg = getenv("DP_H2_STAGGER");
             p.stagger = sg ? atoi(sg) : 0;
-            dp_launch_conv_h2_pp(p, s);
+            dp_launch_conv_h2_pp(p, s, bn);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("conv_igemm_h2_pp");

@@ -45,10 +45,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int NT = 512;
 constexpr int NXCD = 8;
-constexpr int BM = 256, BN = 256;
 constexpr int ROWB = 128;               // bytes per LDS row: 32 channels as (hi, lo) fp16 octets
-constexpr int TILE_B = 256 * ROWB;      // one operand tile of one k-tile
-constexpr int BUF = 2 * TILE_B;         // A tile, then B tile
 
 // LDS-DMA with (scalar base + 32-bit lane offset) addressing, spelled in asm: the builtin lets the
 // compiler strength-reduce the k-loop addresses back into 64-bit VGPR pointers (two VALU adds and two
@@ -70,13 +67,23 @@ __device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const 
 
 // MODE (timing experiments, DP_H2_PP_MODE): bit 0 = no s_setprio; bit 1 = no operand traffic after k-tile 0 (WRONG
 // RESULTS); bit 2 = no barriers in the k-loop (WRONG RESULTS); bit 3 = no ds_reads / bit 4 = no DMA after k-tile 0 / bit 5 = no vmcnt waits (WRONG RESULTS)
-template <int MODE>
+// Tile shapes: <256,256> (waves 2 (M) x 4 (N), 128 KB LDS) and <512,128> for layers with 128 output channels
+// (waves 4 (M) x 2 (N), 160 KB LDS = all of it).  The wave tile is 128 x 64 and the phase schedule identical in
+// both; only the wave -> tile mapping and the number of 64-row DMA pieces per unit differ (NPA, NPB).
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
+    static_assert((BM == 256 && BN == 256) || (BM == 512 && BN == 128), "8 waves of 128 x 64");
+    constexpr int NPA = BM / 128, NPB = BN / 128;          // 64-row DMA pieces (one per thread) per A / B unit
+    constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB;  // operand tiles of one k-tile
+    constexpr int BUF = TILE_A + TILE_B;                   // A tile, then B tile
+    constexpr int CNT_A = 2 * NPA + NPB, CNT_B = 2 * NPB + NPA;   // loads of three consecutive phases ending in an A / a B phase
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int grp = wave >> 2;                                   // waves 0-3 / 4-7 sit on distinct SIMDs
+    const int wr = BM == 256 ? wave >> 2 : wave & 3;             // 128-row block of the tile
+    const int wc = BM == 256 ? wave & 3 : wave >> 2;             // 64-column block of the tile
     int tile;
     {   // XCD-aware bijective remap (speed only)
         const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     // scalar base, so a DMA issue costs no vector ALU work and reads one address VGPR per lane.
     // Activation lane offsets are relative to the centre pixel of the tile's first row (always < 2^31:
     // a tile spans 256 consecutive output pixels).
-    unsigned aoff[2][2];                           // [unit][piece]: A row m0 + piece*128 + unit*64 + u
+    unsigned aoff[2][NPA];                         // [unit][piece]: A row m0 + piece*128 + unit*64 + u
     long long aorg;                                // centre pixel of row m0, in bytes from p.x
     {
         const int b = m0 / HW, rem = m0 - b * HW;
@@ -111,23 +118,23 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             const int m = m0 + i * 128 + a * 64 + u;
             const int b = m / HW, rem = m - b * HW;
             const int oy = rem / p.W, ox = rem - oy * p.W;
             aoff[a][i] = (unsigned)(((long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 - aorg) + ls * 16;
         }
-    unsigned boff[2][2];                           // [unit][piece]: weight row n0 + piece*128 + (u>>5)*64 + unit*32 + (u&31)
+    unsigned boff[2][NPB];                         // [unit][piece]: weight row n0 + piece*128 + (u>>5)*64 + unit*32 + (u&31)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NPB; ++i)
             boff[b][i] = (unsigned)(i * 128 + (u >> 5) * 64 + b * 32 + (u & 31)) * (unsigned)(p.K * 4) + ls * 16;
     const char* const abase = p.x + pp_uniform(aorg);              // uniform
     const char* const bbase = p.w + pp_uniform((long long)n0 * p.K * 4);   // uniform
     const int u0 = wave * 8;                       // first row of this wave inside a piece (wave-uniform)
     const int adst = u0 * ROWB;                                            // + (piece*128 + unit*64) * ROWB
-    const int bdst = TILE_B + ((u0 >> 5) * 64 + (u0 & 31)) * ROWB;         // + (piece*128 + unit*32) * ROWB
+    const int bdst = TILE_A + ((u0 >> 5) * 64 + (u0 & 31)) * ROWB;         // + (piece*128 + unit*32) * ROWB
 
     auto tap_off = [&](int c32, int tap) -> long long {
         const int ky = tap / p.KS, kx = tap - ky * p.KS;
@@ -135,19 +142,19 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     };
     auto stage_a = [&](char* buf, int a, long long off) {
         const char* sb = abase + pp_uniform(off);
-        pp_glds(aoff[a][0], sb, buf + adst + (a * 64) * ROWB);
-        pp_glds(aoff[a][1], sb, buf + adst + (128 + a * 64) * ROWB);
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) pp_glds(aoff[a][i], sb, buf + adst + (i * 128 + a * 64) * ROWB);
     };
     auto stage_b = [&](char* buf, int b, long long off) {
         const char* sb = bbase + pp_uniform(off);
-        pp_glds(boff[b][0], sb, buf + bdst + (b * 32) * ROWB);
-        pp_glds(boff[b][1], sb, buf + bdst + (128 + b * 32) * ROWB);
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) pp_glds(boff[b][i], sb, buf + bdst + (i * 128 + b * 32) * ROWB);
     };
 
     // ---- fragment addressing: lane -> row lr of a 32-row MFMA tile, k-half lk; slot (s*4 + lk*2 + h) ^ key
     const int lr = lane & 31, lk = lane >> 5, key = (lr >> 1) & 7;
     const int arow = (wr * 128 + lr) * ROWB;                 // + (sub*64 + i*32) * ROWB
-    const int brow = TILE_B + (wc * 64 + lr) * ROWB;         // + (sub*32) * ROWB
+    const int brow = TILE_A + (wc * 64 + lr) * ROWB;         // + (sub*32) * ROWB
     int soff[2][2];                                          // [s][h] byte offset of the fragment inside its row
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -190,10 +197,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         }                                                                                                        \
     } while (0)
     // end of a phase's load part .. MFMA part .. end of phase
-#define PP_SYNC_THEN_MFMA(COUNTED, ASUB, BSUB, BH, BL)                             \
+#define PP_SYNC_THEN_MFMA(COUNTED, CNT, ASUB, BSUB, BH, BL)                             \
     do {                                                                           \
         if constexpr (!(MODE & 32)) {                                              \
-            if (COUNTED) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          \
+            if (COUNTED) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
         }                                                                          \
         if constexpr (!(MODE & 4)) PP_BARRIER();                                   \
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     if (nt > 1) stage_b(smem + BUF, 0, 128);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BARRIER();
-    if (wr == 1) PP_BARRIER();          // group 1 runs one interval behind group 0
+    if (grp == 1) PP_BARRIER();         // group 1 runs one interval behind group 0
 
     int c1 = 0, tap1 = 1;               // (slice, tap) of k-tile t+1
     if (tap1 == taps) { tap1 = 0; c1 = 1; }
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             fb0l[s] = *reinterpret_cast<const half8*>(cur + brow + soff[s][1]);
         }
         if (more1 && !(MODE & 64)) stage_a(nxt, 0, offa);
-        PP_SYNC_THEN_MFMA(more1, 0, 0, fb0h, fb0l);
+        PP_SYNC_THEN_MFMA(more1, CNT_A, 0, 0, fb0h, fb0l);
 
         // phase 1: Q01
 #pragma unroll
@@ -244,20 +251,20 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             fb1l[s] = *reinterpret_cast<const half8*>(cur + brow + 32 * ROWB + soff[s][1]);
         }
         if (more1 && !(MODE & 128)) stage_b(nxt, 1, offb1);
-        PP_SYNC_THEN_MFMA(more1, 0, 1, fb1h, fb1l);
+        PP_SYNC_THEN_MFMA(more1, CNT_B, 0, 1, fb1h, fb1l);
 
         // phase 2: Q11
         if (traffic) read_a(cur, 1);
         if (more1 && !(MODE & 64)) stage_a(nxt, 1, offa);
-        PP_SYNC_THEN_MFMA(more1, 1, 1, fb1h, fb1l);
+        PP_SYNC_THEN_MFMA(more1, CNT_A, 1, 1, fb1h, fb1l);
 
         // phase 3: Q10 (B sub-block 0 still in registers); B0 of k-tile t+2 goes into the buffer being computed
         if (more2 && !(MODE & 128)) stage_b(const_cast<char*>(cur), 0, offb1 + 128);
-        PP_SYNC_THEN_MFMA(more2, 1, 0, fb0h, fb0l);
+        PP_SYNC_THEN_MFMA(more2, CNT_B, 1, 0, fb0h, fb0l);
 
         if (++tap1 == taps) { tap1 = 0; ++c1; }
     }
-    if (wr == 0) PP_BARRIER();          // re-align the two groups (barrier counts must match)
+    if (grp == 0) PP_BARRIER();         // re-align the two groups (barrier counts must match)
 #undef PP_SYNC_THEN_MFMA
 #undef PP_MFMA
 
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         if (p.colstats && lk == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col;
+                float* d = p.colstats + (size_t)(tile_m * (BM / 64) + wr * 2 + q) * 2 * p.N + col;
                 d[0] = cs[2 * q] + cs[2 * q + 1];
                 d[p.N] = cq[2 * q] + cq[2 * q + 1];
             }
@@ -326,23 +333,25 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 
 }  // namespace
 
-void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s) {
-    p.tiles_n = p.N / BN;
-    p.tiles = (p.M / BM) * p.tiles_n;
+void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
+    const int bm = bn == 256 ? 256 : 512;
+    p.tiles_n = p.N / bn;
+    p.tiles = (p.M / bm) * p.tiles_n;
     const char* e = getenv("DP_H2_PP_MODE");
     const int mode = e ? atoi(e) : 0;
-#define PP_LAUNCH(M_) hipLaunchKernelGGL(conv_igemm_h2_pp<M_>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
-    switch (mode) {
-        case 1: PP_LAUNCH(1); break;
-        case 2: PP_LAUNCH(2); break;
-        case 6: PP_LAUNCH(6); break;
-        case 8: PP_LAUNCH(8); break;
-        case 16: PP_LAUNCH(16); break;
-        case 32: PP_LAUNCH(32); break;
-        case 256: PP_LAUNCH(256); break;
-        case 96: PP_LAUNCH(96); break;
-        case 160: PP_LAUNCH(160); break;
-        default: PP_LAUNCH(0); break;
+#define PP_LAUNCH(BM_, BN_, M_) hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
+    if (bn == 128) {
+        PP_LAUNCH(512, 128, 0);
+        return;
+    }
+    switch (mode) {     // timing experiments (see MODE)
+        case 1: PP_LAUNCH(256, 256, 1); break;
+        case 2: PP_LAUNCH(256, 256, 2); break;
+        case 6: PP_LAUNCH(256, 256, 6); break;
+        case 8: PP_LAUNCH(256, 256, 8); break;
+        case 16: PP_LAUNCH(256, 256, 16); break;
+        case 256: PP_LAUNCH(256, 256, 256); break;
+        default: PP_LAUNCH(256, 256, 0); break;
     }
 #undef PP_LAUNCH
 }

@@ -263,6 +263,11 @@ PP_CASES = [
     (1, 16, 16, 32, 256, 1, 1, False, 1.0),            # a single k-tile (prologue only)
     (1, 16, 16, 96, 256, 1, 0, True, 1.0),             # 3 k-tiles (all of them in the drained tail)
     (4, 32, 32, 256, 512, 3, 2, True, 1.0),            # 32 tiles, several tiles per sample, 72 k-tiles
+    # N = 128 -> the 512x128 tiling of the same schedule (M % 512 == 0)
+    (2, 16, 16, 128, 128, 3, 2, True, 0.70710678),     # one tile, 36 k-tiles, every epilogue term
+    (1, 32, 16, 32, 128, 1, 1, False, 1.0),            # a single k-tile
+    (8, 32, 32, 128, 384, 3, 2, True, 1.0),            # 16 x 3 tiles (NCSN++ 32x32 level shape, N = 3 x 128)
+    (2, 32, 32, 96, 128, 3, 0, False, 1.0),            # 27 k-tiles
 ]
 
 
