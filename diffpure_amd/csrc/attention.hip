@@ -1,0 +1,277 @@
+// Fused self-attention  out = softmax(q k^T / sqrt(d)) v  on the fp16 matrix cores with fp32-class accuracy
+// (the "f16x3" arithmetic of igemm_h2.hip: operands split into fp16 hi + lo, three MFMA passes per product).
+// Replaces, on the inference path, the QK^T GEMM + row softmax + PV GEMM trio (QKVAttentionLegacy.forward,
+// /root/reference/guided_diffusion/unet.py:345-362; AttnBlockpp's einsums, score_sde/models/layerspp.py:82-86):
+// the [B*heads, T, T] score tensor (2.1 GB per layer at 32x32, B=64) is never written.
+//
+// Two kernels:
+//   attn_pack : qkv [B,T,3C] fp32 -> Q (pre-scaled by 1/sqrt(d)), K as h2 rows [z][T][d], and V TRANSPOSED per
+//               32-key block, [z][T/32][d][32 keys], h2 along the key axis, keys stored in the order the
+//               MFMA accumulator layout hands the probabilities back (see below).     z = b * heads + h
+//   attn_flash: one workgroup = QW waves x 32 queries of one z; K / V^T blocks of 32 keys stream through LDS by
+//               LDS-DMA (double buffered); per block and wave:
+//                 S^T (32 keys x 32 queries) = K_blk Q^T        12 MFMA   (A = K rows, B = Q held in registers)
+//                 online softmax: the C layout gives every lane ONE query (column lane & 31) and 16 of its keys, so
+//                 the running max / sum / rescale are per-lane scalars plus one exchange with lane ^ 32
+//                 O^T (d x 32 queries) += V^T_blk P^T           12 MFMA   (A = V^T rows, B = P straight from the
+//                 accumulator registers - no shuffle: the key order inside a register octet is
+//                 {0,1,2,3,8,9,10,11 | 4,5,6,7,12,13,14,15}, and attn_pack stores V^T in exactly that order)
+// LDS rows are 128 bytes (32 k-values as hi|lo octets) with the XOR swizzle of igemm_h2.hip.
+#include "dp_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int D = 64;                 // head dimension (guided diffusion: num_head_channels = 64)
+constexpr int SL = D / 32;            // 128-byte slices per K row
+constexpr int KB = 32;                // keys per block
+
+__device__ __forceinline__ int swz128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+struct PackArgs {
+    const float* qkv;
+    int B, T, C, NH;
+    int oq, ok, ov, sh;     // channel offsets of q, k, v of head 0 and the head stride
+    float qscale;
+    char* qh;               // [z][T][D*4]
+    char* kh;               // [z][T][D*4]
+    char* vt;               // [z][T/32][D][128]
+};
+
+__device__ __forceinline__ void split8(const float* v, float scale, half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j] * scale;
+        hi[j] = (_Float16)x;
+        lo[j] = (_Float16)(x - (float)hi[j]);
+    }
+}
+
+// grid.x = z * (T/32) + block; 256 threads.  Q/K: thread -> (token, d-octet); V^T: thread -> (d, position octet)
+__global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
+    const int nblk = p.T / KB;
+    const int z = blockIdx.x / nblk, blk = blockIdx.x - z * nblk;
+    const int b = z / p.NH, h = z - b * p.NH;
+    const int tid = threadIdx.x;
+    const size_t row0 = (size_t)b * p.T + (size_t)blk * KB;      // first token of this block in qkv
+    const int c3 = 3 * p.C;
+    {   // Q and K: 32 tokens x 8 octets = 256 items
+        const int tok = tid >> 3, oc = tid & 7;
+        const float* src = p.qkv + (row0 + tok) * c3 + h * p.sh + oc * 8;
+        float v[8];
+        half8 hi, lo;
+        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src + p.oq);
+        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + p.oq + 4);
+        split8(v, p.qscale, hi, lo);
+        half8* dq = reinterpret_cast<half8*>(p.qh + (((size_t)z * p.T + blk * KB + tok) * D + oc * 8) * 4);
+        dq[0] = hi;
+        dq[1] = lo;
+        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src + p.ok);
+        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + p.ok + 4);
+        split8(v, 1.f, hi, lo);
+        half8* dk = reinterpret_cast<half8*>(p.kh + (((size_t)z * p.T + blk * KB + tok) * D + oc * 8) * 4);
+        dk[0] = hi;
+        dk[1] = lo;
+    }
+    {   // V^T: 64 d x 4 position octets = 256 items; lanes run along d (coalesced reads of V rows)
+        const int dd = tid & 63, po = tid >> 6;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // the key whose position is po*8 + j
+            const int pos = po * 8 + j;
+            const int p16 = pos & 15;
+            const int kk = (pos & 16) + ((p16 >> 3) & 1) * 4 + ((p16 >> 2) & 1) * 8 + (p16 & 3);   // inverse of key_pos
+            v[j] = p.qkv[(row0 + kk) * c3 + h * p.sh + p.ov + dd];
+        }
+        half8 hi, lo;
+        split8(v, 1.f, hi, lo);
+        half8* dv = reinterpret_cast<half8*>(p.vt + (((size_t)z * nblk + blk) * D + dd) * 128 + po * 32);
+        dv[0] = hi;
+        dv[1] = lo;
+    }
+}
+
+struct FlashArgs {
+    const char* qh;
+    const char* kh;
+    const char* vt;
+    float* out;         // [B][T][C]
+    int T, C, NH;
+};
+
+#define AT_GLDS(src, dst)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),     \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+// QW waves per workgroup, 32 queries each.  LDS per stage: K tile SL slices x 32 rows x 128 B, V^T tile D rows x 128 B.
+template <int QW>
+__global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
+    constexpr int NT = QW * 64;
+    constexpr int KT = SL * KB * 128, VT = D * 128, STAGE = KT + VT;        // 8 KB + 8 KB
+    constexpr int PIECES = STAGE / (NT * 16);                               // DMA instructions per thread per block
+    constexpr int ROWS_PER_PIECE = NT / 8;                                  // 128-byte rows per workgroup-wide piece
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lk = lane >> 5;
+    const int qblocks = p.T / (QW * 32);
+    const int z = blockIdx.x / qblocks, qb = blockIdx.x - z * qblocks;
+    const int q0 = qb * (QW * 32) + wave * 32;
+    const int nkb = p.T / KB;
+
+    // ---- staging: the stage image is STAGE/128 rows of 128 B: rows [0, SL*32) = K (slice-major), then D rows of V^T
+    const int r_in_piece = tid >> 3, ps = tid & 7;
+    const char* src[PIECES];
+    int sstep[PIECES];          // bytes to advance the source per key block
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int row = i * ROWS_PER_PIECE + r_in_piece;
+        const int ls = ps ^ ((row >> 1) & 7);
+        if (row < SL * KB) {
+            const int sl = row / KB, key = row - sl * KB;
+            src[i] = p.kh + (((size_t)z * p.T + key) * D) * 4 + sl * 128 + ls * 16;
+            sstep[i] = KB * D * 4;
+        } else {
+            const int dd = row - SL * KB;
+            src[i] = p.vt + (((size_t)z * nkb) * D + dd) * 128 + ls * 16;
+            sstep[i] = D * 128;
+        }
+    }
+    const int wdst = wave * 8 * 128;        // this wave's first row inside a piece (wave-uniform)
+    auto issue = [&](int stage) {
+        char* base = smem + stage * STAGE + wdst;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            AT_GLDS(src[i], base + i * ROWS_PER_PIECE * 128);
+            src[i] += sstep[i];
+        }
+    };
+
+    // ---- Q fragments (B operand: column = query lr, k = 8 consecutive d of octet ks*2 + lk), kept in registers
+    half8 qh[D / 16], ql[D / 16];
+    {
+        const char* qrow = p.qh + (((size_t)z * p.T + q0 + lr) * D) * 4;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            const half8* s = reinterpret_cast<const half8*>(qrow + (ks * 2 + lk) * 32);
+            qh[ks] = s[0];
+            ql[ks] = s[1];
+        }
+    }
+
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    issue(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cur = kb & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nkb) issue(cur ^ 1);
+        const char* Ks = smem + cur * STAGE;
+        const char* Vs = Ks + KT;
+
+        // S^T = K_blk Q^T
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            const int sl = ks >> 1, st = ks & 1;
+            const char* rowp = Ks + sl * (KB * 128);
+            const half8 kh = *reinterpret_cast<const half8*>(rowp + swz128(lr, st * 4 + lk * 2));
+            const half8 kl = *reinterpret_cast<const half8*>(rowp + swz128(lr, st * 4 + lk * 2 + 1));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+        }
+
+        // online softmax for query lr: this lane holds 16 of the block's 32 keys, lane ^ 32 the other 16
+        float mb = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mb = fmaxf(mb, s[r]);
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m_run, mb);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+        // O^T += V^T_blk P^T : registers r = 8*g .. 8*g+7 are the B operand of key group g as they stand
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            half8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = s[g * 8 + j];
+                ph[j] = (_Float16)v;
+                pl[j] = (_Float16)(v - (float)ph[j]);
+            }
+#pragma unroll
+            for (int t = 0; t < D / 32; ++t) {
+                const half8 vh = *reinterpret_cast<const half8*>(Vs + swz128(t * 32 + lr, g * 4 + lk * 2));
+                const half8 vl = *reinterpret_cast<const half8*>(Vs + swz128(t * 32 + lr, g * 4 + lk * 2 + 1));
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- O^T tile t: rows = d (t*32 + (r&3) + 8*(r>>2) + 4*lk), column = query lr -> out[b][q0 + lr][h*D + d]
+    const int b = z / p.NH, h = z - b * p.NH;
+    const float inv = 1.f / l_run;
+    float* orow = p.out + ((size_t)b * p.T + q0 + lr) * p.C + h * D;
+#pragma unroll
+    for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {o[t][g * 4] * inv, o[t][g * 4 + 1] * inv, o[t][g * 4 + 2] * inv, o[t][g * 4 + 3] * inv};
+            *reinterpret_cast<f32x4*>(orow + t * 32 + g * 8 + lk * 4) = v;
+        }
+}
+
+}  // namespace
+
+extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, float* out, void* work,
+                                  void* stream) {
+    DP_REQUIRE(qkv && out && work && B > 0 && T > 0 && C > 0 && n_heads > 0, "dp_attention_fused: bad args");
+    DP_REQUIRE(C % n_heads == 0 && C / n_heads == D, "dp_attention_fused: head dimension must be %d (got %d)", D,
+               n_heads ? C / n_heads : 0);
+    DP_REQUIRE(T % 64 == 0, "dp_attention_fused: token count must be a multiple of 64 (got %d)", T);
+    DP_REQUIRE(layout == 0 || layout == 1, "dp_attention_fused: layout %d", layout);
+    DP_REQUIRE(dp_aligned16(qkv) && dp_aligned16(out) && dp_aligned16(work), "dp_attention_fused: misaligned tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t part = (size_t)B * T * C * 4;
+    PackArgs pa;
+    pa.qkv = qkv; pa.B = B; pa.T = T; pa.C = C; pa.NH = n_heads;
+    if (layout == 0) { pa.oq = 0; pa.ok = D; pa.ov = 2 * D; pa.sh = 3 * D; }       // 'legacy': heads x [q | k | v]
+    else { pa.oq = 0; pa.ok = C; pa.ov = 2 * C; pa.sh = D; }                       // 'split' : [Q | K | V]
+    pa.qscale = 1.0f / sqrtf((float)D);
+    pa.qh = (char*)work; pa.kh = pa.qh + part; pa.vt = pa.kh + part;
+    const int Z = B * n_heads;
+    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
+    DP_LAUNCH_CHECK("attn_pack");
+    FlashArgs fa{pa.qh, pa.kh, pa.vt, out, T, C, n_heads};
+    if (T % 128 == 0) hipLaunchKernelGGL(attn_flash_kernel<4>, dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
+    else hipLaunchKernelGGL(attn_flash_kernel<2>, dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
+    DP_LAUNCH_CHECK("attn_flash");
+    return 0;
+}

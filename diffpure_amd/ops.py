@@ -6,6 +6,7 @@ Layout: activations are NHWC fp32 `[B, H, W, C]`; "rows" tensors are `[M, K]`.
 No CPU path exists: tensors must live on a GPU and the library must be built.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -375,6 +376,22 @@ def _attn_offsets(c, d, layout):
     raise ValueError(layout)
 
 
+def attention_fused_ok(t, d):
+    """shapes the flash-style kernel covers (head dimension 64, whole 64-token blocks); DIFFPURE_ATTN_FUSED=0 disables it"""
+    return d == 64 and t % 64 == 0 and os.environ.get("DIFFPURE_ATTN_FUSED", "1") != "0"
+
+
+def attention_fused(qkv, n_heads, layout):
+    """softmax(q k^T / sqrt(d)) v without materialising the scores (csrc/attention.hip); inference path only."""
+    _chk(qkv, "attention_fused.qkv", 3)
+    b, t, c3 = qkv.shape
+    c = c3 // 3
+    out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
+    work = torch.empty((3 * b * t * c,), device=qkv.device, dtype=torch.float32)
+    _lib.call("dp_attention_fused", _ptr(qkv), b, t, c, n_heads, 0 if layout == "legacy" else 1, _ptr(out), _ptr(work), _stream())
+    return out
+
+
 def attention(qkv, n_heads, layout, return_probs=False):
     """softmax(q k^T / sqrt(d)) v for qkv [B, T, 3C] -> [B, T, C]  (, probs [B*heads, T, T]).
     layout 'legacy': channels = heads x [q(d) | k(d) | v(d)]   (QKVAttentionLegacy, unet.py:345-362)
@@ -383,6 +400,8 @@ def attention(qkv, n_heads, layout, return_probs=False):
     b, t, c3 = qkv.shape
     c = c3 // 3
     d = c // n_heads
+    if not return_probs and attention_fused_ok(t, d):
+        return attention_fused(qkv, n_heads, layout)
     oq, ok, ov, sh = _attn_offsets(c, d, layout)
     s = _stream()
     scores = torch.empty((b * n_heads, t, t), device=qkv.device, dtype=torch.float32)

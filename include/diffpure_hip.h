@@ -196,6 +196,14 @@ int dp_softmax_bwd_rows(const float* p, float* dp, long long rows, int cols, voi
 /* out = a + b (gradient accumulation at fan-out points). n % 4 == 0. */
 int dp_add(const float* a, const float* b, float* out, long long n, void* stream);
 
+/* Fused attention for the inference path (no probabilities kept): out[b,t,h*d+:] = softmax(q k^T / sqrt(d)) v per
+ * head on the fp16 matrix cores with split-fp16 operands (fp32-class accuracy), flash-style (the T x T scores stay
+ * in registers).  Same operand conventions as dp_gemm_strided-based attention: qkv [B,T,3C] fp32, layout 0 =
+ * 'legacy' (heads x [q|k|v], QKVAttentionLegacy unet.py:345-362), 1 = 'split' ([Q|K|V]); head dimension 64,
+ * T % 64 == 0.  work: 3 * B * T * C * 4 bytes of 16-byte-aligned scratch (packed Q, K and transposed V). */
+int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, float* out, void* work,
+                       void* stream);
+
 /* ---- the steps either side of the purifier ---------------------------------------
  * y = (bilinear(x) + shift) * scale, PyTorch semantics of F.interpolate(mode='bilinear',
  * align_corners=False), with a free choice of layouts (in_nhwc / out_nhwc: 0 = NCHW, 1 = NHWC).

@@ -137,6 +137,33 @@ def test_attention(dev, case):
     qkv = rnd(B, T, 3 * C, seed=11)
     ref = refops.attention(qkv.double(), heads, layout).float()
     close(ops.attention(qkv.to(dev), heads, layout), ref, rtol=1e-4, atol=1e-5)
+    # the three-kernel path (what the taped forward of the VJP uses) on every shape
+    out3, probs = ops.attention(qkv.to(dev), heads, layout, return_probs=True)
+    close(out3, ref, rtol=1e-4, atol=1e-5)
+    assert probs.shape == (B * heads, T, T)
+
+
+FUSED_ATT_CASES = [(2, 64, 128, 2, "legacy", 1.0), (3, 256, 256, 4, "legacy", 1.0), (1, 1024, 512, 8, "legacy", 1.0),
+                   (2, 256, 128, 2, "split", 1.0), (2, 1024, 128, 2, "legacy", 8.0), (5, 64, 1024, 16, "legacy", 3.0)]
+
+
+@pytest.mark.parametrize("case", FUSED_ATT_CASES, ids=[str(c) for c in FUSED_ATT_CASES])
+def test_attention_fused_flash_kernel(dev, case, monkeypatch):
+    """csrc/attention.hip (scores never materialised, split-fp16 MFMA) against fp64 attention and against the
+    three-kernel fp32 path; `gain` > 1 makes the logits large so that the running-max rescale is exercised."""
+    from diffpure_amd import ops
+    B, T, C, heads, layout, gain = case
+    qkv = rnd(B, T, 3 * C, seed=11) * gain
+    ref = refops.attention(qkv.double(), heads, layout).float()
+    assert ops.attention_fused_ok(T, C // heads)
+    got = ops.attention_fused(qkv.to(dev), heads, layout)
+    # logits of magnitude ~gain^2 * sqrt(d): their 22-bit products (and the fp32 ones of the other path) carry an
+    # absolute error ~gain^2 * 1e-5, which softmax turns into a relative error of the same size on outputs ~gain
+    tol = 2e-5 * gain ** 3
+    close(got, ref, rtol=1e-4, atol=tol)
+    monkeypatch.setenv("DIFFPURE_ATTN_FUSED", "0")
+    close(got, ops.attention(qkv.to(dev), heads, layout).cpu(), rtol=1e-4, atol=tol)
+    assert torch.equal(got, ops.attention_fused(qkv.to(dev), heads, layout))      # deterministic
 
 
 def test_softmax_forced_large_logits(dev):
