@@ -33,7 +33,24 @@ void dp_prof_end(void* rec, hipStream_t s);
 
 static inline bool dp_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-__device__ __forceinline__ float dp_silu_f(float v) { return v / (1.0f + expf(-v)); }
+// exp(x) in ~7 instructions, ~2 ulp: exp2 on the hardware unit with the rounding error of x * log2(e) carried to
+// first order (libm's expf + an IEEE division cost ~25 VALU instructions per SiLU - enough to make GroupNorm-apply
+// instruction-bound instead of HBM-bound).  Overflow -> inf, underflow -> 0 as exp2 gives them.
+__device__ __forceinline__ float dp_exp_f(float x) {
+    const float t = x * 1.44269504088896341f;
+    const float r = fmaf(x, 1.44269504088896341f, -t) + x * 1.92596299112661746e-8f;   // low bits of x * log2(e)
+    const float e = __builtin_amdgcn_exp2f(t);
+    // e == 0 or inf: the argument is out of range and r may be inf - inf; the limit value is e itself
+    return (e > 0.f && e < 3.0e38f) ? fmaf(e, r * 0.693147180559945309f, e) : e;
+}
+// 1 / (1 + exp(-v)): the reciprocal unit is within 1 ulp, one Newton step makes it correctly rounded for practical purposes
+__device__ __forceinline__ float dp_sigmoid_f(float v) {
+    const float d = 1.0f + dp_exp_f(-v);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return d > 3.0e38f ? 0.f : r;          // d = inf: rcp gives 0 but the Newton step would make NaN (inf * 0)
+}
+__device__ __forceinline__ float dp_silu_f(float v) { return v * dp_sigmoid_f(v); }
 
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {

@@ -151,7 +151,7 @@ __device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) 
 // normalisation / FiLM coefficients are formed once, not per pixel) and walks the row's pixels in
 // steps of `slots`, so the inner loop has no integer division: load, fma, SiLU, convert, store.
 // Lanes run along the channels: a wave touches 64 * VEC * 4 contiguous bytes per step.
-template <bool H2>
+template <bool H2, bool ACT>
 __global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
     constexpr int VEC = H2 ? 8 : 4, NQ = VEC / 4;
     constexpr int BORDER = H2 ? 1 : 0;
@@ -219,7 +219,7 @@ __global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float u = v[j] * a[qd][j] + d[qd][j];
-                        v[j] = p.act ? dp_silu_f(u) : u;
+                        v[j] = ACT ? dp_silu_f(u) : u;
                     }
                     return v;
                 };
@@ -325,8 +325,16 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     const int CV = out_fmt ? C / 8 : C / 4;
     const int CVT = CV < 256 ? CV : 256, slots = 256 / CVT;
     const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));
-    if (out_fmt) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots);
-    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots);
+#define GN_APPLY_LAUNCH(H2_, ACT_) \
+    hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_>), dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots)
+    if (out_fmt) {
+        if (act) GN_APPLY_LAUNCH(true, true);
+        else GN_APPLY_LAUNCH(true, false);
+    } else {
+        if (act) GN_APPLY_LAUNCH(false, true);
+        else GN_APPLY_LAUNCH(false, false);
+    }
+#undef GN_APPLY_LAUNCH
     DP_LAUNCH_CHECK("gn_apply");
     return 0;
 }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, i
         float du = da[j];
         if (p.act) {
             const float u = (xh[j] * ga[j] + be[j]) * m[j] + fh[j];
-            const float sg = 1.f / (1.f + expf(-u));
+            const float sg = dp_sigmoid_f(u);
             du *= sg * (1.f + u * (1.f - sg));
         }
         dxh[j] = du * m[j] * ga[j];

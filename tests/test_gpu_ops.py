@@ -383,3 +383,19 @@ def test_conv_epilogue_column_sums_give_groupnorm_stats(dev, case):
     fused2 = ops.group_norm_stats(y, G, 1e-5, y2)
     plain2 = ops.group_norm_stats(y.clone(), G, 1e-5, y2.clone())
     close(fused2, plain2.cpu(), rtol=2e-5, atol=2e-6)
+
+
+def test_fast_silu_accuracy_and_extremes(dev):
+    """dp_silu_f (hardware exp2 + reciprocal with first-order corrections, csrc/dp_common.h) against fp64 SiLU over
+    the whole range, including the arguments where exp overflows / underflows."""
+    from diffpure_amd import ops
+    x = torch.cat([torch.linspace(-120, 120, 200001), torch.tensor([0.0, -0.0, 88.7, -88.7, 89.0, -89.0, 104.0, -104.0, 1e4, -1e4,
+                                                                    1e-30, -1e-30, 3.0e38, -3.0e38])])
+    pad = (-x.numel()) % 4
+    x = torch.cat([x, torch.zeros(pad)])
+    got = ops.silu(x.to(dev)).cpu()
+    ref = (x.double() * torch.sigmoid(x.double())).float()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    # |x| > 88.7: exp overflows in fp32 (as it does in torch's own fp32 SiLU) and results of size ~1e-37 flush to 0
+    assert (err <= 4e-7 * ref.abs() + 2e-36).all(), (err / ref.abs().clamp_min(1e-30)).max()
