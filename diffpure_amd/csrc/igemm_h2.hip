@@ -116,7 +116,12 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
 
     // workgroup-uniform cursor of the k-stage being staged, in weight order: 32-channel slice c32 outermost,
     // then the tap, then (BKH == 16) the half of the slice
-    int cur_c = 0, cur_tap = 0, cur_h = 0;
+    // split-K: this workgroup reduces k-stages [t0, t0 + nt) of the layer's K / BKH
+    const int nt = (p.K / BKH) / p.ksplit;
+    const int t0 = (int)blockIdx.y * nt;
+    int cur_h = t0 % NSUB, cur_tap = (t0 / NSUB) % taps, cur_c = (t0 / NSUB) / taps;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) bptr[it] += (size_t)t0 * bstep[it];
     auto issue = [&](int stage) {
         const int ky = cur_tap / p.KS, kx = cur_tap - ky * p.KS;
         const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)cur_c * 128 + cur_h * ROWB;
@@ -183,7 +188,6 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
         }
     };
 
-    const int nt = p.K / BKH;
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -201,6 +205,22 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
         __syncthreads();
     }
 
+    if (p.ksplit > 1) {      // raw partial sums; bias / temb / residual / scale / column sums happen in splitk_epilogue_kernel
+        float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
+        const int lr_ = lane & 31, lk_ = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn0 + j * 32 + lr_;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk_;
+                    if (row < p.M && col < p.N) wsp[(size_t)row * p.N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // column partials in the tile-shape-independent order of igemm.hip (32-row sub-sums -> 64-row records)
     float* cs_lds = reinterpret_cast<float*>(smem);     // [BM/32][BN][2] floats, tiles released by the last barrier
     // The residual reads of one column block are all issued before their first use (TM x 16 loads in flight per
@@ -270,6 +290,67 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     }
 }
 
+// Split-K second pass: out = scale * (res + temb + bias + sum_s ws[s]) in the fixed order s = 0 .. S-1, plus the
+// per-column (sum, sumsq) of every 64 output rows.  One workgroup = 64 rows x 64 columns: thread (rg = tid / 16,
+// c4 = tid % 16) owns rows rg*4 .. rg*4+3 of columns c4*4 .. c4*4+3; column sums go through LDS in a fixed order.
+// The split factor depends on the layer shape only (never on the batch), so results stay identical for any
+// sharding of a batch.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvH2Args p) {
+    __shared__ float red[16][64][2];
+    const int tid = threadIdx.x, rg = tid >> 4, c4 = tid & 15;
+    const int row0 = blockIdx.y * 64 + rg * 4, col0 = blockIdx.x * 64 + c4 * 4;
+    const int HW = p.H * p.W;
+    const bool cok = col0 < p.N;              // N % 4 == 0 is required by the caller
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};        // bias / temb rows may be unaligned slices of a wider table: scalar loads
+    if (cok && p.bias) bv = f32x4{p.bias[col0], p.bias[col0 + 1], p.bias[col0 + 2], p.bias[col0 + 3]};
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + i;
+        if (!cok || row >= p.M) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (size_t)row * p.N + col0);
+        for (int s = 1; s < p.ksplit; ++s) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + row) * p.N + col0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += w[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += bv[j];
+        if (p.temb) {
+            const float* t = p.temb + (size_t)(row / HW) * p.temb_stride + col0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += t[j];
+        }
+        if (p.res) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] *= p.scale;
+            cs[j] += v[j];
+            cq[j] += v[j] * v[j];
+        }
+        *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col0) = v;
+    }
+    if (!p.colstats) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[rg][c4 * 4 + j][0] = cs[j];
+        red[rg][c4 * 4 + j][1] = cq[j];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int c = tid & 63, which = tid >> 6;
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += red[g][c][which];
+        const int col = blockIdx.x * 64 + c;
+        if (col < p.N) p.colstats[((size_t)blockIdx.y * 2 + which) * p.N + col] = a;
+    }
+}
+
 // fp32 [rows][cols] (row-major, ld) -> h2 [rows][cols/8][2][8]
 __global__ void pack_h2_kernel(const float* src, long long rows, int cols, int ld, _Float16* dst) {
     const long long nblk = rows * (cols / 8);
@@ -308,9 +389,27 @@ const char* zero_page() {
 
 }  // namespace
 
+// Split-K factor of a layer: a function of the layer's own shape ONLY (pixels per sample, reduction length) - never of
+// the batch - so that any sharding of a batch takes the same arithmetic path.  Low-resolution levels (<= 64 pixels per
+// sample) have few output tiles and long reductions (K = 2304 .. 18432): without the split a 4x4 level at B=128 runs
+// 128 workgroups of 144 sequential k-tiles on 256 CUs.
+static int h2_ksplit(int H, int W, int KS, int C, int N) {
+    const int nt = KS * KS * C / 32;
+    if (H * W > 64 || N % 4 != 0) return 1;
+    if (H * W <= 16 && nt >= 32 && nt % 4 == 0) return 4;
+    if (nt >= 16 && nt % 2 == 0) return 2;
+    return 1;
+}
+
+extern "C" long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, int C, int N) {
+    const int s = h2_ksplit(H, W, KS, C, N);
+    return s > 1 ? (long long)s * B * H * W * N * 4 : 0;
+}
+
 extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
                                  const float* bias, const float* temb, int temb_stride, const float* res, int ldr,
-                                 float scale, float* out, int ldo, float* colstats, int* tile_rows, void* stream) {
+                                 float scale, float* out, int ldo, float* colstats, int* tile_rows, void* work,
+                                 long long work_bytes, void* stream) {
     DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
     DP_REQUIRE(KS == 1 || KS == 3, "dp_conv2d_nhwc_h2: kernel size %d unsupported", KS);
     DP_REQUIRE(C > 0 && C % 32 == 0, "dp_conv2d_nhwc_h2: channel count must be a multiple of 32 (got %d)", C);
@@ -326,6 +425,12 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
     p.colstats = colstats;
     p.stagger = 0;
+    p.ksplit = h2_ksplit(H, W, KS, C, N);
+    p.ws = static_cast<float*>(work);
+    DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
+                                 ldo % 4 == 0 && (!res || ldr % 4 == 0)),
+               "dp_conv2d_nhwc_h2: this layer is reduced with split-K and needs dp_conv2d_nhwc_h2_workspace() bytes of scratch "
+               "(and row strides that are multiples of 4)");
     DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc_h2: colstats needs tile_rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // tuning switch: 0 = heuristic below; 1 = s_setprio around the MFMA clusters (measured: no gain);
@@ -338,7 +443,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     do {                                                                                                   \
         p.tiles_n = (N + BN_ - 1) / BN_;                                                                   \
         p.tiles = (int)tiles(BM_, BN_);                                                                    \
-        hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p); \
+        hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_>), dim3((unsigned)p.tiles, (unsigned)p.ksplit), dim3(NT), 0, s, p); \
     } while (0)
     // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
     // also fills the chip (>= one tile per CU); unset = DP_H2_PP_DEFAULT.  Read per call so that a probe can
@@ -353,7 +458,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             return t >= 256 && t * 5 >= rounds * 256 * 4;
         };
         int bn = 0;
-        if (pp != 0 && p.M % 256 == 0 && N % 256 == 0 && (pp == 1 || fills(256, 256))) bn = 256;
+        if (p.ksplit > 1) bn = 0;            // split-K layers never take the ping-pong variants (shape-only rule)
+        else if (pp != 0 && p.M % 256 == 0 && N % 256 == 0 && (pp == 1 || fills(256, 256))) bn = 256;
         else if (pp != 0 && p.M % 512 == 0 && N % 128 == 0 && (pp == 1 || fills(512, 128))) bn = 128;
         if (bn) {
             const char* sg = getenv("DP_H2_STAGGER");
@@ -368,7 +474,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     const bool wide_ok = sw == 11 && tiles(128, 256) >= 384;      // wide variants: experiment only (see above)
     // (thresholds 256 / 512 / 1024 and a <128,64,32> middle variant were tried on the low-resolution shapes:
     //  all within run-to-run noise)
-    if (N <= 64 || tiles(128, 128) < 256) DP_H2_LAUNCH(64, 64, 32, 0);
+    if (N <= 64 || tiles(128, 128) * p.ksplit < 256) DP_H2_LAUNCH(64, 64, 32, 0);
     else if (wide_ok && N % 256 == 0) DP_H2_LAUNCH(128, 256, 16, 0);
     else if (wide_ok && N <= 128) DP_H2_LAUNCH(256, 128, 16, 0);
     else if (sw == 1) DP_H2_LAUNCH(128, 128, 32, 1);
@@ -376,6 +482,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     else if (sw == 3) DP_H2_LAUNCH(128, 128, 32, 3);
     else DP_H2_LAUNCH(128, 128, 32, 0);
 #undef DP_H2_LAUNCH
+    if (p.ksplit > 1)
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, s, p);
     if (tile_rows) *tile_rows = 64;   // column-sum records are per 64 output rows in every variant
     dp_prof_end(rec, s);
     DP_LAUNCH_CHECK("conv_igemm_h2");

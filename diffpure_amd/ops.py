@@ -133,8 +133,12 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
         assert res.shape == out.shape
         ldr = n_out
     cs, tr = _colstats_alloc(b * h * w, n_out, x.device) if colstats else (None, None)
+    # low-resolution levels are reduced with split-K (factor fixed by the layer shape): scratch for the partial sums
+    wbytes = int(_lib.load().dp_conv2d_nhwc_h2_workspace(b, h, w, ksize, c, n_out))
+    work = torch.empty((wbytes // 4,), device=x.device, dtype=torch.float32) if wbytes else None
     _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
-              ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _stream())
+              ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _ptr(work), wbytes,
+              _stream())
     if colstats:
         out._dp_cols = ColStats(cs, tr.value, n_out)
     return out

@@ -82,7 +82,12 @@ int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
                       const float* res, int ldr, float scale,
-                      float* out, int ldo, float* colstats, int* tile_rows, void* stream);
+                      float* out, int ldo, float* colstats, int* tile_rows,
+                      void* work, long long work_bytes, void* stream);
+/* Scratch the call above needs for this layer shape (0 for most): low-resolution levels (H*W <= 64) are reduced with
+ * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
+ * layer shape only, never on B, so that results do not depend on how a batch is sharded. */
+long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, int C, int N);
 /* fp32 [rows][ld] (first `cols` columns, cols % 8 == 0) -> h2 [rows][cols/8][2][8] fp16. */
 int dp_pack_h2(const float* src, long long rows, int cols, int ld, void* dst, void* stream);
 

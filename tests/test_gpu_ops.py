@@ -399,3 +399,27 @@ def test_fast_silu_accuracy_and_extremes(dev):
     err = (got - ref).abs()
     # |x| > 88.7: exp overflows in fp32 (as it does in torch's own fp32 SiLU) and results of size ~1e-37 flush to 0
     assert (err <= 4e-7 * ref.abs() + 2e-36).all(), (err / ref.abs().clamp_min(1e-30)).max()
+
+
+@pytest.mark.parametrize("case", [(6, 4, 4, 256, 256, 3), (6, 8, 8, 512, 256, 3), (4, 8, 8, 1024, 768, 1), (5, 2, 2, 128, 128, 3)], ids=str)
+def test_conv2d_h2_split_k_levels_are_batch_shard_invariant(dev, case):
+    """Low-resolution levels (H*W <= 64) are reduced with split-K; the split factor is a function of the layer shape
+    only, so a batch and any slice of it give bit-identical rows (results AND the GroupNorm column sums when the
+    64-row records line up with the samples), and they match the fp64 convolution."""
+    from diffpure_amd import _lib, ops
+    B, H, W, C, N, k = case
+    assert _lib.load().dp_conv2d_nhwc_h2_workspace(B, H, W, k, C, N) > 0
+    assert _lib.load().dp_conv2d_nhwc_h2_workspace(B, 16, 16, k, C, N) == 0
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(N, C, k, k, seed=3, scale=1.0 / math.sqrt(C * k * k))
+    bias, res = rnd(N, seed=4).to(dev), rnd(B, H, W, N, seed=6).to(dev)
+    wh = ops.pack_conv_weight_h2(w, dev)
+    full = ops.conv2d_h2(_h2_bordered(x, dev), wh, N, k, bias=bias, res=res, scale=0.5, colstats=True)
+    ref = ((torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.cpu().double(), padding=k // 2)
+            .permute(0, 2, 3, 1) + res.cpu().double()) * 0.5).float()
+    close(full, ref, rtol=2e-5, atol=2e-5)
+    for lo, hi in ((0, 1), (1, B), (2, 4)):
+        part = ops.conv2d_h2(_h2_bordered(x[lo:hi], dev), wh, N, k, bias=bias, res=res[lo:hi].contiguous(), scale=0.5, colstats=True)
+        assert torch.equal(part, full[lo:hi])
+        if H * W == 64:     # one 64-row record per sample
+            assert torch.equal(part._dp_cols.buf, full._dp_cols.buf[lo:hi])
