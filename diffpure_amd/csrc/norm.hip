@@ -7,6 +7,8 @@
 //   apply    : y = resample(act(FiLM(norm(x)))), float4 in / float4 out, with the channel
 //              concatenation of two sources and the 2x nearest-up / 2x2-mean-down of the
 //              resampling ResBlocks folded into the same pass.
+#include <stdlib.h>
+
 #include "dp_common.h"
 
 namespace {
@@ -141,6 +143,125 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) {
     const float* src = (c < p.C1) ? (p.x1 + pix * p.C1 + c) : (p.x2 + pix * p.C2 + (c - p.C1));
     return *reinterpret_cast<const f32x4*>(src);
+}
+
+// h2 output, lane-contiguous version: a thread owns ONE channel QUAD (4 channels) of the row's pixels, so that a
+// wave's load is 64 x 16 contiguous bytes (one instruction, whole cache lines) and so is its store.  An h2 octet
+// (8 channels: 16 B of hi, then 16 B of lo) is built by the two lanes that own its quads: they exchange their 4
+// activated values (one DPP swap each), the even lane stores the octet's hi half, the odd lane its lo half - byte
+// offset 16 * quad either way.  Same arithmetic per element as gn_apply_kernel<true, ACT> (bit-identical output).
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT, int slots) {
+    const int CQ = p.C4;                                 // quads per pixel
+    const int Hq = p.Ho + 2, Wq = p.Wo + 2;
+    const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
+    const int oy = qy - 1;
+    const bool zrow = (unsigned)oy >= (unsigned)p.Ho;
+    const int slot = threadIdx.x / CQT;
+    const bool odd = threadIdx.x & 1;                    // CQT is even: lane parity == quad parity
+    const size_t orow = ((size_t)b * Hq + qy) * Wq;
+    for (int cq = threadIdx.x - slot * CQT; cq < CQ; cq += CQT) {
+        const int c = cq * 4;
+        f32x4 a = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};       // y = x*a + d before act
+        if (p.gamma) {
+            const int g = c / p.cpg;
+            const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = rstd * ga[j];
+                d[j] = be[j] - mean * a[j];
+            }
+        }
+        if (p.fscale) {
+            const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
+            const f32x4 fh = *reinterpret_cast<const f32x4*>(p.fshift + (size_t)b * p.film_stride + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m = 1.f + fs[j];
+                a[j] *= m;
+                d[j] = d[j] * m + fh[j];
+            }
+        }
+        auto xf = [&](f32x4 v) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j] * a[j] + d[j];
+                v[j] = ACT ? dp_silu_f(u) : u;
+            }
+            return v;
+        };
+        // the 16 bytes this lane owns of the octet made of (even lane's quad, odd lane's quad)
+        auto half_of_octet = [&](f32x4 mine) {
+            f32x4 other;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) other[j] = __shfl_xor(mine[j], 1, 64);
+            half8 out;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = (j < 4) == !odd ? mine[j & 3] : other[j & 3];      // even lane: [mine | other]; odd: [other | mine]
+                const _Float16 hi = (_Float16)v;
+                out[j] = odd ? (_Float16)(v - (float)hi) : hi;
+            }
+            return out;
+        };
+        int qx = slot;
+        if (p.resample == 0 && !zrow) {
+            // interior pixels four at a time: all four loads are issued before the first use
+            const size_t irow = ((size_t)b * p.H + oy) * p.W;
+            for (; qx + 3 * slots < Wq; qx += 4 * slots) {
+                f32x4 rv[4];
+                bool in[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ox = qx + k * slots - 1;
+                    in[k] = (unsigned)ox < (unsigned)p.Wo;
+                    rv[k] = in[k] ? gn_load(p, irow + ox, c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const size_t opix = orow + qx + k * slots;
+                    half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CQ + cq) * 16);
+                    f32x4 o = xf(rv[k]);
+                    if (!in[k]) o = f32x4{0.f, 0.f, 0.f, 0.f};          // border pixel of the row: zeros
+                    *dst = half_of_octet(o);
+                    if (p.y_raw) *reinterpret_cast<half8*>(p.y_raw + (opix * CQ + cq) * 16) = half_of_octet(rv[k]);
+                }
+            }
+        }
+        for (; qx < Wq; qx += slots) {
+            const int ox = qx - 1;
+            const size_t opix = orow + qx;
+            half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CQ + cq) * 16);
+            half8* dr = p.y_raw ? reinterpret_cast<half8*>(p.y_raw + (opix * CQ + cq) * 16) : nullptr;
+            if (zrow || (unsigned)ox >= (unsigned)p.Wo) {
+                half8 z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+                *dst = z;
+                if (dr) *dr = z;
+                continue;
+            }
+            f32x4 o, raw;
+            if (p.resample == 0) {
+                raw = gn_load(p, ((size_t)b * p.H + oy) * p.W + ox, c);
+                o = xf(raw);
+            } else if (p.resample == 1) {
+                raw = gn_load(p, ((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1), c);
+                o = xf(raw);
+            } else {
+                const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
+                const f32x4 v00 = xf(gn_load(p, r0, c)), v01 = xf(gn_load(p, r0 + 1, c));
+                const f32x4 v10 = xf(gn_load(p, r0 + p.W, c)), v11 = xf(gn_load(p, r0 + p.W + 1, c));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+                raw = o;
+            }
+            *dst = half_of_octet(o);
+            if (dr) *dr = half_of_octet(raw);     // resample == 0 here: the un-normalised input in operand form
+        }
+    }
 }
 
 // One work item = VEC channels of one OUTPUT pixel: VEC = 4 (fp32 out, one float4) or 8 (h2 out:
@@ -327,7 +448,13 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));
 #define GN_APPLY_LAUNCH(H2_, ACT_) \
     hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_>), dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots)
-    if (out_fmt) {
+    // h2 output: the lane-contiguous quad kernel unless DP_GN_APPLY_QUAD=0 (A/B switch; both give identical bytes)
+    static const bool quad = [] { const char* e = getenv("DP_GN_APPLY_QUAD"); return !e || atoi(e) != 0; }();
+    if (out_fmt && quad) {
+        const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;     // C % 8 == 0: CQ and CQT are even
+        if (act) hipLaunchKernelGGL(gn_apply_h2q_kernel<true>, dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+        else hipLaunchKernelGGL(gn_apply_h2q_kernel<false>, dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+    } else if (out_fmt) {
         if (act) GN_APPLY_LAUNCH(true, true);
         else GN_APPLY_LAUNCH(true, false);
     } else {
