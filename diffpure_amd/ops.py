@@ -530,8 +530,17 @@ def ddpm_step(x, out6, sr, srm1, c1, c2, min_log, max_log, nonzero, noise=None, 
 # ---------------------------------------------------------------------------------------------
 # profiling hooks (bench.py roofline leg)
 # ---------------------------------------------------------------------------------------------
+_PROF_ON = False
+
+
 def prof_enable(on=True):
+    global _PROF_ON
+    _PROF_ON = bool(on)
     _lib.call("dp_prof_enable", 1 if on else 0)
+
+
+def prof_enabled():
+    return _PROF_ON
 
 
 def prof_collect():

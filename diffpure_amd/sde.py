@@ -15,6 +15,8 @@ Reference map
   DDPM ancestral sampling      runners/diffpure_guided.py:66-75, guided_diffusion/gaussian_diffusion.py:240-447
 """
 import numpy as np
+import os
+
 import torch
 
 from . import ops
@@ -169,6 +171,7 @@ class Purifier:
         self.net, self.kind, self.device = net, kind, torch.device(device)
         self._abar = discrete_alphas_cumprod()
         self._sched_cache = {}
+        self._graphs = {}
 
     # -- shared pieces ----------------------------------------------------------------------------
     def _diffuse(self, x0, t_int, noise, seed, sample0, abar=None):
@@ -189,18 +192,60 @@ class Purifier:
     def _eps(self, x, table, k):
         return self.net.forward(x, table_row=table[k:k + 1])
 
+    # -- the UNet call of a step as ONE HIP graph launch --------------------------------------------
+    def _graph_wanted(self, shape):
+        """DIFFPURE_GRAPH=1: capture the UNet call of a step as one HIP graph (opt-in).  Measured on MI355X
+        (tests/probes/graph_vs_eager.py): NO gain - a CIFAR step costs 9.8 ms at B=4 and 10.4 ms at B=16 either way,
+        i.e. small batches are bound by the GPU's own per-kernel dispatch of ~650 dependent launches (~15 us each),
+        not by the host; the Python/ctypes launch path already runs ahead of the GPU.  Kept as a switch because a
+        graph also removes the host from the loop (useful under a busy GIL).  Never while the convolution profiler
+        records hipEvents."""
+        mode = os.environ.get("DIFFPURE_GRAPH", "0")
+        if mode == "0" or self.device.type != "cuda" or ops.prof_enabled():
+            return False
+        return mode == "1"
+
+    def _step_fn(self, x, table):
+        """-> (state buffer, eps(k)).  Eager: the state is `x` itself.  Graph: a persistent state buffer per shape
+        (the loop updates it in place, so the captured graph always reads the current state), a persistent
+        time-conditioning row that step k's row is copied into, and one graph replay per UNet call."""
+        shape = tuple(x.shape)
+        if not self._graph_wanted(shape):
+            return x, (lambda k: self._eps(x, table, k))
+        ent = self._graphs.get(shape)
+        if ent is None or ent["row"].shape != table[0:1].shape:
+            xs, row = torch.empty_like(x), table[0:1].clone()
+            xs.copy_(x)
+            side = torch.cuda.Stream(device=self.device)       # warm-up off the capture stream: lazy one-time
+            side.wait_stream(torch.cuda.current_stream(self.device))   # allocations (zero page, caches) happen here
+            with torch.cuda.stream(side):
+                self.net.forward(xs, table_row=row)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eps = self.net.forward(xs, table_row=row)
+            ent = self._graphs[shape] = dict(x=xs, row=row, eps=eps, graph=graph)
+        ent["x"].copy_(x)
+
+        def eps_of(k, ent=ent):
+            ent["row"].copy_(table[k:k + 1])
+            ent["graph"].replay()
+            return ent["eps"]
+
+        return ent["x"], eps_of
+
     # -- reverse VP-SDE (RevGuidedDiffusion.image_editing_sample) ---------------------------------
     def sde(self, x_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0, nhwc=False):
         x0 = _state_in(x_nchw, self.device, nhwc)
         sched = sde_schedule(self.kind, t_int, dt)
         table = self._tables(("sde", t_int, dt), sched)
-        x = self._diffuse(x0, t_int, noise, seed, sample0)
+        x, eps_of = self._step_fn(self._diffuse(x0, t_int, noise, seed, sample0), table)
         for k, st in enumerate(sched):
-            eps = self._eps(x, table, k)
+            eps = eps_of(k)
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
             x = ops.em_step(x, eps, st["nhb"], st["gg"], st["sc"], st["div"], st["h"], st["g"], st["sqrt_h"], noise=z,
                             seed=seed, sample0=sample0, step=k, out=x)
-        return _state_out(x, nhwc)
+        return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
 
     def sde_vjp(self, x_final_nchw, grad_out_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0, nhwc=False):
         """Stochastic adjoint of `sde` (upstream: torchsde.sdeint_adjoint behind
@@ -245,10 +290,10 @@ class Purifier:
             x = ops.axpby(x0, sa, e_nhwc, s1a)
         else:
             x = self._diffuse(x0, t_int, noise, seed, sample0)
+        x, eps_of = self._step_fn(x, table)
         for k, st in enumerate(sched):
-            eps = self._eps(x, table, k)
-            x = ops.em_step(x, eps, st["nhb"], st["gg"], st["sc"], st["div"], st["h"], 0.0, 0.0, out=x)
-        return _state_out(x, nhwc)
+            x = ops.em_step(x, eps_of(k), st["nhb"], st["gg"], st["sc"], st["div"], st["h"], 0.0, 0.0, out=x)
+        return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
 
     # -- adjoint of the probability-flow ODE: dL/dx for adaptive attacks ---------------------------
     def ode_vjp(self, x_final_nchw, grad_out_nchw, t_int, step=1e-3, nhwc=False):
@@ -290,10 +335,11 @@ class Purifier:
         # respace._WrappedModel: timestep_map[i] * (1000 / original_num_steps), as float
         sched = [dict(model_time=float(i) * (1000.0 / diffusion_steps)) for i in idx]
         table = self._tables(("ddpm", t_int, diffusion_steps), sched)
+        x, eps_of = self._step_fn(x, table)
         for k, i in enumerate(idx):
-            out6 = self._eps(x, table, k)
+            out6 = eps_of(k)
             c = ds.at(i)
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
             x = ops.ddpm_step(x, out6, c["sr"], c["srm1"], c["c1"], c["c2"], c["min_log"], c["max_log"], i != 0, noise=z,
                               seed=seed, sample0=sample0, step=k, out=x)
-        return _state_out(x, nhwc)
+        return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
