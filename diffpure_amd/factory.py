@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import guided_unet, ncsnpp, synth
+from . import ddpm_unet, guided_unet, ncsnpp, synth
 
 
 def _ns_to_dict(ns):
@@ -84,6 +84,24 @@ def build_ncsnpp(args, config, device, model_dir="pretrained/score_sde"):
     else:
         raise FileNotFoundError(f"{path} not found (set args.synthetic_weights=True or DIFFPURE_SYNTH_WEIGHTS=1 "
                                 "to run on seeded synthetic weights)")
+    net.load_state_dict(sd)
+    return net, cfg
+
+
+def build_celeba(args, config, device, model_dir="pretrained"):
+    """CelebA-HQ DDPM UNet of runners/diffpure_ddpm.py:60-75.  The reference downloads `celeba_hq.ckpt` with
+    torch.hub; here it is looked up locally (`<model_dir>/celeba_hq.ckpt`, then the torch.hub checkpoint cache)."""
+    cfg = ddpm_unet.parse_config(_ns_to_dict(config))
+    net = ddpm_unet.DdpmUNet(cfg, device, precision_of(args))
+    cands = [f"{model_dir}/celeba_hq.ckpt", os.path.join(torch.hub.get_dir(), "checkpoints", "celeba_hq.ckpt")]
+    path = next((c for c in cands if os.path.exists(c)), None)
+    if path is not None:
+        sd = torch.load(path, map_location="cpu")
+    elif want_synthetic(args):
+        sd = synth.synth_state_dict(ddpm_unet.param_shapes(cfg), getattr(args, "seed", 1234) or 1234)
+    else:
+        raise FileNotFoundError(f"celeba_hq.ckpt not found in {cands} (there is no network here; set args.synthetic_weights=True "
+                                "or DIFFPURE_SYNTH_WEIGHTS=1 to run on seeded synthetic weights)")
     net.load_state_dict(sd)
     return net, cfg
 

@@ -139,6 +139,35 @@ class DdpmSchedule:
                     max_log=f(self.max_log))
 
 
+class CelebaSchedule:
+    """Schedule of runners/diffpure_ddpm.py (reference :80-98): float64 numpy betas / posterior variance,
+    coefficients of the denoising step (:36-55) taken exactly as the reference forms them in float32."""
+
+    def __init__(self, beta_start=1e-4, beta_end=2e-2, steps=1000, var_type="fixedsmall"):
+        betas64 = np.linspace(beta_start, beta_end, steps, dtype=np.float64)
+        self.betas = torch.from_numpy(betas64).float()
+        alphas64 = 1.0 - betas64
+        ac = np.cumprod(alphas64, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        post_var = betas64 * (1.0 - ac_prev) / (1.0 - ac)
+        if var_type == "fixedlarge":
+            logvar = np.log(np.append(post_var[1], betas64[1:]))
+        elif var_type == "fixedsmall":
+            logvar = np.log(np.maximum(post_var, 1e-20))
+        else:
+            raise ValueError(f"unknown var_type {var_type}")
+        self.logvar = torch.tensor(logvar, dtype=torch.float)
+        alphas = 1.0 - self.betas                                   # float32 from here on, as in :41-46
+        self.abar = alphas.cumprod(dim=0)
+        self.inv_sqrt_alpha = 1 / torch.sqrt(alphas)
+        self.weighted_score = self.betas / torch.sqrt(1 - self.abar)
+
+    def at(self, i):
+        """x_{i-1} = isa * (x - ws * eps) + sigma * z  (sigma = 0 at i == 0)"""
+        return dict(isa=float(self.inv_sqrt_alpha[i]), ws=float(self.weighted_score[i]),
+                    sigma=float(torch.exp(0.5 * self.logvar[i])) if i != 0 else 0.0)
+
+
 def to_nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
@@ -342,4 +371,22 @@ class Purifier:
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
             x = ops.ddpm_step(x, out6, c["sr"], c["srm1"], c["c1"], c["c2"], c["min_log"], c["max_log"], i != 0, noise=z,
                               seed=seed, sample0=sample0, step=k, out=x)
+        return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
+
+    # -- CelebA-HQ DDPM denoising loop (runners/diffpure_ddpm.py:116-131) ----------------------------
+    def celeba_ddpm(self, x_nchw, t_int, sched, noise=None, seed=0, sample0=0, nhwc=False):
+        """x = x0 sqrt(abar[t-1]) + e sqrt(1 - abar[t-1]); then for i = t-1 .. 0:
+        x <- (x - ws_i eps(x, i)) / sqrt(alpha_i) + [i > 0] exp(logvar_i / 2) z.  The update is the fused SDE-step
+        kernel with (h, drift, diffusion) = (1, (1 - isa) x + isa ws eps, sigma)."""
+        assert self.kind == "ddpm_celeba"
+        x0 = _state_in(x_nchw, self.device, nhwc)
+        x = self._diffuse(x0, t_int, noise, seed, sample0, abar=sched.abar)
+        idx = list(reversed(range(t_int)))
+        table = self._tables(("celeba", t_int), [dict(model_time=float(i)) for i in idx])
+        x, eps_of = self._step_fn(x, table)
+        for k, i in enumerate(idx):
+            c = sched.at(i)
+            z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
+            x = ops.em_step(x, eps_of(k), 1.0 - c["isa"], 1.0, -c["isa"] * c["ws"], False, 1.0, c["sigma"], 1.0, noise=z,
+                            seed=seed, sample0=sample0, step=k, out=x)
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)

@@ -46,6 +46,16 @@ def import_reference():
     sys.modules["score_sde.op"] = op
 
 
+def ref_module(name, relpath):
+    """Import a reference file by path (the reference's `runners/` has no __init__.py, so a plain
+    `import runners.x` would resolve to THIS repository's drop-in package of the same name)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(SCRATCH, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def d2n(c):
     ns = argparse.Namespace()
     for k, v in c.items():
@@ -77,8 +87,8 @@ def load_synth(module, seed):
 def main():
     import_reference()
     from guided_diffusion.script_util import create_model, create_gaussian_diffusion, model_and_diffusion_defaults
-    from runners.diffpure_ode import VPODE
-    from runners.diffpure_sde import RevVPSDE
+    VPODE = ref_module("ref_diffpure_ode", "runners/diffpure_ode.py").VPODE
+    RevVPSDE = ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
     from score_sde.models import utils as mutils
 
     torch.manual_seed(0)

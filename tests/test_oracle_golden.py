@@ -92,3 +92,34 @@ def test_solver_clocks():
     ts = torch.linspace(0.1, 1e-5, 2)
     tau = osol.ode_grid(-ts, 1e-3)
     assert len(tau) == 101 and tau[0] == -ts[0] and tau[-1] == -ts[1]
+
+
+# ---- CelebA-HQ DDPM UNet and its denoising step ---------------------------------------
+def test_ddpm_unet_small_and_full_vs_reference_golden():
+    from oracle import ddpm_unet as od
+    for name, rtol, atol in (("ddpm_unet_small.pt", 1e-4, 1e-5), ("ddpm_unet_full.pt", 1e-3, 1e-4)):
+        g = load_golden(name)
+        cfg = od.parse_ddpm_config(g["cfg"])
+        sd = synth_state_dict(dict(zip(g["keys"], g["shapes"])), g["seed"])
+        res = cfg["resolution"]
+        x = g["x"] if "x" in g else torch.rand(1, 3, res, res, generator=torch.Generator().manual_seed(g["x_seed"])) * 2 - 1
+        with torch.no_grad():
+            y = od.unet_forward(sd, cfg, x, g["t"])
+        if "y" in g:
+            torch.testing.assert_close(y, g["y"], rtol=rtol, atol=atol)
+        else:
+            torch.testing.assert_close(y[:, :, ::8, ::8], g["y_crop"], rtol=rtol, atol=atol)
+            torch.testing.assert_close(y.abs().mean(), g["y_abs_mean"], rtol=1e-4, atol=0)
+
+
+def test_celeba_denoising_step_vs_reference_golden():
+    from oracle import ddpm_unet as od
+    g, s = load_golden("ddpm_unet_small.pt"), load_golden("celeba_step.pt")
+    cfg = od.parse_ddpm_config(g["cfg"])
+    sd = synth_state_dict(dict(zip(g["keys"], g["shapes"])), g["seed"])
+    d = g["cfg"]["diffusion"]
+    sched = od.CelebaSchedule(d["beta_start"], d["beta_end"], d["num_diffusion_timesteps"], "fixedsmall")
+    unet = lambda x, t: od.unet_forward(sd, cfg, x, t)
+    with torch.no_grad():
+        for i, ref in s["out"].items():
+            torch.testing.assert_close(od.denoising_step(unet, sched, s["x"], i, s["z"]), ref, rtol=1e-5, atol=1e-6)
