@@ -45,7 +45,7 @@ def resize_affine(x, size, shift, scale, in_nhwc=False, out_nhwc=False):
 
 
 def build_runner(args, config, device):
-    """The runner dispatch of eval_sde_adv.py:43-56 (ldsde is outside the scope contract)."""
+    """The runner dispatch of eval_sde_adv.py:43-56."""
     if args.diffusion_type == "ddpm":
         from runners.diffpure_guided import GuidedDiffusion
         return GuidedDiffusion(args, config, device=device)
@@ -55,6 +55,9 @@ def build_runner(args, config, device):
     if args.diffusion_type == "ode":
         from runners.diffpure_ode import OdeGuidedDiffusion
         return OdeGuidedDiffusion(args, config, device=device)
+    if args.diffusion_type == "ldsde":
+        from runners.diffpure_ldsde import LDGuidedDiffusion
+        return LDGuidedDiffusion(args, config, device=device)
     if args.diffusion_type == "celebahq-ddpm":
         from runners.diffpure_ddpm import Diffusion
         return Diffusion(args, config, device=device)

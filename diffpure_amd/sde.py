@@ -14,6 +14,8 @@ Reference map
   probability-flow ODE         runners/diffpure_ode.py:90-131, torchdiffeq 0.2.1 fixed-grid Euler
   DDPM ancestral sampling      runners/diffpure_guided.py:66-75, guided_diffusion/gaussian_diffusion.py:240-447
 """
+import math
+
 import numpy as np
 import os
 
@@ -389,4 +391,26 @@ class Purifier:
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
             x = ops.em_step(x, eps_of(k), 1.0 - c["isa"], 1.0, -c["isa"] * c["ws"], False, 1.0, c["sigma"], 1.0, noise=z,
                             seed=seed, sample0=sample0, step=k, out=x)
+        return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
+
+    # -- Langevin-dynamics SDE (LDGuidedDiffusion.image_editing_sample, diffpure_ldsde.py:198-252) -------------
+    def ldsde(self, x_nchw, t_int, sigma2, lambda_ld, eta, dt=1e-2, noise=None, seed=0, sample0=0, nhwc=False):
+        """x <- x + f h + g sqrt(h) z on the reverse-SDE clock with dt = 1e-2, f = -0.5 lambda (-score(x, s=1e-2) +
+        (x - x_init) / sigma2), g = sqrt(lambda) eta; the score network is always asked at noise level 1e-2 (:93), the
+        loop starts from the input itself (no forward diffusion).  The anchor term needs x_init, so a step is the fused
+        SDE-step kernel (which covers -0.5 lambda / sigma2 * x and the score) plus one axpby for +0.5 lambda / sigma2 * h * x_init."""
+        x_init = _state_in(x_nchw, self.device, nhwc)
+        s = torch.zeros((), dtype=torch.float32) + 1e-2
+        coef, div, mt = _score_scalars(self.kind, s)
+        grid = sde_clock(t_int, dt)
+        table = self._tables(("ldsde",), [dict(model_time=mt)])
+        x, eps_of = self._step_fn(x_init.clone(), table)
+        kk = 0.5 * lambda_ld / sigma2
+        g = math.sqrt(lambda_ld) * eta
+        for k in range(len(grid) - 1):
+            h = grid[k + 1] - grid[k]
+            z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
+            x = ops.em_step(x, eps_of(0), kk, 0.5 * lambda_ld, coef, div, h.item(), g, torch.sqrt(h).item(), noise=z, seed=seed,
+                            sample0=sample0, step=k, out=x)
+            x.copy_(ops.axpby(x, 1.0, x_init, kk * h.item()))
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)

@@ -275,3 +275,33 @@ def ddpm_purify(unet_fn, x0, e, noises, t_int, steps=1000):
     for k, i in enumerate(reversed(range(t_int))):
         x = ddpm_p_sample(unet_fn, sched, x, i, noises[k])
     return x
+
+
+# ---- Langevin-dynamics SDE runner (/root/reference/runners/diffpure_ldsde.py) ---------------------------------
+LD_T = 1e-2     # the noise level every score evaluation is frozen at (ldsde_fn, :93)
+
+
+def ldsde_f(score_fn, x, x_init, sigma2, lambda_ld):
+    """LDSDE.f (:91-127,:133-140) on image-shaped x: drift = -0.5 (-score(x, 1e-2) + (x - x_init) / sigma2) lambda."""
+    s = torch.zeros(x.shape[0], dtype=torch.float) + LD_T
+    return -0.5 * (-score_fn(x, s) + (x - x_init) / sigma2) * lambda_ld
+
+
+def ldsde_g(b, lambda_ld, eta):
+    """LDSDE.g (:129-131,:142-149)."""
+    import numpy as np
+    return torch.tensor([np.sqrt(lambda_ld) * eta], dtype=torch.float).expand(b)
+
+
+def ldsde_purify(score_fn, x0, noises, t_int, sigma2, lambda_ld, eta, dt=1e-2):
+    """LDGuidedDiffusion.image_editing_sample (:198-252), sample_step=1: NO forward diffusion, Euler-Maruyama with
+    dt = 1e-2 on the clock linspace(1 - t/1000, 1 - 1e-5, 2), noise injected per step."""
+    x = x0
+    grid = sde_time_grid(t_int, dt)
+    assert len(noises) >= len(grid) - 1, (len(noises), len(grid))
+    for k in range(len(grid) - 1):
+        h = grid[k + 1] - grid[k]
+        f = ldsde_f(score_fn, x, x0, sigma2, lambda_ld)
+        g = ldsde_g(x.shape[0], lambda_ld, eta)[:, None, None, None]
+        x = x + f * h + g * (noises[k] * torch.sqrt(h))
+    return x

@@ -1,0 +1,66 @@
+"""Drop-in for /root/reference/runners/diffpure_ldsde.py: `LDGuidedDiffusion(args, config, device)` - Langevin
+dynamics anchored at the input, score frozen at noise level 1e-2 (`--diffusion_type ldsde`, eval_sde_adv.py:50-51) -
+with `.image_editing_sample(img, bs_id=0, tag=None)` (reference :198-252) on the MI355X engine.  Reads
+args.{t, sigma2, lambda_ld, eta, sample_step, score_type, seed, log_dir}.  torch.no_grad: the attack scripts that use
+this runner never differentiate it on this engine (no adjoint is provided for it)."""
+import os
+
+import torch
+
+from diffpure_amd import dist as ddist
+from diffpure_amd import factory
+from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC, Purifier
+
+from . import _common
+
+
+class LDGuidedDiffusion(torch.nn.Module):
+    def __init__(self, args, config, device=None):
+        super().__init__()
+        self.args = args
+        self.config = config
+        if device is None:
+            device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        net, kind, img_shape = factory.build_for_dataset(args, config, self.device)
+        want = factory.SCORE_TYPE_TO_KIND.get(args.score_type)
+        if want is None:
+            raise NotImplementedError(f"Unknown score type in RevVPSDE: {args.score_type}!")
+        if want != kind:
+            raise ValueError(f"score_type {args.score_type} does not match dataset {config.data.dataset}")
+        self.model = net
+        self.img_shape = img_shape
+        self.purifier = Purifier(net, kind, self.device)
+        self.betas = torch.linspace(BETA_MIN / N_DISC, BETA_MAX / N_DISC, N_DISC).float().to(self.device)
+        self.args_dict = {"method": "euler", "adaptive": False, "dt": 1e-2}
+        self._calls = 0
+        print(f"use_bm: {args.use_bm}")
+        print(f"args_dict: {self.args_dict}")
+
+    def image_editing_sample(self, img, bs_id=0, tag=None, noise=None, nhwc=False):
+        assert isinstance(img, torch.Tensor)
+        assert img.ndim == 4, img.ndim
+        with torch.no_grad():
+            out_dir = _common.out_dir_for(self.args, bs_id, tag)
+            log = bs_id < 2 and out_dir is not None
+            x0 = img.to(self.device)
+            if log:
+                os.makedirs(out_dir, exist_ok=True)
+                _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
+            print(f"sigma2: {self.args.sigma2}, lambda_ld: {self.args.lambda_ld}, eta: {self.args.eta}")
+            seed = int(getattr(self.args, "seed", 0) or 0)
+            xs = []
+            for it in range(self.args.sample_step):
+                call_seed = seed + 1000003 * self._calls
+                self._calls += 1
+
+                def run(xl, sample0, call_seed=call_seed):
+                    return self.purifier.ldsde(xl, self.args.t, float(self.args.sigma2), float(self.args.lambda_ld),
+                                               float(self.args.eta), dt=self.args_dict["dt"], noise=noise, seed=call_seed,
+                                               sample0=sample0, nhwc=nhwc)
+
+                x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
+                if log:
+                    _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
+                xs.append(x0)
+            return torch.cat(xs, dim=0)

@@ -5,6 +5,7 @@ Imports the reference's ddpm/unet_ddpm.py and runners/diffpure_ddpm.py from the 
 (make_golden.import_reference) and stores, for seeded synthetic weights (diffpure_amd.synth, keyed by name):
   ddpm_unet_small.pt   Model(ch=128, ch_mult [1,2,2], 2 res blocks, attention at 8x8, 16x16 images) forward, B=2
   ddpm_unet_full.pt    configs/celeba.yml Model (ch=128, [1,1,2,2,4,4], attention at 16x16, 256x256) forward, B=1, strided crop
+  ldsde_fg.pt          LDSDE.f / .g (runners/diffpure_ldsde.py) on the two small score networks of make_golden.py
   celeba_step.pt       image_editing_denoising_step_flexible_mask (fixedsmall variance) on the small model with the
                        noise injected (torch.randn_like patched), steps i = 7 and i = 0
 """
@@ -75,6 +76,29 @@ def main():
         torch.randn_like = orig
     torch.save(dict(x=x, z=z, out=steps), os.path.join(HERE, "celeba_step.pt"))
     print("step", {k: float(v.abs().mean()) for k, v in steps.items()})
+
+    # ---- LDSDE.f / .g on the small NCSN++ and guided UNet (same models and inputs as ncsnpp_small.pt / guided_small.pt)
+    from guided_diffusion.script_util import create_model
+    from score_sde.models import utils as mutils
+    ld = mg.ref_module("ref_diffpure_ldsde", "runners/diffpure_ldsde.py")
+    torch.set_grad_enabled(False)
+    gn, gg = torch.load(os.path.join(HERE, "ncsnpp_small.pt")), torch.load(os.path.join(HERE, "guided_small.pt"))
+    nmod = mg.load_synth(mutils.create_model(mg.d2n(gn["cfg"])), 1234)
+    kw = {k: gg["cfg"][k] for k in ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma", "class_cond",
+                                    "attention_resolutions", "num_heads", "num_head_channels", "num_heads_upsample",
+                                    "use_scale_shift_norm", "resblock_updown", "use_fp16", "use_new_attention_order")}
+    gmod = mg.load_synth(create_model(**kw), 1234)
+    rec, sigma2, lam, eta = {}, 0.001, 0.01, 5
+    for name, mod, x0, shape in (("score_sde", nmod, gn["x"], (3, 16, 16)), ("guided_diffusion", gmod, gg["x"], (3, 32, 32))):
+        xc = x0 + 0.05 * torch.randn(x0.shape, generator=torch.Generator().manual_seed(11))      # current state != anchor
+        sde = ld.LDSDE(model=mod, x_init=x0.reshape(2, -1), score_type=name, img_shape=shape, sigma2=sigma2, lambda_ld=lam, eta=eta,
+                       model_kwargs=None)
+        t = torch.tensor(0.93, dtype=torch.float32)
+        rec[(name, "x")] = xc
+        rec[(name, "f")] = sde.f(t, xc.reshape(2, -1)).reshape(xc.shape)
+        rec[(name, "g")] = sde.g(t, xc.reshape(2, -1))[:, 0].clone()
+    torch.save(dict(rec=rec, sigma2=sigma2, lambda_ld=lam, eta=eta), os.path.join(HERE, "ldsde_fg.pt"))
+    print("ldsde", {k: float(v.abs().mean()) for k, v in rec.items()})
 
 
 if __name__ == "__main__":

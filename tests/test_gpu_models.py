@@ -345,3 +345,37 @@ def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path):
     parts = torch.cat([runner.purifier.celeba_ddpm(xb[:2], 8, runner.sched, seed=3, sample0=0),
                        runner.purifier.celeba_ddpm(xb[2:], 8, runner.sched, seed=3, sample0=2)])
     assert torch.equal(full, parts)
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
+def test_ldsde_runner_loop_vs_oracle(kind):
+    """Langevin-dynamics runner (runners/diffpure_ldsde.py) on the HIP engine against the oracle loop, injected noise."""
+    from diffpure_amd import guided_unet as pg
+    from diffpure_amd import ncsnpp as pn
+    from diffpure_amd.sde import Purifier
+    from oracle import guided_unet as og
+    from oracle import ncsnpp as on
+    from oracle import solvers as osol
+    if kind == "ncsnpp":
+        g = load_golden("ncsnpp_small.pt")
+        cfg = pn.parse_config(g["cfg"])
+        sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+        net = pn.NCSNpp(cfg, DEV, precision="f16x3").load_state_dict(sd)
+        score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    else:
+        g = load_golden("guided_small.pt")
+        cfg = pg.parse_config(g["cfg"])
+        sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
+        net = pg.GuidedUNet(cfg, DEV, precision="f16x3").load_state_dict(sd)
+        score = osol.make_score_fn("guided", sd, og.parse_guided_config(g["cfg"]))
+    x0 = g["x"]
+    gen = torch.Generator().manual_seed(7)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(10)]
+    with torch.no_grad():
+        ref = osol.ldsde_purify(score, x0, zs, 100, 0.001, 0.01, 5)
+    pur = Purifier(net, kind, DEV)
+    out = pur.ldsde(x0, 100, 0.001, 0.01, 5, noise=dict(z=zs)).cpu()
+    assert (out - ref).abs().max() < 1e-3
+    xb = torch.rand(4, *x0.shape[1:], generator=torch.Generator().manual_seed(2)) * 2 - 1
+    full = pur.ldsde(xb, 100, 0.001, 0.01, 5, seed=9)
+    assert torch.equal(full, torch.cat([pur.ldsde(xb[:1], 100, 0.001, 0.01, 5, seed=9), pur.ldsde(xb[1:], 100, 0.001, 0.01, 5, seed=9, sample0=1)]))

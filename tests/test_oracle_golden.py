@@ -123,3 +123,23 @@ def test_celeba_denoising_step_vs_reference_golden():
     with torch.no_grad():
         for i, ref in s["out"].items():
             torch.testing.assert_close(od.denoising_step(unet, sched, s["x"], i, s["z"]), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_ldsde_f_g_vs_reference_golden():
+    """oracle/solvers.py ldsde_f / ldsde_g against LDSDE.f / .g of runners/diffpure_ldsde.py on both small networks."""
+    r = load_golden("ldsde_fg.pt")
+    for kind, name, gname in (("ncsnpp", "score_sde", "ncsnpp_small.pt"), ("guided", "guided_diffusion", "guided_small.pt")):
+        g = load_golden(gname)
+        if kind == "ncsnpp":
+            cfg, shapes = on.parse_ncsnpp_config(g["cfg"]), None
+            from diffpure_amd import ncsnpp as pn
+            sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), g["seed"])
+        else:
+            cfg = og.parse_guided_config(g["cfg"])
+            from diffpure_amd import guided_unet as pg
+            sd = synth_state_dict(pg.param_shapes(pg.parse_config(g["cfg"])), g["seed"])
+        score = osol.make_score_fn(kind, sd, cfg)
+        with torch.no_grad():
+            f = osol.ldsde_f(score, r["rec"][(name, "x")], g["x"], r["sigma2"], r["lambda_ld"])
+        torch.testing.assert_close(f, r["rec"][(name, "f")], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(osol.ldsde_g(2, r["lambda_ld"], r["eta"]), r["rec"][(name, "g")], rtol=1e-6, atol=0)
