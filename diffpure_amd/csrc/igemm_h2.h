@@ -20,7 +20,6 @@ struct ConvH2Args {
     const char* zero;   // >= 128 zero bytes in device memory (weight rows n >= N)
     int ksplit;         // > 1: split-K - blockIdx.y handles k-tiles [y, y+1) * nt / ksplit and stores RAW partial sums
     float* ws;          //      into ws[y][M][N]; dp_conv2d_nhwc_h2 then runs the reduction + epilogue kernel
-    int stagger;        // ping-pong variant: start-up stagger of the first round, in units of 64 clocks over 256 workgroups
     float* colstats;    // optional [M/64][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
 };
 

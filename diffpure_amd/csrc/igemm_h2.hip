@@ -47,16 +47,15 @@ constexpr int NXCD = 8;
 constexpr int DP_H2_PP_DEFAULT = 2;   // see the dispatcher
 
 
-// Tile variants (all: 256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS
-// stages, two workgroups per CU):
+// Tile variants of THIS file (256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS stages, two
+// workgroups per CU) - used where the 8-wave ping-pong kernel of igemm_h2_pp.hip does not apply (few tiles, ragged
+// shapes, split-K levels):
 //   <128,128,32>  TM=TN=2   64 KB LDS   8 DMA + 16 ds_read per 24 MFMA per wave   (general)
-//   <64,64,32>    TM=TN=1   32 KB LDS                                              (few tiles)
-//   <128,256,16>, <256,128,16>  TM x TN = 2x4 / 4x2, 48 KB LDS, 6 DMA + 12 ds_read per 24 MFMA: built and
-//                 tested, but NOT faster (342 vs 344 TFLOP/s on 256^2 x 256->256): their 64-byte DMA rows are
-//                 half cache lines, so line transactions per MFMA rise 1.5x.  Only used with DP_H2_PRIO=11.
-// Timing ablations on <128,128,32> (256^2 x 256->256, B=8): as is 337 TFLOP/s; without the per-tile
-// wait+barrier 338 (synchronisation is NOT the cost); without any operand DMA 445 = 1.33 PFLOP/s of executed
-// fp16 MFMA, the rate the best plain-HIP GEMM reaches on random data under this chip's DVFS.
+//   <64,64,32>    TM=TN=1   32 KB LDS                                              (few tiles, N <= 64)
+// The template also instantiates with BKH = 16 and 4-wave wide tiles (<128,256,16>, <256,128,16>: 342 vs 344 TFLOP/s,
+// not faster - 64-byte DMA rows are half cache lines) and with ABL = 1..3 (s_setprio / timing ablations: as is 337
+// TFLOP/s on 256^2 x 256->256 at B=8, without the per-tile wait+barrier 338, without any operand DMA 445); none of
+// those is built any more.
 // BKH = k elements per LDS stage (32 or 16); an LDS row holds BKH (hi,lo) pairs = BKH*4 bytes = SPR 16-byte
 // slots.  XOR swizzle of the slot index with row bits chosen so that 16 consecutive rows at one logical slot
 // cover 16 distinct 16-byte bank positions: (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows.
@@ -424,7 +423,6 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.zero = zero_page();
     DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
     p.colstats = colstats;
-    p.stagger = 0;
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
@@ -433,9 +431,6 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
                "(and row strides that are multiples of 4)");
     DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc_h2: colstats needs tile_rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // tuning switch: 0 = heuristic below; 1 = s_setprio around the MFMA clusters (measured: no gain);
-    // 2 / 3 = timing ablations (WRONG RESULTS); 10 = force <128,128,32>; 11 = force the wide variants
-    static const int sw = [] { const char* e = getenv("DP_H2_PRIO"); return e ? atoi(e) : 0; }();
     void* rec = nullptr;
     dp_prof_begin(KS == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
@@ -462,8 +457,6 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         else if (pp != 0 && p.M % 256 == 0 && N % 256 == 0 && (pp == 1 || fills(256, 256))) bn = 256;
         else if (pp != 0 && p.M % 512 == 0 && N % 128 == 0 && (pp == 1 || fills(512, 128))) bn = 128;
         if (bn) {
-            const char* sg = getenv("DP_H2_STAGGER");
-            p.stagger = sg ? atoi(sg) : 0;
             dp_launch_conv_h2_pp(p, s, bn);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
@@ -471,15 +464,9 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             return 0;
         }
     }
-    const bool wide_ok = sw == 11 && tiles(128, 256) >= 384;      // wide variants: experiment only (see above)
-    // (thresholds 256 / 512 / 1024 and a <128,64,32> middle variant were tried on the low-resolution shapes:
-    //  all within run-to-run noise)
+    // (thresholds 256 / 512 / 1024, a <128,64,32> middle variant and wide 4-wave tiles <128,256,16> / <256,128,16> were
+    //  tried on these shapes: all within run-to-run noise or slower; the wide ones are superseded by igemm_h2_pp.hip)
     if (N <= 64 || tiles(128, 128) * p.ksplit < 256) DP_H2_LAUNCH(64, 64, 32, 0);
-    else if (wide_ok && N % 256 == 0) DP_H2_LAUNCH(128, 256, 16, 0);
-    else if (wide_ok && N <= 128) DP_H2_LAUNCH(256, 128, 16, 0);
-    else if (sw == 1) DP_H2_LAUNCH(128, 128, 32, 1);
-    else if (sw == 2) DP_H2_LAUNCH(128, 128, 32, 2);
-    else if (sw == 3) DP_H2_LAUNCH(128, 128, 32, 3);
     else DP_H2_LAUNCH(128, 128, 32, 0);
 #undef DP_H2_LAUNCH
     if (p.ksplit > 1)

@@ -94,12 +94,6 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
 
-    // EXPERIMENT: de-correlate the epilogue store bursts of the CUs (first round only; later workgroups inherit
-    // the offsets because a CU takes its next workgroup when it finishes the previous one)
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        for (int n = (int)blockIdx.x * p.stagger / 256; n > 0; n -= 16) __builtin_amdgcn_s_sleep(16);
-    }
-
     // ---- staging geometry: a unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7
     const int u = tid >> 3;
     const int ls = (tid & 7) ^ ((u >> 1) & 7);     // logical slot fetched (XOR swizzle applied on the source side)
@@ -311,7 +305,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
                 if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
                 if (resp) v += rv[i][r];
                 v *= p.scale;
-                if (p.stagger != -1 || v == 12345.678f) outp[(size_t)row * p.ldo + col] = v;   // -1: timing ablation without stores
+                outp[(size_t)row * p.ldo + col] = v;
                 cs[i] += v;
                 cq[i] += v * v;
             }

@@ -237,10 +237,10 @@ H2_CASES = [
     (2, 32, 32, 32, 32, 3, 0, False, 1.0),             # Cin = 32: one channel slice
     (1, 64, 64, 64, 192, 3, 0, False, 1.0),            # larger M, 128x128 with N not a multiple of 128
     (3, 9, 9, 96, 160, 3, 0, False, 1.0),              # tile tail rows re-read the last pixel (M % 128 != 0)
-    (2, 160, 160, 64, 256, 3, 2, True, 0.70710678),    # wide variant <128,256,16>: 400 tiles of 128 x 256
-    (2, 160, 160, 32, 128, 3, 0, False, 1.0),          # wide variant <256,128,16>
-    (3, 130, 130, 32, 96, 3, 1, True, 1.0),            # <256,128,16> with ragged M (50700) and N < BN
-    (2, 160, 160, 64, 512, 1, 0, False, 1.0),          # <128,256,16>, 1x1, two n-tiles
+    (2, 160, 160, 64, 256, 3, 2, True, 0.70710678),    # M = 51200 (% 256 == 0), N = 256: 200 tiles of 256 x 256 -> 128x128 tiles
+    (2, 160, 160, 32, 128, 3, 0, False, 1.0),          # M = 51200 (% 512 == 0), N = 128: 100 tiles of 512 x 128 -> 128x128 tiles
+    (3, 130, 130, 32, 96, 3, 1, True, 1.0),            # ragged M (50700) and N < BN
+    (2, 160, 160, 64, 512, 1, 0, False, 1.0),          # 1x1, four n-tiles
 ]
 
 
@@ -252,8 +252,7 @@ def _h2_bordered(x, dev):
     return ops.pack_h2(xp.reshape(-1, C).to(dev)).reshape(B, H + 2, W + 2, 2 * C)
 
 
-# the last four shapes are large enough for the wide tile variants when they are enabled (DP_H2_PRIO=11);
-# by default they run on <128,128,32> like every other large shape
+# the last four shapes are large but do not fill the chip with ping-pong tiles: they run on <128,128,32>
 @pytest.mark.parametrize("case", H2_CASES, ids=[str(c) for c in H2_CASES])
 def test_conv2d_h2_split_fp16(dev, case):
     from diffpure_amd import ops
