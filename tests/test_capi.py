@@ -43,3 +43,26 @@ def test_product_does_not_import_oracle_or_reference():
                     code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("#", '"""')))
                     m = re.search(r"^\s*(from|import)\s+(oracle|refops|tests)\b", code, re.M)
                     assert m is None, f"{pkg}/{f} imports test infrastructure: {m.group(0)}"
+
+
+def test_hot_kernels_do_not_spill_registers(tmp_path):
+    """The ping-pong convolution runs at exactly 256 VGPRs per lane; an innocent edit of its epilogue once made the
+    register allocator spill ~110 values there (-5 % on the whole kernel, invisible in any functional test).  Compile the
+    hot kernels to assembly and read the spill counts from the kernel metadata."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "diffpure_amd", "csrc")
+    for src, must in (("igemm_h2_pp.hip", ("conv_igemm_h2_ppILi256ELi256ELi0E", "conv_igemm_h2_ppILi512ELi128ELi0E")),
+                      ("igemm_h2.hip", ("conv_igemm_h2ILi128ELi128ELi32ELi0E", "conv_igemm_h2ILi64ELi64ELi32ELi0E")),
+                      ("attention.hip", ("attn_flash_kernelILi4E", "attn_flash_kernelILi2E"))):
+        out = tmp_path / (src + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                        "-o", str(out), os.path.join(csrc, src)], check=True, capture_output=True)
+        text = out.read_text()
+        for name in must:
+            m = re.search(r"\.name:\s+\S*" + re.escape(name) + r"\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+            assert m, f"{name} not found in the metadata of {src}"
+            assert int(m.group(1)) == 0, f"{name} spills {m.group(1)} VGPRs"
