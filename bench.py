@@ -230,7 +230,13 @@ def main():
                                    "conv_igemm_h2 (3x3 implicit GEMM, 3 x v_mfma_f32_32x32x16_f16 per product; "
                                    "executed MFMA flops = 3 x achieved)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": None if ach is None else ach / peak,
-                         "traffic": None, "launches": prof["n3x3"],
+                         # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes), which cannot be
+                         # collected from inside this process: measured offline for the dominant kernel, see the note
+                         "traffic": None,
+                         "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on conv_igemm_h2_pp, 256^2 x 256->256, B=16: "
+                                         "1.44 GB fetched (gfx950-corrected) + 1.07 GB written per launch vs 2.16 GB algorithmic "
+                                         "= 0.84 TB/s of 8 TB/s (profiles/README.md, section 1)",
+                         "launches": prof["n3x3"],
                          # f16x3 spends 3 fp16 MFMA passes per algorithmic MAC: the matrix pipe executes 3x `achieved`
                          "mfma_passes": 3 if a.precision == "f16x3" else 1,
                          "executed_frac": None if ach is None else ach * (3 if a.precision == "f16x3" else 1) / peak,
