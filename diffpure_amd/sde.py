@@ -414,3 +414,33 @@ class Purifier:
                             sample0=sample0, step=k, out=x)
             x.copy_(ops.axpby(x, 1.0, x_init, kk * h.item()))
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
+
+    def ldsde_vjp(self, x_final_nchw, grad_out_nchw, x_init_nchw, t_int, sigma2, lambda_ld, eta, dt=1e-2, noise=None, seed=0,
+                  sample0=0, nhwc=False):
+        """Stochastic adjoint of `ldsde` w.r.t. its INITIAL STATE (what torchsde.sdeint_adjoint returns upstream, where the
+        anchor x_init is a plain tensor attribute and not an adjoint parameter).  Same scheme as `sde_vjp`:
+        y_k = y_{k+1} - f(y_{k+1}) h - g dW_k,  a_k = a_{k+1} + h (df/dy)^T a_{k+1},  (df/dy)^T a = -kk a + 0.5 lambda c J^T a."""
+        y = _state_in(x_final_nchw, self.device, nhwc).clone()
+        a = _state_in(grad_out_nchw, self.device, nhwc)
+        x_init = _state_in(x_init_nchw, self.device, nhwc)
+        s = torch.zeros((), dtype=torch.float32) + 1e-2
+        coef, div, mt = _score_scalars(self.kind, s)
+        grid = sde_clock(t_int, dt)
+        table = self._tables(("ldsde",), [dict(model_time=mt)])
+        kk = 0.5 * lambda_ld / sigma2
+        g = math.sqrt(lambda_ld) * eta
+        c = (-1.0 / coef) if div else coef                    # score = c * eps
+        for k in reversed(range(len(grid) - 1)):
+            h = (grid[k + 1] - grid[k]).item()
+            tape = []
+            eps = self.net.forward(y, table_row=table[0:1], tape=tape)
+            gj = self.net.vjp(tape, a)
+            del tape
+            a_new = ops.axpby(a, 1.0 - h * kk, gj, h * 0.5 * lambda_ld * c)
+            z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
+            # y - f h - g dW with f = -(kk y - 0.5 lambda score) + kk x_init: the fused step with (h, g) -> (-h, -g), then the anchor
+            y = ops.em_step(y, eps, kk, 0.5 * lambda_ld, coef, div, -h, -g, math.sqrt(h), noise=z, seed=seed, sample0=sample0,
+                            step=k, out=y)
+            y.copy_(ops.axpby(y, 1.0, x_init, -kk * h))
+            a = a_new
+        return _state_out(a, nhwc)

@@ -305,3 +305,23 @@ def ldsde_purify(score_fn, x0, noises, t_int, sigma2, lambda_ld, eta, dt=1e-2):
         g = ldsde_g(x.shape[0], lambda_ld, eta)[:, None, None, None]
         x = x + f * h + g * (noises[k] * torch.sqrt(h))
     return x
+
+
+def ldsde_adjoint_grad(score_fn, x_final, grad_out, x_init, noises, t_int, sigma2, lambda_ld, eta, dt=1e-2):
+    """Stochastic adjoint of the Langevin runner's solve, same scheme as sde_adjoint_grad (state-independent diffusion:
+    da = -a^T df/dy dt, state re-integrated backward along the same Brownian increments).  Upstream LDSDE keeps the
+    anchor `x_init` as a plain tensor attribute (diffpure_ldsde.py:63), not as an adjoint parameter, so
+    torchsde.sdeint_adjoint returns the gradient THROUGH THE INITIAL STATE ONLY; the anchor term's own dependence on the
+    input is not differentiated there, and is not here.  -> dL/dx0 (as the initial state)."""
+    grid = sde_time_grid(t_int, dt)
+    y, a = x_final.clone(), grad_out.clone()
+    for k in reversed(range(len(grid) - 1)):
+        h = grid[k + 1] - grid[k]
+        with torch.enable_grad():
+            yy = y.detach().requires_grad_(True)
+            f = ldsde_f(score_fn, yy, x_init, sigma2, lambda_ld)
+            (vjp,) = torch.autograd.grad(f, yy, a)
+        g = ldsde_g(y.shape[0], lambda_ld, eta)[:, None, None, None]
+        y = y - f.detach() * h - g * (noises[k] * torch.sqrt(h))
+        a = a + h * vjp
+    return a

@@ -2,7 +2,8 @@
 dynamics anchored at the input, score frozen at noise level 1e-2 (`--diffusion_type ldsde`, eval_sde_adv.py:50-51) -
 with `.image_editing_sample(img, bs_id=0, tag=None)` (reference :198-252) on the MI355X engine.  Reads
 args.{t, sigma2, lambda_ld, eta, sample_step, score_type, seed, log_dir}.  torch.no_grad: the attack scripts that use
-this runner never differentiate it on this engine (no adjoint is provided for it)."""
+this runner differentiate it through `sdeint_adjoint` upstream; here the backward is the stochastic adjoint on the HIP engine
+(gradient through the initial state, exactly what torchsde returns for a module whose anchor is a plain tensor attribute)."""
 import os
 
 import torch
@@ -12,6 +13,26 @@ from diffpure_amd import factory
 from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC, Purifier
 
 from . import _common
+
+
+class _LdPurify(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, runner, cfg, noise, seed, sample0, nhwc):
+        with torch.no_grad():
+            out = runner.purifier.ldsde(img, *cfg, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc)
+        ctx.runner, ctx.cfg = runner, (cfg, noise, seed, sample0, nhwc)
+        ctx.save_for_backward(out, img.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        out, img = ctx.saved_tensors
+        cfg, noise, seed, sample0, nhwc = ctx.cfg
+        t, sigma2, lam, eta, dt = cfg
+        with torch.no_grad():
+            a = ctx.runner.purifier.ldsde_vjp(out, grad_out, img, t, sigma2, lam, eta, dt=dt, noise=noise, seed=seed,
+                                              sample0=sample0, nhwc=nhwc)
+        return a, None, None, None, None, None, None
 
 
 class LDGuidedDiffusion(torch.nn.Module):
@@ -40,7 +61,10 @@ class LDGuidedDiffusion(torch.nn.Module):
     def image_editing_sample(self, img, bs_id=0, tag=None, noise=None, nhwc=False):
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim
-        with torch.no_grad():
+        need_grad = img.requires_grad and torch.is_grad_enabled()
+        if need_grad and getattr(self.args, "shard_batch", False):
+            raise NotImplementedError("gradients through a batch-sharded purification call: run the attack per rank")
+        with torch.set_grad_enabled(need_grad):
             out_dir = _common.out_dir_for(self.args, bs_id, tag)
             log = bs_id < 2 and out_dir is not None
             x0 = img.to(self.device)
@@ -49,15 +73,17 @@ class LDGuidedDiffusion(torch.nn.Module):
                 _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
             print(f"sigma2: {self.args.sigma2}, lambda_ld: {self.args.lambda_ld}, eta: {self.args.eta}")
             seed = int(getattr(self.args, "seed", 0) or 0)
+            cfg = (self.args.t, float(self.args.sigma2), float(self.args.lambda_ld), float(self.args.eta), self.args_dict["dt"])
             xs = []
             for it in range(self.args.sample_step):
                 call_seed = seed + 1000003 * self._calls
                 self._calls += 1
 
                 def run(xl, sample0, call_seed=call_seed):
-                    return self.purifier.ldsde(xl, self.args.t, float(self.args.sigma2), float(self.args.lambda_ld),
-                                               float(self.args.eta), dt=self.args_dict["dt"], noise=noise, seed=call_seed,
-                                               sample0=sample0, nhwc=nhwc)
+                    if need_grad:
+                        return _LdPurify.apply(xl, self, cfg, noise, call_seed, sample0, nhwc)
+                    t, sigma2, lam, eta, dt = cfg
+                    return self.purifier.ldsde(xl, t, sigma2, lam, eta, dt=dt, noise=noise, seed=call_seed, sample0=sample0, nhwc=nhwc)
 
                 x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
                 if log:

@@ -265,3 +265,23 @@ def test_adv_model_host_logic_vs_oracle(monkeypatch):
         torch.testing.assert_close(model(x.repeat(3, 1, 1, 1), mode="purify_and_classify"), model.resnet(pur))
     with pytest.raises(NotImplementedError):
         model(x, mode="nonsense")
+
+
+def test_ldsde_stochastic_adjoint_matches_oracle():
+    """Purifier.ldsde_vjp against the oracle's restated adjoint (gradient through the initial state), and the runner's
+    autograd wrapper returns it."""
+    g = load_golden("ncsnpp_small.pt")
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    net = pn.NCSNpp(cfg, "cpu").load_state_dict(sd)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    gen = torch.Generator().manual_seed(4)
+    x0 = g["x"]
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(10)]
+    cot = torch.randn(x0.shape, generator=gen)
+    with torch.no_grad():
+        xf = osol.ldsde_purify(score, x0, zs, 100, 0.001, 0.01, 5)
+    ref = osol.ldsde_adjoint_grad(score, xf, cot, x0, zs, 100, 0.001, 0.01, 5)
+    pur = psde.Purifier(net, "ncsnpp", "cpu")
+    got = pur.ldsde_vjp(xf, cot, x0, 100, 0.001, 0.01, 5, noise=dict(z=zs))
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
