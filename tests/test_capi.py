@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -66,3 +68,15 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
             m = re.search(r"\.name:\s+\S*" + re.escape(name) + r"\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
             assert m, f"{name} not found in the metadata of {src}"
             assert int(m.group(1)) == 0, f"{name} spills {m.group(1)} VGPRs"
+
+
+def test_torch_dispatcher_registration():
+    """diffpure_amd.torch_ops registers the hot operators as torch.ops.diffpure_hip.* for the CUDA (= HIP) key only:
+    they resolve, carry schemas, and refuse CPU tensors (no CPU kernel exists behind them)."""
+    import torch
+    from diffpure_amd import torch_ops
+    for name in torch_ops.OPERATORS:
+        op = getattr(torch.ops.diffpure_hip, name)
+        assert "diffpure_hip::" + name in str(op.default._schema)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.diffpure_hip.attention(torch.zeros(1, 64, 3 * 64), 1, True)

@@ -422,3 +422,23 @@ def test_conv2d_h2_split_k_levels_are_batch_shard_invariant(dev, case):
         assert torch.equal(part, full[lo:hi])
         if H * W == 64:     # one 64-row record per sample
             assert torch.equal(part._dp_cols.buf, full._dp_cols.buf[lo:hi])
+
+
+def test_torch_ops_namespace_runs_the_hip_kernels(dev):
+    """torch.ops.diffpure_hip.* (diffpure_amd/torch_ops.py) dispatch to the same kernels as diffpure_amd.ops."""
+    from diffpure_amd import ops, torch_ops  # noqa: F401
+    x = rnd(2, 16, 16, 128, seed=1).to(dev)
+    w = rnd(96, 128, 3, 3, seed=2, scale=0.05)
+    bias = rnd(96, seed=3).to(dev)
+    wp = ops.pack_conv_weight(w).to(dev)
+    assert torch.equal(torch.ops.diffpure_hip.conv2d_nhwc(x, wp, bias, 96, 3), ops.conv2d(x, wp, 96, 3, bias=bias))
+    gamma, beta = (1 + 0.1 * rnd(128, seed=4)).to(dev), (0.1 * rnd(128, seed=5)).to(dev)
+    xh = torch.ops.diffpure_hip.group_norm_silu(x, gamma, beta, 32, 1e-5, True, True)
+    assert torch.equal(xh, ops.group_norm(x, 32, 1e-5, gamma, beta, act=True, split=True))
+    wh = ops.pack_conv_weight_h2(w, dev)
+    assert torch.equal(torch.ops.diffpure_hip.conv2d_h2(xh, wh, None, 96, 3), ops.conv2d_h2(xh, wh, 96, 3))
+    qkv = rnd(2, 64, 3 * 128, seed=6).to(dev)
+    assert torch.equal(torch.ops.diffpure_hip.attention(qkv, 2, True), ops.attention(qkv, 2, "legacy"))
+    img = torch.rand(2, 3, 28, 28).to(dev)
+    assert torch.equal(torch.ops.diffpure_hip.resize_affine(img, 32, 32, -0.5, 2.0, False, True),
+                       ops.resize_affine(img, (32, 32), -0.5, 2.0, False, True))
