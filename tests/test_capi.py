@@ -80,3 +80,16 @@ def test_torch_dispatcher_registration():
         assert "diffpure_hip::" + name in str(op.default._schema)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.diffpure_hip.attention(torch.zeros(1, 64, 3 * 64), 1, True)
+
+
+def test_split_k_factor_depends_on_the_layer_shape_only():
+    """dp_conv2d_nhwc_h2_workspace is a pure host function: the split-K factor it implies (bytes / (B*H*W*N*4)) must not
+    change with the batch - that is what keeps results identical for any sharding of a batch - and only the <= 64-pixel
+    levels are split."""
+    from diffpure_amd import _lib
+    lib = _lib.load()
+    for (h, w, ks, c, n) in [(4, 4, 3, 256, 256), (8, 8, 3, 512, 256), (8, 8, 3, 1024, 1024), (2, 2, 3, 128, 128), (8, 8, 1, 1024, 768)]:
+        factors = {lib.dp_conv2d_nhwc_h2_workspace(b, h, w, ks, c, n) // (b * h * w * n * 4) for b in (1, 2, 7, 64, 256, 1000)}
+        assert len(factors) == 1 and factors.pop() in (2, 4), (h, w, ks, c, n)
+    for (h, w, ks, c, n) in [(16, 16, 3, 256, 256), (32, 32, 3, 128, 128), (256, 256, 3, 256, 256), (8, 8, 1, 256, 768), (9, 9, 3, 512, 256)]:
+        assert all(lib.dp_conv2d_nhwc_h2_workspace(b, h, w, ks, c, n) == 0 for b in (1, 16, 256)), (h, w, ks, c, n)
