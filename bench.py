@@ -29,7 +29,8 @@ import torch.distributed as dist  # noqa: E402
 
 # MI355X_MICROARCH.md: fp32-input MFMA = 157.3 TF; dense fp16 MFMA ~2.5 PF (the f16x3 path spends
 # three fp16 MFMA passes per algorithmic MAC, so its matrix ceiling in ALGORITHMIC flops is 2500/3).
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0, "f16": 2500.0}
+MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2, "f16": 1}
 WORKLOADS = {
     # name: (kind, config file section, image size, algorithmic GFLOP / image / UNet call, 3x3 share)
     "imagenet256_guided": dict(kind="guided", hw=256, gflop=2239.67, gflop3x3=2115.44),
@@ -124,7 +125,7 @@ def main():
     ap.add_argument("--no-conv-profile", action="store_true",
                     help="do not time the convolution launches with hipEvents (roofline.achieved = null); needed to see the "
                          "HIP-graph step of small batches, which is never used while that profiler records")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x3", "f16x2", "f16"],
                     help="f32: fp32-input MFMA; f16x3: split-fp16 3-pass MFMA (fp32-class accuracy)")
     a = ap.parse_args()
 
@@ -238,8 +239,8 @@ def main():
                                          "= 0.84 TB/s of 8 TB/s (profiles/README.md, section 1)",
                          "launches": prof["n3x3"],
                          # f16x3 spends 3 fp16 MFMA passes per algorithmic MAC: the matrix pipe executes 3x `achieved`
-                         "mfma_passes": 3 if a.precision == "f16x3" else 1,
-                         "executed_frac": None if ach is None else ach * (3 if a.precision == "f16x3" else 1) / peak,
+                         "mfma_passes": MFMA_PASSES[a.precision],
+                         "executed_frac": None if ach is None else ach * MFMA_PASSES[a.precision] / peak,
                          "avg_launch_ms": prof["ms3x3"] / max(1, prof["n3x3"]),
                          "time_share_of_step": prof["ms3x3"] * 1e-3 / el,
                          "end_to_end_unet_tflops_per_gpu": unet_tflops},

@@ -3,7 +3,7 @@
 #include "dp_common.h"
 
 struct ConvH2Args {
-    const char* x;      // [B][H+2][W+2][C] h2, zero border
+    const char* x;      // [B][H+2][W+2][C] h2 (afmt 0) or plain fp16 (afmt 1), zero border
     int C;
     int B, H, W, KS, pad;
     const char* w;
@@ -21,6 +21,10 @@ struct ConvH2Args {
     int ksplit;         // > 1: split-K - blockIdx.y handles k-tiles [y, y+1) * nt / ksplit and stores RAW partial sums
     float* ws;          //      into ws[y][M][N]; dp_conv2d_nhwc_h2 then runs the reduction + epilogue kernel
     float* colstats;    // optional [M/64][2][N] per-column (sum, sumsq) of the final values (see igemm.hip)
+    int passes;         // MFMA passes per product: 3 = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi ("f16x3"); 2 = a_hi*w_lo + a_hi*w_hi
+                        // (activations rounded to fp16, weights to 22 bits); 12 = a_lo*w_hi + a_hi*w_hi (weights rounded);
+                        // 1 = a_hi*w_hi (plain fp16 operands, fp32 accumulation)
+    int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
 };
 
 // 8-wave "ping-pong" variants (igemm_h2_pp.hip): bn = 256 -> 256x256 tiles (needs M % 256 == 0, N % 256 == 0),

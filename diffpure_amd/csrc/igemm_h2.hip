@@ -59,20 +59,28 @@ constexpr int DP_H2_PP_DEFAULT = 2;   // see the dispatcher
 // BKH = k elements per LDS stage (32 or 16); an LDS row holds BKH (hi,lo) pairs = BKH*4 bytes = SPR 16-byte
 // slots.  XOR swizzle of the slot index with row bits chosen so that 16 consecutive rows at one logical slot
 // cover 16 distinct 16-byte bank positions: (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows.
-template <int BKH>
+template <int ROWBYTES>
 __device__ __forceinline__ int swz(int row, int slot) {
-    if constexpr (BKH == 32) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
-    else return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+    if constexpr (ROWBYTES == 128) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    else if constexpr (ROWBYTES == 64) return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+    else return row * 32 + ((slot ^ ((row >> 3) & 1)) << 4);
 }
 
-template <int BM, int BN, int BKH, int ABL>
+// A16: the activation operand is PLAIN fp16 ("h1": [B][H+2][W+2][C] fp16, zero border) - 2 bytes per element, LDS rows of
+// BKH * 2 bytes - and only a_hi exists: PASSES is 2 (a_hi*w_lo + a_hi*w_hi, "f16x2") or 1 (a_hi*w_hi, "f16").  The
+// per-element accumulation order is the one of the h2-operand kernel with the a_lo pass left out.
+template <int BM, int BN, int BKH, int ABL, int PASSES, bool A16>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
+    static_assert(A16 ? (PASSES == 2 || PASSES == 1) : (PASSES == 3 || PASSES == 12), "operand format / passes");
     constexpr int TM = BM / 64, TN = BN / 64;           // 2x2 waves, 32x32 MFMA tiles
-    constexpr int ROWB = BKH * 4, SPR = BKH / 4;        // bytes / 16-byte slots per LDS row
-    constexpr int RPP = NT / SPR, RPI = 64 / SPR;       // rows staged per pass of the workgroup / per DMA instruction
-    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+    constexpr int ESZ = A16 ? 2 : 4;                    // bytes per activation element
+    constexpr int AROWB = BKH * ESZ, ASPR = AROWB / 16; // bytes / 16-byte slots per LDS row of the A tile
+    constexpr int ROWB = BKH * 4, SPR = BKH / 4;        // ... of the B (weight, always hi|lo) tile
+    constexpr int ARPP = NT / ASPR, ARPI = 64 / ASPR;   // A rows staged per pass of the workgroup / per DMA instruction
+    constexpr int RPP = NT / SPR, RPI = 64 / SPR;       // B rows ...
+    constexpr int A_IT = BM / ARPP, B_IT = BN / RPP;
     constexpr int NS = BKH / 16, NSUB = 32 / BKH;       // k16 sub-steps per stage; stages per 32-channel slice
-    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int STAGE = BM * AROWB + BN * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,10 +94,11 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W;
-    const int r0 = tid / SPR;
+    const int r0 = tid / SPR, r0a = tid / ASPR;
     // logical slot this lane fetches: physical slot (tid % SPR) un-swizzled with the row key, which is the
-    // same for every pass because RPP is a multiple of 16
-    const int ls = (BKH == 32) ? ((tid & 7) ^ ((r0 >> 1) & 7)) : ((tid & 3) ^ ((r0 >> 2) & 3));
+    // same for every pass because RPP / ARPP are multiples of 16
+    const int ls = (ROWB == 128) ? ((tid & 7) ^ ((r0 >> 1) & 7)) : ((tid & 3) ^ ((r0 >> 2) & 3));
+    const int lsa = (AROWB == 128) ? ((tid & 7) ^ ((r0a >> 1) & 7)) : (AROWB == 64 ? ((tid & 3) ^ ((r0a >> 2) & 3)) : ((tid & 1) ^ ((r0a >> 3) & 1)));
     const int taps = p.KS * p.KS;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: LDS-DMA bases stay scalar
     const int Wp = p.W + 2;
@@ -98,10 +107,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     const char* ctr[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int m = min(m0 + r0 + it * RPP, p.M - 1);   // tail rows re-read the last pixel; never stored
+        const int m = min(m0 + r0a + it * ARPP, p.M - 1);   // tail rows re-read the last pixel; never stored
         const int b = m / HW, rem = m - b * HW;
         const int oy = rem / p.W, ox = rem - oy * p.W;
-        ctr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 + ls * 16;
+        ctr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * ESZ + lsa * 16;
     }
     const char* bptr[B_IT];
     int bstep[B_IT];
@@ -123,13 +132,13 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     for (int it = 0; it < B_IT; ++it) bptr[it] += (size_t)t0 * bstep[it];
     auto issue = [&](int stage) {
         const int ky = cur_tap / p.KS, kx = cur_tap - ky * p.KS;
-        const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)cur_c * 128 + cur_h * ROWB;
-        char* As = smem + stage * STAGE + wave_u * RPI * ROWB;
-        char* Bs = As + BM * ROWB;
+        const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * ESZ + (long long)cur_c * (32 * ESZ) + cur_h * AROWB;
+        char* As = smem + stage * STAGE + wave_u * ARPI * AROWB;
+        char* Bs = smem + stage * STAGE + BM * AROWB + wave_u * RPI * ROWB;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ctr[it] + off),
-                                             (__attribute__((address_space(3))) void*)(As + it * RPP * ROWB), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(As + it * ARPP * AROWB), 16, 0, 0);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     const int lr = lane & 31, lk = lane >> 5;
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE;
-        const char* Bs = As + BM * ROWB;
+        const char* Bs = As + BM * AROWB;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             half8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -161,24 +170,32 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm0 + i * 32 + lr;
-                ah[i] = *reinterpret_cast<const half8*>(As + swz<BKH>(row, sl));
-                al[i] = *reinterpret_cast<const half8*>(As + swz<BKH>(row, sl + 1));
+                if constexpr (A16) {
+                    ah[i] = *reinterpret_cast<const half8*>(As + swz<AROWB>(row, s * 2 + lk));
+                } else {
+                    ah[i] = *reinterpret_cast<const half8*>(As + swz<AROWB>(row, sl));
+                    al[i] = *reinterpret_cast<const half8*>(As + swz<AROWB>(row, sl + 1));
+                }
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lr;
-                bh[j] = *reinterpret_cast<const half8*>(Bs + swz<BKH>(row, sl));
-                bl[j] = *reinterpret_cast<const half8*>(Bs + swz<BKH>(row, sl + 1));
+                bh[j] = *reinterpret_cast<const half8*>(Bs + swz<ROWB>(row, sl));
+                bl[j] = *reinterpret_cast<const half8*>(Bs + swz<ROWB>(row, sl + 1));
             }
             if constexpr (ABL == 1) __builtin_amdgcn_s_setprio(1);
+            if constexpr (PASSES == 3 || PASSES == 12) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            if constexpr (PASSES == 3 || PASSES == 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -408,9 +425,12 @@ extern "C" long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, in
 extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
                                  const float* bias, const float* temb, int temb_stride, const float* res, int ldr,
                                  float scale, float* out, int ldo, float* colstats, int* tile_rows, void* work,
-                                 long long work_bytes, void* stream) {
+                                 long long work_bytes, int passes, int a_fmt, void* stream) {
     DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
     DP_REQUIRE(KS == 1 || KS == 3, "dp_conv2d_nhwc_h2: kernel size %d unsupported", KS);
+    DP_REQUIRE((a_fmt == 0 && (passes == 3 || passes == 12)) || (a_fmt == 1 && (passes == 2 || passes == 1)),
+               "dp_conv2d_nhwc_h2: (a_fmt, passes) must be (0, 3 | 12) for h2 activations or (1, 2 | 1) for plain fp16 ones (got %d, %d)",
+               a_fmt, passes);
     DP_REQUIRE(C > 0 && C % 32 == 0, "dp_conv2d_nhwc_h2: channel count must be a multiple of 32 (got %d)", C);
     DP_REQUIRE(dp_aligned16(x) && dp_aligned16(w), "dp_conv2d_nhwc_h2: misaligned operand");
     DP_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && (long long)B * H * W < (1ll << 31), "dp_conv2d_nhwc_h2: bad shape");
@@ -423,6 +443,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.zero = zero_page();
     DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
     p.colstats = colstats;
+    p.passes = passes;
+    p.afmt = a_fmt;
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
@@ -438,7 +460,11 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     do {                                                                                                   \
         p.tiles_n = (N + BN_ - 1) / BN_;                                                                   \
         p.tiles = (int)tiles(BM_, BN_);                                                                    \
-        hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_>), dim3((unsigned)p.tiles, (unsigned)p.ksplit), dim3(NT), 0, s, p); \
+        const dim3 g_((unsigned)p.tiles, (unsigned)p.ksplit);                                              \
+        if (p.afmt == 1 && p.passes == 2) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 2, true>), g_, dim3(NT), 0, s, p);        \
+        else if (p.afmt == 1) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 1, true>), g_, dim3(NT), 0, s, p);                    \
+        else if (p.passes == 12) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 12, false>), g_, dim3(NT), 0, s, p);               \
+        else hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 3, false>), g_, dim3(NT), 0, s, p);                                    \
     } while (0)
     // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
     // also fills the chip (>= one tile per CU); unset = DP_H2_PP_DEFAULT.  Read per call so that a probe can

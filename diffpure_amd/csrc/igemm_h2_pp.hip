@@ -70,11 +70,19 @@ __device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const 
 // Tile shapes: <256,256> (waves 2 (M) x 4 (N), 128 KB LDS) and <512,128> for layers with 128 output channels
 // (waves 4 (M) x 2 (N), 160 KB LDS = all of it).  The wave tile is 128 x 64 and the phase schedule identical in
 // both; only the wave -> tile mapping and the number of 64-row DMA pieces per unit differ (NPA, NPB).
-template <int BM, int BN, int MODE>
+// A16: the activation operand is plain fp16 ("h1", 2 bytes per element): A rows are 64 bytes in LDS (4 slots, XOR key
+// (row >> 2) & 3), an A unit is half as many DMA instructions (one instruction stages 128 rows), only a_hi fragments
+// exist and PASSES is 2 (a_hi*w_lo + a_hi*w_hi) or 1.  B (weights, hi|lo) and the whole phase schedule are unchanged;
+// LDS drops to 96 KB.
+template <int BM, int BN, int MODE, int PASSES, bool A16>
 __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     static_assert((BM == 256 && BN == 256) || (BM == 512 && BN == 128), "8 waves of 128 x 64");
-    constexpr int NPA = BM / 128, NPB = BN / 128;          // 64-row DMA pieces (one per thread) per A / B unit
-    constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB;  // operand tiles of one k-tile
+    static_assert(A16 ? (PASSES == 2 || PASSES == 1) : (PASSES == 3 || PASSES == 12), "operand format / passes");
+    constexpr int ESZ = A16 ? 2 : 4;                       // bytes per activation element
+    constexpr int AROWB = 32 * ESZ;                        // bytes per LDS row of the A tile
+    constexpr int NPA = A16 ? BM / 256 : BM / 128;         // DMA pieces (one instruction per thread) per A unit
+    constexpr int NPB = BN / 128;                          // ... per B unit (64-row pieces)
+    constexpr int TILE_A = BM * AROWB, TILE_B = BN * ROWB; // operand tiles of one k-tile
     constexpr int BUF = TILE_A + TILE_B;                   // A tile, then B tile
     constexpr int CNT_A = 2 * NPA + NPB, CNT_B = 2 * NPB + NPA;   // loads of three consecutive phases ending in an A / a B phase
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
@@ -94,29 +102,34 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
 
-    // ---- staging geometry: a unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7
+    // ---- staging geometry: a B unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7.
+    // An A unit is the rows {blk*128 + unit*64 + 0..63} of every 128-row block blk of the tile.  h2 operand: one piece per
+    // block (64 rows x 128 B, lane -> row u, slot tid & 7); h1 operand: one piece per TWO blocks (128 rows x 64 B, lane ->
+    // row ua = tid >> 2 of the piece, slot tid & 3).
     const int u = tid >> 3;
     const int ls = (tid & 7) ^ ((u >> 1) & 7);     // logical slot fetched (XOR swizzle applied on the source side)
+    const int ua = A16 ? tid >> 2 : u;
+    const int lsa = A16 ? ((tid & 3) ^ ((ua >> 2) & 3)) : ls;
     // Sources are addressed as (scalar 64-bit base) + (32-bit lane offset): the lane offsets are loop
     // invariant and the per-k-tile part (tap shift, channel slice, weight column block) lives in the
     // scalar base, so a DMA issue costs no vector ALU work and reads one address VGPR per lane.
     // Activation lane offsets are relative to the centre pixel of the tile's first row (always < 2^31:
     // a tile spans 256 consecutive output pixels).
-    unsigned aoff[2][NPA];                         // [unit][piece]: A row m0 + piece*128 + unit*64 + u
+    unsigned aoff[2][NPA];                         // [unit][piece]
     long long aorg;                                // centre pixel of row m0, in bytes from p.x
     {
         const int b = m0 / HW, rem = m0 - b * HW;
         const int oy = rem / p.W, ox = rem - oy * p.W;
-        aorg = ((long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4;
+        aorg = ((long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * ESZ;
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
-            const int m = m0 + i * 128 + a * 64 + u;
+            const int m = A16 ? m0 + (2 * i + (ua >> 6)) * 128 + a * 64 + (ua & 63) : m0 + i * 128 + a * 64 + u;
             const int b = m / HW, rem = m - b * HW;
             const int oy = rem / p.W, ox = rem - oy * p.W;
-            aoff[a][i] = (unsigned)(((long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 4 - aorg) + ls * 16;
+            aoff[a][i] = (unsigned)(((long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * ESZ - aorg) + lsa * 16;
         }
     unsigned boff[2][NPB];                         // [unit][piece]: weight row n0 + piece*128 + (u>>5)*64 + unit*32 + (u&31)
 #pragma unroll
@@ -126,18 +139,20 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             boff[b][i] = (unsigned)(i * 128 + (u >> 5) * 64 + b * 32 + (u & 31)) * (unsigned)(p.K * 4) + ls * 16;
     const char* const abase = p.x + pp_uniform(aorg);              // uniform
     const char* const bbase = p.w + pp_uniform((long long)n0 * p.K * 4);   // uniform
-    const int u0 = wave * 8;                       // first row of this wave inside a piece (wave-uniform)
-    const int adst = u0 * ROWB;                                            // + (piece*128 + unit*64) * ROWB
+    const int u0 = wave * 8;                       // first row of this wave inside a 64-row piece (wave-uniform)
+    const int ua0 = wave * 16;                     // ... inside a 128-row h1 A piece
+    // LDS rows of the A tile are the tile's rows; a wave's DMA instruction fills 1 KB = 8 (h2) / 16 (h1) consecutive rows
+    const int adst = A16 ? ((ua0 >> 6) * 128 + (ua0 & 63)) * AROWB : u0 * AROWB;   // + (piece*{256|128} + unit*64) * AROWB
     const int bdst = TILE_A + ((u0 >> 5) * 64 + (u0 & 31)) * ROWB;         // + (piece*128 + unit*32) * ROWB
 
     auto tap_off = [&](int c32, int tap) -> long long {
         const int ky = tap / p.KS, kx = tap - ky * p.KS;
-        return ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 4 + (long long)c32 * 128;
+        return ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * ESZ + (long long)c32 * (32 * ESZ);
     };
     auto stage_a = [&](char* buf, int a, long long off) {
         const char* sb = abase + pp_uniform(off);
 #pragma unroll
-        for (int i = 0; i < NPA; ++i) pp_glds(aoff[a][i], sb, buf + adst + (i * 128 + a * 64) * ROWB);
+        for (int i = 0; i < NPA; ++i) pp_glds(aoff[a][i], sb, buf + adst + (i * (A16 ? 256 : 128) + a * 64) * AROWB);
     };
     auto stage_b = [&](char* buf, int b, long long off) {
         const char* sb = bbase + pp_uniform(off);
@@ -147,13 +162,16 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 
     // ---- fragment addressing: lane -> row lr of a 32-row MFMA tile, k-half lk; slot (s*4 + lk*2 + h) ^ key
     const int lr = lane & 31, lk = lane >> 5, key = (lr >> 1) & 7;
-    const int arow = (wr * 128 + lr) * ROWB;                 // + (sub*64 + i*32) * ROWB
+    const int arow = (wr * 128 + lr) * AROWB;                // + (sub*64 + i*32) * AROWB
     const int brow = TILE_A + (wc * 64 + lr) * ROWB;         // + (sub*32) * ROWB
-    int soff[2][2];                                          // [s][h] byte offset of the fragment inside its row
+    int soff[2][2];                                          // [s][h] byte offset of the fragment inside its (128-byte) row
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int h = 0; h < 2; ++h) soff[s][h] = ((s * 4 + lk * 2 + h) ^ key) << 4;
+    int soffa[2];                                            // h1 A rows (64 bytes): slot s*2 + lk, key (row >> 2) & 3
+#pragma unroll
+    for (int s = 0; s < 2; ++s) soffa[s] = ((s * 2 + lk) ^ ((lr >> 2) & 3)) << 4;
 
     half8 fah[2][2], fal[2][2];     // A fragments of the current 64-row half: [m-tile i][k16 step s]
     half8 fb0h[2], fb0l[2];         // B fragments, column sub-block 0 (kept from phase 0 to phase 3)
@@ -163,9 +181,13 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const char* r = buf + arow + (sub * 64 + i * 32) * ROWB;
-                fah[i][s] = *reinterpret_cast<const half8*>(r + soff[s][0]);
-                fal[i][s] = *reinterpret_cast<const half8*>(r + soff[s][1]);
+                const char* r = buf + arow + (sub * 64 + i * 32) * AROWB;
+                if constexpr (A16) {
+                    fah[i][s] = *reinterpret_cast<const half8*>(r + soffa[s]);
+                } else {
+                    fah[i][s] = *reinterpret_cast<const half8*>(r + soff[s][0]);
+                    fal[i][s] = *reinterpret_cast<const half8*>(r + soff[s][1]);
+                }
             }
     };
 
@@ -182,10 +204,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 #define PP_MFMA(ASUB, BSUB, BH, BL)                                                                              \
     do {                                                                                                         \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                          \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                              \
-                __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i][s], BH[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);     \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                              \
-                __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], BL[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);     \
+            if constexpr (PASSES == 3 || PASSES == 12) {                                                         \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                          \
+                    __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i][s], BH[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0); \
+            }                                                                                                    \
+            if constexpr (PASSES == 3 || PASSES == 2) {                                                          \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                          \
+                    __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], BL[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0); \
+            }                                                                                                    \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                              \
                 __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], BH[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);     \
         }                                                                                                        \
@@ -349,7 +375,15 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
     p.tiles = (p.M / bm) * p.tiles_n;
     const char* e = getenv("DP_H2_PP_MODE");
     const int mode = e ? atoi(e) : 0;
-#define PP_LAUNCH(BM_, BN_, M_) hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
+#define PP_LAUNCH1(BM_, BN_, M_, P_, A_) \
+    hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_, P_, A_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
+#define PP_LAUNCH(BM_, BN_, M_)                                          \
+    do {                                                                 \
+        if (p.afmt == 1 && p.passes == 2) PP_LAUNCH1(BM_, BN_, 0, 2, true);   \
+        else if (p.afmt == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true);          \
+        else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false); \
+        else PP_LAUNCH1(BM_, BN_, M_, 3, false);                         \
+    } while (0)
     if (bn == 128) {
         PP_LAUNCH(512, 128, 0);
         return;
@@ -364,4 +398,5 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
         default: PP_LAUNCH(256, 256, 0); break;
     }
 #undef PP_LAUNCH
+#undef PP_LAUNCH1
 }

@@ -150,7 +150,10 @@ __device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) 
 // (8 channels: 16 B of hi, then 16 B of lo) is built by the two lanes that own its quads: they exchange their 4
 // activated values (one DPP swap each), the even lane stores the octet's hi half, the odd lane its lo half - byte
 // offset 16 * quad either way.  Same arithmetic per element as gn_apply_kernel<true, ACT> (bit-identical output).
-template <bool ACT>
+// FMT = 2 ("h1": plain fp16, 2 bytes per element, the operand of the two-pass / one-pass convolutions): a lane simply
+// stores its own quad as 4 fp16 (8 bytes at byte offset 8 * quad) - same values as the hi halves of the h2 form.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+template <bool ACT, int FMT>
 __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT, int slots) {
     const int CQ = p.C4;                                 // quads per pixel
     const int Hq = p.Ho + 2, Wq = p.Wo + 2;
@@ -206,6 +209,17 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
             }
             return out;
         };
+        // store this lane's share of pixel `opix` of the operand tensor `base`
+        auto put = [&](char* base, size_t opix, f32x4 v) {
+            if constexpr (FMT == 1) {
+                *reinterpret_cast<half8*>(base + (opix * CQ + cq) * 16) = half_of_octet(v);
+            } else {
+                half4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
+                *reinterpret_cast<half4*>(base + (opix * CQ + cq) * 8) = h;
+            }
+        };
         int qx = slot;
         if (p.resample == 0 && !zrow) {
             // interior pixels four at a time: all four loads are issued before the first use
@@ -222,25 +236,20 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const size_t opix = orow + qx + k * slots;
-                    half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CQ + cq) * 16);
                     f32x4 o = xf(rv[k]);
                     if (!in[k]) o = f32x4{0.f, 0.f, 0.f, 0.f};          // border pixel of the row: zeros
-                    *dst = half_of_octet(o);
-                    if (p.y_raw) *reinterpret_cast<half8*>(p.y_raw + (opix * CQ + cq) * 16) = half_of_octet(rv[k]);
+                    put(reinterpret_cast<char*>(p.y), opix, o);
+                    if (p.y_raw) put(p.y_raw, opix, rv[k]);
                 }
             }
         }
         for (; qx < Wq; qx += slots) {
             const int ox = qx - 1;
             const size_t opix = orow + qx;
-            half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CQ + cq) * 16);
-            half8* dr = p.y_raw ? reinterpret_cast<half8*>(p.y_raw + (opix * CQ + cq) * 16) : nullptr;
             if (zrow || (unsigned)ox >= (unsigned)p.Wo) {
-                half8 z;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
-                *dst = z;
-                if (dr) *dr = z;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                put(reinterpret_cast<char*>(p.y), opix, z);
+                if (p.y_raw) put(p.y_raw, opix, z);
                 continue;
             }
             f32x4 o, raw;
@@ -258,8 +267,8 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
                 for (int j = 0; j < 4; ++j) o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
                 raw = o;
             }
-            *dst = half_of_octet(o);
-            if (dr) *dr = half_of_octet(raw);     // resample == 0 here: the un-normalised input in operand form
+            put(reinterpret_cast<char*>(p.y), opix, o);
+            if (p.y_raw) put(p.y_raw, opix, raw);     // resample == 0 here: the un-normalised input in operand form
         }
     }
 }
@@ -438,8 +447,8 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     DP_REQUIRE(resample != 2 || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply: 2x2 mean needs even H, W");
     DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(y), "dp_gn_apply: misaligned tensor");
     DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply: misaligned FiLM rows");
-    DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && C % 8 == 0 && C1 % 8 == 0), "dp_gn_apply: out_fmt %d needs channel counts that are multiples of 8", out_fmt);
-    DP_REQUIRE(!y_raw || (out_fmt == 1 && resample == 0), "dp_gn_apply: the raw h2 output needs out_fmt=1 and no resampling");
+    DP_REQUIRE(out_fmt == 0 || ((out_fmt == 1 || out_fmt == 2) && C % 8 == 0 && C1 % 8 == 0), "dp_gn_apply: out_fmt %d needs channel counts that are multiples of 8", out_fmt);
+    DP_REQUIRE(!y_raw || (out_fmt != 0 && resample == 0), "dp_gn_apply: the raw operand output needs out_fmt=1|2 and no resampling");
     ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
                 C / 4, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
                 resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W), (char*)y_raw};
@@ -450,10 +459,14 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_>), dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots)
     // h2 output: the lane-contiguous quad kernel unless DP_GN_APPLY_QUAD=0 (A/B switch; both give identical bytes)
     static const bool quad = [] { const char* e = getenv("DP_GN_APPLY_QUAD"); return !e || atoi(e) != 0; }();
-    if (out_fmt && quad) {
+    if (out_fmt == 2) {
+        const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;
+        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 2>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 2>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+    } else if (out_fmt && quad) {
         const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;     // C % 8 == 0: CQ and CQT are even
-        if (act) hipLaunchKernelGGL(gn_apply_h2q_kernel<true>, dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
-        else hipLaunchKernelGGL(gn_apply_h2q_kernel<false>, dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 1>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 1>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
     } else if (out_fmt) {
         if (act) GN_APPLY_LAUNCH(true, true);
         else GN_APPLY_LAUNCH(true, false);

@@ -17,6 +17,8 @@ main engines:
 import math
 from collections import OrderedDict
 
+import functools
+
 import torch
 
 from . import ops
@@ -123,9 +125,14 @@ class DdpmUNet:
     """noise-prediction network: NHWC in, NHWC out ([B, H, W, out_ch]); `timesteps` = integer step index."""
 
     def __init__(self, cfg, device, precision="f16x3"):
-        if precision not in ("f32", "f16x3"):
+        if precision != "f32" and precision not in ops.H2_MODES:
             raise ValueError(f"unknown precision {precision!r}")
         self.cfg, self.precision, self.device = cfg, precision, torch.device(device)
+        # fp16-matrix-core convolution path: MFMA passes per product and the operand format GroupNorm-apply emits
+        self.h2mode = precision in ops.H2_MODES
+        passes, ofmt = ops.H2_MODES.get(precision, (3, ops.FMT_H2))
+        self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
+        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes)
         self.plan = _plan(cfg)
         self.p = {}
         half = cfg["ch"] // 2
@@ -145,7 +152,7 @@ class DdpmUNet:
             return sd[k].detach().float().contiguous().to(dev)
 
         def conv_w(k, cin):
-            if self.precision == "f16x3" and cin % 32 == 0:
+            if self.h2mode and cin % 32 == 0:
                 return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
             return ops.pack_conv_weight(sd[k].detach()).to(dev), False
 
@@ -173,7 +180,7 @@ class DdpmUNet:
             elif r["kind"] == "attn":
                 P[n + ".g"], P[n + ".b"] = vec(n + ".norm.weight"), vec(n + ".norm.bias")
                 wq = torch.cat([sd[n + f".{j}.weight"].detach().float() for j in ("q", "k", "v")], dim=0)      # [3C, C, 1, 1]
-                r["h2"] = self.precision == "f16x3" and r["ch"] % 32 == 0
+                r["h2"] = self.h2mode and r["ch"] % 32 == 0
                 P[n + ".wqkv"] = ops.pack_conv_weight_h2(wq, dev) if r["h2"] else ops.pack_conv_weight(wq).to(dev)
                 P[n + ".cqkv"] = torch.cat([sd[n + f".{j}.bias"].detach().float() for j in ("q", "k", "v")]).contiguous().to(dev)
                 P[n + ".w3"], P[n + ".c3"] = ops.pack_conv_weight(sd[n + ".proj_out.weight"].detach()).to(dev), vec(n + ".proj_out.bias")
@@ -190,20 +197,20 @@ class DdpmUNet:
     # -- blocks ---------------------------------------------------------------------------------------
     def _res(self, r, x, x2, dense):
         P, n, co = self.p, r["name"], r["cout"]
-        conv0 = ops.conv2d_h2 if r["h2_0"] else ops.conv2d
-        conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
+        conv0 = self._ch2 if r["h2_0"] else ops.conv2d
+        conv1 = self._ch2 if r["h2_1"] else ops.conv2d
         st0 = ops.group_norm_stats(x, GN_GROUPS, GN_EPS, x2)
         want_raw = r.get("h2_s", False)
-        h = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True, split=r["h2_0"], stats=st0,
+        h = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True, split=r["h2_0"] and self._ofmt, stats=st0,
                            raw=want_raw)
         if want_raw:
             h, xraw = h
         off = r["dense_off"]
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True)
         st1 = ops.group_norm_stats(h, GN_GROUPS, GN_EPS)
-        h = ops.group_norm(h, GN_GROUPS, GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"], stats=st1)
+        h = ops.group_norm(h, GN_GROUPS, GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
         if want_raw:
-            skip = ops.conv2d_h2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+            skip = self._ch2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
         else:
@@ -214,8 +221,8 @@ class DdpmUNet:
         P, n, c = self.p, r["name"], r["ch"]
         b, hh, ww, _ = x.shape
         st = ops.group_norm_stats(x, GN_GROUPS, GN_EPS)
-        hn = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"], stats=st)
-        qkv = (ops.conv2d_h2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        hn = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
+        qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")           # one head of dimension C, scale C^-1/2
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, colstats=True)
 
@@ -223,7 +230,7 @@ class DdpmUNet:
         """pad (0,1,0,1) + 3x3 stride 2 == positions (2i+1, 2j+1) of the same-padded stride-1 convolution."""
         P, n, c = self.p, r["name"], r["ch"]
         if r["h2"]:
-            z = ops.conv2d_h2(ops.to_h2(x), P[n + ".w"], c, 3, bias=P[n + ".c"])
+            z = self._ch2(ops.to_h2(x, fmt=self._ofmt), P[n + ".w"], c, 3, bias=P[n + ".c"])
         else:
             z = ops.conv2d(x, P[n + ".w"], c, 3, bias=P[n + ".c"])
         return z[:, 1::2, 1::2, :].contiguous()
@@ -231,7 +238,7 @@ class DdpmUNet:
     def _up(self, r, x):
         P, n, c = self.p, r["name"], r["ch"]
         if r["h2"]:
-            return ops.conv2d_h2(ops.to_h2(x, ops.RESAMPLE_UP), P[n + ".w"], c, 3, bias=P[n + ".c"], colstats=True)
+            return self._ch2(ops.to_h2(x, ops.RESAMPLE_UP, fmt=self._ofmt), P[n + ".w"], c, 3, bias=P[n + ".c"], colstats=True)
         return ops.conv2d(ops.resample(x, ops.RESAMPLE_UP), P[n + ".w"], c, 3, bias=P[n + ".c"], colstats=True)
 
     # -- time conditioning ------------------------------------------------------------------------------
@@ -268,6 +275,6 @@ class DdpmUNet:
                 h = self._res(r, h, hs.pop(), dense)
         assert not hs
         sth = ops.group_norm_stats(h, GN_GROUPS, GN_EPS)
-        h = ops.group_norm(h, GN_GROUPS, GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2, stats=sth)
-        conv = ops.conv2d_h2 if self._out_h2 else ops.conv2d
+        h = ops.group_norm(h, GN_GROUPS, GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2 and self._ofmt, stats=sth)
+        conv = self._ch2 if self._out_h2 else ops.conv2d
         return conv(h, P["out.w"], self.cfg["out_ch"], 3, bias=P["out.c"])

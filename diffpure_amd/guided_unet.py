@@ -19,6 +19,8 @@ activations, and every record runs on the HIP kernels of libdiffpure_hip.so:
 import math
 from collections import OrderedDict
 
+import functools
+
 import torch
 
 from . import ops
@@ -176,10 +178,15 @@ class GuidedUNet:
                       "f16x3" = split-fp16 three-pass MFMA for every convolution whose input is a
                       GroupNorm output (all 3x3 convolutions but the stem, and the qkv 1x1):
                       fp32-class accuracy, ~5x the matrix ceiling (csrc/igemm_h2.hip)."""
-        if precision not in ("f32", "f16x3"):
+        if precision != "f32" and precision not in ops.H2_MODES:
             raise ValueError(f"unknown precision {precision!r}")
         self.cfg = cfg
         self.precision = precision
+        # fp16-matrix-core convolution path: MFMA passes per product and the operand format GroupNorm-apply emits
+        self.h2mode = precision in ops.H2_MODES
+        passes, ofmt = ops.H2_MODES.get(precision, (3, ops.FMT_H2))
+        self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
+        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes)
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -208,7 +215,7 @@ class GuidedUNet:
 
         def conv_w(k, cin):
             """-> (packed weight, is_h2)"""
-            if self.precision == "f16x3" and cin % 32 == 0:
+            if self.h2mode and cin % 32 == 0:
                 return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
             return ops.pack_conv_weight(sd[k].detach()).to(dev), False
 
@@ -265,11 +272,11 @@ class GuidedUNet:
         P, n, co = self.p, r["name"], r["cout"]
         G, eps = self.GN_GROUPS, self.GN_EPS
         mode = r["mode"]
-        conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
-        conv2 = ops.conv2d_h2 if r["h2_2"] else ops.conv2d
+        conv1 = self._ch2 if r["h2_1"] else ops.conv2d
+        conv2 = self._ch2 if r["h2_2"] else ops.conv2d
         st1 = ops.group_norm_stats(x, G, eps, x2)
         want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False)
-        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"], stats=st1,
+        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
                            raw=want_raw)
         if want_raw:
             h, xraw = h
@@ -279,11 +286,11 @@ class GuidedUNet:
         st2 = ops.group_norm_stats(h, G, eps)
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
-        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"], stats=st2)
+        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
         if mode:
             skip = ops.resample(x, mode)
         elif want_raw:
-            skip = ops.conv2d_h2(xraw, P[n + ".ws"], co, 1, bias=P[n + ".cs"])
+            skip = self._ch2(xraw, P[n + ".ws"], co, 1, bias=P[n + ".cs"])
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".ws"], co, 1, bias=P[n + ".cs"], x2=x2)
         else:
@@ -294,8 +301,8 @@ class GuidedUNet:
         P, n, c = self.p, r["name"], r["ch"]
         b, hh, ww, _ = x.shape
         st = ops.group_norm_stats(x, self.GN_GROUPS, self.GN_EPS)
-        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"], stats=st)
-        qkv = (ops.conv2d_h2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
+        qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
         if tape is None:
             a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
@@ -345,8 +352,8 @@ class GuidedUNet:
         st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=st))
-        h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2, stats=st)
-        return (ops.conv2d_h2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["out_channels"], 3, bias=P["out.c"])
+        h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2 and self._ofmt, stats=st)
+        return (self._ch2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["out_channels"], 3, bias=P["out.c"])
 
     __call__ = forward
 
@@ -368,7 +375,7 @@ class GuidedUNet:
             wd = ops.dgrad_weight(w)                       # [I, O, kh, kw]
             if lo is not None:
                 wd = wd[lo:hi]
-            if self.precision == "f16x3" and n_in_dgrad % 32 == 0:
+            if self.h2mode and n_in_dgrad % 32 == 0:
                 return ops.pack_conv_weight_h2(wd, dev), True
             return ops.pack_conv_weight(wd).to(dev), False
 
@@ -396,7 +403,7 @@ class GuidedUNet:
         if is_h2:
             if dy.dtype != torch.float16:
                 dy = ops.to_h2(dy)
-            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale)
+            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale)    # gradients: h2 operand, three passes
         return ops.conv2d(dy, self.p[key], n_out, ksize, scale=scale)
 
     def _res_bwd(self, t, dout):

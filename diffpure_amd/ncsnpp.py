@@ -15,6 +15,8 @@ BigGAN ResBlocks, fir False, progressive none, positional embedding); loads the 
 import math
 from collections import OrderedDict
 
+import functools
+
 import torch
 
 from . import ops
@@ -134,10 +136,15 @@ class NCSNpp:
     def __init__(self, cfg, device, precision="f32"):
         """precision: "f32" exact fp32-input MFMA; "f16x3" split-fp16 three-pass MFMA for every
         convolution fed by a GroupNorm (see GuidedUNet / csrc/igemm_h2.hip)."""
-        if precision not in ("f32", "f16x3"):
+        if precision != "f32" and precision not in ops.H2_MODES:
             raise ValueError(f"unknown precision {precision!r}")
         self.cfg = cfg
         self.precision = precision
+        # fp16-matrix-core convolution path: MFMA passes per product and the operand format GroupNorm-apply emits
+        self.h2mode = precision in ops.H2_MODES
+        passes, ofmt = ops.H2_MODES.get(precision, (3, ops.FMT_H2))
+        self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
+        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes)
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -170,7 +177,7 @@ class NCSNpp:
             return sd[k].detach().float().contiguous().to(dev)
 
         def conv_w(k, cin):
-            if self.precision == "f16x3" and cin % 32 == 0:
+            if self.h2mode and cin % 32 == 0:
                 return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
             return ops.pack_conv_weight(sd[k].detach()).to(dev), False
 
@@ -204,7 +211,7 @@ class NCSNpp:
             else:
                 P[n + ".g"], P[n + ".b"] = vec(p + ".GroupNorm_0.weight"), vec(p + ".GroupNorm_0.bias")
                 wq = torch.cat([sd[p + f".NIN_{j}.W"].detach().float() for j in range(3)], dim=1)
-                r["h2"] = self.precision == "f16x3" and r["ch"] % 32 == 0
+                r["h2"] = self.h2mode and r["ch"] % 32 == 0
                 # NIN W is [in, out]; the h2 packer wants [out, in] (conv OI layout)
                 P[n + ".wqkv"] = ops.pack_conv_weight_h2(wq.t().contiguous(), dev) if r["h2"] else ops.pack_nin_weight(wq).to(dev)
                 P[n + ".cqkv"] = torch.cat([sd[p + f".NIN_{j}.b"].detach().float() for j in range(3)]).contiguous().to(dev)
@@ -221,13 +228,13 @@ class NCSNpp:
     def _res(self, r, x, x2, dense, tape=None):
         P, n, co = self.p, str(r["idx"]), r["cout"]
         mode = r["mode"]
-        conv0 = ops.conv2d_h2 if r["h2_0"] else ops.conv2d
-        conv1 = ops.conv2d_h2 if r["h2_1"] else ops.conv2d
+        conv0 = self._ch2 if r["h2_0"] else ops.conv2d
+        conv1 = self._ch2 if r["h2_1"] else ops.conv2d
         st0 = ops.group_norm_stats(x, self._groups(r["cin"]), self.GN_EPS, x2)
         h2s = r.get("h2_s", False)
         want_raw = h2s and not mode
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
-                           resample=mode, split=r["h2_0"], stats=st0, raw=want_raw)
+                           resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw)
         if want_raw:
             h, xraw = h
         off = r["dense_off"]
@@ -235,14 +242,14 @@ class NCSNpp:
         st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
-        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"], stats=st1)
+        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
         if mode:
             if h2s:
-                skip = ops.conv2d_h2(ops.to_h2(x, mode), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+                skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
             else:
                 skip = ops.conv2d(ops.resample(x, mode), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
         elif want_raw:
-            skip = ops.conv2d_h2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+            skip = self._ch2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
         else:
@@ -253,8 +260,8 @@ class NCSNpp:
         P, n, c = self.p, str(r["idx"]), r["ch"]
         b, hh, ww, _ = x.shape
         st = ops.group_norm_stats(x, self._groups(c), self.GN_EPS)
-        hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"], stats=st)
-        qkv = (ops.conv2d_h2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
+        qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         if tape is None:
             a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
         else:
@@ -297,8 +304,8 @@ class NCSNpp:
         sth = ops.group_norm_stats(h, g, self.GN_EPS)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=sth))
-        h = ops.group_norm(h, g, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2, stats=sth)
-        return (ops.conv2d_h2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["channels"], 3, bias=P["out.c"])
+        h = ops.group_norm(h, g, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2 and self._ofmt, stats=sth)
+        return (self._ch2 if self._out_h2 else ops.conv2d)(h, P["out.w"], self.cfg["channels"], 3, bias=P["out.c"])
 
     __call__ = forward
 
@@ -313,7 +320,7 @@ class NCSNpp:
             wd = ops.dgrad_weight(w.detach().float())
             if lo is not None:
                 wd = wd[lo:hi]
-            if self.precision == "f16x3" and n_in_dgrad % 32 == 0:
+            if self.h2mode and n_in_dgrad % 32 == 0:
                 return ops.pack_conv_weight_h2(wd, dev), True
             return ops.pack_conv_weight(wd).to(dev), False
 
@@ -341,7 +348,7 @@ class NCSNpp:
         if is_h2:
             if dy.dtype != torch.float16:
                 dy = ops.to_h2(dy)
-            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale)
+            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale)    # gradients: h2 operand, three passes
         return ops.conv2d(dy, self.p[key], n_out, ksize, scale=scale)
 
     def _res_bwd(self, t, dout):

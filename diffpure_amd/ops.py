@@ -111,13 +111,44 @@ def _colstats_alloc(m, n, device):
     return torch.empty(((m + 63) // 64, 2, n), device=device, dtype=torch.float32), ctypes.c_int(0)
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False):
-    """conv2d on h2 (split-fp16) activations/weights with three fp16 MFMA passes per product; same
-    epilogue contract as conv2d.  x: [B, H+2, W+2, 2*C] fp16 (h2 with a one-pixel zero border, as
-    group_norm(split=True) writes it), wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2)."""
+# precision name -> (MFMA passes per product, activation operand format of the fp16-matrix-core convolutions)
+#   operand format 1 = "h2": per 8 channels [8 x fp16 hi | 8 x fp16 lo]  (4 bytes per element, 22 significant bits)
+#                  2 = "h1": plain fp16                                   (2 bytes per element)
+# Weights are always h2.  See include/diffpure_hip.h (dp_conv2d_nhwc_h2) for the arithmetic of each mode.
+H2_MODES = {"f16x3": (3, 1), "f16x2": (2, 2), "f16": (1, 2), "f16x2w": (12, 1)}
+FMT_F32, FMT_H2, FMT_H1 = 0, 1, 2
+
+
+def _fmt_of(split):
+    """group_norm / to_h2 `split` argument -> output format code: False / None / 0 -> fp32, True / 'h2' / 1 -> h2, 'h1' / 2 -> h1."""
+    if split is True or split == "h2":
+        return FMT_H2
+    if split is None or split is False:
+        return FMT_F32
+    if split == "h1":
+        return FMT_H1
+    if split in (FMT_F32, FMT_H2, FMT_H1):
+        return int(split)
+    raise ValueError(f"unknown operand format {split!r}")
+
+
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None):
+    """conv2d on the fp16 matrix cores; same epilogue contract as conv2d.  wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2).
+    x: zero-bordered operand as group_norm(split=...) writes it - h2 [B, H+2, W+2, 2*C] fp16 (three MFMA passes per
+    product, `passes` 3, or 12 for the weights-rounded study mode) or h1 [B, H+2, W+2, C] fp16 (`passes` 2 or 1).
+    The operand format is read off the shapes; `passes` defaults to the full arithmetic of the format (3 / 2)."""
     _chk_h2(x, "conv2d_h2.x")
-    b, h, w, c = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3] // 2
     _chk_h2(wh, "conv2d_h2.w")
+    b, h, w = x.shape[0], x.shape[1] - 2, x.shape[2] - 2
+    c = wh.shape[1] // (2 * ksize * ksize)
+    if x.shape[3] == 2 * c:
+        a_fmt = 0
+    elif x.shape[3] == c:
+        a_fmt = 1
+    else:
+        raise _lib.DiffpureHipError(f"conv2d_h2: operand {tuple(x.shape)} does not match the weight panel {tuple(wh.shape)} (ksize {ksize})")
+    if passes is None:
+        passes = 2 if a_fmt else 3
     assert wh.shape == (n_out, 2 * ksize * ksize * c), (wh.shape, n_out, ksize, c)
     if bias is not None:
         _chk(bias, "conv2d_h2.bias", 1)
@@ -138,7 +169,7 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     work = torch.empty((wbytes // 4,), device=x.device, dtype=torch.float32) if wbytes else None
     _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
               ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _ptr(work), wbytes,
-              _stream())
+              int(passes), a_fmt, _stream())
     if colstats:
         out._dp_cols = ColStats(cs, tr.value, n_out)
     return out
@@ -227,9 +258,10 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
                split=False, raw=False):
     """y = resample(act(FiLM(GroupNorm(cat(x, x2))))).  film = (scale [R,C], shift [R,C]) with R in
     {1, B}; the two may be column views of one [R, 2C] tensor (row stride is taken from them).
-    split=True writes the "h2" split-fp16 operand format of conv2d_h2 with its one-pixel zero border
-    ([B, Ho+2, Wo+2, 2C] fp16).  raw=True (with split, no resampling) additionally returns the
-    un-normalised cat(x, x2) in the same operand format (input of a 1x1 skip convolution)."""
+    split=True / "h2" writes the split-fp16 operand format of conv2d_h2 with its one-pixel zero border
+    ([B, Ho+2, Wo+2, 2C] fp16), split="h1" the plain-fp16 operand ([B, Ho+2, Wo+2, C] fp16).  raw=True (with
+    split, no resampling) additionally returns the un-normalised cat(x, x2) in the same operand format (input of
+    a 1x1 skip convolution)."""
     _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
@@ -245,16 +277,17 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         assert fs.shape[0] in (1, b)
         fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
     ho, wo = (h * 2, w * 2) if resample == RESAMPLE_UP else ((h // 2, w // 2) if resample == RESAMPLE_DOWN else (h, w))
-    if split:
-        y = torch.empty((b, ho + 2, wo + 2, 2 * c), device=x.device, dtype=torch.float16)
+    fmt = _fmt_of(split)
+    if fmt:
+        y = torch.empty((b, ho + 2, wo + 2, (2 * c) if fmt == FMT_H2 else c), device=x.device, dtype=torch.float16)
     else:
         y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
     yr = None
     if raw:
-        assert split and resample == RESAMPLE_NONE
+        assert fmt and resample == RESAMPLE_NONE
         yr = torch.empty_like(y)
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, 1 if split else 0, _ptr(y), _ptr(yr), _stream())
+              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), _stream())
     return (y, yr) if raw else y
 
 
@@ -338,14 +371,16 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
     return dx
 
 
-def to_h2(x, mode=RESAMPLE_NONE):
-    """fp32 NHWC -> zero-bordered h2 operand ([B, H'+2, W'+2, 2C] fp16) without normalisation,
-    optionally through the 2x resampler (`mode`)."""
+def to_h2(x, mode=RESAMPLE_NONE, fmt="h2"):
+    """fp32 NHWC -> zero-bordered convolution operand without normalisation, optionally through the 2x resampler
+    (`mode`): fmt "h2" -> [B, H'+2, W'+2, 2C] fp16 (hi|lo octets), "h1" -> [B, H'+2, W'+2, C] plain fp16."""
     _chk(x, "to_h2.x", 4)
     b, h, w, c = x.shape
+    f = _fmt_of(fmt)
+    assert f, fmt
     ho, wo = (h * 2, w * 2) if mode == RESAMPLE_UP else ((h // 2, w // 2) if mode == RESAMPLE_DOWN else (h, w))
-    y = torch.empty((b, ho + 2, wo + 2, 2 * c), device=x.device, dtype=torch.float16)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 1, _ptr(y), None, _stream())
+    y = torch.empty((b, ho + 2, wo + 2, (2 * c) if f == FMT_H2 else c), device=x.device, dtype=torch.float16)
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, f, _ptr(y), None, _stream())
     return y
 
 

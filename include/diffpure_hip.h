@@ -77,13 +77,27 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
  *   k' = (c32*KS*KS + (ky*KS+kx))*32 + ci%32, c32 = ci/32 (channel slices outermost, taps innermost:
  *   the 9 taps re-read the same halo strip from L1/L2), produced by dp_pack_h2 from the fp32 panel
  *   [N][K'] (diffpure_amd/ops.py:pack_conv_weight_h2).
- *   H, W are the OUTPUT (= interior) sizes; bias/temb/res/out are fp32 as above. */
+ *   H, W are the OUTPUT (= interior) sizes; bias/temb/res/out are fp32 as above.
+ * a_fmt / passes select the activation operand and the arithmetic per product (all accumulate in fp32):
+ *   a_fmt 0 = x in h2 form (above), passes 3  = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi   ("f16x3": 22-bit operands)
+ *                                   passes 12 = a_lo*w_hi + a_hi*w_hi               ("f16x2w": weights rounded to fp16;
+ *                                                                                     precision study only)
+ *   a_fmt 1 = x in "h1" form: PLAIN fp16 [B][H+2][W+2][C] with the same zero border (dp_gn_apply(out_fmt=2)), i.e. the
+ *             activations are rounded to fp16 once; weights stay h2:
+ *                                   passes 2  = a_hi*w_lo + a_hi*w_hi               ("f16x2": weights kept to 22 bits)
+ *                                   passes 1  = a_hi*w_hi                           ("f16": the arithmetic of the reference's
+ *             own use_fp16 torso, /root/reference/configs/imagenet.yml:18, guided_diffusion/unet.py:626-632, with fp32
+ *             accumulation and fp32 GroupNorm)
+ *   Measured on the full loops (tests/probes/precision_loops.py, 100 EM steps, max-abs on purified pixels vs the exact
+ *   fp32 engine): f16x3 3.9e-6, f16x2 1.3e-4, f16x2w 1.0e-3, f16 1.0e-3 (guided 256^2); 2.3e-6 / 9.4e-5 / 8.6e-4 / 8.6e-4
+ *   (NCSN++): rounding the WEIGHTS is what costs accuracy (a fixed perturbation of the model, coherent over the steps),
+ *   rounding the activations averages out. */
 int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
                       const float* res, int ldr, float scale,
                       float* out, int ldo, float* colstats, int* tile_rows,
-                      void* work, long long work_bytes, void* stream);
+                      void* work, long long work_bytes, int passes, int a_fmt, void* stream);
 /* Scratch the call above needs for this layer shape (0 for most): low-resolution levels (H*W <= 64) are reduced with
  * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
  * layer shape only, never on B, so that results do not depend on how a batch is sharded. */
@@ -120,7 +134,7 @@ int dp_softmax_rows(float* x, long long rows, int cols, void* stream);
  *   resampling ResBlock, unet.py:249 / layerspp.py:249,256).
  *   act: 0 none, 1 SiLU.  resample: 0 none, 1 nearest x2 (out 2H x 2W), 2 mean 2x2 (out H/2 x W/2).
  *   out_fmt: 0 = fp32 NHWC [B][Ho][Wo][C]; 1 = "h2" split-fp16 with a one-pixel zero border,
- *   [B][Ho+2][Wo+2][C] (see dp_conv2d_nhwc_h2).
+ *   [B][Ho+2][Wo+2][C] (see dp_conv2d_nhwc_h2); 2 = "h1" plain fp16 with the same border (a_fmt 1 there).
  *   y_raw (optional, out_fmt=1 and resample=0 only): second output = the UN-normalised input
  *   cat(x1, x2) in the same bordered h2 form, the operand of a 1x1 skip convolution
  *   (unet.py:229-234 / layerspp.py:235) - written in the same pass that reads it.

@@ -1,0 +1,195 @@
+"""Loop-level golden vectors FROM THE REFERENCE'S OWN MODULES, at the step counts north_star names.
+
+Run in the build container only (needs /root/reference; ~25 min on 8 cores):
+    python tests/golden/make_golden_loops.py [guided_loop] [ncsnpp_loop] [ode_adjoint] [guided_full] [guided_vjp]
+
+What is driven and by what
+  * the score network is the reference's own nn.Module (guided_diffusion.unet.UNetModel built from
+    configs/imagenet.yml with use_fp16=False, score_sde NCSNpp built from configs/cifar10.yml);
+  * drift / diffusion are the reference's own `RevVPSDE.f` / `.g` (runners/diffpure_sde.py:131-147) and
+    `VPODE.forward` (runners/diffpure_ode.py:124-131), called with the flat [B, D] state exactly as
+    torchsde / torchdiffeq call them;
+  * the stepping is the fixed-step Euler(-Maruyama) update on the float32 clock (torchsde / torchdiffeq are
+    not installable here: oracle/solvers.py header), the adjoint's vector-Jacobian products are torch.autograd
+    through the reference module;
+  * the noise is the engine's Philox stream restated in numpy (tests/refops.py::philox_normal), keyed by
+    (seed, global sample index, step) over the NHWC state - so the GPU test runs the PRODUCT path (in-kernel
+    noise, no injection) against these files.
+
+Files
+  guided_loop100.pt        256x256 guided UNet, B=2, t*=0.1, dt=1e-3, 100 EM steps: x0, purified x (full tensors),
+                           plus the state after 10 and 25 steps
+  ncsnpp_loop100.pt        CIFAR NCSN++, B=4, t*=0.1, dt=1e-3, 100 EM steps
+  ncsnpp_ode_adjoint100.pt CIFAR NCSN++, B=2: 100 Euler steps of the probability-flow ODE + 100 steps of the
+                           continuous adjoint for a seeded cotangent (BASELINE.json configs[4] at reduced batch)
+  guided_full.pt           (rewritten) one forward of the full guided UNet, B=1: the WHOLE [1,6,256,256] output
+  guided_full_vjp.pt       dL/dx of that forward for a seeded cotangent on the eps channels (torch.autograd)
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+import make_golden as mg  # noqa: E402
+import refops  # noqa: E402
+from oracle import solvers as osol  # noqa: E402
+
+SEED = 1234
+
+
+def philox_nchw(shape_nchw, seed, sample0, step):
+    b, c, h, w = shape_nchw
+    return refops.philox_normal((b, h, w, c), seed, sample0, step).permute(0, 3, 1, 2).contiguous()
+
+
+def build_guided():
+    from guided_diffusion.script_util import create_model, model_and_diffusion_defaults
+    mc = model_and_diffusion_defaults()
+    mc.update(yaml.safe_load(open(os.path.join(mg.REF, "configs/imagenet.yml")))["model"])
+    mc["use_fp16"] = False
+    keys = ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma", "class_cond",
+            "attention_resolutions", "num_heads", "num_head_channels", "num_heads_upsample", "use_scale_shift_norm",
+            "resblock_updown", "use_fp16", "use_new_attention_order")
+    kw = {k: mc[k] for k in keys}
+    return mg.load_synth(create_model(**kw), SEED), kw
+
+
+def build_ncsnpp():
+    from score_sde.models import utils as mutils
+    cfg = yaml.safe_load(open(os.path.join(mg.REF, "configs/cifar10.yml")))
+    return mg.load_synth(mutils.create_model(mg.d2n(cfg)), SEED), cfg
+
+
+def em_loop(rv, x0, t_int, dt, seed, snaps=()):
+    """diffuse (runners/diffpure_sde.py:222-223) + fixed-step Euler-Maruyama on the reference's f / g."""
+    b = x0.shape[0]
+    e = philox_nchw(x0.shape, seed, 0, -1)
+    x = osol.diffuse(x0, e, t_int)
+    grid = osol.sde_time_grid(t_int, dt)
+    keep = {}
+    t0 = time.time()
+    for k in range(len(grid) - 1):
+        tk, tn = grid[k], grid[k + 1]
+        h = tn - tk
+        xf = x.reshape(b, -1)
+        f = rv.f(tk, xf).reshape(x.shape)
+        g = rv.g(tk, xf).reshape(x.shape)
+        z = philox_nchw(x0.shape, seed, 0, k)
+        x = x + f * h + g * (z * torch.sqrt(h))
+        if k + 1 in snaps:
+            keep[k + 1] = x.clone()
+        if k % 10 == 0:
+            print(f"  step {k}: {time.time() - t0:.0f} s", flush=True)
+    return x, keep, len(grid) - 1
+
+
+def guided_loop():
+    RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
+    mod, kw = build_guided()
+    rv = RevVPSDE(model=mod, score_type="guided_diffusion", img_shape=(3, 256, 256), model_kwargs=None)
+    x0 = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(99)) * 2 - 1
+    with torch.no_grad():
+        x, keep, n = em_loop(rv, x0, 100, 1e-3, SEED, snaps=(1, 10, 25))
+    torch.save(dict(cfg=kw, seed=SEED, noise_seed=SEED, t=100, dt=1e-3, steps=n, x0=x0, out=x, snaps=keep),
+               os.path.join(HERE, "guided_loop100.pt"))
+    print("guided_loop100", n, float(x.abs().mean()))
+
+
+def ncsnpp_loop():
+    RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
+    mod, cfg = build_ncsnpp()
+    rv = RevVPSDE(model=mod, score_type="score_sde", img_shape=(3, 32, 32), model_kwargs=None)
+    x0 = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(98)) * 2 - 1
+    with torch.no_grad():
+        x, keep, n = em_loop(rv, x0, 100, 1e-3, SEED, snaps=(25,))
+    torch.save(dict(cfg=cfg, seed=SEED, noise_seed=SEED, t=100, dt=1e-3, steps=n, x0=x0, out=x, snaps=keep),
+               os.path.join(HERE, "ncsnpp_loop100.pt"))
+    print("ncsnpp_loop100", n, float(x.abs().mean()))
+
+
+def ode_adjoint():
+    VPODE = mg.ref_module("ref_diffpure_ode", "runners/diffpure_ode.py").VPODE
+    mod, cfg = build_ncsnpp()
+    vo = VPODE(model=mod, score_type="score_sde", img_shape=(3, 32, 32), model_kwargs=None)
+    b, t_int, step = 2, 100, 1e-3
+    x0 = torch.rand(b, 3, 32, 32, generator=torch.Generator().manual_seed(97)) * 2 - 1
+    cot = torch.randn(b, 3, 32, 32, generator=torch.Generator().manual_seed(96))
+    e = philox_nchw(x0.shape, SEED, 0, -1)
+    # forward: torchdiffeq fixed-grid Euler on tau = -s (decreasing span), runners/diffpure_ode.py:229-238
+    ts = torch.linspace(t_int * 1.0 / 1000, 1e-5, 2)
+    tau = osol.ode_grid(-ts, step)
+    x = osol.diffuse(x0, e, t_int)
+    with torch.no_grad():
+        for k in range(len(tau) - 1):
+            dtau = tau[k + 1] - tau[k]
+            F = vo(-tau[k], (x.reshape(b, -1),))[0].reshape(x.shape)
+            x = x + dtau * (-F)
+    x_final = x.clone()
+    # adjoint: augmented Euler over the flipped span, da/ds = -a^T dF/dy
+    grid = osol.ode_grid(ts.flip(0), step)
+    y, a = x_final.clone(), cot.clone()
+    for k in range(len(grid) - 1):
+        ds = grid[k + 1] - grid[k]
+        with torch.enable_grad():
+            yy = y.detach().requires_grad_(True)
+            F = vo(grid[k], (yy.reshape(b, -1),))[0].reshape(y.shape)
+            (vjp,) = torch.autograd.grad(F, yy, -a)
+        y = y + ds * F.detach()
+        a = a + ds * vjp
+    grad = osol.ode_diffuse_grad(a, t_int)
+    torch.save(dict(cfg=cfg, seed=SEED, noise_seed=SEED, t=t_int, step=step, x0=x0, cot=cot, x_final=x_final, grad=grad,
+                    steps=len(tau) - 1), os.path.join(HERE, "ncsnpp_ode_adjoint100.pt"))
+    print("ncsnpp_ode_adjoint100", len(tau) - 1, float(x_final.abs().mean()), float(grad.abs().mean()))
+
+
+def guided_full(with_vjp):
+    mod, kw = build_guided()
+    xb = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(4321)) * 2 - 1
+    tb = torch.tensor([100])
+    if with_vjp:
+        cot = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(4322))
+        xr = xb.clone().requires_grad_(True)
+        with torch.enable_grad():
+            ob = mod(xr, tb)
+            (dx,) = torch.autograd.grad(ob[:, :3], xr, cot)
+        ob = ob.detach()
+        torch.save(dict(cfg=kw, seed=SEED, x_seed=4321, cot_seed=4322, t=tb, dx=dx), os.path.join(HERE, "guided_full_vjp.pt"))
+        print("guided_full_vjp", float(dx.abs().mean()), float(dx.abs().max()))
+    else:
+        with torch.no_grad():
+            ob = mod(xb, tb)
+    torch.save(dict(cfg=kw, seed=SEED, x_seed=4321, t=tb, out=ob.clone(), out_crop=ob[:, :, ::16, ::16].clone(),
+                    out_absmean=ob.abs().mean().item(), out_std=ob.std().item()), os.path.join(HERE, "guided_full.pt"))
+    print("guided_full", float(ob.abs().mean()))
+
+
+def main():
+    mg.import_reference()
+    torch.manual_seed(0)
+    what = sys.argv[1:] or ["ncsnpp_loop", "ode_adjoint", "guided_vjp", "guided_loop"]
+    for w in what:
+        t0 = time.time()
+        if w == "guided_loop":
+            guided_loop()
+        elif w == "ncsnpp_loop":
+            ncsnpp_loop()
+        elif w == "ode_adjoint":
+            ode_adjoint()
+        elif w == "guided_full":
+            guided_full(False)
+        elif w == "guided_vjp":
+            guided_full(True)
+        else:
+            raise SystemExit(f"unknown target {w}")
+        print(f"{w}: {time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

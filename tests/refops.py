@@ -49,12 +49,25 @@ def pack_conv_weight_h2(w, device=None):
     return h2_encode(w.float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).reshape(o, kh * kw * i))
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False):
-    """Statement of the f16x3 contract: exact products of the (hi+lo) operands (the dropped
-    lo*lo term is ~2^-22 relative, below the test tolerance). x carries a one-pixel zero border."""
-    xin = h2_decode(x)[:, 1:-1, 1:-1, :]
-    cin = xin.shape[3]
-    wf = h2_decode(wh).reshape(n_out, cin // 32, ksize, ksize, 32)       # [N, c32, ky, kx, 32]
+def _h2_hi(t):
+    """h2 [..., 2C] -> the hi halves only ([..., C], double)."""
+    shp = t.shape
+    return t.reshape(-1, shp[-1] // 16, 2, 8).double()[:, :, 0].reshape(*shp[:-1], shp[-1] // 2)
+
+
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None):
+    """Statement of the fp16-matrix-core contract (include/diffpure_hip.h, dp_conv2d_nhwc_h2): exact products of the
+    operands each mode keeps - f16x3 (h2 activations, passes 3): (hi+lo) x (hi+lo) (the dropped lo*lo term is ~2^-22
+    relative, below the test tolerance); passes 12: (hi+lo) x w_hi; h1 activations (plain fp16): passes 2: a x (w_hi+w_lo),
+    passes 1: a x w_hi.  x carries a one-pixel zero border."""
+    cin = wh.shape[1] // (2 * ksize * ksize)
+    h1 = x.shape[3] == cin
+    if passes is None:
+        passes = 2 if h1 else 3
+    assert (h1 and passes in (1, 2)) or (not h1 and passes in (3, 12)), (x.shape, wh.shape, passes)
+    xin = (x.double() if h1 else h2_decode(x))[:, 1:-1, 1:-1, :]
+    wdec = _h2_hi(wh) if passes in (1, 12) else h2_decode(wh)
+    wf = wdec.reshape(n_out, cin // 32, ksize, ksize, 32)       # [N, c32, ky, kx, 32]
     wt = wf.permute(0, 1, 4, 2, 3).reshape(n_out, cin, ksize, ksize).contiguous()
     y = F.conv2d(xin.permute(0, 3, 1, 2), wt, None, padding=ksize // 2).permute(0, 2, 3, 1)
     if bias is not None:
@@ -117,9 +130,17 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     if act:
         y = F.silu(y)
     y = _resample(y, resample).contiguous()
+    enc = _operand_encoder(split)
     if raw:
-        return h2_encode(F.pad(y, (0, 0, 1, 1, 1, 1))), h2_encode(F.pad(xin, (0, 0, 1, 1, 1, 1)))
-    return h2_encode(F.pad(y, (0, 0, 1, 1, 1, 1))) if split else y
+        return enc(F.pad(y, (0, 0, 1, 1, 1, 1))), enc(F.pad(xin, (0, 0, 1, 1, 1, 1)))
+    return enc(F.pad(y, (0, 0, 1, 1, 1, 1))) if enc else y
+
+
+def _operand_encoder(split):
+    """split argument of ops.group_norm / fmt of ops.to_h2 -> encoder of the bordered operand (None = fp32 output)."""
+    from diffpure_amd import ops
+    fmt = ops._fmt_of(split)
+    return {ops.FMT_F32: None, ops.FMT_H2: h2_encode, ops.FMT_H1: lambda t: t.half()}[fmt]
 
 
 def resample(x, mode):
@@ -192,8 +213,8 @@ def add(a, b):
     return a + b
 
 
-def to_h2(x, mode=RESAMPLE_NONE):
-    return h2_encode(F.pad(_resample(x, mode), (0, 0, 1, 1, 1, 1)))
+def to_h2(x, mode=RESAMPLE_NONE, fmt="h2"):
+    return _operand_encoder(fmt)(F.pad(_resample(x, mode), (0, 0, 1, 1, 1, 1)))
 
 
 def silu(x):

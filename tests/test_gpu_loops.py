@@ -1,0 +1,140 @@
+"""-m gpu: the HIP engine over the FULL loops north_star names, against golden vectors produced by the
+REFERENCE'S OWN MODULES (tests/golden/make_golden_loops.py: UNetModel / NCSNpp + RevVPSDE.f/.g / VPODE.forward
+driven over 100 fixed steps on the float32 clock, torch.autograd for the adjoint's vector-Jacobian products).
+
+The golden loops drew their noise from the numpy restatement of the engine's Philox stream, keyed like the
+kernels key it, so these tests run the PRODUCT path - in-kernel noise, nothing injected - and compare whole tensors.
+
+Tolerances (north_star: purified pixels within 1e-3 max-abs of the reference at fixed seed):
+  purified pixels, 100 steps        max-abs < 1e-3 for every shipped precision mode
+                                    (measured: f32 1e-6, f16x3 4e-6, f16x2 (default) 1.3e-4; tests/probes/precision_loops.py)
+  adjoint dL/dx, 100 + 100 steps    max-abs < 5e-3 of the largest entry
+  single forward, whole tensor      max-abs < 1e-3 (f32, f16x3: measured 9e-6) / < 5e-3 (f16x2: measured 1.7e-3 on outputs of
+                                    std 0.56 - the fp16 rounding of the activations is a zero-mean perturbation of eps that
+                                    enters the state scaled by beta*h/sigma ~ 3e-3 per step and averages out over the loop,
+                                    which is why the purified pixels hold 1.3e-4); input gradient of one forward < 2e-3 of
+                                    the largest entry
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from diffpure_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+_ENGINES = {}
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def guided_full(precision):
+    """one resident engine per precision for the whole module (552.8 M parameters: building it costs ~20 s)"""
+    from diffpure_amd import guided_unet as pg
+    key = ("guided", precision)
+    if key not in _ENGINES:
+        g = load_golden("guided_full.pt")
+        cfg = pg.parse_config(g["cfg"])
+        sd = _ENGINES.setdefault("guided_sd", synth_state_dict(pg.param_shapes(cfg), g["seed"]))
+        _ENGINES[key] = pg.GuidedUNet(cfg, DEV, precision).load_state_dict(sd)
+    return _ENGINES[key]
+
+
+def ncsnpp_full(precision):
+    from diffpure_amd import ncsnpp as pn
+    key = ("ncsnpp", precision)
+    if key not in _ENGINES:
+        g = load_golden("ncsnpp_full.pt")
+        cfg = pn.parse_config(g["cfg"])
+        sd = _ENGINES.setdefault("ncsnpp_sd", synth_state_dict(pn.param_shapes(cfg), g["seed"]))
+        _ENGINES[key] = pn.NCSNpp(cfg, DEV, precision).load_state_dict(sd)
+    return _ENGINES[key]
+
+
+def maxabs(a, b):
+    return (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2"])
+def test_guided_full_forward_whole_tensor_vs_reference_golden(precision):
+    """ONE forward of the full 256x256 guided UNet, B=1: every one of the 393 216 outputs (round 1 compared a ::16 crop)."""
+    g = load_golden("guided_full.pt")
+    net = guided_full(precision)
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(g["x_seed"])) * 2 - 1
+    out = nchw(net.forward(nhwc(x).to(DEV), g["t"].float().to(DEV))).cpu()
+    assert out.shape == g["out"].shape == (1, 6, 256, 256)
+    err = maxabs(out, g["out"])
+    print(f"guided full forward [{precision}]: max-abs {err:.3e} (output std {g['out_std']:.3f})")
+    assert err < (5e-3 if precision == "f16x2" else 1e-3), err
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+def test_guided_loop_100_steps_vs_reference_golden(precision):
+    """BASELINE.json headline loop at B=2: 256x256 guided UNet, t*=0.1, dt=1e-3, 100 Euler-Maruyama steps, product path
+    (in-kernel Philox) against the reference modules' loop - including the float32-clock hazards of the 100-step grid
+    (last short step, (s*1000).long() truncation: SURVEY.md appendix C #1-2)."""
+    from diffpure_amd.sde import Purifier, sde_schedule
+    g = load_golden("guided_loop100.pt")
+    assert g["steps"] == 100 == len(sde_schedule("guided", g["t"], g["dt"]))
+    pur = Purifier(guided_full(precision), "guided", DEV)
+    out = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    err = maxabs(out, g["out"])
+    print(f"guided 100-step loop [{precision}]: purified max-abs vs reference modules {err:.3e}, mean-abs {(out - g['out']).abs().mean():.3e}")
+    assert err < 1e-3, err
+    # shards reproduce the batch bit for bit on this path as well (sample 1 alone, keyed by its global index)
+    one = pur.sde(g["x0"][1:], g["t"], g["dt"], seed=g["noise_seed"], sample0=1).cpu()
+    assert torch.equal(one, out[1:])
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2"])
+def test_ncsnpp_loop_100_steps_vs_reference_golden(precision):
+    """CIFAR-10 NCSN++ (full size), B=4, t*=0.1, dt=1e-3, 100 EM steps (BASELINE.json configs[1] at a small batch)."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("ncsnpp_loop100.pt")
+    pur = Purifier(ncsnpp_full(precision), "ncsnpp", DEV)
+    out = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    err = maxabs(out, g["out"])
+    print(f"NCSN++ 100-step loop [{precision}]: purified max-abs vs reference modules {err:.3e}")
+    assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+def test_config5_adjoint_ode_100_plus_100_steps_vs_reference_golden(precision):
+    """BASELINE.json configs[4] at B=2 and FULL length: 100 Euler steps of the probability-flow ODE, then 100 steps of the
+    continuous adjoint (dL/dx) - against the reference's VPODE.forward + torch.autograd through the reference NCSNpp."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("ncsnpp_ode_adjoint100.pt")
+    assert g["steps"] == 100
+    pur = Purifier(ncsnpp_full(precision), "ncsnpp", DEV)
+    xf = pur.ode(g["x0"], g["t"], g["step"], seed=g["noise_seed"], sample0=0)
+    err_x = maxabs(xf.cpu(), g["x_final"])
+    grad = (pur.ode_vjp(xf, g["cot"], g["t"], g["step"]) * pur.diffuse_scale(g["t"])).cpu()
+    err_g = maxabs(grad, g["grad"])
+    scale = g["grad"].abs().max().item()
+    print(f"adjoint-ODE 100+100 [{precision}]: x(1e-5) max-abs {err_x:.3e}; dL/dx max-abs {err_g:.3e} (largest entry {scale:.3f})")
+    assert err_x < 1e-3, err_x
+    assert err_g < 5e-3 * scale, (err_g, scale)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+def test_guided_full_vjp_vs_reference_autograd(precision):
+    """Input gradient of one forward of the FULL guided UNet (B=1) against torch.autograd through the reference module."""
+    g = load_golden("guided_full_vjp.pt")
+    net = guided_full(precision)
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(g["x_seed"])) * 2 - 1
+    cot = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(g["cot_seed"]))
+    tape = []
+    net.forward(nhwc(x).to(DEV), g["t"].float().to(DEV), tape=tape)
+    dx = nchw(net.vjp(tape, nhwc(cot).to(DEV))).cpu()
+    del tape
+    torch.cuda.empty_cache()
+    scale = g["dx"].abs().max().item()
+    err = maxabs(dx, g["dx"])
+    print(f"guided full VJP [{precision}]: max-abs {err:.3e} (largest entry {scale:.3f})")
+    assert err < 2e-3 * scale, (err, scale)

@@ -331,6 +331,72 @@ def test_conv2d_h2_pingpong_variant_is_bit_identical(dev, case, monkeypatch):
     close(got, ref, rtol=2e-5, atol=2e-5)
 
 
+def _h1_bordered(x, dev):
+    """fp32 [B,H,W,C] -> zero-bordered plain-fp16 operand [B,H+2,W+2,C] ("h1")."""
+    return torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1)).half().contiguous().to(dev)
+
+
+H1_CASES = H2_CASES + PP_CASES + [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (8, 64, 64, 128, 256, 3, 0, False, 1.0),
+                                  (8, 64, 64, 64, 128, 3, 1, True, 1.0)]       # the last two fill the chip: ping-pong by default
+
+
+@pytest.mark.parametrize("passes", [2, 1])
+@pytest.mark.parametrize("case", H1_CASES, ids=[str(c) for c in H1_CASES])
+def test_conv2d_h1_fp16_activations(dev, case, passes, monkeypatch):
+    """Plain-fp16 activation operand ("h1") x split-fp16 weights: passes=2 ("f16x2") must equal the exact convolution of
+    the fp16-ROUNDED activations with the full weights to fp32-class accuracy, passes=1 ("f16") the one with the
+    fp16-rounded weights as well; every tile variant gives the same bits (column-sum records included)."""
+    from diffpure_amd import ops
+    B, H, W, C, N, k, temb_rows, has_res, scale = case
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(N, C, k, k, seed=3, scale=1.0 / math.sqrt(C * k * k))
+    bias = rnd(N, seed=4).to(dev)
+    table = rnd(B if temb_rows == 2 else 1, N + 8, seed=5).to(dev) if temb_rows else None
+    res = rnd(B, H, W, N, seed=6).to(dev) if has_res else None
+    wr = w.half().double() if passes == 1 else w.double()
+    ref = torch.nn.functional.conv2d(x.half().double().permute(0, 3, 1, 2), wr, bias.cpu().double(), padding=k // 2).permute(0, 2, 3, 1)
+    if table is not None:
+        ref = ref + table.cpu()[:, 4:4 + N].double().reshape(-1, 1, 1, N)
+    if res is not None:
+        ref = ref + res.cpu().double()
+    ref = (ref * scale).float()
+    xh, wh = _h1_bordered(x, dev), ops.pack_conv_weight_h2(w, dev)
+
+    def run():
+        y = ops.conv2d_h2(xh, wh, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale,
+                          colstats=True, passes=passes)
+        return y, y._dp_cols.buf.clone()
+
+    monkeypatch.setenv("DP_H2_PP", "0")
+    base, base_cs = run()
+    close(base, ref, rtol=2e-5, atol=2e-5)
+    if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
+        monkeypatch.setenv("DP_H2_PP", "1")
+        for _ in range(4):
+            got, got_cs = run()
+            assert torch.equal(got, base)
+            assert torch.equal(got_cs, base_cs)
+    monkeypatch.delenv("DP_H2_PP")
+    got, got_cs = run()                      # the dispatcher's own choice
+    assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
+
+
+def test_group_norm_h1_output_is_the_fp16_rounding_of_the_fp32_output(dev):
+    from diffpure_amd import ops
+    x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)
+    x2 = rnd(2, 8, 8, 128, seed=2).to(dev)
+    gamma, beta = (1 + 0.1 * rnd(384, seed=3)).to(dev), (0.1 * rnd(384, seed=4)).to(dev)
+    for rs in (0, 1, 2):
+        y32 = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, resample=rs)
+        yh = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, resample=rs, split="h1")
+        assert yh.dtype == torch.float16 and yh.shape == (2, y32.shape[1] + 2, y32.shape[2] + 2, 384)
+        assert torch.equal(yh.cpu(), torch.nn.functional.pad(y32.cpu(), (0, 0, 1, 1, 1, 1)).half())
+        assert torch.equal(ops.to_h2(x, rs, fmt="h1").cpu(), torch.nn.functional.pad(ops.resample(x, rs).cpu() if rs else x.cpu(), (0, 0, 1, 1, 1, 1)).half())
+    y, yr = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, split="h1", raw=True)
+    assert torch.equal(y, ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, split="h1"))
+    assert torch.equal(yr.cpu(), torch.nn.functional.pad(torch.cat([x, x2], dim=3).cpu(), (0, 0, 1, 1, 1, 1)).half())
+
+
 def test_group_norm_split_output_is_bordered_h2_of_fp32_output(dev):
     from diffpure_amd import ops
     x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)

@@ -142,23 +142,28 @@ def test_philox_reference_stream_is_shard_invariant():
     assert not torch.equal(full, other)
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16"])
 @pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
-def test_f16x3_mode_engine_wiring(kind):
-    """precision="f16x3": GroupNorm emits the split-fp16 operand format and the 3x3 / qkv convolutions
-    consume it with pre-split weights; on CPU the ops are the torch statements of the same contract."""
+def test_f16x3_mode_engine_wiring(kind, precision):
+    """precision="f16x3" / "f16x2" / "f16": GroupNorm emits the convolution operand format of the mode (split-fp16 "h2" or
+    plain fp16 "h1") and the 3x3 / qkv convolutions consume it with pre-split weights; on CPU the ops are the torch
+    statements of the same contract."""
+    tol = dict(f16x3=(2e-4, 3e-5), f16x2=(2e-3, 2e-3), f16=(1e-2, 1e-2))[precision]
     if kind == "ncsnpp":
         g = load_golden("ncsnpp_small.pt")
         cfg = pn.parse_config(g["cfg"])
-        net = pn.NCSNpp(cfg, "cpu", precision="f16x3").load_state_dict(synth_state_dict(pn.param_shapes(cfg), g["seed"]))
+        net = pn.NCSNpp(cfg, "cpu", precision=precision).load_state_dict(synth_state_dict(pn.param_shapes(cfg), g["seed"]))
         out = nchw(net.forward(nhwc(g["x"]), g["labels"]))
         assert all(r["h2_0"] and r["h2_1"] for b in net.plan["down"] for r in b if r["kind"] == "res")
     else:
         g = load_golden("guided_small.pt")
         cfg = pg.parse_config(g["cfg"])
-        net = pg.GuidedUNet(cfg, "cpu", precision="f16x3").load_state_dict(synth_state_dict(pg.param_shapes(cfg), g["seed"]))
+        net = pg.GuidedUNet(cfg, "cpu", precision=precision).load_state_dict(synth_state_dict(pg.param_shapes(cfg), g["seed"]))
         out = nchw(net.forward(nhwc(g["x"]), g["t"].float()))
         assert net._out_h2 and net.p["out.w"].dtype == torch.float16
-    torch.testing.assert_close(out, g["out"], rtol=2e-4, atol=3e-5)
+    torch.testing.assert_close(out, g["out"], rtol=tol[0], atol=tol[1])
+    if precision != "f16x3":
+        assert (out - g["out"]).abs().max() > 1e-6       # the mode really rounds its operands
 
 
 def test_h2_format_roundtrip():
