@@ -46,6 +46,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int NT = 512;
 constexpr int NXCD = 8;
 constexpr int ROWB = 128;               // bytes per LDS row: 32 channels as (hi, lo) fp16 octets
+constexpr int DP_H2_PP_SCHED_DEFAULT = 1;   // measured (tests/probes/pp_ablate.py, B=16): 621-661 vs 495-635 TFLOP/s, bit-identical
 
 // LDS-DMA with (scalar base + 32-bit lane offset) addressing, spelled in asm: the builtin lets the
 // compiler strength-reduce the k-loop addresses back into 64-bit VGPR pointers (two VALU adds and two
@@ -74,8 +75,17 @@ __device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const 
 // (row >> 2) & 3), an A unit is half as many DMA instructions (one instruction stages 128 rows), only a_hi fragments
 // exist and PASSES is 2 (a_hi*w_lo + a_hi*w_hi) or 1.  B (weights, hi|lo) and the whole phase schedule are unchanged;
 // LDS drops to 96 KB.
-template <int BM, int BN, int MODE, int PASSES, bool A16>
+// SCHED 1 (A16 only): TWO phases per k-tile instead of four - half the barriers and role swaps, 16 (PASSES 2) MFMAs
+// per phase.  Phase 0 reads {A0, A1, B0} (256x256: quadrants Q00, Q10) or {A0, B0, B1} (512x128: Q00, Q01), phase 1
+// the remaining unit and computes the other two quadrants from fragments that are still in registers.  Every
+// phase stages, into the OTHER buffer, exactly the units the same phase of the next k-tile reads:
+//   staged in phase j  ->  retired by every wave's counted vmcnt in phase j+1 (before its first barrier; only that
+//   phase's own loads may still be in flight)  ->  read in phase j+2.
+//   RAW: the earliest reader (group 0, phase j+2, interval 2j+4) has passed the barrier closing interval 2j+3, in
+//        which group 1 did its phase-(j+1) wait.   WAR: a unit is re-staged two phases after its last read.
+template <int BM, int BN, int MODE, int PASSES, bool A16, int SCHED>
 __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
+    static_assert(SCHED == 0 || A16, "the two-phase schedule keeps both A halves in registers: fp16 operand only");
     static_assert((BM == 256 && BN == 256) || (BM == 512 && BN == 128), "8 waves of 128 x 64");
     static_assert(A16 ? (PASSES == 2 || PASSES == 1) : (PASSES == 3 || PASSES == 12), "operand format / passes");
     constexpr int ESZ = A16 ? 2 : 4;                       // bytes per activation element
@@ -233,6 +243,111 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         if constexpr (!(MODE & 4)) PP_BARRIER();                                   \
     } while (0)
 
+    if constexpr (SCHED == 1) {
+        constexpr bool RF = BM == 256;                 // rows first: phase 0 = {A0, A1, B0}; else {A0, B0, B1}
+        constexpr int N0 = RF ? 2 * NPA + NPB : NPA + 2 * NPB, N1 = RF ? NPB : NPA;    // DMA loads per thread per phase
+        half8 fa2[2][2][2];                            // [half][m-tile i][k16 step s]
+        auto read_a2 = [&](const char* buf, int sub) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    fa2[sub][i][s] = *reinterpret_cast<const half8*>(buf + arow + (sub * 64 + i * 32) * AROWB + soffa[s]);
+        };
+        auto read_b0 = [&](const char* buf) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                fb0h[s] = *reinterpret_cast<const half8*>(buf + brow + soff[s][0]);
+                fb0l[s] = *reinterpret_cast<const half8*>(buf + brow + soff[s][1]);
+            }
+        };
+        auto read_b1 = [&](const char* buf) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                fb1h[s] = *reinterpret_cast<const half8*>(buf + brow + 32 * ROWB + soff[s][0]);
+                fb1l[s] = *reinterpret_cast<const half8*>(buf + brow + 32 * ROWB + soff[s][1]);
+            }
+        };
+#define PP_MFMA2(ASUB, BSUB, BH, BL)                                                                                   \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                \
+            if constexpr (PASSES == 2) {                                                                               \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                                \
+                    __builtin_amdgcn_mfma_f32_32x32x16_f16(fa2[ASUB][i][s], BL[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);  \
+            }                                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[ASUB * 2 + i][BSUB] =                                    \
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(fa2[ASUB][i][s], BH[s], acc[ASUB * 2 + i][BSUB], 0, 0, 0);      \
+        }                                                                                                              \
+    } while (0)
+#define PP_SYNC2(COUNTED, CNT)                                                      \
+    do {                                                                            \
+        if (COUNTED) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");     \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+        PP_BARRIER();                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    } while (0)
+#define PP_END2()                                   \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        PP_BARRIER();                               \
+    } while (0)
+        // prologue: all of k-tile 0, drained
+        stage_a(smem, 0, tap_off(0, 0));
+        stage_b(smem, 0, 0);
+        stage_b(smem, 1, 0);
+        stage_a(smem, 1, tap_off(0, 0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        if (grp == 1) PP_BARRIER();         // group 1 runs one interval behind group 0
+        int c1 = 0, tap1 = 1;               // (slice, tap) of k-tile t+1
+        if (tap1 == taps) { tap1 = 0; c1 = 1; }
+        for (int t = 0; t < nt; ++t) {
+            const char* cur = smem + (t & 1) * BUF;
+            char* nxt = smem + ((t + 1) & 1) * BUF;
+            const bool traffic = !(MODE & (2 | 8)) || t == 0;
+            const bool more1 = (!(MODE & (2 | 16)) || t == 0) && t + 1 < nt;
+            const long long offa = tap_off(c1, tap1);
+            const long long offb1 = (long long)(t + 1) * 128;
+            // phase 0
+            if (traffic) {
+                read_a2(cur, 0);
+                read_b0(cur);
+                if constexpr (RF) read_a2(cur, 1);
+                else read_b1(cur);
+            }
+            if (more1) {
+                stage_a(nxt, 0, offa);
+                stage_b(nxt, 0, offb1);
+                if constexpr (RF) stage_a(nxt, 1, offa);
+                else stage_b(nxt, 1, offb1);
+            }
+            PP_SYNC2(more1, N0);
+            PP_MFMA2(0, 0, fb0h, fb0l);
+            if constexpr (RF) PP_MFMA2(1, 0, fb0h, fb0l);
+            else PP_MFMA2(0, 1, fb1h, fb1l);
+            PP_END2();
+            // phase 1
+            if (traffic) {
+                if constexpr (RF) read_b1(cur);
+                else read_a2(cur, 1);
+            }
+            if (more1) {
+                if constexpr (RF) stage_b(nxt, 1, offb1);
+                else stage_a(nxt, 1, offa);
+            }
+            PP_SYNC2(more1, N1);
+            PP_MFMA2(1, 1, fb1h, fb1l);
+            if constexpr (RF) PP_MFMA2(0, 1, fb1h, fb1l);
+            else PP_MFMA2(1, 0, fb0h, fb0l);
+            PP_END2();
+            if (++tap1 == taps) { tap1 = 0; ++c1; }
+        }
+        if (grp == 0) PP_BARRIER();
+#undef PP_MFMA2
+#undef PP_SYNC2
+#undef PP_END2
+    } else {
     // ---- prologue: all of k-tile 0 and B0 of k-tile 1, drained
     stage_a(smem, 0, tap_off(0, 0));
     stage_b(smem, 0, 0);
@@ -285,6 +400,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         if (++tap1 == taps) { tap1 = 0; ++c1; }
     }
     if (grp == 0) PP_BARRIER();         // re-align the two groups (barrier counts must match)
+    }
 #undef PP_SYNC_THEN_MFMA
 #undef PP_MFMA
 
@@ -375,14 +491,19 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
     p.tiles = (p.M / bm) * p.tiles_n;
     const char* e = getenv("DP_H2_PP_MODE");
     const int mode = e ? atoi(e) : 0;
-#define PP_LAUNCH1(BM_, BN_, M_, P_, A_) \
-    hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_, P_, A_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
+#define PP_LAUNCH1(BM_, BN_, M_, P_, A_, S_) \
+    hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_, P_, A_, S_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
+    // DP_H2_PP_SCHED: schedule of the fp16-operand kernels (0 = four phases per k-tile, 1 = two); A/B switch
+    const char* es = getenv("DP_H2_PP_SCHED");
+    const int sched = es ? atoi(es) : DP_H2_PP_SCHED_DEFAULT;
 #define PP_LAUNCH(BM_, BN_, M_)                                          \
     do {                                                                 \
-        if (p.afmt == 1 && p.passes == 2) PP_LAUNCH1(BM_, BN_, 0, 2, true);   \
-        else if (p.afmt == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true);          \
-        else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false); \
-        else PP_LAUNCH1(BM_, BN_, M_, 3, false);                         \
+        if (p.afmt == 1 && p.passes == 2 && sched == 1) PP_LAUNCH1(BM_, BN_, M_, 2, true, 1);   \
+        else if (p.afmt == 1 && p.passes == 2) PP_LAUNCH1(BM_, BN_, M_, 2, true, 0);   \
+        else if (p.afmt == 1 && sched == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 1); \
+        else if (p.afmt == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 0);       \
+        else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false, 0); \
+        else PP_LAUNCH1(BM_, BN_, M_, 3, false, 0);                      \
     } while (0)
     if (bn == 128) {
         PP_LAUNCH(512, 128, 0);
