@@ -31,6 +31,17 @@ import torch.distributed as dist  # noqa: E402
 # three fp16 MFMA passes per algorithmic MAC, so its matrix ceiling in ALGORITHMIC flops is 2500/3).
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0, "f16": 2500.0}
 MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2, "f16": 1}
+DTYPE_NOTES = {
+    "f32": "fp32-input MFMA, exact fp32 products and accumulation",
+    "f16x3": "split-fp16 operands (22 significant bits each), 3 fp16 MFMA passes per product, fp32 accumulation; purified "
+             "pixels 4e-6 from the reference modules over the 100-step 256^2 loop (tests/test_gpu_loops.py)",
+    "f16x2": "fp16 activations x split-fp16 weights (22 bits), 2 fp16 MFMA passes per product, fp32 accumulation, fp32 "
+             "GroupNorm / residuals / SDE state; purified pixels 1.3e-4 max-abs from the reference modules over the 100-step "
+             "256^2 loop (north_star bar 1e-3; tests/test_gpu_loops.py) - wider than the reference's own use_fp16 torso "
+             "(configs/imagenet.yml:18)",
+    "f16": "fp16 activations x fp16 weights, 1 MFMA pass, fp32 accumulation = the arithmetic of the reference's use_fp16 "
+           "torso; purified pixels 1.0e-3 from fp32 (at the north_star bar, not under it: not the default)",
+}
 WORKLOADS = {
     # name: (kind, config file section, image size, algorithmic GFLOP / image / UNet call, 3x3 share)
     "imagenet256_guided": dict(kind="guided", hw=256, gflop=2239.67, gflop3x3=2115.44),
@@ -51,6 +62,74 @@ CIFAR_CFG = dict(
                fir=False, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type="biggan", progressive="none",
                progressive_input="none", progressive_combine="sum", attention_type="ddpm", init_scale=0.0,
                embedding_type="positional", fourier_scale=16, conv_size=3))   # configs/cifar10.yml
+
+
+class SclkSampler:
+    """Samples the GPU's current shader clock (MHz) from sysfs (pp_dpm_sclk: the level marked '*') every 0.5 s while the
+    timed region runs: the roofline fraction is quoted against a peak that assumes 2.4 GHz, the chip clocks to its
+    power budget (~1.8-2.0 GHz under MFMA load), so the clock belongs next to the number."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.samples, self._stop, self._th, self.path = [], threading.Event(), None, None
+        try:
+            bus = torch.cuda.get_device_properties(dev).pci_bus_id
+        except Exception:
+            bus = None
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        for c in cands:
+            link = os.path.realpath(os.path.dirname(c))
+            if bus is not None and f":{bus:02x}:" in link:
+                self.path = c
+        if self.path is None and len(cands) == 1:
+            self.path = cands[0]
+        if self.path:
+            self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(0.5)
+
+    def start(self):
+        if self._th:
+            self._th.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._th:
+            self._th.join()
+        if not self.samples:
+            return None
+        s_ = sorted(self.samples)
+        return dict(median=s_[len(s_) // 2], min=s_[0], max=s_[-1], samples=len(s_), source=self.path)
+
+
+def pmc_traffic(workload, batch, precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc table (separate FETCH_SIZE and
+    WRITE_SIZE passes over this very workload; profiles/README.md): PMC counters cannot be read from inside the
+    process being timed, so the table is collected offline and looked up here.  None if no pass matches."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    for row in table.get("rows", []):
+        if row["workload"] == workload and row["per_gpu_batch"] == batch and row["precision"] == precision:
+            return row
+    return None
 
 
 def build_engine(workload, device, seed, precision):
@@ -179,14 +258,27 @@ def main():
     for i in range(a.warmup):
         one_call(i)
     fence()
-    ops.prof_enable(not a.no_conv_profile)
+    # Instrumentation: per-launch hipEvents on the convolution launches of the FIRST timed step only (sampling: a 100-step
+    # purification is 8 600 3x3 launches, the record buffer holds 65 536, and event pairs around every launch of every
+    # step would sit inside the timed region for nothing); its GPU window is bracketed by two events on the same stream.
+    sample = not a.no_conv_profile
+    win0, win1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    clock = SclkSampler(dev)
+    clock.start()
     t0 = time.time()
     for i in range(a.steps):
+        if i == 0 and sample:
+            win0.record()
+            ops.prof_enable(True)
         y = one_call(a.warmup + i)
+        if i == 0 and sample:
+            ops.prof_enable(False)
+            win1.record()
     fence()
     el = time.time() - t0
-    prof = ops.prof_collect()
-    ops.prof_enable(False)
+    sclk = clock.stop()
+    prof = ops.prof_collect() if sample else None
+    window_ms = win0.elapsed_time(win1) if sample else None
     assert torch.isfinite(y).all()
 
     if world > 1:
@@ -198,9 +290,44 @@ def main():
 
     out = None
     if rank == 0:
-        ach = prof["flop3x3"] / (prof["ms3x3"] * 1e-3) / 1e12 if prof["ms3x3"] > 0 else None
         peak = PEAK_TFLOPS[a.precision]
+        passes = MFMA_PASSES[a.precision]
         unet_tflops = value / world * wl["gflop"] * n_steps / 1e3
+        roof = {"bound": "mfma",
+                "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
+                          f"conv_igemm_h2_pp (3x3 implicit GEMM on the 8-wave ping-pong kernel, {passes} x v_mfma_f32_32x32x16_f16 "
+                          f"per product; executed MFMA flops = {passes} x achieved)",
+                "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "peak_note": "dense fp16 MFMA peak at the 2.4 GHz nominal clock (MI355X_MICROARCH.md); see sclk_mhz for the clock this run held",
+                "mfma_passes": passes, "sclk_mhz": sclk, "end_to_end_unet_tflops_per_gpu": unet_tflops}
+        if prof is not None:
+            dom = prof["pp3x3"] if prof["pp3x3"]["n"] else prof["other3x3"]      # f32 / tiny shapes never reach the ping-pong kernel
+            if dom["ms"] > 0:
+                ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+                launches_per_call = dom["n"]
+                roof.update({
+                    "achieved": ach, "frac": ach / peak, "executed_frac": ach * passes / peak,
+                    "avg_launch_ms": dom["ms"] / dom["n"],
+                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
+                    "algorithmic_gflop_per_launch": dom["flop"] / dom["n"] / 1e9,
+                    # sampling: hipEvent pairs on the launches of the first timed step only
+                    "sampled_launches": dom["n"], "sampled_of_total": 1.0 / a.steps,
+                    "launches_in_timed_region": launches_per_call * a.steps, "dropped_records": prof["dropped"],
+                    "time_share_of_step": dom["ms"] / window_ms,
+                    "sampled_step_ms": window_ms,
+                    "other_kernels_share_of_step": {"3x3 on other tile variants (stem, head, split-K levels)": prof["other3x3"]["ms"] / window_ms,
+                                                    "1x1 convolutions / linear": (prof["conv1x1"]["ms"] + prof["pp1x1"]["ms"]) / window_ms},
+                })
+                row = pmc_traffic(a.workload, B, a.precision)
+                if row is not None:
+                    # rocprofv3 aggregates per kernel NAME: the ping-pong kernel's 3x3 and 1x1 launches together
+                    allpp_n = prof["pp3x3"]["n"] + prof["pp1x1"]["n"]
+                    roof["algorithmic_bytes_per_launch_all_pingpong_launches"] = (prof["pp3x3"]["bytes"] + prof["pp1x1"]["bytes"]) / max(1, allpp_n)
+                    roof["traffic"] = row["hbm_bytes_per_launch"]
+                    roof["traffic_detail"] = {k: row[k] for k in row if k not in ("workload", "per_gpu_batch", "precision")}
+                else:
+                    roof["traffic_note"] = ("no rocprofv3 --pmc pass committed for this (workload, batch, precision): "
+                                            "profiles/pmc_traffic.json")
         out = {
             "metric": "purified images/sec (whole node), 256x256 GuidedDiff VP-SDE t*=0.1 100-step"
             if a.workload == "imagenet256_guided" and a.t == 100 and n_steps == 100
@@ -217,6 +344,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": a.precision,
+            "dtype_note": DTYPE_NOTES[a.precision],
             "data": "synthetic (seeded uniform images in [-1,1]; seeded non-trivial random weights of the named "
                     "architecture; Philox noise)",
             "config": {"workload": (f"{a.workload}: probability-flow ODE purification ({n_steps} Euler steps) + continuous-adjoint "
@@ -226,24 +354,7 @@ def main():
                                     f"{n_steps} Euler-Maruyama steps, one UNet call per step"),
                        "per_gpu_batch": B, "global_batch": world * B, "image": f"3x{hw}x{hw}",
                        "parallelism": f"batch-sharded x{world}, one all_gather of outputs"},
-            "roofline": {"bound": "mfma",
-                         "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
-                                   "conv_igemm_h2 (3x3 implicit GEMM, 3 x v_mfma_f32_32x32x16_f16 per product; "
-                                   "executed MFMA flops = 3 x achieved)",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": None if ach is None else ach / peak,
-                         # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes), which cannot be
-                         # collected from inside this process: measured offline for the dominant kernel, see the note
-                         "traffic": None,
-                         "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on conv_igemm_h2_pp, 256^2 x 256->256, B=16: "
-                                         "1.44 GB fetched (gfx950-corrected) + 1.07 GB written per launch vs 2.16 GB algorithmic "
-                                         "= 0.84 TB/s of 8 TB/s (profiles/README.md, section 1)",
-                         "launches": prof["n3x3"],
-                         # f16x3 spends 3 fp16 MFMA passes per algorithmic MAC: the matrix pipe executes 3x `achieved`
-                         "mfma_passes": MFMA_PASSES[a.precision],
-                         "executed_frac": None if ach is None else ach * MFMA_PASSES[a.precision] / peak,
-                         "avg_launch_ms": prof["ms3x3"] / max(1, prof["n3x3"]),
-                         "time_share_of_step": prof["ms3x3"] * 1e-3 / el,
-                         "end_to_end_unet_tflops_per_gpu": unet_tflops},
+            "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, sd, a.t, n_steps)

@@ -21,7 +21,7 @@ SIGNATURES = {
     "dp_abi_version": [],
     "dp_last_error": [],
     "dp_prof_enable": [_i],
-    "dp_prof_collect": [_p, _p, _p, _p, _p, _p],
+    "dp_prof_collect": [_p, _p, _p, _p, _p],
     "dp_conv2d_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _p, _p, _p],
     "dp_gn_finalize_cols": [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p],
     "dp_gemm_strided": [_p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _p],

@@ -11,8 +11,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void dp_set_error(const char* fmt, ...);
 // per-launch hipEvent profiling (igemm.hip); rec is opaque
-void dp_prof_begin(int kind, double flop, hipStream_t s, void** rec);
+void dp_prof_begin(int kind, double flop, double bytes, hipStream_t s, void** rec);
 void dp_prof_end(void* rec, hipStream_t s);
+void dp_prof_set_kind(void* rec, int kind);
 
 #define DP_REQUIRE(cond, ...)        \
     do {                             \

@@ -476,27 +476,35 @@ __global__ __launch_bounds__(NT) void gemm_strided_f32(GemmArgs p) {
 constexpr int PROF_MAX = 1 << 16;
 struct ProfRec {
     hipEvent_t e0, e1;
-    double flop;
-    int kind;  // 0: 3x3, 1: 1x1/linear
+    double flop, bytes;
+    int kind;  // DP_PROF_* (include/diffpure_hip.h)
 };
 bool g_prof_on = false;
 int g_prof_n = 0;
+long long g_prof_dropped = 0;
 ProfRec* g_prof = nullptr;
 
 }  // namespace
 
-void dp_prof_begin(int kind, double flop, hipStream_t s, void** rec_out) {
+void dp_prof_begin(int kind, double flop, double bytes, hipStream_t s, void** rec_out) {
     *rec_out = nullptr;
-    if (g_prof_on && g_prof_n < PROF_MAX) {
-        ProfRec* rec = &g_prof[g_prof_n++];
-        rec->flop = flop;
-        rec->kind = kind;
-        (void)hipEventRecord(rec->e0, s);
-        *rec_out = rec;
+    if (!g_prof_on) return;
+    if (g_prof_n >= PROF_MAX) {      // never silently: dp_prof_collect reports the count
+        ++g_prof_dropped;
+        return;
     }
+    ProfRec* rec = &g_prof[g_prof_n++];
+    rec->flop = flop;
+    rec->bytes = bytes;
+    rec->kind = kind;
+    (void)hipEventRecord(rec->e0, s);
+    *rec_out = rec;
 }
 void dp_prof_end(void* rec, hipStream_t s) {
     if (rec) (void)hipEventRecord(static_cast<ProfRec*>(rec)->e1, s);
+}
+void dp_prof_set_kind(void* rec, int kind) {
+    if (rec) static_cast<ProfRec*>(rec)->kind = kind;
 }
 
 extern "C" int dp_prof_enable(int on) {
@@ -509,31 +517,41 @@ extern "C" int dp_prof_enable(int on) {
             }
         }
     }
+    if (on) {                 // a new recording window; dp_prof_enable(0) only stops recording (records are kept for collect)
+        g_prof_n = 0;
+        g_prof_dropped = 0;
+    }
     g_prof_on = on != 0;
-    g_prof_n = 0;
     return 0;
 }
 
-extern "C" int dp_prof_collect(double* ms3, long long* n3, double* f3, double* ms1, long long* n1, double* f1) {
-    *ms3 = *ms1 = *f3 = *f1 = 0.0;
-    *n3 = *n1 = 0;
+extern "C" int dp_prof_collect(double* ms, long long* n, double* flop, double* bytes, long long* dropped) {
+    for (int k = 0; k < DP_PROF_KINDS; ++k) {
+        ms[k] = 0.0;
+        flop[k] = 0.0;
+        bytes[k] = 0.0;
+        n[k] = 0;
+    }
     for (int i = 0; i < g_prof_n; ++i) {
         if (hipEventSynchronize(g_prof[i].e1) != hipSuccess) {
             dp_set_error("hipEventSynchronize failed");
             return 1;
         }
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1) != hipSuccess) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1) != hipSuccess) {
             dp_set_error("hipEventElapsedTime failed");
             return 1;
         }
-        if (g_prof[i].kind == 0) {
-            *ms3 += ms; *n3 += 1; *f3 += g_prof[i].flop;
-        } else {
-            *ms1 += ms; *n1 += 1; *f1 += g_prof[i].flop;
-        }
+        const int k = g_prof[i].kind;
+        if (k < 0 || k >= DP_PROF_KINDS) continue;
+        ms[k] += t;
+        n[k] += 1;
+        flop[k] += g_prof[i].flop;
+        bytes[k] += g_prof[i].bytes;
     }
+    if (dropped) *dropped = g_prof_dropped;
     g_prof_n = 0;
+    g_prof_dropped = 0;
     return 0;
 }
 
@@ -561,7 +579,9 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     void* rec = nullptr;
-    dp_prof_begin(KH == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
+    // algorithmic HBM bytes: every operand once (activations, weights, residual) + the output once
+    dp_prof_begin(KH == 3 ? DP_PROF_3X3_OTHER : DP_PROF_1X1, 2.0 * p.M * (double)p.N * p.K,
+                  4.0 * ((double)p.M * (C1 + C2) + (double)p.K * N + (double)p.M * N * (res ? 2 : 1)), s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     int bm = 128;
     if (!vec) {

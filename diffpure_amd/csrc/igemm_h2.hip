@@ -454,7 +454,10 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc_h2: colstats needs tile_rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     void* rec = nullptr;
-    dp_prof_begin(KS == 3 ? 0 : 1, 2.0 * p.M * (double)p.N * p.K, s, &rec);
+    // algorithmic HBM bytes: the activation operand once (4 or 2 bytes per element), the h2 weights once, the residual and
+    // the fp32 output once
+    dp_prof_begin(KS == 3 ? DP_PROF_3X3_OTHER : DP_PROF_1X1, 2.0 * p.M * (double)p.N * p.K,
+                  (double)p.M * C * (a_fmt ? 2 : 4) + 4.0 * ((double)p.K * N + (double)p.M * N * (res ? 2 : 1)), s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
 #define DP_H2_LAUNCH(BM_, BN_, BK_, ABL_)                                                                  \
     do {                                                                                                   \
@@ -484,6 +487,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         else if (pp != 0 && p.M % 512 == 0 && N % 128 == 0 && (pp == 1 || fills(512, 128))) bn = 128;
         if (bn) {
             dp_launch_conv_h2_pp(p, s, bn);
+            dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("conv_igemm_h2_pp");

@@ -7,6 +7,11 @@ keyed by the GLOBAL sample index), so the only exchange step of the whole path i
 Weights stay resident on every GPU; nothing is broadcast per call - unlike the reference's
 `nn.DataParallel` (/root/reference/eval_sde_adv.py:227-228), which re-broadcasts 552.8 M parameters
 on every forward.
+
+Gradients: an adaptive attack differentiates through the purifier.  In the replicated-driver model this module
+serves (every rank holds the same adversarial batch `x` and computes the same loss on the reassembled output),
+the backward pass mirrors the forward: each rank back-propagates ITS slice of dL/dy through its shard (the
+adjoint solve on its own GPU) and one more all-gather reassembles the full dL/dx on every rank.
 """
 import torch
 import torch.distributed as dist
@@ -26,26 +31,61 @@ def shard_bounds(n, rank, world_size):
     return lo, min(n, lo + per), per
 
 
+def _gather_rows(local, per, n, ws, group):
+    """[k <= per, ...] local rows of every rank -> [n, ...] on every rank (tail ranks pad; all padding sits at the end
+    because slices are contiguous)."""
+    send = local.new_zeros((per,) + tuple(local.shape[1:]))
+    send[: local.shape[0]] = local
+    recv = local.new_empty((ws * per,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    return recv if ws * per == n else recv[:n].contiguous()
+
+
+class _TakeShard(torch.autograd.Function):
+    """x (full batch, replicated) -> x[lo:hi]; backward: all-gather of the per-rank input gradients."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi, per, ws, group):
+        ctx.cfg = (x.shape[0], per, ws, group)
+        return x[lo:hi].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        n, per, ws, group = ctx.cfg
+        return _gather_rows(g.contiguous(), per, n, ws, group), None, None, None, None, None
+
+
+class _GatherShards(torch.autograd.Function):
+    """y_local -> y (full batch on every rank); backward: this rank's rows of dL/dy (the loss is replicated: every
+    rank holds the same dL/dy, so no reduction is due)."""
+
+    @staticmethod
+    def forward(ctx, y_local, lo, hi, per, n, ws, group):
+        ctx.cfg = (lo, hi)
+        return _gather_rows(y_local, per, n, ws, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        lo, hi = ctx.cfg
+        return g[lo:hi].contiguous(), None, None, None, None, None, None
+
+
 def sharded_purify(fn, x, group=None):
     """Run `fn(x_local, sample0) -> y_local` on this rank's slice of the batch and reassemble the
     full result on every rank.  `x` is the FULL batch (identical on every rank, as it is when an
-    attack drives all ranks with the same adversarial batch)."""
+    attack drives all ranks with the same adversarial batch); `fn` keeps the shape of its input (a purifier does).
+    Differentiable w.r.t. `x` when `fn` is (see the module docstring)."""
     rank, ws = world()
     if ws == 1:
         return fn(x, 0)
     n = x.shape[0]
     lo, hi, per = shard_bounds(n, rank, ws)
-    if hi > lo:
-        y = fn(x[lo:hi], lo)
-        out_shape, dtype, device = tuple(y.shape[1:]), y.dtype, y.device
-    else:  # more ranks than images: contribute padding only
-        probe = fn(x[:1], 0)
-        y = probe[:0]
-        out_shape, dtype, device = tuple(probe.shape[1:]), probe.dtype, probe.device
-    send = torch.zeros((per,) + out_shape, dtype=dtype, device=device)
-    send[: hi - lo] = y
-    recv = torch.empty((ws * per,) + out_shape, dtype=dtype, device=device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    if ws * per == n:
-        return recv
-    return recv[:n].contiguous()  # all padding sits at the tail because slices are contiguous
+    need_grad = x.requires_grad and torch.is_grad_enabled()
+    xl = _TakeShard.apply(x, lo, hi, per, ws, group) if need_grad else x[lo:hi]
+    # a rank without images (more ranks than images) contributes padding only: the purified batch has the shape and
+    # dtype of the input batch, so nothing has to be run to learn them (and the empty slice keeps the graph connected,
+    # so that this rank still takes part in the backward all-gather)
+    y = fn(xl, lo) if hi > lo else xl * 1.0
+    if need_grad:
+        return _GatherShards.apply(y, lo, hi, per, n, ws, group)
+    return _gather_rows(y, per, n, ws, group)

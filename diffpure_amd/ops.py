@@ -569,6 +569,7 @@ _PROF_ON = False
 
 
 def prof_enable(on=True):
+    """on=True opens a new recording window (old records are discarded); on=False closes it, keeping the records."""
     global _PROF_ON
     _PROF_ON = bool(on)
     _lib.call("dp_prof_enable", 1 if on else 0)
@@ -578,10 +579,17 @@ def prof_enabled():
     return _PROF_ON
 
 
+PROF_KINDS = ("pp3x3", "conv1x1", "other3x3", "pp1x1")       # DP_PROF_* of include/diffpure_hip.h
+
+
 def prof_collect():
+    """-> {kind: dict(ms, n, flop, bytes)} for the launches of the last recording window, plus 'dropped' (launches beyond the
+    record buffer: a non-zero value means the window was too long and the totals are a prefix of it)."""
     import ctypes as C
-    ms3, ms1, f3, f1 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
-    n3, n1 = C.c_longlong(), C.c_longlong()
-    _lib.call("dp_prof_collect", C.addressof(ms3), C.addressof(n3), C.addressof(f3), C.addressof(ms1), C.addressof(n1),
-              C.addressof(f1))
-    return dict(ms3x3=ms3.value, n3x3=n3.value, flop3x3=f3.value, ms1x1=ms1.value, n1x1=n1.value, flop1x1=f1.value)
+    k = len(PROF_KINDS)
+    ms, n, fl, by = (C.c_double * k)(), (C.c_longlong * k)(), (C.c_double * k)(), (C.c_double * k)()
+    dropped = C.c_longlong()
+    _lib.call("dp_prof_collect", C.addressof(ms), C.addressof(n), C.addressof(fl), C.addressof(by), C.addressof(dropped))
+    out = {name: dict(ms=ms[i], n=n[i], flop=fl[i], bytes=by[i]) for i, name in enumerate(PROF_KINDS)}
+    out["dropped"] = dropped.value
+    return out

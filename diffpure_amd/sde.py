@@ -188,6 +188,21 @@ def _state_out(x, nhwc):
     return x if nhwc else to_nchw(x)
 
 
+def _on_own_device(method):
+    """Run an engine entry point with ITS device current: kernels launch on torch's current stream of the current
+    device and the library's per-device scratch is keyed by hipGetDevice(), so a Purifier built for cuda:1 must not
+    run with cuda:0 current (what a caller that never calls torch.cuda.set_device would otherwise get)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *a, **kw):
+        if self.device.type != "cuda":
+            return method(self, *a, **kw)
+        with torch.cuda.device(self.device):
+            return method(self, *a, **kw)
+    return wrapped
+
+
 class Purifier:
     """Runs the purification loops for one score network on one GPU.
 
@@ -266,11 +281,15 @@ class Purifier:
         return ent["x"], eps_of
 
     # -- reverse VP-SDE (RevGuidedDiffusion.image_editing_sample) ---------------------------------
-    def sde(self, x_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0, nhwc=False):
+    @_on_own_device
+    def sde(self, x_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0, nhwc=False, t_diffuse=None):
+        """t_int fixes the solver span t' in [1 - t_int/1000, 1 - 1e-5] and the score schedule; t_diffuse (default
+        t_int) the forward-diffusion level - the reference's `rand_t` randomises ONLY the latter
+        (runners/diffpure_sde.py:218-223 vs :226-229)."""
         x0 = _state_in(x_nchw, self.device, nhwc)
         sched = sde_schedule(self.kind, t_int, dt)
         table = self._tables(("sde", t_int, dt), sched)
-        x, eps_of = self._step_fn(self._diffuse(x0, t_int, noise, seed, sample0), table)
+        x, eps_of = self._step_fn(self._diffuse(x0, t_int if t_diffuse is None else t_diffuse, noise, seed, sample0), table)
         for k, st in enumerate(sched):
             eps = eps_of(k)
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
@@ -278,6 +297,7 @@ class Purifier:
                             seed=seed, sample0=sample0, step=k, out=x)
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
 
+    @_on_own_device
     def sde_vjp(self, x_final_nchw, grad_out_nchw, t_int, dt=1e-3, noise=None, seed=0, sample0=0, nhwc=False):
         """Stochastic adjoint of `sde` (upstream: torchsde.sdeint_adjoint behind
         runners/diffpure_sde.py:236-238).  g(t) is state-independent, so the adjoint has no noise term:
@@ -312,6 +332,7 @@ class Purifier:
         return _state_out(a, nhwc)
 
     # -- probability-flow ODE forward (OdeGuidedDiffusion.image_editing_sample) -------------------
+    @_on_own_device
     def ode(self, x_nchw, t_int, step=1e-3, noise=None, seed=0, sample0=0, e_nhwc=None, nhwc=False):
         x0 = _state_in(x_nchw, self.device, nhwc)
         sched = ode_schedule(self.kind, t_int, step)
@@ -327,6 +348,7 @@ class Purifier:
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
 
     # -- adjoint of the probability-flow ODE: dL/dx for adaptive attacks ---------------------------
+    @_on_own_device
     def ode_vjp(self, x_final_nchw, grad_out_nchw, t_int, step=1e-3, nhwc=False):
         """Continuous adjoint as torchdiffeq's odeint_adjoint integrates it (diffpure_ode.py:229-238):
         the augmented state (y, a) starts at (x(1e-5), dL/dx(1e-5)) and is Euler-stepped on the grid
@@ -355,6 +377,7 @@ class Purifier:
         return diffusion_coeffs(t_int, self._abar)[0]
 
     # -- DDPM ancestral sampling (GuidedDiffusion.image_editing_sample) ---------------------------
+    @_on_own_device
     def ddpm(self, x_nchw, t_int, noise=None, seed=0, sample0=0, diffusion_steps=1000, nhwc=False):
         assert self.kind == "guided"
         x0 = _state_in(x_nchw, self.device, nhwc)
@@ -376,6 +399,7 @@ class Purifier:
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
 
     # -- CelebA-HQ DDPM denoising loop (runners/diffpure_ddpm.py:116-131) ----------------------------
+    @_on_own_device
     def celeba_ddpm(self, x_nchw, t_int, sched, noise=None, seed=0, sample0=0, nhwc=False):
         """x = x0 sqrt(abar[t-1]) + e sqrt(1 - abar[t-1]); then for i = t-1 .. 0:
         x <- (x - ws_i eps(x, i)) / sqrt(alpha_i) + [i > 0] exp(logvar_i / 2) z.  The update is the fused SDE-step
@@ -394,17 +418,22 @@ class Purifier:
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
 
     # -- Langevin-dynamics SDE (LDGuidedDiffusion.image_editing_sample, diffpure_ldsde.py:198-252) -------------
-    def ldsde(self, x_nchw, t_int, sigma2, lambda_ld, eta, dt=1e-2, noise=None, seed=0, sample0=0, nhwc=False):
+    @_on_own_device
+    def ldsde(self, x_nchw, t_int, sigma2, lambda_ld, eta, dt=1e-2, noise=None, seed=0, sample0=0, nhwc=False, x_init=None):
         """x <- x + f h + g sqrt(h) z on the reverse-SDE clock with dt = 1e-2, f = -0.5 lambda (-score(x, s=1e-2) +
         (x - x_init) / sigma2), g = sqrt(lambda) eta; the score network is always asked at noise level 1e-2 (:93), the
         loop starts from the input itself (no forward diffusion).  The anchor term needs x_init, so a step is the fused
         SDE-step kernel (which covers -0.5 lambda / sigma2 * x and the score) plus one axpby for +0.5 lambda / sigma2 * h * x_init."""
-        x_init = _state_in(x_nchw, self.device, nhwc)
+        # x_init: the anchor of the Langevin drift.  Upstream builds LDSDE ONCE per call with x_init = the original input
+        # (diffpure_ldsde.py:212-214), so with sample_step > 1 every repeat stays anchored at the original image while
+        # only the loop state is chained: the runner passes it separately.  Default: the loop's own initial state.
+        x_start = _state_in(x_nchw, self.device, nhwc)
+        x_init = x_start if x_init is None else _state_in(x_init, self.device, nhwc)
         s = torch.zeros((), dtype=torch.float32) + 1e-2
         coef, div, mt = _score_scalars(self.kind, s)
         grid = sde_clock(t_int, dt)
         table = self._tables(("ldsde",), [dict(model_time=mt)])
-        x, eps_of = self._step_fn(x_init.clone(), table)
+        x, eps_of = self._step_fn(x_start.clone(), table)
         kk = 0.5 * lambda_ld / sigma2
         g = math.sqrt(lambda_ld) * eta
         for k in range(len(grid) - 1):
@@ -415,6 +444,7 @@ class Purifier:
             x.copy_(ops.axpby(x, 1.0, x_init, kk * h.item()))
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
 
+    @_on_own_device
     def ldsde_vjp(self, x_final_nchw, grad_out_nchw, x_init_nchw, t_int, sigma2, lambda_ld, eta, dt=1e-2, noise=None, seed=0,
                   sample0=0, nhwc=False):
         """Stochastic adjoint of `ldsde` w.r.t. its INITIAL STATE (what torchsde.sdeint_adjoint returns upstream, where the

@@ -30,13 +30,18 @@ extern "C" {
 int dp_abi_version(void);
 const char* dp_last_error(void);
 
-/* Per-launch timing of the convolution kernels with hipEvents recorded on the launch stream
- * (bench.py's roofline leg).  dp_prof_enable(1) starts recording; dp_prof_collect() synchronises
- * the recorded events and returns totals since enable: milliseconds, launches and algorithmic
- * FLOPs (2*M*N*K) separately for 3x3 and for 1x1/linear launches. */
+/* Per-launch timing of the convolution kernels with hipEvents recorded on the launch stream (bench.py's roofline leg).
+ * dp_prof_enable(1) opens a recording window (previous records are discarded), dp_prof_enable(0) closes it (records are
+ * kept); dp_prof_collect() synchronises the recorded events and returns, per launch kind, total milliseconds, launches
+ * algorithmic FLOPs (2*M*N*K) and algorithmic HBM bytes (every operand and the output once), plus the number of launches that were NOT recorded because the window exceeded the
+ * record buffer (65 536 launches) - callers must report a non-zero `dropped`. */
+enum { DP_PROF_3X3_PP = 0,      /* 3x3 convolutions on the 8-wave ping-pong kernel (the dominant kernel) */
+       DP_PROF_1X1 = 1,         /* 1x1 convolutions / linear layers, any kernel */
+       DP_PROF_3X3_OTHER = 2,   /* 3x3 convolutions on the other tile variants (stem, head, split-K levels, small shapes) */
+       DP_PROF_1X1_PP = 3,      /* 1x1 convolutions that ran on the ping-pong kernel (a rocprofv3 per-kernel total covers kinds 0 + 3) */
+       DP_PROF_KINDS = 4 };
 int dp_prof_enable(int on);
-int dp_prof_collect(double* ms3x3, long long* n3x3, double* flop3x3,
-                    double* ms1x1, long long* n1x1, double* flop1x1);
+int dp_prof_collect(double* ms, long long* n, double* flop, double* bytes, long long* dropped);
 
 /* ---- convolution / linear: implicit GEMM on MFMA -------------------------------------------
  * Replaces nn.Conv2d / nn.Conv1d(k=1) / nn.Linear / NIN at

@@ -1,9 +1,13 @@
-"""Shared pieces of the drop-in runners (logging side effects of the reference's
-image_editing_sample, kept behind the same `bs_id < 2` guard)."""
+"""Shared pieces of the drop-in runners: the logging side effects of the reference's image_editing_sample (kept
+behind the same `bs_id < 2` guard), the engine pool that lets the unchanged driver's nn.DataParallel work, and the
+dispatch of one purification over the ranks / the local GPU."""
 import os
 import random
+import threading
 
 import torch
+
+from diffpure_amd import dist as ddist
 
 
 def out_dir_for(args, bs_id, tag):
@@ -29,3 +33,81 @@ def as_nchw(x, nhwc):
 
 def as_nchw_shape(shape, nhwc):
     return (shape[0], shape[3], shape[1], shape[2]) if nhwc else tuple(shape)
+
+
+def _dev_key(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        return ("cuda", torch.cuda.current_device())
+    return (device.type, device.index)
+
+
+class EnginePool:
+    """One resident purification engine per GPU of this process.
+
+    The reference driver wraps the whole defence in `nn.DataParallel` when several GPUs are visible
+    (/root/reference/eval_sde_adv.py:227-228): `replicate()` shallow-copies the runner module for every device and
+    calls `forward` from one thread per replica with that device's slice of the batch.  The engines here are not
+    nn.Parameters (their weights are packed, kernel-specific panels), so replication cannot move them; instead every
+    replica shares THIS pool (a plain attribute survives the shallow copy) and asks it for the engine of the device its
+    input slice lives on.  The first call on a new device builds that device's engine (weights packed and uploaded
+    once, then resident - no per-call broadcast as DataParallel does for module parameters)."""
+
+    def __init__(self, build, home):
+        self._build, self._lock, self._by_dev = build, threading.Lock(), {}
+        self.home = torch.device(home)
+        self.get(self.home)
+
+    def get(self, device):
+        key = _dev_key(device)
+        with self._lock:
+            if key not in self._by_dev:
+                self._by_dev[key] = self._build(torch.device(key[0], key[1]) if key[1] is not None else torch.device(key[0]))
+            return self._by_dev[key]
+
+    def for_input(self, img):
+        """the engine of the GPU `img` lives on (DataParallel replica), else the home engine"""
+        if isinstance(img, torch.Tensor) and img.is_cuda and _dev_key(img.device) != _dev_key(self.home):
+            return self.get(img.device)
+        return self.get(self.home)
+
+    def devices(self):
+        with self._lock:
+            return sorted(self._by_dev)
+
+
+def build_purifier(args, config, device):
+    """The model-construction half of the sde / ode / ldsde runners' constructors (reference diffpure_sde.py:151-195):
+    dataset -> score network, checked against args.score_type.  -> Purifier (with .net, .kind, .img_shape)."""
+    from diffpure_amd import factory
+    from diffpure_amd.sde import Purifier
+    want = factory.SCORE_TYPE_TO_KIND.get(args.score_type)
+    if want is None:
+        raise NotImplementedError(f"Unknown score type in RevVPSDE: {args.score_type}!")
+    net, kind, img_shape = factory.build_for_dataset(args, config, device)
+    if want != kind:
+        raise ValueError(f"score_type {args.score_type} does not match dataset {config.data.dataset}")
+    pur = Purifier(net, kind, device)
+    pur.img_shape = img_shape
+    return pur
+
+
+def sample_offset(args):
+    """First GLOBAL sample index of this process's batch when the call is NOT batch-sharded.  The Philox stream is keyed
+    by (args.seed + call counter, global sample index, step): ranks of a multi-process evaluation that each purify their
+    own images share the seed and the call count, so their sample indices must differ or they would draw identical noise
+    paths.  `args.sample_offset` overrides; default = rank * 2^40 (0 in a single process).  NOTE: the noise is a pure
+    function of args.seed - pass a different seed per program run if independent randomness across runs is wanted
+    (upstream draws from the global RNG; a missing or zero args.seed here means the SAME noise on every run)."""
+    off = getattr(args, "sample_offset", None)
+    if off is not None:
+        return int(off)
+    rank, ws = ddist.world()
+    return rank << 40 if ws > 1 else 0
+
+
+def dispatch(args, run, x):
+    """One purification of the batch `x`: sharded over the ranks (`args.shard_batch`) or on this process's GPU."""
+    if getattr(args, "shard_batch", False):
+        return ddist.sharded_purify(run, x)
+    return run(x, sample_offset(args))

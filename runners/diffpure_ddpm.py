@@ -9,7 +9,6 @@ import os
 
 import torch
 
-from diffpure_amd import dist as ddist
 from diffpure_amd import factory
 from diffpure_amd.sde import CelebaSchedule, Purifier
 
@@ -27,8 +26,17 @@ class Diffusion(torch.nn.Module):
         print("Loading model")
         if self.config.data.dataset != "CelebA_HQ":
             raise ValueError
-        net, cfg = factory.build_celeba(args, config, self.device)
-        self.model = net
+        cfgs = {}
+
+        def build(dev):
+            net, cfg = factory.build_celeba(args, config, dev)
+            cfgs["cfg"] = cfg
+            return Purifier(net, "ddpm_celeba", dev)
+
+        self._pool = _common.EnginePool(build, self.device)      # one resident engine per GPU (nn.DataParallel replicas)
+        self.purifier = self._pool.get(self.device)
+        self.model = self.purifier.net
+        cfg = cfgs["cfg"]
         self.img_shape = (cfg["in_channels"], cfg["resolution"], cfg["resolution"])
         self.model_var_type = config.model.var_type
         d = config.diffusion
@@ -36,7 +44,6 @@ class Diffusion(torch.nn.Module):
         self.betas = self.sched.betas
         self.logvar = self.sched.logvar.numpy()
         self.num_timesteps = self.betas.shape[0]
-        self.purifier = Purifier(net, "ddpm_celeba", self.device)
         self._calls = 0
 
     def image_editing_sample(self, img=None, bs_id=0, tag=None, noise=None, nhwc=False):
@@ -46,7 +53,8 @@ class Diffusion(torch.nn.Module):
             assert img.ndim == 4, img.ndim
             out_dir = _common.out_dir_for(self.args, bs_id, tag)
             log = bs_id < 2 and out_dir is not None
-            x0 = img.to(self.device)
+            pur = self._pool.for_input(img)
+            x0 = img.to(pur.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
                 _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
@@ -57,10 +65,10 @@ class Diffusion(torch.nn.Module):
                 self._calls += 1
 
                 def run(xl, sample0, call_seed=call_seed):
-                    return self.purifier.celeba_ddpm(xl, self.args.t, self.sched, noise=noise, seed=call_seed, sample0=sample0,
+                    return pur.celeba_ddpm(xl, self.args.t, self.sched, noise=noise, seed=call_seed, sample0=sample0,
                                                      nhwc=nhwc)
 
-                x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
+                x0 = _common.dispatch(self.args, run, x0)
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

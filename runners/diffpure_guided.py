@@ -4,7 +4,6 @@ import os
 
 import torch
 
-from diffpure_amd import dist as ddist
 from diffpure_amd import factory
 from diffpure_amd.sde import DdpmSchedule, Purifier
 
@@ -19,12 +18,20 @@ class GuidedDiffusion(torch.nn.Module):
         if device is None:
             device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
         self.device = torch.device(device)
-        net, mc = factory.build_guided(args, config, self.device, model_dir=model_dir)
-        self.model = net
+        mcs = {}
+
+        def build(dev):
+            net, mc = factory.build_guided(args, config, dev, model_dir=model_dir)
+            mcs["mc"] = mc
+            return Purifier(net, "guided", dev)
+
+        self._pool = _common.EnginePool(build, self.device)      # one resident engine per GPU (nn.DataParallel replicas)
+        self.purifier = self._pool.get(self.device)
+        self.model = self.purifier.net
+        mc = mcs["mc"]
         self.diffusion_steps = int(mc.get("diffusion_steps", 1000))
         if str(mc.get("timestep_respacing", "")) not in ("", str(self.diffusion_steps)):
             raise NotImplementedError("timestep_respacing other than the full schedule is not used by DiffPure")
-        self.purifier = Purifier(net, "guided", self.device)
         self.betas = torch.from_numpy(DdpmSchedule(self.diffusion_steps).betas).float().to(self.device)
         self._calls = 0
 
@@ -35,7 +42,8 @@ class GuidedDiffusion(torch.nn.Module):
             assert img.ndim == 4, img.ndim
             out_dir = _common.out_dir_for(self.args, bs_id, tag)
             log = bs_id < 2 and out_dir is not None
-            x0 = img.to(self.device)
+            pur = self._pool.for_input(img)
+            x0 = img.to(pur.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
                 _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
@@ -46,10 +54,10 @@ class GuidedDiffusion(torch.nn.Module):
                 self._calls += 1
 
                 def run(xl, sample0, call_seed=call_seed):
-                    return self.purifier.ddpm(xl, self.args.t, noise=noise, seed=call_seed, sample0=sample0,
+                    return pur.ddpm(xl, self.args.t, noise=noise, seed=call_seed, sample0=sample0,
                                               diffusion_steps=self.diffusion_steps, nhwc=nhwc)
 
-                x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
+                x0 = _common.dispatch(self.args, run, x0)
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

@@ -8,31 +8,31 @@ import os
 
 import torch
 
-from diffpure_amd import dist as ddist
-from diffpure_amd import factory
-from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC, Purifier
+from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC
 
 from . import _common
 
 
 class _LdPurify(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, runner, cfg, noise, seed, sample0, nhwc):
+    def forward(ctx, img, anchor, pur, cfg, noise, seed, sample0, nhwc):
+        """img: the loop's initial state; anchor: x_init of the Langevin drift (the ORIGINAL input of the call - a plain
+        tensor attribute upstream, diffpure_ldsde.py:63,:212-214 - not differentiated, as upstream)."""
         with torch.no_grad():
-            out = runner.purifier.ldsde(img, *cfg, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc)
-        ctx.runner, ctx.cfg = runner, (cfg, noise, seed, sample0, nhwc)
-        ctx.save_for_backward(out, img.detach())
+            out = pur.ldsde(img, *cfg, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc, x_init=anchor)
+        ctx.pur, ctx.cfg = pur, (cfg, noise, seed, sample0, nhwc)
+        ctx.save_for_backward(out, anchor.detach())
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        out, img = ctx.saved_tensors
+        out, anchor = ctx.saved_tensors
         cfg, noise, seed, sample0, nhwc = ctx.cfg
         t, sigma2, lam, eta, dt = cfg
         with torch.no_grad():
-            a = ctx.runner.purifier.ldsde_vjp(out, grad_out, img, t, sigma2, lam, eta, dt=dt, noise=noise, seed=seed,
-                                              sample0=sample0, nhwc=nhwc)
-        return a, None, None, None, None, None, None
+            a = ctx.pur.ldsde_vjp(out, grad_out, anchor, t, sigma2, lam, eta, dt=dt, noise=noise, seed=seed,
+                                  sample0=sample0, nhwc=nhwc)
+        return a, None, None, None, None, None, None, None
 
 
 class LDGuidedDiffusion(torch.nn.Module):
@@ -43,15 +43,10 @@ class LDGuidedDiffusion(torch.nn.Module):
         if device is None:
             device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
         self.device = torch.device(device)
-        net, kind, img_shape = factory.build_for_dataset(args, config, self.device)
-        want = factory.SCORE_TYPE_TO_KIND.get(args.score_type)
-        if want is None:
-            raise NotImplementedError(f"Unknown score type in RevVPSDE: {args.score_type}!")
-        if want != kind:
-            raise ValueError(f"score_type {args.score_type} does not match dataset {config.data.dataset}")
-        self.model = net
-        self.img_shape = img_shape
-        self.purifier = Purifier(net, kind, self.device)
+        self._pool = _common.EnginePool(lambda dev: _common.build_purifier(args, config, dev), self.device)
+        self.purifier = self._pool.get(self.device)
+        self.model = self.purifier.net
+        self.img_shape = self.purifier.img_shape
         self.betas = torch.linspace(BETA_MIN / N_DISC, BETA_MAX / N_DISC, N_DISC).float().to(self.device)
         self.args_dict = {"method": "euler", "adaptive": False, "dt": 1e-2}
         self._calls = 0
@@ -62,12 +57,12 @@ class LDGuidedDiffusion(torch.nn.Module):
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim
         need_grad = img.requires_grad and torch.is_grad_enabled()
-        if need_grad and getattr(self.args, "shard_batch", False):
-            raise NotImplementedError("gradients through a batch-sharded purification call: run the attack per rank")
+        pur = self._pool.for_input(img)          # DataParallel replica: the engine of the GPU this slice lives on
         with torch.set_grad_enabled(need_grad):
             out_dir = _common.out_dir_for(self.args, bs_id, tag)
             log = bs_id < 2 and out_dir is not None
-            x0 = img.to(self.device)
+            x0 = img.to(pur.device)
+            anchor = x0.detach()           # x_init: every repeat is anchored at the ORIGINAL input (reference :212-214)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
                 _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
@@ -80,12 +75,15 @@ class LDGuidedDiffusion(torch.nn.Module):
                 self._calls += 1
 
                 def run(xl, sample0, call_seed=call_seed):
+                    lo = sample0 if getattr(self.args, "shard_batch", False) else 0      # this shard's rows of the anchor
+                    al = anchor[lo:lo + xl.shape[0]]
                     if need_grad:
-                        return _LdPurify.apply(xl, self, cfg, noise, call_seed, sample0, nhwc)
+                        return _LdPurify.apply(xl, al, pur, cfg, noise, call_seed, sample0, nhwc)
                     t, sigma2, lam, eta, dt = cfg
-                    return self.purifier.ldsde(xl, t, sigma2, lam, eta, dt=dt, noise=noise, seed=call_seed, sample0=sample0, nhwc=nhwc)
+                    return pur.ldsde(xl, t, sigma2, lam, eta, dt=dt, noise=noise, seed=call_seed, sample0=sample0, nhwc=nhwc,
+                                     x_init=al)
 
-                x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
+                x0 = _common.dispatch(self.args, run, x0)
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

@@ -8,9 +8,7 @@ import os
 
 import torch
 
-from diffpure_amd import dist as ddist
-from diffpure_amd import factory
-from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC, Purifier
+from diffpure_amd.sde import BETA_MAX, BETA_MIN, N_DISC
 
 from . import _common
 
@@ -20,10 +18,10 @@ class _OdePurify(torch.autograd.Function):
     (what torchdiffeq.odeint_adjoint provides upstream, runners/diffpure_ode.py:229-238)."""
 
     @staticmethod
-    def forward(ctx, img, runner, t, step, noise, seed, sample0, nhwc=False):
+    def forward(ctx, img, pur, t, step, noise, seed, sample0, nhwc=False):
         with torch.no_grad():
-            out = runner.purifier.ode(img, t, step, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc)
-        ctx.runner, ctx.t, ctx.step, ctx.nhwc = runner, t, step, nhwc
+            out = pur.ode(img, t, step, noise=noise, seed=seed, sample0=sample0, nhwc=nhwc)
+        ctx.pur, ctx.t, ctx.step, ctx.nhwc = pur, t, step, nhwc
         ctx.save_for_backward(out)
         return out
 
@@ -31,8 +29,8 @@ class _OdePurify(torch.autograd.Function):
     def backward(ctx, grad_out):
         (out,) = ctx.saved_tensors
         with torch.no_grad():
-            a = ctx.runner.purifier.ode_vjp(out, grad_out, ctx.t, ctx.step, nhwc=ctx.nhwc)
-            a = a * ctx.runner.purifier.diffuse_scale(ctx.t)
+            a = ctx.pur.ode_vjp(out, grad_out, ctx.t, ctx.step, nhwc=ctx.nhwc)
+            a = a * ctx.pur.diffuse_scale(ctx.t)
         return a, None, None, None, None, None, None, None
 
 
@@ -44,15 +42,10 @@ class OdeGuidedDiffusion(torch.nn.Module):
         if device is None:
             device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
         self.device = torch.device(device)
-        net, kind, img_shape = factory.build_for_dataset(args, config, self.device)
-        want = factory.SCORE_TYPE_TO_KIND.get(args.score_type)
-        if want is None:
-            raise NotImplementedError(f"Unknown score type in RevVPSDE: {args.score_type}!")
-        if want != kind:
-            raise ValueError(f"score_type {args.score_type} does not match dataset {config.data.dataset}")
-        self.model = net
-        self.img_shape = img_shape
-        self.purifier = Purifier(net, kind, self.device)
+        self._pool = _common.EnginePool(lambda dev: _common.build_purifier(args, config, dev), self.device)
+        self.purifier = self._pool.get(self.device)
+        self.model = self.purifier.net
+        self.img_shape = self.purifier.img_shape
         self.betas = torch.linspace(BETA_MIN / N_DISC, BETA_MAX / N_DISC, N_DISC).float().to(self.device)
         self.atol, self.rtol = 1e-3, 1e-3
         self.method = "euler"
@@ -66,10 +59,9 @@ class OdeGuidedDiffusion(torch.nn.Module):
         out_dir = _common.out_dir_for(self.args, bs_id, tag)
         log = bs_id < 2 and out_dir is not None
         need_grad = img.requires_grad and torch.is_grad_enabled()
-        if need_grad and getattr(self.args, "shard_batch", False):
-            raise NotImplementedError("gradients through a batch-sharded purification call: run the attack per rank")
+        pur = self._pool.for_input(img)          # DataParallel replica: the engine of the GPU this slice lives on
         with torch.set_grad_enabled(need_grad):
-            x0 = img.to(self.device)
+            x0 = img.to(pur.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
                 _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, "original_input.png"))
@@ -87,12 +79,13 @@ class OdeGuidedDiffusion(torch.nn.Module):
                 self._calls += 1
 
                 def run(xl, sample0, inj=inj, call_seed=call_seed):
-                    loc = inj if inj is None else dict(e=inj["e"][sample0:sample0 + xl.shape[0]], z=[])
+                    lo = sample0 if getattr(self.args, "shard_batch", False) else 0      # this shard's rows of injected noise
+                    loc = inj if inj is None else dict(e=inj["e"][lo:lo + xl.shape[0]], z=[])
                     if need_grad:
-                        return _OdePurify.apply(xl, self, self.args.t, step, loc, call_seed, sample0, nhwc)
-                    return self.purifier.ode(xl, self.args.t, step, noise=loc, seed=call_seed, sample0=sample0, nhwc=nhwc)
+                        return _OdePurify.apply(xl, pur, self.args.t, step, loc, call_seed, sample0, nhwc)
+                    return pur.ode(xl, self.args.t, step, noise=loc, seed=call_seed, sample0=sample0, nhwc=nhwc)
 
-                x0 = ddist.sharded_purify(run, x0) if getattr(self.args, "shard_batch", False) else run(x0, 0)
+                x0 = _common.dispatch(self.args, run, x0)
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

@@ -263,3 +263,111 @@ def test_reference_driver_imports_resolve():
     from runners.diffpure_ldsde import LDGuidedDiffusion  # noqa: F401
     from runners.diffpure_ode import OdeGuidedDiffusion  # noqa: F401
     from runners.diffpure_sde import RevGuidedDiffusion  # noqa: F401
+
+
+def _runner_args(**kw):
+    import argparse
+    base = dict(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=None, score_type="score_sde", seed=1234,
+                synthetic_weights=True, dt=2e-2, precision="f32")
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def _small_config():
+    import argparse
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device("cpu")
+    return g, config
+
+
+def test_rand_t_randomises_the_diffusion_level_only(monkeypatch):
+    """/root/reference/runners/diffpure_sde.py:218-229: `rand_t` changes total_noise_levels of the forward diffusion; the
+    reverse SDE is still integrated from t0 = 1 - args.t/1000 with the score schedule of args.t."""
+    import numpy as np
+    from runners.diffpure_sde import RevGuidedDiffusion
+    g, config = _small_config()
+    runner = RevGuidedDiffusion(_runner_args(rand_t=True, t_delta=15), config, device="cpu")
+    monkeypatch.setattr(np.random, "randint", lambda lo, hi: 9)
+    x0 = g["x"]
+    n = len(osol.sde_time_grid(100, 2e-2)) - 1
+    gen = torch.Generator().manual_seed(3)
+    e = torch.randn(x0.shape, generator=gen)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(n)]
+    out = runner.image_editing_sample(x0, bs_id=9, noise=dict(e=e, z=zs))
+    sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+    with torch.no_grad():
+        x = osol.diffuse(x0, e, 109)                       # diffusion at the randomised level ...
+        grid = osol.sde_time_grid(100, 2e-2)               # ... solve over the span of args.t
+        for k in range(len(grid) - 1):
+            h = grid[k + 1] - grid[k]
+            x = x + osol.rev_sde_f(score, grid[k], x) * h + osol.rev_sde_g(grid[k], x.shape[0])[:, None, None, None] * (zs[k] * torch.sqrt(h))
+    torch.testing.assert_close(out, x, rtol=1e-4, atol=1e-4)
+    wrong = osol.sde_purify(score, x0, e, zs[: len(osol.sde_time_grid(109, 2e-2)) - 1] + zs, 109, 2e-2)   # the round-1 reading
+    assert (out - wrong).abs().max() > 1e-3
+
+
+def test_engine_pool_serves_one_engine_per_device_and_survives_replication():
+    """nn.DataParallel shallow-copies the runner for every GPU (eval_sde_adv.py:227-228): replicas share the pool and ask it
+    for the engine of the device their input lives on; an engine is built once per device."""
+    import copy
+    from runners import _common
+    built = []
+
+    class FakePur:
+        def __init__(self, dev):
+            self.device = dev
+
+    pool = _common.EnginePool(lambda dev: built.append(dev) or FakePur(dev), "cpu")
+    assert pool.get("cpu") is pool.get(torch.device("cpu")) and len(built) == 1
+    replica = copy.copy(pool)                                   # what replicate() does to plain attributes
+    other = replica.get(torch.device("meta"))
+    assert other.device.type == "meta" and len(built) == 2
+    assert pool.get("meta") is other and len(built) == 2        # shared between replicas, built once
+    assert pool.for_input(torch.zeros(1)) is pool.get("cpu")    # host tensors go to the home engine
+    assert pool.devices() == [("cpu", None), ("meta", None)]
+
+
+def test_ldsde_repeats_stay_anchored_at_the_original_input():
+    """sample_step > 1: upstream builds LDSDE once with x_init = the ORIGINAL input (diffpure_ldsde.py:212-214); only the
+    loop state is chained over the repeats."""
+    from runners.diffpure_ldsde import LDGuidedDiffusion
+    g, config = _small_config()
+    args = _runner_args(sample_step=2, t=100, sigma2=0.001, lambda_ld=0.01, eta=5)
+    runner = LDGuidedDiffusion(args, config, device="cpu")
+    x0 = g["x"]
+    grid = osol.sde_time_grid(100, 1e-2)
+    gen = torch.Generator().manual_seed(4)
+    zs = [torch.randn(x0.shape, generator=gen) for _ in range(len(grid) - 1)]
+    out = runner.image_editing_sample(x0, bs_id=9, noise=dict(e=None, z=zs))
+    sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
+    score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
+
+    def loop(x, anchor):
+        for k in range(len(grid) - 1):
+            h = grid[k + 1] - grid[k]
+            f = osol.ldsde_f(score, x, anchor, 0.001, 0.01)
+            x = x + f * h + osol.ldsde_g(x.shape[0], 0.01, 5)[:, None, None, None] * (zs[k] * torch.sqrt(h))
+        return x
+
+    with torch.no_grad():
+        a = loop(x0, x0)
+        b = loop(a, x0)                      # second repeat: state chained, anchor still the original input
+    torch.testing.assert_close(out, torch.cat([a, b]), rtol=1e-4, atol=1e-4)
+
+
+def test_sample_offset_separates_ranks_of_an_unsharded_evaluation(monkeypatch):
+    from runners import _common
+    import argparse
+    assert _common.sample_offset(argparse.Namespace()) == 0
+    assert _common.sample_offset(argparse.Namespace(sample_offset=77)) == 77
+    monkeypatch.setattr(_common.ddist, "world", lambda: (3, 8))
+    assert _common.sample_offset(argparse.Namespace()) == 3 << 40

@@ -99,7 +99,7 @@ def test_ode_runner_is_differentiable():
     config = ns(g["cfg"])
     config.device = torch.device("cpu")
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=None, score_type="score_sde",
-                              seed=1234, synthetic_weights=True, step_size=2e-2)
+                              seed=1234, synthetic_weights=True, step_size=2e-2, precision="f16x3")
     runner = OdeGuidedDiffusion(args, config, device="cpu")
     x0 = g["x"].clone().requires_grad_(True)
     e = torch.randn(x0.shape, generator=torch.Generator().manual_seed(9))
