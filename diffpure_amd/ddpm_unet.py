@@ -195,11 +195,13 @@ class DdpmUNet:
         return self
 
     # -- blocks ---------------------------------------------------------------------------------------
-    def _res(self, r, x, x2, dense):
+    def _res(self, r, xa, x2a, dense):
+        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
+        x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
         P, n, co = self.p, r["name"], r["cout"]
         conv0 = self._ch2 if r["h2_0"] else ops.conv2d
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
-        st0 = ops.group_norm_stats(x, GN_GROUPS, GN_EPS, x2)
+        st0 = ops.group_norm_stats(xa, GN_GROUPS, GN_EPS, x2a)
         want_raw = r.get("h2_s", False)
         h = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True, split=r["h2_0"] and self._ofmt, stats=st0,
                            raw=want_raw)
@@ -208,6 +210,7 @@ class DdpmUNet:
         off = r["dense_off"]
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True)
         st1 = ops.group_norm_stats(h, GN_GROUPS, GN_EPS)
+        h = h.t
         h = ops.group_norm(h, GN_GROUPS, GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
         if want_raw:
             skip = self._ch2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
@@ -217,10 +220,11 @@ class DdpmUNet:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
         return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, colstats=True)
 
-    def _attn(self, r, x):
+    def _attn(self, r, xa):
         P, n, c = self.p, r["name"], r["ch"]
+        x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(x, GN_GROUPS, GN_EPS)
+        st = ops.group_norm_stats(xa, GN_GROUPS, GN_EPS)
         hn = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")           # one head of dimension C, scale C^-1/2
@@ -229,6 +233,7 @@ class DdpmUNet:
     def _down(self, r, x):
         """pad (0,1,0,1) + 3x3 stride 2 == positions (2i+1, 2j+1) of the same-padded stride-1 convolution."""
         P, n, c = self.p, r["name"], r["ch"]
+        x = ops.tensor_of(x)
         if r["h2"]:
             z = self._ch2(ops.to_h2(x, fmt=self._ofmt), P[n + ".w"], c, 3, bias=P[n + ".c"])
         else:
@@ -237,6 +242,7 @@ class DdpmUNet:
 
     def _up(self, r, x):
         P, n, c = self.p, r["name"], r["ch"]
+        x = ops.tensor_of(x)
         if r["h2"]:
             return self._ch2(ops.to_h2(x, ops.RESAMPLE_UP, fmt=self._ofmt), P[n + ".w"], c, 3, bias=P[n + ".c"], colstats=True)
         return ops.conv2d(ops.resample(x, ops.RESAMPLE_UP), P[n + ".w"], c, 3, bias=P[n + ".c"], colstats=True)
@@ -275,6 +281,7 @@ class DdpmUNet:
                 h = self._res(r, h, hs.pop(), dense)
         assert not hs
         sth = ops.group_norm_stats(h, GN_GROUPS, GN_EPS)
+        h = ops.tensor_of(h)
         h = ops.group_norm(h, GN_GROUPS, GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2 and self._ofmt, stats=sth)
         conv = self._ch2 if self._out_h2 else ops.conv2d
         return conv(h, P["out.w"], self.cfg["out_ch"], 3, bias=P["out.c"])

@@ -268,13 +268,15 @@ class GuidedUNet:
         return self
 
     # -- blocks ----------------------------------------------------------------------------------
-    def _res(self, r, x, x2, film_table, tape=None):
+    def _res(self, r, xa, x2a, film_table, tape=None):
+        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
+        x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
         P, n, co = self.p, r["name"], r["cout"]
         G, eps = self.GN_GROUPS, self.GN_EPS
         mode = r["mode"]
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
         conv2 = self._ch2 if r["h2_2"] else ops.conv2d
-        st1 = ops.group_norm_stats(x, G, eps, x2)
+        st1 = ops.group_norm_stats(xa, G, eps, x2a)
         want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False)
         h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
                            raw=want_raw)
@@ -284,6 +286,7 @@ class GuidedUNet:
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
         st2 = ops.group_norm_stats(h, G, eps)
+        h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
         h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
@@ -297,10 +300,11 @@ class GuidedUNet:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
         return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip, colstats=True)
 
-    def _attn(self, r, x, tape=None):
+    def _attn(self, r, xa, tape=None):
         P, n, c = self.p, r["name"], r["ch"]
+        x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(x, self.GN_GROUPS, self.GN_EPS)
+        st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS)
         xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
@@ -350,6 +354,7 @@ class GuidedUNet:
         for blk in self.plan["out"]:
             h = self._run(blk, h, hs.pop(), film, tape)
         st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS)
+        h = ops.tensor_of(h)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=st))
         h = ops.group_norm(h, self.GN_GROUPS, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2 and self._ofmt, stats=st)

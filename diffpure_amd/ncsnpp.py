@@ -225,12 +225,14 @@ class NCSNpp:
         self.p = P
         return self
 
-    def _res(self, r, x, x2, dense, tape=None):
+    def _res(self, r, xa, x2a, dense, tape=None):
+        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
+        x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
         P, n, co = self.p, str(r["idx"]), r["cout"]
         mode = r["mode"]
         conv0 = self._ch2 if r["h2_0"] else ops.conv2d
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
-        st0 = ops.group_norm_stats(x, self._groups(r["cin"]), self.GN_EPS, x2)
+        st0 = ops.group_norm_stats(xa, self._groups(r["cin"]), self.GN_EPS, x2a)
         h2s = r.get("h2_s", False)
         want_raw = h2s and not mode
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
@@ -240,6 +242,7 @@ class NCSNpp:
         off = r["dense_off"]
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True)
         st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
+        h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
         h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
@@ -256,10 +259,11 @@ class NCSNpp:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
         return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2, colstats=True)
 
-    def _attn(self, r, x, tape=None):
+    def _attn(self, r, xa, tape=None):
         P, n, c = self.p, str(r["idx"]), r["ch"]
+        x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(x, self._groups(c), self.GN_EPS)
+        st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS)
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         if tape is None:
@@ -302,6 +306,7 @@ class NCSNpp:
         assert not hs
         g = self._groups(self.plan["final_ch"])
         sth = ops.group_norm_stats(h, g, self.GN_EPS)
+        h = ops.tensor_of(h)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=sth))
         h = ops.group_norm(h, g, self.GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2 and self._ofmt, stats=sth)

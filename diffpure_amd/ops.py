@@ -107,6 +107,25 @@ class ColStats:
         self.buf, self.tile_rows, self.n = buf, tile_rows, n
 
 
+class Act:
+    """An activation tensor `t` together with the column-statistics records `cols` its producing convolution left
+    behind (conv2d / conv2d_h2 with colstats=True return one).  The pair travels EXPLICITLY through the engines: the
+    records are not an attribute of the tensor, so no view / clone / dispatcher hop can silently drop them."""
+    __slots__ = ("t", "cols")
+
+    def __init__(self, t, cols=None):
+        self.t, self.cols = t, cols
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+def tensor_of(x):
+    """Act | Tensor | None -> Tensor | None"""
+    return x.t if isinstance(x, Act) else x
+
+
 def _colstats_alloc(m, n, device):
     return torch.empty(((m + 63) // 64, 2, n), device=device, dtype=torch.float32), ctypes.c_int(0)
 
@@ -170,14 +189,12 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
               ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _ptr(work), wbytes,
               int(passes), a_fmt, _stream())
-    if colstats:
-        out._dp_cols = ColStats(cs, tr.value, n_out)
-    return out
+    return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
 
 def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False):
     """out = scale * (res + bias + temb[b] + conv_{ksize x ksize, same}(cat(x, x2)))   (NHWC).
-    colstats=True: the epilogue also leaves per-column partial sums on the result (`out._dp_cols`), which
+    colstats=True: the epilogue also reduces per-column partial sums and the call returns Act(out, records), which
     `group_norm_stats` turns into GroupNorm statistics without reading the tensor again."""
     _chk(x, "conv2d.x", 4)
     b, h, w, c1 = x.shape
@@ -208,9 +225,7 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
     _lib.call("dp_conv2d_nhwc", _ptr(x), c1, _ptr(x2), c2, b, h, w, ksize, ksize, _ptr(wp), wp.shape[1], n_out,
               _ptr(bias), _ptr(temb), ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, 0, _ptr(cs),
               None if tr is None else ctypes.addressof(tr), _stream())
-    if colstats:
-        out._dp_cols = ColStats(cs, tr.value, n_out)
-    return out
+    return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
 
 def linear(x, wp, n_out, bias=None):
@@ -233,15 +248,17 @@ def _nsplit(hw):
 
 
 def group_norm_stats(x, groups, eps, x2=None):
-    """-> stats [B, G, 2] = (mean, rstd) of cat(x, x2) per (sample, group)."""
+    """-> stats [B, G, 2] = (mean, rstd) of cat(x, x2) per (sample, group).  x / x2: tensors, or `Act` pairs whose
+    column records (from the producing convolutions' epilogues) make the pass over the data unnecessary."""
+    k1 = x.cols if isinstance(x, Act) else None
+    k2 = x2.cols if isinstance(x2, Act) else None
+    x, x2 = tensor_of(x), tensor_of(x2)
     _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else _chk(x2, "gn.x2", 4).shape[3]
     hw = h * w
     stats = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
     s = _stream()
-    k1 = getattr(x, "_dp_cols", None)
-    k2 = getattr(x2, "_dp_cols", None) if x2 is not None else None
     if k1 is not None and hw % k1.tile_rows == 0 and (x2 is None or (k2 is not None and hw % k2.tile_rows == 0)):
         # the producing convolutions already reduced this tensor per column: no pass over the data
         _lib.call("dp_gn_finalize_cols", _ptr(k1.buf), c1, k1.tile_rows, None if k2 is None else _ptr(k2.buf), c2,

@@ -59,7 +59,7 @@ def main_pp(which, batch):
                 os.environ["DP_H2_PP"] = "1"
                 yb = fn()
                 tb.append(timeit(fn, iters))
-                same = same and torch.equal(ya, yb) and torch.equal(ya._dp_cols.buf, yb._dp_cols.buf)
+                same = same and torch.equal(ya.t, yb.t) and torch.equal(ya.cols.buf, yb.cols.buf)
             a, b = statistics.median(ta), statistics.median(tb)
             tot["a"] += a * cnt
             tot["b"] += min(a, b) * cnt

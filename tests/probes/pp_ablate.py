@@ -48,7 +48,7 @@ def main():
             os.environ["DP_H2_PP_SCHED"] = str(sched)
             os.environ["DP_H2_PP_MODE"] = "0"
             y = fn()
-            same = torch.equal(y, base) and torch.equal(y._dp_cols.buf, base._dp_cols.buf)
+            same = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
             res = []
             for mode in (0, 2, 8, 16, 256):
                 os.environ["DP_H2_PP_MODE"] = str(mode)

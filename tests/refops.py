@@ -76,7 +76,13 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
         y = y + temb[:, :n_out].reshape(-1, 1, 1, n_out)
     if res is not None:
         y = y + res
-    return (y * scale).float().contiguous()
+    y = (y * scale).float().contiguous()
+    return _act(y) if colstats else y
+
+
+def _act(y):
+    from diffpure_amd import ops
+    return ops.Act(y, None)
 
 
 def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False):
@@ -93,8 +99,8 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
     y = (y * scale).contiguous()
     if out is not None:
         out.copy_(y)
-        return out
-    return y
+        y = out
+    return _act(y) if colstats else y
 
 
 def linear(x, wp, n_out, bias=None):
@@ -103,7 +109,8 @@ def linear(x, wp, n_out, bias=None):
 
 
 def group_norm_stats(x, groups, eps, x2=None):
-    xin = _cat(x, x2)
+    from diffpure_amd import ops
+    xin = _cat(ops.tensor_of(x), ops.tensor_of(x2))
     b, h, w, c = xin.shape
     v = xin.reshape(b, h * w, groups, c // groups).double()
     mean = v.mean(dim=(1, 3))

@@ -72,8 +72,9 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
 
 
 def test_torch_dispatcher_registration():
-    """diffpure_amd.torch_ops registers the hot operators as torch.ops.diffpure_hip.* for the CUDA (= HIP) key only:
-    they resolve, carry schemas, and refuse CPU tensors (no CPU kernel exists behind them)."""
+    """diffpure_amd.torch_ops loads csrc/libdiffpure_torch.so, whose TORCH_LIBRARY block registers the hot operators as
+    torch.ops.diffpure_hip.* for the CUDA (= HIP) key only: they resolve, carry schemas, and refuse CPU tensors (no CPU
+    kernel exists behind them)."""
     import torch
     from diffpure_amd import torch_ops
     for name in torch_ops.OPERATORS:

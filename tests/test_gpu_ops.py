@@ -319,7 +319,7 @@ def test_conv2d_h2_pingpong_variant_is_bit_identical(dev, case, monkeypatch):
     def run():
         y = ops.conv2d_h2(xh, wh, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale,
                           colstats=True)
-        return y, y._dp_cols.buf.clone()
+        return y.t, y.cols.buf.clone()
 
     monkeypatch.setenv("DP_H2_PP", "0")
     base, base_cs = run()
@@ -365,7 +365,7 @@ def test_conv2d_h1_fp16_activations(dev, case, passes, monkeypatch):
     def run():
         y = ops.conv2d_h2(xh, wh, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale,
                           colstats=True, passes=passes)
-        return y, y._dp_cols.buf.clone()
+        return y.t, y.cols.buf.clone()
 
     monkeypatch.setenv("DP_H2_PP", "0")
     base, base_cs = run()
@@ -438,15 +438,15 @@ def test_conv_epilogue_column_sums_give_groupnorm_stats(dev, case):
         y = ops.conv2d_h2(_h2_bordered(x, dev), ops.pack_conv_weight_h2(w, dev), N, k, bias=bias, res=res, scale=0.7, colstats=True)
     else:
         y = ops.conv2d(x.to(dev), ops.pack_conv_weight(w).to(dev), N, k, bias=bias, res=res, scale=0.7, colstats=True)
-    assert hasattr(y, "_dp_cols")
+    assert isinstance(y, ops.Act) and y.cols is not None
     G = 32
     fused = ops.group_norm_stats(y, G, 1e-5)
-    plain = ops.group_norm_stats(y.clone(), G, 1e-5)         # clone drops the partials -> reduction kernel
+    plain = ops.group_norm_stats(y.t, G, 1e-5)               # the bare tensor -> reduction kernel
     close(fused, plain.cpu(), rtol=2e-5, atol=2e-6)
     # channel-split pair: both sources carry partials
     y2 = ops.conv2d(x.to(dev), ops.pack_conv_weight(rnd(128, C, 1, 1, seed=8)).to(dev), 128, 1, colstats=True)
     fused2 = ops.group_norm_stats(y, G, 1e-5, y2)
-    plain2 = ops.group_norm_stats(y.clone(), G, 1e-5, y2.clone())
+    plain2 = ops.group_norm_stats(y.t, G, 1e-5, y2.t)
     close(fused2, plain2.cpu(), rtol=2e-5, atol=2e-6)
 
 
@@ -482,29 +482,48 @@ def test_conv2d_h2_split_k_levels_are_batch_shard_invariant(dev, case):
     full = ops.conv2d_h2(_h2_bordered(x, dev), wh, N, k, bias=bias, res=res, scale=0.5, colstats=True)
     ref = ((torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.cpu().double(), padding=k // 2)
             .permute(0, 2, 3, 1) + res.cpu().double()) * 0.5).float()
-    close(full, ref, rtol=2e-5, atol=2e-5)
+    close(full.t, ref, rtol=2e-5, atol=2e-5)
     for lo, hi in ((0, 1), (1, B), (2, 4)):
         part = ops.conv2d_h2(_h2_bordered(x[lo:hi], dev), wh, N, k, bias=bias, res=res[lo:hi].contiguous(), scale=0.5, colstats=True)
-        assert torch.equal(part, full[lo:hi])
+        assert torch.equal(part.t, full.t[lo:hi])
         if H * W == 64:     # one 64-row record per sample
-            assert torch.equal(part._dp_cols.buf, full._dp_cols.buf[lo:hi])
+            assert torch.equal(part.cols.buf, full.cols.buf[lo:hi])
 
 
 def test_torch_ops_namespace_runs_the_hip_kernels(dev):
-    """torch.ops.diffpure_hip.* (diffpure_amd/torch_ops.py) dispatch to the same kernels as diffpure_amd.ops."""
+    """torch.ops.diffpure_hip.* - registered from C++ (csrc/torch_binding.cpp, TORCH_LIBRARY) - run the same kernels as
+    diffpure_amd.ops, bit for bit, with the column statistics as an explicit second return."""
     from diffpure_amd import ops, torch_ops  # noqa: F401
+    T = torch.ops.diffpure_hip
     x = rnd(2, 16, 16, 128, seed=1).to(dev)
     w = rnd(96, 128, 3, 3, seed=2, scale=0.05)
     bias = rnd(96, seed=3).to(dev)
     wp = ops.pack_conv_weight(w).to(dev)
-    assert torch.equal(torch.ops.diffpure_hip.conv2d_nhwc(x, wp, bias, 96, 3), ops.conv2d(x, wp, 96, 3, bias=bias))
+    assert torch.equal(T.conv2d_nhwc(x, wp, bias, 96, 3), ops.conv2d(x, wp, 96, 3, bias=bias))
+    y, cols = T.conv2d_nhwc_stats(x, wp, bias, 96, 3)
+    ref = ops.conv2d(x, wp, 96, 3, bias=bias, colstats=True)
+    assert torch.equal(y, ref.t) and torch.equal(cols, ref.cols.buf)
+    assert torch.equal(T.group_norm_stats_from_cols(cols, 2, 256, 32, 1e-5), ops.group_norm_stats(ref, 32, 1e-5))
     gamma, beta = (1 + 0.1 * rnd(128, seed=4)).to(dev), (0.1 * rnd(128, seed=5)).to(dev)
-    xh = torch.ops.diffpure_hip.group_norm_silu(x, gamma, beta, 32, 1e-5, True, True)
-    assert torch.equal(xh, ops.group_norm(x, 32, 1e-5, gamma, beta, act=True, split=True))
+    for fmt, split in ((0, False), (1, "h2"), (2, "h1")):
+        assert torch.equal(T.group_norm_silu(x, gamma, beta, 32, 1e-5, True, fmt), ops.group_norm(x, 32, 1e-5, gamma, beta, act=True, split=split))
+    st = ops.group_norm_stats(x, 32, 1e-5)
+    assert torch.equal(T.group_norm_silu(x, gamma, beta, 32, 1e-5, True, 2, st), ops.group_norm(x, 32, 1e-5, gamma, beta, act=True, split="h1", stats=st))
     wh = ops.pack_conv_weight_h2(w, dev)
-    assert torch.equal(torch.ops.diffpure_hip.conv2d_h2(xh, wh, None, 96, 3), ops.conv2d_h2(xh, wh, 96, 3))
-    qkv = rnd(2, 64, 3 * 128, seed=6).to(dev)
-    assert torch.equal(torch.ops.diffpure_hip.attention(qkv, 2, True), ops.attention(qkv, 2, "legacy"))
+    for split, passes in (("h2", 3), ("h1", 2), ("h1", 1)):
+        xh = ops.group_norm(x, 32, 1e-5, gamma, beta, act=True, split=split)
+        assert torch.equal(T.conv2d_h2(xh, wh, None, 96, 3, passes), ops.conv2d_h2(xh, wh, 96, 3, passes=passes))
+        y2, c2 = T.conv2d_h2_stats(xh, wh, bias, 96, 3)          # passes = 0: the full arithmetic of the operand format
+        r2 = ops.conv2d_h2(xh, wh, 96, 3, bias=bias, colstats=True)
+        assert torch.equal(y2, r2.t) and torch.equal(c2, r2.cols.buf)
+    for heads, c in ((2, 128), (3, 96)):                 # head dimension 64: flash kernel; 32: GEMM + softmax path
+        qkv = rnd(2, 64, 3 * c, seed=6).to(dev)
+        assert torch.equal(T.attention(qkv, heads, True), ops.attention(qkv, heads, "legacy"))
+        assert torch.equal(T.attention(qkv, heads, False), ops.attention(qkv, heads, "split"))
     img = torch.rand(2, 3, 28, 28).to(dev)
-    assert torch.equal(torch.ops.diffpure_hip.resize_affine(img, 32, 32, -0.5, 2.0, False, True),
-                       ops.resize_affine(img, (32, 32), -0.5, 2.0, False, True))
+    assert torch.equal(T.resize_affine(img, 32, 32, -0.5, 2.0, False, True), ops.resize_affine(img, (32, 32), -0.5, 2.0, False, True))
+    xs, eps = rnd(2, 8, 8, 3, seed=7).to(dev), rnd(2, 8, 8, 6, seed=8).to(dev)
+    assert torch.equal(T.em_step(xs, eps, -0.5, 1.1, -2.0, False, 1e-3, 1.05, 0.0316, 77, 5, 3),
+                       ops.em_step(xs, eps, -0.5, 1.1, -2.0, False, 1e-3, 1.05, 0.0316, seed=77, sample0=5, step=3))
+    with pytest.raises(RuntimeError):
+        T.conv2d_nhwc(x, wp[:, :8].contiguous(), bias, 96, 3)     # TORCH_CHECK -> RuntimeError with the library's message

@@ -1,0 +1,122 @@
+"""The UNCHANGED reference driver over this repository's runners (build container only: needs /root/reference).
+
+/root/reference/eval_sde_adv.py is loaded from a scratch copy exactly as it is; only the packages that are not
+installable here and have nothing to do with the path are stubbed (autoattack, stadv_eot, and the reference's own
+utils.py, whose imports pull torchvision / lmdb / robustbench).  `from runners.diffpure_sde import RevGuidedDiffusion`
+etc. (eval_sde_adv.py:27-31) then resolve to THIS repository's drop-in package, the reference's own
+`SDE_Adv_Model(args, config)` is constructed (:34-60) and its `forward` (:67-93) and the gradient an adaptive attack
+takes through it are run.  Device work goes through the torch statements of the HIP operators (tests/refops.py) - the
+kernels themselves are covered on the GPU (tests/test_gpu_*.py); what is proven here is the boundary: module paths,
+class names, constructor and method signatures, nn.Module ownership, differentiability, buffers / .eval() / .to()."""
+import argparse
+import importlib.util
+import os
+import shutil
+import sys
+import types
+
+import pytest
+import torch
+
+import refops
+from conftest import ROOT, load_golden
+
+REF_DRIVER = "/root/reference/eval_sde_adv.py"
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference checkout is not present on this machine")
+
+
+class _Classifier(torch.nn.Module):
+    """stands in for utils.get_image_classifier(...) (the classifier zoo is outside the scope contract)"""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.randn(7, 3, generator=torch.Generator().manual_seed(3)))
+
+    def forward(self, x):
+        assert x.dim() == 4
+        return x.mean(dim=(2, 3)) @ self.w.t()
+
+
+@pytest.fixture()
+def ref_driver(tmp_path, monkeypatch):
+    refops.patch_ops(monkeypatch)
+    monkeypatch.setenv("DIFFPURE_SYNTH_WEIGHTS", "1")        # no checkpoint files here; the driver's args stay untouched
+    monkeypatch.setenv("DIFFPURE_PRECISION", "f32")
+    scratch = tmp_path / "eval_sde_adv.py"
+    shutil.copyfile(REF_DRIVER, scratch)
+    stubs = {}
+    aa = types.ModuleType("autoattack")
+    aa.AutoAttack = object
+    stubs["autoattack"] = aa
+    st = types.ModuleType("stadv_eot")
+    sta = types.ModuleType("stadv_eot.attacks")
+    sta.StAdvAttack = object
+    st.attacks = sta
+    stubs["stadv_eot"], stubs["stadv_eot.attacks"] = st, sta
+    ut = types.ModuleType("utils")
+    ut.str2bool = lambda v: str(v).lower() in ("1", "true", "yes")
+    ut.get_accuracy = lambda *a, **k: 0.0
+    ut.load_data = lambda *a, **k: None
+    ut.get_image_classifier = lambda name: _Classifier()
+    ut.Logger = object
+    stubs["utils"] = ut
+    for k, v in stubs.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    monkeypatch.syspath_prepend(ROOT)                         # `runners` = this repository's drop-in package
+    for k in [k for k in sys.modules if k == "runners" or k.startswith("runners.")]:
+        monkeypatch.delitem(sys.modules, k)
+    spec = importlib.util.spec_from_file_location("ref_eval_sde_adv", str(scratch))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.RevGuidedDiffusion.__module__ == "runners.diffpure_sde"
+    assert os.path.realpath(sys.modules["runners"].__path__[0]) == os.path.realpath(os.path.join(ROOT, "runners"))
+    return mod
+
+
+def _ns(d):
+    n = argparse.Namespace()
+    for k, v in d.items():
+        setattr(n, k, _ns(v) if isinstance(v, dict) else v)
+    return n
+
+
+def _args(diffusion_type, tmp_path, **kw):
+    # the fields the reference's argparse defines and the runners read (eval_sde_adv.py:176-213)
+    base = dict(diffusion_type=diffusion_type, domain="cifar10", classifier_name="cifar10-wideresnet-28-10", t=100, rand_t=False,
+                t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path / "log"), score_type="score_sde", seed=1234,
+                step_size=5e-2, sigma2=1e-3, lambda_ld=1e-2, eta=5.0, eot_iter=1)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+@pytest.mark.parametrize("diffusion_type", ["sde", "ode", "ldsde"])
+def test_reference_sde_adv_model_runs_and_differentiates_over_the_drop_in_runners(ref_driver, tmp_path, diffusion_type):
+    g = load_golden("ncsnpp_small.pt")
+    config = _ns(g["cfg"])
+    config.device = torch.device("cpu")
+    args = _args(diffusion_type, tmp_path, dt=5e-2)
+    model = ref_driver.SDE_Adv_Model(args, config)            # the reference's class, unchanged
+    assert isinstance(model.runner, torch.nn.Module) and type(model.runner).__module__.startswith("runners.")
+    model = model.eval().to(config.device)                    # as the driver does (:228)
+    model.set_tag("t0")
+    x = torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+    logits = model(x)                                         # SDE_Adv_Model.forward (:67-93)
+    assert logits.shape == (2, 7) and torch.isfinite(logits).all()
+    assert model.counter.item() == 1
+    assert os.path.isdir(os.path.join(args.log_dir, "bs0.0_t0"))     # bs_id arrives as a Python float (counter.item())
+    (gx,) = torch.autograd.grad(logits.sum(), x)              # what AutoAttack's APGD takes
+    assert gx.shape == x.shape and torch.isfinite(gx).all() and gx.abs().max() > 0
+    again = model(x.detach())                                  # counter = 1: no logging, different noise (call counter)
+    assert again.shape == (2, 7) and not torch.equal(again, logits.detach())
+
+
+def test_reference_sde_adv_model_ddpm_on_the_guided_runner(ref_driver, tmp_path):
+    g = load_golden("guided_small.pt")
+    config = _ns(dict(model=g["cfg"], data=dict(dataset="ImageNet", image_size=32)))
+    config.device = torch.device("cpu")
+    args = _args("ddpm", tmp_path, t=4, score_type="guided_diffusion")
+    model = ref_driver.SDE_Adv_Model(args, config).eval().to(config.device)
+    x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        logits = model(x)
+    assert logits.shape == (2, 7) and torch.isfinite(logits).all()
