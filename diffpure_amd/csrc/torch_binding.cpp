@@ -11,8 +11,8 @@
 // Built by diffpure_amd/build.py into libdiffpure_torch.so (host C++ only; links libdiffpure_hip.so); loaded by
 // diffpure_amd/torch_ops.py with torch.ops.load_library.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
 #include "../../include/diffpure_hip.h"
@@ -21,7 +21,9 @@ namespace {
 
 using at::Tensor;
 
-void* cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// On a ROCm build of PyTorch HIP devices carry the DeviceType "cuda": the stream comes from the masquerading accessor and the
+// device guard is the generic one (it dispatches on the tensor's device type).
+void* cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 void chk_f32(const Tensor& t, const char* name, int64_t dim = -1) {
     TORCH_CHECK(t.is_cuda(), "diffpure_hip: ", name, " must be a GPU tensor (there is no CPU kernel)");
@@ -45,7 +47,7 @@ std::tuple<Tensor, Tensor> conv2d_nhwc_impl(const Tensor& x, const Tensor& wp, c
     chk_f32(x, "x", 4);
     chk_f32(wp, "wp", 2);
     TORCH_CHECK(wp.size(0) == ksize * ksize * x.size(3) && wp.size(1) >= n_out, "diffpure_hip: weight panel does not match");
-    c10::hip::HIPGuard guard(x.device());
+    c10::DeviceGuard guard(x.device());
     const int64_t B = x.size(0), H = x.size(1), W = x.size(2);
     Tensor out = at::empty({B, H, W, n_out}, x.options());
     Tensor cols;
@@ -74,7 +76,7 @@ std::tuple<Tensor, Tensor> conv2d_h2_impl(const Tensor& xh, const Tensor& wh, co
     const int a_fmt = xh.size(3) == C ? 1 : 0;                 // plain fp16 ("h1") or hi|lo octets ("h2")
     TORCH_CHECK(a_fmt == 1 || xh.size(3) == 2 * C, "diffpure_hip: activation operand does not match the weight panel");
     if (passes == 0) passes = a_fmt ? 2 : 3;
-    c10::hip::HIPGuard guard(xh.device());
+    c10::DeviceGuard guard(xh.device());
     const int64_t B = xh.size(0), H = xh.size(1) - 2, W = xh.size(2) - 2;
     auto fopt = xh.options().dtype(at::kFloat);
     Tensor out = at::empty({B, H, W, n_out}, fopt);
@@ -100,7 +102,7 @@ std::tuple<Tensor, Tensor> conv2d_h2_stats(const Tensor& xh, const Tensor& wh, c
 // ---- GroupNorm ---------------------------------------------------------------------------------------------------
 Tensor group_norm_stats_from_cols(const Tensor& cols, int64_t batch, int64_t hw, int64_t groups, double eps) {
     chk_f32(cols, "cols", 3);
-    c10::hip::HIPGuard guard(cols.device());
+    c10::DeviceGuard guard(cols.device());
     Tensor stats = at::empty({batch, groups, 2}, cols.options());
     DP_CALL(dp_gn_finalize_cols(cols.data_ptr<float>(), (int)cols.size(2), 64, nullptr, 0, 0, (int)batch, (int)hw, (int)groups,
                                 (float)eps, stats.data_ptr<float>(), cur_stream(cols)));
@@ -112,7 +114,7 @@ Tensor group_norm_silu(const Tensor& x, const Tensor& gamma, const Tensor& beta,
     chk_f32(gamma, "gamma", 1);
     chk_f32(beta, "beta", 1);
     TORCH_CHECK(out_fmt >= 0 && out_fmt <= 2, "diffpure_hip: out_fmt 0 (fp32), 1 (h2) or 2 (h1)");
-    c10::hip::HIPGuard guard(x.device());
+    c10::DeviceGuard guard(x.device());
     const int64_t B = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
     void* s = cur_stream(x);
     Tensor stats;
@@ -139,7 +141,7 @@ Tensor group_norm_silu(const Tensor& x, const Tensor& gamma, const Tensor& beta,
 // ---- attention -----------------------------------------------------------------------------------------------------
 Tensor attention(const Tensor& qkv, int64_t n_heads, bool legacy_layout) {
     chk_f32(qkv, "qkv", 3);
-    c10::hip::HIPGuard guard(qkv.device());
+    c10::DeviceGuard guard(qkv.device());
     const int64_t B = qkv.size(0), T = qkv.size(1), C = qkv.size(2) / 3, d = C / n_heads;
     void* s = cur_stream(qkv);
     Tensor out = at::empty({B, T, C}, qkv.options());
@@ -168,7 +170,7 @@ Tensor em_step(const Tensor& x, const Tensor& eps, double nhb, double gg, double
     chk_f32(eps, "eps", 4);
     TORCH_CHECK(eps.size(0) == x.size(0) && eps.size(1) == x.size(1) && eps.size(2) == x.size(2) && eps.size(3) >= x.size(3),
                 "diffpure_hip: em_step shapes");
-    c10::hip::HIPGuard guard(x.device());
+    c10::DeviceGuard guard(x.device());
     Tensor out = at::empty_like(x);
     DP_CALL(dp_em_step(x.data_ptr<float>(), eps.data_ptr<float>(), (int)eps.size(3), (int)x.size(0), (int)(x.size(1) * x.size(2)),
                        (int)x.size(3), (float)nhb, (float)gg, (float)sc, div ? 1 : 0, (float)h, (float)g, (float)sqrt_h, nullptr,
@@ -177,7 +179,7 @@ Tensor em_step(const Tensor& x, const Tensor& eps, double nhb, double gg, double
 }
 Tensor resize_affine(const Tensor& x, int64_t ho, int64_t wo, double shift, double scale, bool in_nhwc, bool out_nhwc) {
     chk_f32(x, "x", 4);
-    c10::hip::HIPGuard guard(x.device());
+    c10::DeviceGuard guard(x.device());
     const int64_t B = x.size(0), C = in_nhwc ? x.size(3) : x.size(1), Hi = in_nhwc ? x.size(1) : x.size(2),
                   Wi = in_nhwc ? x.size(2) : x.size(3);
     Tensor y = out_nhwc ? at::empty({B, ho, wo, C}, x.options()) : at::empty({B, C, ho, wo}, x.options());

@@ -181,7 +181,7 @@ def test_ode_runner_autograd_on_gpu(tmp_path):
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path),
-                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=1e-2)
+                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=1e-2, precision="f16x3")
     runner = OdeGuidedDiffusion(args, config, device=config.device)
     x = (torch.rand(3, 3, 16, 16) * 2 - 1).to(DEV).requires_grad_(True)
     out = runner.image_editing_sample(x, bs_id=9)
@@ -280,7 +280,7 @@ def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, 
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path),
-                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=2e-2, dt=2e-2,
+                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=2e-2, dt=2e-2, precision="f16x3",
                               diffusion_type=diffusion_type, domain="cifar10", classifier_name="none", diffusion_size=(16, 16))
     model = SDE_Adv_Model(args, config, classifier=_TinyClassifier())
     runner = model.runner
@@ -333,7 +333,7 @@ def test_ldsde_runner_autograd_on_gpu_vs_oracle_adjoint(tmp_path):
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path), score_type="score_sde",
-                              seed=1234, synthetic_weights=True, sigma2=0.001, lambda_ld=0.01, eta=5)
+                              seed=1234, synthetic_weights=True, sigma2=0.001, lambda_ld=0.01, eta=5, precision="f16x3")
     runner = LDGuidedDiffusion(args, config, device=config.device)
     sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
     score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))

@@ -174,7 +174,7 @@ def test_drop_in_runner_boundary(tmp_path):
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=2, log_dir=str(tmp_path),
-                              score_type="score_sde", seed=1234, synthetic_weights=True, dt=1e-2)
+                              score_type="score_sde", seed=1234, synthetic_weights=True, dt=1e-2, precision="f16x3")
     runner = RevGuidedDiffusion(args, config, device=config.device)
     assert isinstance(runner, torch.nn.Module)
     x = torch.rand(3, 3, 16, 16) * 2 - 1
@@ -326,7 +326,7 @@ def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path):
             setattr(n, k, ns(v) if isinstance(v, dict) else v)
         return n
 
-    args = argparse.Namespace(t=8, sample_step=1, log_dir=str(tmp_path), seed=g["seed"], synthetic_weights=True)
+    args = argparse.Namespace(t=8, sample_step=1, log_dir=str(tmp_path), seed=g["seed"], synthetic_weights=True, precision="f16x3")
     runner = Diffusion(args, ns(g["cfg"]), device=DEV)
     sd = synth_state_dict(dict(zip(g["keys"], g["shapes"])), g["seed"])
     ocfg = od.parse_ddpm_config(g["cfg"])
