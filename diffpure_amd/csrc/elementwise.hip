@@ -237,6 +237,57 @@ extern "C" int dp_softmax_rows(float* x, long long rows, int cols, void* stream)
     return 0;
 }
 
+// fp32 -> fp16 over a flat weight buffer; STOCH: unbiased stochastic rounding.  h0 = the fp16 neighbour towards zero,
+// h1 = the next one away from zero (bit pattern + 1: fp16 magnitudes are ordered like their bit patterns, through the
+// subnormal range as well); w goes to h1 with probability (|w| - |h0|) / (|h1| - |h0|), decided by 24 Philox bits keyed by
+// (seed, key, element quad).  A value beyond the largest finite fp16 number stays at it (weights never get there).
+template <bool STOCH>
+__global__ void round_weights_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long nquads,
+                                     unsigned long long seed, long long key) {
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nquads; q += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + q * 4);
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        half4 o;
+        if constexpr (STOCH) {
+            U4 c{(uint32_t)((unsigned long long)q & 0xffffffffu), (uint32_t)((unsigned long long)q >> 32),
+                 (uint32_t)((unsigned long long)key & 0xffffffffu), (uint32_t)((unsigned long long)key >> 32)};
+            const U4 r = philox4x32_10(c, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32));
+            const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = v[j], aw = fabsf(w);
+                const _Float16 hn = (_Float16)aw;                               // nearest; step back if it overshot: towards zero
+                unsigned short b0 = __builtin_bit_cast(unsigned short, hn);
+                if ((float)hn > aw) --b0;                                       // (aw >= 0: hn > aw implies b0 >= 1; inf steps to 65504)
+                const _Float16 h0 = __builtin_bit_cast(_Float16, b0);
+                const float f0 = (float)h0;
+                _Float16 h = h0;
+                if (aw > f0 && b0 < 0x7bff) {                                   // not exactly representable, not at the top
+                    const _Float16 h1 = __builtin_bit_cast(_Float16, (unsigned short)(b0 + 1));
+                    const float p = (aw - f0) / ((float)h1 - f0);               // in (0, 1)
+                    if (u01(rr[j]) < p) h = h1;
+                }
+                o[j] = w < 0.f ? -h : h;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+        }
+        *reinterpret_cast<half4*>(dst + q * 4) = o;
+    }
+}
+
+extern "C" int dp_round_weights(const float* src, void* dst, long long n, int stochastic, unsigned long long seed, long long key,
+                                void* stream) {
+    DP_REQUIRE(src && dst && n > 0 && n % 8 == 0 && dp_aligned16(src) && dp_aligned16(dst), "dp_round_weights: n must be a positive multiple of 8, buffers 16-byte aligned");
+    const long long nq = n / 4;
+    const unsigned grid = grid_for(nq);
+    if (stochastic) hipLaunchKernelGGL(round_weights_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, nq, seed, key);
+    else hipLaunchKernelGGL(round_weights_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, nq, seed, key);
+    DP_LAUNCH_CHECK("round_weights");
+    return 0;
+}
+
 extern "C" int dp_philox_normal(float* out, int B, long long per_sample, unsigned long long seed, long long sample0,
                                 int step, void* stream) {
     DP_REQUIRE(out && B > 0 && per_sample > 0 && per_sample % 4 == 0, "dp_philox_normal: per_sample must be a positive multiple of 4");

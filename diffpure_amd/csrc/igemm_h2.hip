@@ -69,13 +69,18 @@ __device__ __forceinline__ int swz(int row, int slot) {
 // A16: the activation operand is PLAIN fp16 ("h1": [B][H+2][W+2][C] fp16, zero border) - 2 bytes per element, LDS rows of
 // BKH * 2 bytes - and only a_hi exists: PASSES is 2 (a_hi*w_lo + a_hi*w_hi, "f16x2") or 1 (a_hi*w_hi, "f16").  The
 // per-element accumulation order is the one of the h2-operand kernel with the a_lo pass left out.
-template <int BM, int BN, int BKH, int ABL, int PASSES, bool A16>
+// W16 (with A16, PASSES 1): the weight panel is plain fp16 as well ([N][K'] fp16, same k' order; rounded once at load
+// ("f16") or re-rounded stochastically from the fp32 masters before every network call ("f16sr", dp_round_weights)):
+// B rows are BKH * 2 bytes and only w_hi fragments exist.
+template <int BM, int BN, int BKH, int ABL, int PASSES, bool A16, bool W16>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     static_assert(A16 ? (PASSES == 2 || PASSES == 1) : (PASSES == 3 || PASSES == 12), "operand format / passes");
+    static_assert(!W16 || (A16 && PASSES == 1), "fp16 weights: one pass, fp16 activations");
     constexpr int TM = BM / 64, TN = BN / 64;           // 2x2 waves, 32x32 MFMA tiles
     constexpr int ESZ = A16 ? 2 : 4;                    // bytes per activation element
     constexpr int AROWB = BKH * ESZ, ASPR = AROWB / 16; // bytes / 16-byte slots per LDS row of the A tile
-    constexpr int ROWB = BKH * 4, SPR = BKH / 4;        // ... of the B (weight, always hi|lo) tile
+    constexpr int WSZ = W16 ? 2 : 4;                    // bytes per weight element (plain fp16, or hi|lo)
+    constexpr int ROWB = BKH * WSZ, SPR = ROWB / 16;    // ... of the B (weight) tile
     constexpr int ARPP = NT / ASPR, ARPI = 64 / ASPR;   // A rows staged per pass of the workgroup / per DMA instruction
     constexpr int RPP = NT / SPR, RPI = 64 / SPR;       // B rows ...
     constexpr int A_IT = BM / ARPP, B_IT = BN / RPP;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     const int r0 = tid / SPR, r0a = tid / ASPR;
     // logical slot this lane fetches: physical slot (tid % SPR) un-swizzled with the row key, which is the
     // same for every pass because RPP / ARPP are multiples of 16
-    const int ls = (ROWB == 128) ? ((tid & 7) ^ ((r0 >> 1) & 7)) : ((tid & 3) ^ ((r0 >> 2) & 3));
+    const int ls = (ROWB == 128) ? ((tid & 7) ^ ((r0 >> 1) & 7)) : (ROWB == 64 ? ((tid & 3) ^ ((r0 >> 2) & 3)) : ((tid & 1) ^ ((r0 >> 3) & 1)));
     const int lsa = (AROWB == 128) ? ((tid & 7) ^ ((r0a >> 1) & 7)) : (AROWB == 64 ? ((tid & 3) ^ ((r0a >> 2) & 3)) : ((tid & 1) ^ ((r0a >> 3) & 1)));
     const int taps = p.KS * p.KS;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably uniform: LDS-DMA bases stay scalar
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     for (int it = 0; it < B_IT; ++it) {
         const int n = n0 + r0 + it * RPP;
         const bool ok = n < p.N;
-        bptr[it] = ok ? p.w + (size_t)n * p.K * 4 + ls * 16 : p.zero + ls * 16;
+        bptr[it] = ok ? p.w + (size_t)n * p.K * WSZ + ls * 16 : p.zero + ls * 16;
         bstep[it] = ok ? ROWB : 0;
     }
 
@@ -180,8 +185,12 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + lr;
-                bh[j] = *reinterpret_cast<const half8*>(Bs + swz<ROWB>(row, sl));
-                bl[j] = *reinterpret_cast<const half8*>(Bs + swz<ROWB>(row, sl + 1));
+                if constexpr (W16) {
+                    bh[j] = *reinterpret_cast<const half8*>(Bs + swz<ROWB>(row, s * 2 + lk));
+                } else {
+                    bh[j] = *reinterpret_cast<const half8*>(Bs + swz<ROWB>(row, sl));
+                    bl[j] = *reinterpret_cast<const half8*>(Bs + swz<ROWB>(row, sl + 1));
+                }
             }
             if constexpr (ABL == 1) __builtin_amdgcn_s_setprio(1);
             if constexpr (PASSES == 3 || PASSES == 12) {
@@ -425,12 +434,14 @@ extern "C" long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, in
 extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
                                  const float* bias, const float* temb, int temb_stride, const float* res, int ldr,
                                  float scale, float* out, int ldo, float* colstats, int* tile_rows, void* work,
-                                 long long work_bytes, int passes, int a_fmt, void* stream) {
+                                 long long work_bytes, int passes, int a_fmt, int w_fmt, void* stream) {
     DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
     DP_REQUIRE(KS == 1 || KS == 3, "dp_conv2d_nhwc_h2: kernel size %d unsupported", KS);
     DP_REQUIRE((a_fmt == 0 && (passes == 3 || passes == 12)) || (a_fmt == 1 && (passes == 2 || passes == 1)),
                "dp_conv2d_nhwc_h2: (a_fmt, passes) must be (0, 3 | 12) for h2 activations or (1, 2 | 1) for plain fp16 ones (got %d, %d)",
                a_fmt, passes);
+    DP_REQUIRE(w_fmt == 0 || (w_fmt == 1 && a_fmt == 1 && passes == 1),
+               "dp_conv2d_nhwc_h2: plain fp16 weights (w_fmt 1) go with plain fp16 activations and one pass (got a_fmt %d, passes %d)", a_fmt, passes);
     DP_REQUIRE(C > 0 && C % 32 == 0, "dp_conv2d_nhwc_h2: channel count must be a multiple of 32 (got %d)", C);
     DP_REQUIRE(dp_aligned16(x) && dp_aligned16(w), "dp_conv2d_nhwc_h2: misaligned operand");
     DP_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && (long long)B * H * W < (1ll << 31), "dp_conv2d_nhwc_h2: bad shape");
@@ -445,6 +456,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.colstats = colstats;
     p.passes = passes;
     p.afmt = a_fmt;
+    p.wfmt = w_fmt;
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
@@ -457,17 +469,18 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     // algorithmic HBM bytes: the activation operand once (4 or 2 bytes per element), the h2 weights once, the residual and
     // the fp32 output once
     dp_prof_begin(KS == 3 ? DP_PROF_3X3_OTHER : DP_PROF_1X1, 2.0 * p.M * (double)p.N * p.K,
-                  (double)p.M * C * (a_fmt ? 2 : 4) + 4.0 * ((double)p.K * N + (double)p.M * N * (res ? 2 : 1)), s, &rec);
+                  (double)p.M * C * (a_fmt ? 2 : 4) + (w_fmt ? 2.0 : 4.0) * p.K * N + 4.0 * (double)p.M * N * (res ? 2 : 1), s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
 #define DP_H2_LAUNCH(BM_, BN_, BK_, ABL_)                                                                  \
     do {                                                                                                   \
         p.tiles_n = (N + BN_ - 1) / BN_;                                                                   \
         p.tiles = (int)tiles(BM_, BN_);                                                                    \
         const dim3 g_((unsigned)p.tiles, (unsigned)p.ksplit);                                              \
-        if (p.afmt == 1 && p.passes == 2) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 2, true>), g_, dim3(NT), 0, s, p);        \
-        else if (p.afmt == 1) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 1, true>), g_, dim3(NT), 0, s, p);                    \
-        else if (p.passes == 12) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 12, false>), g_, dim3(NT), 0, s, p);               \
-        else hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 3, false>), g_, dim3(NT), 0, s, p);                                    \
+        if (p.wfmt == 1) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 1, true, true>), g_, dim3(NT), 0, s, p);                   \
+        else if (p.afmt == 1 && p.passes == 2) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 2, true, false>), g_, dim3(NT), 0, s, p); \
+        else if (p.afmt == 1) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 1, true, false>), g_, dim3(NT), 0, s, p);             \
+        else if (p.passes == 12) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 12, false, false>), g_, dim3(NT), 0, s, p);        \
+        else hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 3, false, false>), g_, dim3(NT), 0, s, p);                             \
     } while (0)
     // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
     // also fills the chip (>= one tile per CU); unset = DP_H2_PP_DEFAULT.  Read per call so that a probe can

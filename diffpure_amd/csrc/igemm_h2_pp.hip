@@ -83,16 +83,22 @@ __device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const 
 //   phase's own loads may still be in flight)  ->  read in phase j+2.
 //   RAW: the earliest reader (group 0, phase j+2, interval 2j+4) has passed the barrier closing interval 2j+3, in
 //        which group 1 did its phase-(j+1) wait.   WAR: a unit is re-staged two phases after its last read.
-template <int BM, int BN, int MODE, int PASSES, bool A16, int SCHED>
+// W16 (A16, PASSES 1, SCHED 1): plain fp16 weights as well - B rows are 64 bytes, a B unit of the 256-wide tile is ONE DMA
+// instruction per thread (128 rows), the whole B tile of the 128-wide tile is one (staged in phase 0); LDS 64 KB.
+template <int BM, int BN, int MODE, int PASSES, bool A16, int SCHED, bool W16>
 __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     static_assert(SCHED == 0 || A16, "the two-phase schedule keeps both A halves in registers: fp16 operand only");
+    static_assert(!W16 || (A16 && PASSES == 1 && SCHED == 1), "fp16 weights: one pass, fp16 activations, two-phase schedule");
     static_assert((BM == 256 && BN == 256) || (BM == 512 && BN == 128), "8 waves of 128 x 64");
     static_assert(A16 ? (PASSES == 2 || PASSES == 1) : (PASSES == 3 || PASSES == 12), "operand format / passes");
     constexpr int ESZ = A16 ? 2 : 4;                       // bytes per activation element
     constexpr int AROWB = 32 * ESZ;                        // bytes per LDS row of the A tile
     constexpr int NPA = A16 ? BM / 256 : BM / 128;         // DMA pieces (one instruction per thread) per A unit
-    constexpr int NPB = BN / 128;                          // ... per B unit (64-row pieces)
-    constexpr int TILE_A = BM * AROWB, TILE_B = BN * ROWB; // operand tiles of one k-tile
+    constexpr int BROWB = W16 ? 64 : ROWB;                 // bytes per LDS row of the B tile
+    constexpr bool BWHOLE = W16 && BN == 128;              // the one DMA piece of a unit IS the whole B tile (both units)
+    constexpr int NPB = W16 ? 1 : BN / 128;                // DMA pieces per B unit (h2: 64-row pieces; fp16: one 128-row piece)
+    constexpr int WSZ = W16 ? 2 : 4;                       // bytes per weight element
+    constexpr int TILE_A = BM * AROWB, TILE_B = BN * BROWB; // operand tiles of one k-tile
     constexpr int BUF = TILE_A + TILE_B;                   // A tile, then B tile
     constexpr int CNT_A = 2 * NPA + NPB, CNT_B = 2 * NPB + NPA;   // loads of three consecutive phases ending in an A / a B phase
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
@@ -145,15 +151,22 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < NPB; ++i)
-            boff[b][i] = (unsigned)(i * 128 + (u >> 5) * 64 + b * 32 + (u & 31)) * (unsigned)(p.K * 4) + ls * 16;
+        for (int i = 0; i < NPB; ++i) {
+            if constexpr (W16) {   // 128-row piece, lane -> row ua of the piece (tid >> 2), 4 slots per 64-byte row
+                const int row = BWHOLE ? ua : (ua >> 5) * 64 + b * 32 + (ua & 31);
+                boff[b][i] = (unsigned)row * (unsigned)(p.K * 2) + lsa * 16;     // slot key (row >> 2) & 3 == (ua >> 2) & 3
+            } else {
+                boff[b][i] = (unsigned)(i * 128 + (u >> 5) * 64 + b * 32 + (u & 31)) * (unsigned)(p.K * 4) + ls * 16;
+            }
+        }
     const char* const abase = p.x + pp_uniform(aorg);              // uniform
-    const char* const bbase = p.w + pp_uniform((long long)n0 * p.K * 4);   // uniform
+    const char* const bbase = p.w + pp_uniform((long long)n0 * p.K * WSZ);   // uniform
     const int u0 = wave * 8;                       // first row of this wave inside a 64-row piece (wave-uniform)
     const int ua0 = wave * 16;                     // ... inside a 128-row h1 A piece
     // LDS rows of the A tile are the tile's rows; a wave's DMA instruction fills 1 KB = 8 (h2) / 16 (h1) consecutive rows
     const int adst = A16 ? ((ua0 >> 6) * 128 + (ua0 & 63)) * AROWB : u0 * AROWB;   // + (piece*{256|128} + unit*64) * AROWB
-    const int bdst = TILE_A + ((u0 >> 5) * 64 + (u0 & 31)) * ROWB;         // + (piece*128 + unit*32) * ROWB
+    const int bdst = W16 ? TILE_A + (BWHOLE ? ua0 : (ua0 >> 5) * 64 + (ua0 & 31)) * BROWB   // + unit*32 * BROWB (256-wide tile)
+                         : TILE_A + ((u0 >> 5) * 64 + (u0 & 31)) * ROWB;  // + (piece*128 + unit*32) * ROWB
 
     auto tap_off = [&](int c32, int tap) -> long long {
         const int ky = tap / p.KS, kx = tap - ky * p.KS;
@@ -167,13 +180,13 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     auto stage_b = [&](char* buf, int b, long long off) {
         const char* sb = bbase + pp_uniform(off);
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) pp_glds(boff[b][i], sb, buf + bdst + (i * 128 + b * 32) * ROWB);
+        for (int i = 0; i < NPB; ++i) pp_glds(boff[b][i], sb, buf + bdst + (BWHOLE ? 0 : (i * 128 + b * 32) * BROWB));
     };
 
     // ---- fragment addressing: lane -> row lr of a 32-row MFMA tile, k-half lk; slot (s*4 + lk*2 + h) ^ key
     const int lr = lane & 31, lk = lane >> 5, key = (lr >> 1) & 7;
     const int arow = (wr * 128 + lr) * AROWB;                // + (sub*64 + i*32) * AROWB
-    const int brow = TILE_A + (wc * 64 + lr) * ROWB;         // + (sub*32) * ROWB
+    const int brow = TILE_A + (wc * 64 + lr) * BROWB;        // + (sub*32) * BROWB
     int soff[2][2];                                          // [s][h] byte offset of the fragment inside its (128-byte) row
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
 
     if constexpr (SCHED == 1) {
         constexpr bool RF = BM == 256;                 // rows first: phase 0 = {A0, A1, B0}; else {A0, B0, B1}
-        constexpr int N0 = RF ? 2 * NPA + NPB : NPA + 2 * NPB, N1 = RF ? NPB : NPA;    // DMA loads per thread per phase
+        constexpr int N0 = RF ? 2 * NPA + NPB : NPA + (BWHOLE ? 1 : 2 * NPB), N1 = RF ? NPB : NPA;    // DMA loads per thread per phase
         half8 fa2[2][2][2];                            // [half][m-tile i][k16 step s]
         auto read_a2 = [&](const char* buf, int sub) {
 #pragma unroll
@@ -257,15 +270,23 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         auto read_b0 = [&](const char* buf) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                fb0h[s] = *reinterpret_cast<const half8*>(buf + brow + soff[s][0]);
-                fb0l[s] = *reinterpret_cast<const half8*>(buf + brow + soff[s][1]);
+                if constexpr (W16) {
+                    fb0h[s] = *reinterpret_cast<const half8*>(buf + brow + soffa[s]);
+                } else {
+                    fb0h[s] = *reinterpret_cast<const half8*>(buf + brow + soff[s][0]);
+                    fb0l[s] = *reinterpret_cast<const half8*>(buf + brow + soff[s][1]);
+                }
             }
         };
         auto read_b1 = [&](const char* buf) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                fb1h[s] = *reinterpret_cast<const half8*>(buf + brow + 32 * ROWB + soff[s][0]);
-                fb1l[s] = *reinterpret_cast<const half8*>(buf + brow + 32 * ROWB + soff[s][1]);
+                if constexpr (W16) {
+                    fb1h[s] = *reinterpret_cast<const half8*>(buf + brow + 32 * BROWB + soffa[s]);
+                } else {
+                    fb1h[s] = *reinterpret_cast<const half8*>(buf + brow + 32 * BROWB + soff[s][0]);
+                    fb1l[s] = *reinterpret_cast<const half8*>(buf + brow + 32 * BROWB + soff[s][1]);
+                }
             }
         };
 #define PP_MFMA2(ASUB, BSUB, BH, BL)                                                                                   \
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         // prologue: all of k-tile 0, drained
         stage_a(smem, 0, tap_off(0, 0));
         stage_b(smem, 0, 0);
-        stage_b(smem, 1, 0);
+        if constexpr (!BWHOLE) stage_b(smem, 1, 0);
         stage_a(smem, 1, tap_off(0, 0));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_BARRIER();
@@ -308,7 +329,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             const bool traffic = !(MODE & (2 | 8)) || t == 0;
             const bool more1 = (!(MODE & (2 | 16)) || t == 0) && t + 1 < nt;
             const long long offa = tap_off(c1, tap1);
-            const long long offb1 = (long long)(t + 1) * 128;
+            const long long offb1 = (long long)(t + 1) * (32 * WSZ);
             // phase 0
             if (traffic) {
                 read_a2(cur, 0);
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
                 stage_a(nxt, 0, offa);
                 stage_b(nxt, 0, offb1);
                 if constexpr (RF) stage_a(nxt, 1, offa);
-                else stage_b(nxt, 1, offb1);
+                else if constexpr (!BWHOLE) stage_b(nxt, 1, offb1);
             }
             PP_SYNC2(more1, N0);
             PP_MFMA2(0, 0, fb0h, fb0l);
@@ -491,19 +512,20 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
     p.tiles = (p.M / bm) * p.tiles_n;
     const char* e = getenv("DP_H2_PP_MODE");
     const int mode = e ? atoi(e) : 0;
-#define PP_LAUNCH1(BM_, BN_, M_, P_, A_, S_) \
-    hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_, P_, A_, S_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
+#define PP_LAUNCH1(BM_, BN_, M_, P_, A_, S_, W_) \
+    hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_, P_, A_, S_, W_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
     // DP_H2_PP_SCHED: schedule of the fp16-operand kernels (0 = four phases per k-tile, 1 = two); A/B switch
     const char* es = getenv("DP_H2_PP_SCHED");
     const int sched = es ? atoi(es) : DP_H2_PP_SCHED_DEFAULT;
 #define PP_LAUNCH(BM_, BN_, M_)                                          \
     do {                                                                 \
-        if (p.afmt == 1 && p.passes == 2 && sched == 1) PP_LAUNCH1(BM_, BN_, M_, 2, true, 1);   \
-        else if (p.afmt == 1 && p.passes == 2) PP_LAUNCH1(BM_, BN_, M_, 2, true, 0);   \
-        else if (p.afmt == 1 && sched == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 1); \
-        else if (p.afmt == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 0);       \
-        else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false, 0); \
-        else PP_LAUNCH1(BM_, BN_, M_, 3, false, 0);                      \
+        if (p.wfmt == 1) PP_LAUNCH1(BM_, BN_, M_, 1, true, 1, true);     \
+        else if (p.afmt == 1 && p.passes == 2 && sched == 1) PP_LAUNCH1(BM_, BN_, M_, 2, true, 1, false);   \
+        else if (p.afmt == 1 && p.passes == 2) PP_LAUNCH1(BM_, BN_, M_, 2, true, 0, false);   \
+        else if (p.afmt == 1 && sched == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 1, false); \
+        else if (p.afmt == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 0, false);       \
+        else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false, 0, false); \
+        else PP_LAUNCH1(BM_, BN_, M_, 3, false, 0, false);                      \
     } while (0)
     if (bn == 128) {
         PP_LAUNCH(512, 128, 0);

@@ -68,14 +68,15 @@ std::tuple<Tensor, Tensor> conv2d_nhwc_stats(const Tensor& x, const Tensor& wp, 
 }
 
 std::tuple<Tensor, Tensor> conv2d_h2_impl(const Tensor& xh, const Tensor& wh, const c10::optional<Tensor>& bias, int64_t n_out,
-                                          int64_t ksize, int64_t passes, bool want_stats) {
+                                          int64_t ksize, int64_t passes, int64_t w_fmt, bool want_stats) {
     chk_h(xh, "xh");
     chk_h(wh, "wh");
     TORCH_CHECK(xh.dim() == 4 && wh.dim() == 2 && wh.size(0) == n_out, "diffpure_hip: conv2d_h2 operand shapes");
-    const int64_t C = wh.size(1) / (2 * ksize * ksize);
+    TORCH_CHECK(w_fmt == 0 || w_fmt == 1, "diffpure_hip: w_fmt 0 (hi|lo weights) or 1 (plain fp16 weights)");
+    const int64_t C = wh.size(1) / ((w_fmt ? 1 : 2) * ksize * ksize);
     const int a_fmt = xh.size(3) == C ? 1 : 0;                 // plain fp16 ("h1") or hi|lo octets ("h2")
     TORCH_CHECK(a_fmt == 1 || xh.size(3) == 2 * C, "diffpure_hip: activation operand does not match the weight panel");
-    if (passes == 0) passes = a_fmt ? 2 : 3;
+    if (passes == 0) passes = w_fmt ? 1 : (a_fmt ? 2 : 3);
     c10::DeviceGuard guard(xh.device());
     const int64_t B = xh.size(0), H = xh.size(1) - 2, W = xh.size(2) - 2;
     auto fopt = xh.options().dtype(at::kFloat);
@@ -88,15 +89,16 @@ std::tuple<Tensor, Tensor> conv2d_h2_impl(const Tensor& xh, const Tensor& wh, co
     DP_CALL(dp_conv2d_nhwc_h2(xh.data_ptr(), (int)C, (int)B, (int)H, (int)W, (int)ksize, wh.data_ptr(), (int)n_out,
                               opt_ptr(bias, "bias"), nullptr, 0, nullptr, 0, 1.f, out.data_ptr<float>(), (int)n_out,
                               want_stats ? cols.data_ptr<float>() : nullptr, want_stats ? &tile_rows : nullptr,
-                              wbytes ? work.data_ptr() : nullptr, wbytes, (int)passes, a_fmt, cur_stream(xh)));
+                              wbytes ? work.data_ptr() : nullptr, wbytes, (int)passes, a_fmt, (int)w_fmt, cur_stream(xh)));
     return {out, cols};
 }
-Tensor conv2d_h2(const Tensor& xh, const Tensor& wh, const c10::optional<Tensor>& bias, int64_t n_out, int64_t ksize, int64_t passes) {
-    return std::get<0>(conv2d_h2_impl(xh, wh, bias, n_out, ksize, passes, false));
+Tensor conv2d_h2(const Tensor& xh, const Tensor& wh, const c10::optional<Tensor>& bias, int64_t n_out, int64_t ksize, int64_t passes,
+                 int64_t w_fmt) {
+    return std::get<0>(conv2d_h2_impl(xh, wh, bias, n_out, ksize, passes, w_fmt, false));
 }
 std::tuple<Tensor, Tensor> conv2d_h2_stats(const Tensor& xh, const Tensor& wh, const c10::optional<Tensor>& bias, int64_t n_out,
-                                           int64_t ksize, int64_t passes) {
-    return conv2d_h2_impl(xh, wh, bias, n_out, ksize, passes, true);
+                                           int64_t ksize, int64_t passes, int64_t w_fmt) {
+    return conv2d_h2_impl(xh, wh, bias, n_out, ksize, passes, w_fmt, true);
 }
 
 // ---- GroupNorm ---------------------------------------------------------------------------------------------------
@@ -193,8 +195,8 @@ Tensor resize_affine(const Tensor& x, int64_t ho, int64_t wo, double shift, doub
 TORCH_LIBRARY(diffpure_hip, m) {
     m.def("conv2d_nhwc(Tensor x, Tensor wp, Tensor? bias, int n_out, int ksize) -> Tensor");
     m.def("conv2d_nhwc_stats(Tensor x, Tensor wp, Tensor? bias, int n_out, int ksize) -> (Tensor, Tensor)");
-    m.def("conv2d_h2(Tensor xh, Tensor wh, Tensor? bias, int n_out, int ksize, int passes=0) -> Tensor");
-    m.def("conv2d_h2_stats(Tensor xh, Tensor wh, Tensor? bias, int n_out, int ksize, int passes=0) -> (Tensor, Tensor)");
+    m.def("conv2d_h2(Tensor xh, Tensor wh, Tensor? bias, int n_out, int ksize, int passes=0, int w_fmt=0) -> Tensor");
+    m.def("conv2d_h2_stats(Tensor xh, Tensor wh, Tensor? bias, int n_out, int ksize, int passes=0, int w_fmt=0) -> (Tensor, Tensor)");
     m.def("group_norm_stats_from_cols(Tensor cols, int batch, int hw, int groups, float eps) -> Tensor");
     m.def("group_norm_silu(Tensor x, Tensor gamma, Tensor beta, int groups, float eps, bool act, int out_fmt, Tensor? stats=None) -> Tensor");
     m.def("attention(Tensor qkv, int n_heads, bool legacy_layout) -> Tensor");

@@ -132,7 +132,8 @@ class DdpmUNet:
         self.h2mode = precision in ops.H2_MODES
         passes, ofmt = ops.H2_MODES.get(precision, (3, ops.FMT_H2))
         self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
-        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes)
+        self._pool = ops.WeightPool(self.device, stochastic=precision == "f16sr") if precision in ops.W16_MODES else None
+        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes, w_fmt=1 if self._pool is not None else 0)
         self.plan = _plan(cfg)
         self.p = {}
         half = cfg["ch"] // 2
@@ -153,7 +154,7 @@ class DdpmUNet:
 
         def conv_w(k, cin):
             if self.h2mode and cin % 32 == 0:
-                return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
+                return self._pack_h2w(sd[k].detach()), True
             return ops.pack_conv_weight(sd[k].detach()).to(dev), False
 
         P["t0.w"], P["t0.b"] = ops.pack_linear_weight(sd["temb.dense.0.weight"].detach()).to(dev), vec("temb.dense.0.bias")
@@ -171,7 +172,7 @@ class DdpmUNet:
                     # the 1x1 shortcut reads the RAW block input: GroupNorm-apply emits it in operand form as a second output
                     r["h2_s"] = r["h2_0"] and r.get("c1", r["cin"]) % 8 == 0
                     w2 = sd[n + ".nin_shortcut.weight"].detach()
-                    P[n + ".w2"] = ops.pack_conv_weight_h2(w2, dev) if r["h2_s"] else ops.pack_conv_weight(w2).to(dev)
+                    P[n + ".w2"] = self._pack_h2w(w2) if r["h2_s"] else ops.pack_conv_weight(w2).to(dev)
                     P[n + ".c2"] = vec(n + ".nin_shortcut.bias")
                 dw.append(sd[n + ".temb_proj.weight"].detach().float())
                 db.append(sd[n + ".temb_proj.bias"].detach().float())
@@ -181,7 +182,7 @@ class DdpmUNet:
                 P[n + ".g"], P[n + ".b"] = vec(n + ".norm.weight"), vec(n + ".norm.bias")
                 wq = torch.cat([sd[n + f".{j}.weight"].detach().float() for j in ("q", "k", "v")], dim=0)      # [3C, C, 1, 1]
                 r["h2"] = self.h2mode and r["ch"] % 32 == 0
-                P[n + ".wqkv"] = ops.pack_conv_weight_h2(wq, dev) if r["h2"] else ops.pack_conv_weight(wq).to(dev)
+                P[n + ".wqkv"] = self._pack_h2w(wq) if r["h2"] else ops.pack_conv_weight(wq).to(dev)
                 P[n + ".cqkv"] = torch.cat([sd[n + f".{j}.bias"].detach().float() for j in ("q", "k", "v")]).contiguous().to(dev)
                 P[n + ".w3"], P[n + ".c3"] = ops.pack_conv_weight(sd[n + ".proj_out.weight"].detach()).to(dev), vec(n + ".proj_out.bias")
             else:
@@ -191,10 +192,33 @@ class DdpmUNet:
         self.dense_cols = off
         P["out.g"], P["out.b"] = vec("norm_out.weight"), vec("norm_out.bias")
         (P["out.w"], self._out_h2), P["out.c"] = conv_w("conv_out.weight", self.plan["final_ch"]), vec("conv_out.bias")
+        self._resolve_pool(P)
         self.p = P
         return self
 
     # -- blocks ---------------------------------------------------------------------------------------
+    # -- forward-path weights of the fp16-matrix-core convolutions --------------------------------------------------
+    def _pack_h2w(self, w):
+        """h2 (hi|lo) panel, or - precision "f16" / "f16sr" - a slot of the network's fp16 weight pool (ops.WeightPool)"""
+        if self._pool is None:
+            return ops.pack_conv_weight_h2(w, self.device)
+        name = f"w{len(self._pool._pending)}"
+        self._pool.add(name, w)
+        return ops.PoolSlot(name)
+
+    def _resolve_pool(self, P):
+        if self._pool is not None:
+            self._pool.finalize()
+            for k, v in list(P.items()):
+                if isinstance(v, ops.PoolSlot):
+                    P[k] = self._pool.view(v.name)
+
+    def reround(self, key):
+        """precision "f16sr": re-round every fp16 weight panel stochastically for this network call (one launch); the
+        purification loops pass the step index.  No-op in every other mode."""
+        if self._pool is not None:
+            self._pool.round(key)
+
     def _res(self, r, xa, x2a, dense):
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
         x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)

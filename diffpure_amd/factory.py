@@ -31,8 +31,15 @@ def guided_model_defaults():
 
 
 def precision_of(args):
-    """args.precision: "f16x2" (default: fp16 activations x 22-bit split weights, two MFMA passes; purified pixels 1.3e-4 from fp32 over the 100-step loops) | "f16x3" (fp32-class, three passes) | "f16" | "f32"."""
-    return getattr(args, "precision", None) or os.environ.get("DIFFPURE_PRECISION", "f16x2")
+    """args.precision / DIFFPURE_PRECISION - the arithmetic of the 3x3 / 1x1 convolutions that follow a GroupNorm (fp32
+    accumulation, fp32 GroupNorm, residual stream and solver state in every mode):
+      "f16sr" (default) fp16 activations x fp16 weights, one MFMA pass; the fp16 weight panels are re-rounded stochastically
+                        from the fp32 masters before every UNet call (purified pixels 2.2e-4 from the reference over 100 steps)
+      "f16x2"           fp16 activations x 22-bit split weights, two passes (1.3e-4)
+      "f16x3"           22-bit split operands, three passes (4e-6: fp32-class)
+      "f16"             fp16 x fp16 with round-to-nearest weights = the reference's use_fp16 torso (1.0e-3)
+      "f32"             fp32-input MFMA everywhere (1e-6)"""
+    return getattr(args, "precision", None) or os.environ.get("DIFFPURE_PRECISION", "f16sr")
 
 
 def want_synthetic(args):

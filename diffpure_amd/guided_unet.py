@@ -186,7 +186,8 @@ class GuidedUNet:
         self.h2mode = precision in ops.H2_MODES
         passes, ofmt = ops.H2_MODES.get(precision, (3, ops.FMT_H2))
         self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
-        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes)
+        self._pool = ops.WeightPool(torch.device(device), stochastic=precision == "f16sr") if precision in ops.W16_MODES else None
+        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes, w_fmt=1 if self._pool is not None else 0)
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -216,7 +217,7 @@ class GuidedUNet:
         def conv_w(k, cin):
             """-> (packed weight, is_h2)"""
             if self.h2mode and cin % 32 == 0:
-                return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
+                return self._pack_h2w(sd[k].detach()), True
             return ops.pack_conv_weight(sd[k].detach()).to(dev), False
 
         P["te0.w"] = ops.pack_linear_weight(sd["time_embed.0.weight"].detach()).to(dev)
@@ -243,7 +244,7 @@ class GuidedUNet:
                     c1 = r.get("split", r["cin"])
                     r["h2_s"] = r["h2_1"] and c1 % 8 == 0
                     if r["h2_s"]:
-                        P[n + ".ws"] = ops.pack_conv_weight_h2(sd[n + ".skip_connection.weight"].detach(), dev)
+                        P[n + ".ws"] = self._pack_h2w(sd[n + ".skip_connection.weight"].detach())
                     else:
                         P[n + ".ws"] = ops.pack_conv_weight(sd[n + ".skip_connection.weight"].detach()).to(dev)
                     P[n + ".cs"] = vec(n + ".skip_connection.bias")
@@ -264,10 +265,33 @@ class GuidedUNet:
         P["out.g"], P["out.b"] = vec("out.0.weight"), vec("out.0.bias")
         P["out.w"], self._out_h2 = conv_w("out.2.weight", self.plan["final_ch"])
         P["out.c"] = vec("out.2.bias")
+        self._resolve_pool(P)
         self.p = P
         return self
 
     # -- blocks ----------------------------------------------------------------------------------
+    # -- forward-path weights of the fp16-matrix-core convolutions --------------------------------------------------
+    def _pack_h2w(self, w):
+        """h2 (hi|lo) panel, or - precision "f16" / "f16sr" - a slot of the network's fp16 weight pool (ops.WeightPool)"""
+        if self._pool is None:
+            return ops.pack_conv_weight_h2(w, self.device)
+        name = f"w{len(self._pool._pending)}"
+        self._pool.add(name, w)
+        return ops.PoolSlot(name)
+
+    def _resolve_pool(self, P):
+        if self._pool is not None:
+            self._pool.finalize()
+            for k, v in list(P.items()):
+                if isinstance(v, ops.PoolSlot):
+                    P[k] = self._pool.view(v.name)
+
+    def reround(self, key):
+        """precision "f16sr": re-round every fp16 weight panel stochastically for this network call (one launch); the
+        purification loops pass the step index.  No-op in every other mode."""
+        if self._pool is not None:
+            self._pool.round(key)
+
     def _res(self, r, xa, x2a, film_table, tape=None):
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
         x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)

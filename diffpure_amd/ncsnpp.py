@@ -144,7 +144,8 @@ class NCSNpp:
         self.h2mode = precision in ops.H2_MODES
         passes, ofmt = ops.H2_MODES.get(precision, (3, ops.FMT_H2))
         self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
-        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes)
+        self._pool = ops.WeightPool(torch.device(device), stochastic=precision == "f16sr") if precision in ops.W16_MODES else None
+        self._ch2 = functools.partial(ops.conv2d_h2, passes=passes, w_fmt=1 if self._pool is not None else 0)
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -178,7 +179,7 @@ class NCSNpp:
 
         def conv_w(k, cin):
             if self.h2mode and cin % 32 == 0:
-                return ops.pack_conv_weight_h2(sd[k].detach(), dev), True
+                return self._pack_h2w(sd[k].detach()), True
             return ops.pack_conv_weight(sd[k].detach()).to(dev), False
 
         P["t0.w"], P["t0.b"] = ops.pack_linear_weight(sd[M + "0.weight"].detach()).to(dev), vec(M + "0.bias")
@@ -200,7 +201,7 @@ class NCSNpp:
                     # the resampler emit it in operand form, so the 1x1 runs on the fp16 matrix path too
                     r["h2_s"] = r["h2_0"] and r.get("c1", r["cin"]) % 8 == 0
                     if r["h2_s"]:
-                        P[n + ".w2"] = ops.pack_conv_weight_h2(sd[p + ".Conv_2.weight"].detach(), dev)
+                        P[n + ".w2"] = self._pack_h2w(sd[p + ".Conv_2.weight"].detach())
                     else:
                         P[n + ".w2"] = ops.pack_conv_weight(sd[p + ".Conv_2.weight"].detach()).to(dev)
                     P[n + ".c2"] = vec(p + ".Conv_2.bias")
@@ -213,7 +214,7 @@ class NCSNpp:
                 wq = torch.cat([sd[p + f".NIN_{j}.W"].detach().float() for j in range(3)], dim=1)
                 r["h2"] = self.h2mode and r["ch"] % 32 == 0
                 # NIN W is [in, out]; the h2 packer wants [out, in] (conv OI layout)
-                P[n + ".wqkv"] = ops.pack_conv_weight_h2(wq.t().contiguous(), dev) if r["h2"] else ops.pack_nin_weight(wq).to(dev)
+                P[n + ".wqkv"] = self._pack_h2w(wq.t().contiguous()) if r["h2"] else ops.pack_nin_weight(wq).to(dev)
                 P[n + ".cqkv"] = torch.cat([sd[p + f".NIN_{j}.b"].detach().float() for j in range(3)]).contiguous().to(dev)
                 P[n + ".w3"], P[n + ".c3"] = ops.pack_nin_weight(sd[p + ".NIN_3.W"].detach()).to(dev), vec(p + ".NIN_3.b")
         P["dense.w"] = ops.pack_linear_weight(torch.cat(dw, dim=0)).to(dev)
@@ -222,8 +223,31 @@ class NCSNpp:
         gi, ci = self.plan["gn_idx"], self.plan["conv_idx"]
         P["out.g"], P["out.b"] = vec(M + f"{gi}.weight"), vec(M + f"{gi}.bias")
         (P["out.w"], self._out_h2), P["out.c"] = conv_w(M + f"{ci}.weight", self.plan["final_ch"]), vec(M + f"{ci}.bias")
+        self._resolve_pool(P)
         self.p = P
         return self
+
+    # -- forward-path weights of the fp16-matrix-core convolutions --------------------------------------------------
+    def _pack_h2w(self, w):
+        """h2 (hi|lo) panel, or - precision "f16" / "f16sr" - a slot of the network's fp16 weight pool (ops.WeightPool)"""
+        if self._pool is None:
+            return ops.pack_conv_weight_h2(w, self.device)
+        name = f"w{len(self._pool._pending)}"
+        self._pool.add(name, w)
+        return ops.PoolSlot(name)
+
+    def _resolve_pool(self, P):
+        if self._pool is not None:
+            self._pool.finalize()
+            for k, v in list(P.items()):
+                if isinstance(v, ops.PoolSlot):
+                    P[k] = self._pool.view(v.name)
+
+    def reround(self, key):
+        """precision "f16sr": re-round every fp16 weight panel stochastically for this network call (one launch); the
+        purification loops pass the step index.  No-op in every other mode."""
+        if self._pool is not None:
+            self._pool.round(key)
 
     def _res(self, r, xa, x2a, dense, tape=None):
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""

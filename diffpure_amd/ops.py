@@ -89,6 +89,72 @@ def pack_conv_weight_h2(w, device):
     return pack_h2(wk.contiguous().to(device))
 
 
+def order_conv_weight_h2(w):
+    """OIHW / OI / OIk weight -> fp32 panel [N, K] in the reduction order of csrc/igemm_h2.hip (host side)."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, :, None]
+    o, i, kh, kw = w.shape
+    assert i % 32 == 0, i
+    return w.float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).reshape(o, kh * kw * i).contiguous()
+
+
+class PoolSlot:
+    """placeholder of a panel registered with a WeightPool until finalize() hands out the views"""
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+
+class WeightPool:
+    """Every plain-fp16 convolution panel of one network in ONE flat buffer, next to its fp32 masters (same layout), so
+    that (re-)rounding all weights is one kernel launch per network call: `round(key)`.  stochastic=False ("f16"):
+    round to nearest, done once; stochastic=True ("f16sr"): unbiased stochastic rounding keyed by (seed, key) - the
+    solver passes the step index, so the rounding error of the weights differs from step to step and averages out over
+    the loop instead of accumulating as a fixed perturbation of the model (tests/probes/sr_weights_probe.py:
+    purified pixels 2.2e-4 instead of 1.0e-3 from the reference over the 100-step 256^2 loop)."""
+
+    def __init__(self, device, stochastic, seed=0x5EEDC0DE):
+        self.device, self.stochastic, self.seed = torch.device(device), bool(stochastic), int(seed)
+        self._pending, self.master, self.work, self._views, self._last_key = [], None, None, {}, None
+
+    def add(self, name, w):
+        """register the OIHW / OI / OIk weight `w` under `name`; the panel view is available after finalize()"""
+        self._pending.append((name, order_conv_weight_h2(w.detach())))
+
+    def finalize(self):
+        total = sum(p.numel() for _, p in self._pending)
+        pad = (-total) % 8
+        self.master = torch.empty(total + pad, dtype=torch.float32, device=self.device)
+        self.work = torch.empty(total + pad, dtype=torch.float16, device=self.device)
+        if pad:
+            self.master[total:].zero_()
+        off = 0
+        for name, p in self._pending:
+            n = p.numel()
+            self.master[off:off + n].copy_(p.reshape(-1).to(self.device))
+            self._views[name] = self.work[off:off + n].view(p.shape)
+            off += n
+        self._pending = []
+        self.round(0)
+        return self
+
+    def view(self, name):
+        return self._views[name]
+
+    def round(self, key):
+        """master fp32 -> working fp16 panels.  Round-to-nearest pools are rounded once (key ignored afterwards)."""
+        if not self.stochastic and self._last_key is not None:
+            return
+        if self.master is None or self.master.numel() == 0:
+            return
+        _lib.call("dp_round_weights", _ptr(self.master), _ptr(self.work), self.master.numel(), 1 if self.stochastic else 0,
+                  self.seed, int(key), _stream())
+        self._last_key = key
+
+
 def _chk_h2(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
         raise _lib.DiffpureHipError(f"{name}: expected a contiguous fp16 (h2 split format) GPU tensor")
@@ -134,7 +200,10 @@ def _colstats_alloc(m, n, device):
 #   operand format 1 = "h2": per 8 channels [8 x fp16 hi | 8 x fp16 lo]  (4 bytes per element, 22 significant bits)
 #                  2 = "h1": plain fp16                                   (2 bytes per element)
 # Weights are always h2.  See include/diffpure_hip.h (dp_conv2d_nhwc_h2) for the arithmetic of each mode.
-H2_MODES = {"f16x3": (3, 1), "f16x2": (2, 2), "f16": (1, 2), "f16x2w": (12, 1)}
+# "f16" / "f16sr" additionally keep the WEIGHTS as plain fp16 (w_fmt 1): rounded to nearest once at load ("f16"), or
+# re-rounded stochastically from the fp32 masters before every network call ("f16sr": WeightPool.round).
+H2_MODES = {"f16x3": (3, 1), "f16x2": (2, 2), "f16": (1, 2), "f16sr": (1, 2), "f16x2w": (12, 1)}
+W16_MODES = ("f16", "f16sr")
 FMT_F32, FMT_H2, FMT_H1 = 0, 1, 2
 
 
@@ -151,15 +220,16 @@ def _fmt_of(split):
     raise ValueError(f"unknown operand format {split!r}")
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None):
-    """conv2d on the fp16 matrix cores; same epilogue contract as conv2d.  wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2).
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0):
+    """conv2d on the fp16 matrix cores; same epilogue contract as conv2d.  wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2),
+    or with w_fmt=1 the plain fp16 panel [N, K] (WeightPool; one pass, h1 activations).
     x: zero-bordered operand as group_norm(split=...) writes it - h2 [B, H+2, W+2, 2*C] fp16 (three MFMA passes per
     product, `passes` 3, or 12 for the weights-rounded study mode) or h1 [B, H+2, W+2, C] fp16 (`passes` 2 or 1).
-    The operand format is read off the shapes; `passes` defaults to the full arithmetic of the format (3 / 2)."""
+    The activation format is read off the shapes; `passes` defaults to the full arithmetic of the formats (3 / 2 / 1)."""
     _chk_h2(x, "conv2d_h2.x")
     _chk_h2(wh, "conv2d_h2.w")
     b, h, w = x.shape[0], x.shape[1] - 2, x.shape[2] - 2
-    c = wh.shape[1] // (2 * ksize * ksize)
+    c = wh.shape[1] // ((1 if w_fmt else 2) * ksize * ksize)
     if x.shape[3] == 2 * c:
         a_fmt = 0
     elif x.shape[3] == c:
@@ -167,8 +237,8 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     else:
         raise _lib.DiffpureHipError(f"conv2d_h2: operand {tuple(x.shape)} does not match the weight panel {tuple(wh.shape)} (ksize {ksize})")
     if passes is None:
-        passes = 2 if a_fmt else 3
-    assert wh.shape == (n_out, 2 * ksize * ksize * c), (wh.shape, n_out, ksize, c)
+        passes = 1 if w_fmt else (2 if a_fmt else 3)
+    assert wh.shape == (n_out, (1 if w_fmt else 2) * ksize * ksize * c), (wh.shape, n_out, ksize, c)
     if bias is not None:
         _chk(bias, "conv2d_h2.bias", 1)
     ts = 0
@@ -188,7 +258,7 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     work = torch.empty((wbytes // 4,), device=x.device, dtype=torch.float32) if wbytes else None
     _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
               ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _ptr(work), wbytes,
-              int(passes), a_fmt, _stream())
+              int(passes), a_fmt, int(w_fmt), _stream())
     return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
 

@@ -235,7 +235,14 @@ class Purifier:
             self._sched_cache = {key: self.net.time_table(times)}
         return self._sched_cache[key]
 
-    def _eps(self, x, table, k):
+    def _reround(self, k):
+        """precision "f16sr": a fresh stochastic rounding of the fp16 weight panels for UNet call `k` of the loop"""
+        rr = getattr(self.net, "reround", None)
+        if rr is not None:
+            rr(k)
+
+    def _eps(self, x, table, k, key=None):
+        self._reround(k if key is None else key)
         return self.net.forward(x, table_row=table[k:k + 1])
 
     # -- the UNet call of a step as ONE HIP graph launch --------------------------------------------
@@ -257,7 +264,7 @@ class Purifier:
         time-conditioning row that step k's row is copied into, and one graph replay per UNet call."""
         shape = tuple(x.shape)
         if not self._graph_wanted(shape):
-            return x, (lambda k: self._eps(x, table, k))
+            return x, (lambda k, key=None: self._eps(x, table, k, key))
         ent = self._graphs.get(shape)
         if ent is None or ent["row"].shape != table[0:1].shape:
             xs, row = torch.empty_like(x), table[0:1].clone()
@@ -273,8 +280,9 @@ class Purifier:
             ent = self._graphs[shape] = dict(x=xs, row=row, eps=eps, graph=graph)
         ent["x"].copy_(x)
 
-        def eps_of(k, ent=ent):
+        def eps_of(k, key=None, ent=ent):
             ent["row"].copy_(table[k:k + 1])
+            self._reround(k if key is None else key)     # outside the captured graph: the panels are rewritten in place
             ent["graph"].replay()
             return ent["eps"]
 
@@ -317,6 +325,7 @@ class Purifier:
         for k in reversed(range(len(sched))):
             st, en = sched[k], ends[k]
             tape = []
+            self._reround(k)
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             gj = self.net.vjp(tape, a)                      # (d eps / d y)^T a
             del tape
@@ -362,6 +371,7 @@ class Purifier:
         table = self._tables(("ode_rev", t_int, step), sched)
         for k, st in enumerate(sched):
             tape = []
+            self._reround(k)
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             g = self.net.vjp(tape, a)                       # (d eps / d y)^T a
             del tape
@@ -439,7 +449,7 @@ class Purifier:
         for k in range(len(grid) - 1):
             h = grid[k + 1] - grid[k]
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
-            x = ops.em_step(x, eps_of(0), kk, 0.5 * lambda_ld, coef, div, h.item(), g, torch.sqrt(h).item(), noise=z, seed=seed,
+            x = ops.em_step(x, eps_of(0, k), kk, 0.5 * lambda_ld, coef, div, h.item(), g, torch.sqrt(h).item(), noise=z, seed=seed,
                             sample0=sample0, step=k, out=x)
             x.copy_(ops.axpby(x, 1.0, x_init, kk * h.item()))
         return _state_out(x, nhwc).clone() if nhwc and self._graphs else _state_out(x, nhwc)
@@ -463,6 +473,7 @@ class Purifier:
         for k in reversed(range(len(grid) - 1)):
             h = (grid[k + 1] - grid[k]).item()
             tape = []
+            self._reround(k)
             eps = self.net.forward(y, table_row=table[0:1], tape=tape)
             gj = self.net.vjp(tape, a)
             del tape

@@ -93,22 +93,36 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
  *                                   passes 1  = a_hi*w_hi                           ("f16": the arithmetic of the reference's
  *             own use_fp16 torso, /root/reference/configs/imagenet.yml:18, guided_diffusion/unet.py:626-632, with fp32
  *             accumulation and fp32 GroupNorm)
+ *   w_fmt 0 = weights in h2 form (above); w_fmt 1 (with a_fmt 1, passes 1) = PLAIN fp16 weights [N][K'] in the same k'
+ *             order: "f16" when rounded to nearest once at load, "f16sr" when the panel is re-rounded STOCHASTICALLY from
+ *             the fp32 masters before every network call (dp_round_weights) - the rounding error of the weights then
+ *             changes from call to call and averages out over the solver steps like the activation rounding does,
+ *             instead of accumulating coherently as a fixed perturbation of the model.
  *   Measured on the full loops (tests/probes/precision_loops.py, 100 EM steps, max-abs on purified pixels vs the exact
  *   fp32 engine): f16x3 3.9e-6, f16x2 1.3e-4, f16x2w 1.0e-3, f16 1.0e-3 (guided 256^2); 2.3e-6 / 9.4e-5 / 8.6e-4 / 8.6e-4
  *   (NCSN++): rounding the WEIGHTS is what costs accuracy (a fixed perturbation of the model, coherent over the steps),
- *   rounding the activations averages out. */
+ *   rounding the activations averages out; "f16sr": 2.2e-4 (guided) / 1.6e-4 (NCSN++) against the reference modules
+ *   (tests/probes/sr_weights_probe.py, tests/test_gpu_loops.py). */
 int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
                       const float* res, int ldr, float scale,
                       float* out, int ldo, float* colstats, int* tile_rows,
-                      void* work, long long work_bytes, int passes, int a_fmt, void* stream);
+                      void* work, long long work_bytes, int passes, int a_fmt, int w_fmt, void* stream);
 /* Scratch the call above needs for this layer shape (0 for most): low-resolution levels (H*W <= 64) are reduced with
  * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
  * layer shape only, never on B, so that results do not depend on how a batch is sharded. */
 long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, int C, int N);
 /* fp32 [rows][ld] (first `cols` columns, cols % 8 == 0) -> h2 [rows][cols/8][2][8] fp16. */
 int dp_pack_h2(const float* src, long long rows, int cols, int ld, void* dst, void* stream);
+/* fp32 -> fp16 over a flat buffer of n elements (n % 8 == 0; every fp16 weight panel of a network lives in ONE buffer so
+ * that this is one launch per network call).  stochastic = 0: round to nearest even ("f16").  stochastic = 1 ("f16sr"):
+ * unbiased stochastic rounding - a value between two fp16 neighbours goes to either with probability proportional to its
+ * distance from the other - with Philox4x32-10 bits keyed by (seed, key, element index): the same (seed, key) always gives
+ * the same panel (results stay reproducible and independent of batch sharding), different keys give independent roundings
+ * (the solver passes the step index). */
+int dp_round_weights(const float* src, void* dst, long long n, int stochastic, unsigned long long seed, long long key,
+                     void* stream);
 
 /* ---- strided batched GEMM (attention cores, forward and backward) --------------------------------
  * Replaces the einsums at unet.py:355-359 / :389-396 and layerspp.py:82,86 (and their autograd).

@@ -55,18 +55,19 @@ def _h2_hi(t):
     return t.reshape(-1, shp[-1] // 16, 2, 8).double()[:, :, 0].reshape(*shp[:-1], shp[-1] // 2)
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0):
     """Statement of the fp16-matrix-core contract (include/diffpure_hip.h, dp_conv2d_nhwc_h2): exact products of the
     operands each mode keeps - f16x3 (h2 activations, passes 3): (hi+lo) x (hi+lo) (the dropped lo*lo term is ~2^-22
     relative, below the test tolerance); passes 12: (hi+lo) x w_hi; h1 activations (plain fp16): passes 2: a x (w_hi+w_lo),
     passes 1: a x w_hi.  x carries a one-pixel zero border."""
-    cin = wh.shape[1] // (2 * ksize * ksize)
+    cin = wh.shape[1] // ((1 if w_fmt else 2) * ksize * ksize)
     h1 = x.shape[3] == cin
     if passes is None:
-        passes = 2 if h1 else 3
+        passes = 1 if w_fmt else (2 if h1 else 3)
     assert (h1 and passes in (1, 2)) or (not h1 and passes in (3, 12)), (x.shape, wh.shape, passes)
+    assert not w_fmt or (h1 and passes == 1)
     xin = (x.double() if h1 else h2_decode(x))[:, 1:-1, 1:-1, :]
-    wdec = _h2_hi(wh) if passes in (1, 12) else h2_decode(wh)
+    wdec = wh.double() if w_fmt else (_h2_hi(wh) if passes in (1, 12) else h2_decode(wh))
     wf = wdec.reshape(n_out, cin // 32, ksize, ksize, 32)       # [N, c32, ky, kx, 32]
     wt = wf.permute(0, 1, 4, 2, 3).reshape(n_out, cin, ksize, ksize).contiguous()
     y = F.conv2d(xin.permute(0, 3, 1, 2), wt, None, padding=ksize // 2).permute(0, 2, 3, 1)
@@ -78,6 +79,25 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
         y = y + res
     y = (y * scale).float().contiguous()
     return _act(y) if colstats else y
+
+
+def round_weights(master, work, stochastic, seed, key):
+    """torch statement of dp_round_weights: round to nearest, or unbiased stochastic rounding (a DIFFERENT random stream
+    than the kernel's Philox bits - the host-logic tests need the contract, not the bits)."""
+    if not stochastic:
+        work.copy_(master.half())
+        return
+    g = torch.Generator().manual_seed((int(seed) * 1000003 + int(key)) & 0x7FFFFFFF)
+    aw = master.abs()
+    hn = aw.half()
+    bits = hn.view(torch.int16).clone()
+    bits -= (hn.float() > aw).to(torch.int16)                     # towards zero
+    h0 = bits.view(torch.float16)
+    h1 = (bits + 1).view(torch.float16)
+    f0, f1 = h0.float(), h1.float()
+    p = torch.where(aw > f0, (aw - f0) / (f1 - f0), torch.zeros_like(aw))
+    up = torch.rand(aw.shape, generator=g) < p
+    work.copy_(torch.where(up, h1, h0) * torch.sign(master).half())
 
 
 def _act(y):
@@ -349,3 +369,11 @@ def patch_ops(monkeypatch):
     me = sys.modules[__name__]
     for name in PATCHED:
         monkeypatch.setattr(ops, name, getattr(me, name))
+
+    def pool_round(self, key):
+        if not self.stochastic and self._last_key is not None:
+            return
+        round_weights(self.master, self.work, self.stochastic, self.seed, key)
+        self._last_key = key
+
+    monkeypatch.setattr(ops.WeightPool, "round", pool_round)

@@ -7,9 +7,10 @@ kernels key it, so these tests run the PRODUCT path - in-kernel noise, nothing i
 
 Tolerances (north_star: purified pixels within 1e-3 max-abs of the reference at fixed seed):
   purified pixels, 100 steps        max-abs < 1e-3 for every shipped precision mode
-                                    (measured: f32 1e-6, f16x3 4e-6, f16x2 (default) 1.3e-4; tests/probes/precision_loops.py)
+                                    (measured: f32 1e-6, f16x3 4e-6, f16x2 1.3e-4, f16sr (default) 2.2e-4;
+                                    tests/probes/precision_loops.py, sr_weights_probe.py)
   adjoint dL/dx, 100 + 100 steps    max-abs < 5e-3 of the largest entry
-  single forward, whole tensor      max-abs < 1e-3 (f32, f16x3: measured 9e-6) / < 5e-3 (f16x2: measured 1.7e-3 on outputs of
+  single forward, whole tensor      max-abs < 1e-3 (f32, f16x3: measured 9e-6) / < 5e-3 (f16x2: measured 1.7e-3; f16sr < 8e-3) on outputs of
                                     std 0.56 - the fp16 rounding of the activations is a zero-mean perturbation of eps that
                                     enters the state scaled by beta*h/sigma ~ 3e-3 per step and averages out over the loop,
                                     which is why the purified pixels hold 1.3e-4); input gradient of one forward < 2e-3 of
@@ -61,7 +62,7 @@ def maxabs(a, b):
     return (a - b).abs().max().item()
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2", "f16sr"])
 def test_guided_full_forward_whole_tensor_vs_reference_golden(precision):
     """ONE forward of the full 256x256 guided UNet, B=1: every one of the 393 216 outputs (round 1 compared a ::16 crop)."""
     g = load_golden("guided_full.pt")
@@ -71,10 +72,10 @@ def test_guided_full_forward_whole_tensor_vs_reference_golden(precision):
     assert out.shape == g["out"].shape == (1, 6, 256, 256)
     err = maxabs(out, g["out"])
     print(f"guided full forward [{precision}]: max-abs {err:.3e} (output std {g['out_std']:.3f})")
-    assert err < (5e-3 if precision == "f16x2" else 1e-3), err
+    assert err < dict(f16x2=5e-3, f16sr=8e-3).get(precision, 1e-3), err
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16sr"])
 def test_guided_loop_100_steps_vs_reference_golden(precision):
     """BASELINE.json headline loop at B=2: 256x256 guided UNet, t*=0.1, dt=1e-3, 100 Euler-Maruyama steps, product path
     (in-kernel Philox) against the reference modules' loop - including the float32-clock hazards of the 100-step grid
@@ -92,7 +93,7 @@ def test_guided_loop_100_steps_vs_reference_golden(precision):
     assert torch.equal(one, out[1:])
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2", "f16sr"])
 def test_ncsnpp_loop_100_steps_vs_reference_golden(precision):
     """CIFAR-10 NCSN++ (full size), B=4, t*=0.1, dt=1e-3, 100 EM steps (BASELINE.json configs[1] at a small batch)."""
     from diffpure_amd.sde import Purifier
@@ -104,7 +105,7 @@ def test_ncsnpp_loop_100_steps_vs_reference_golden(precision):
     assert err < 1e-3, err
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16sr"])
 def test_config5_adjoint_ode_100_plus_100_steps_vs_reference_golden(precision):
     """BASELINE.json configs[4] at B=2 and FULL length: 100 Euler steps of the probability-flow ODE, then 100 steps of the
     continuous adjoint (dL/dx) - against the reference's VPODE.forward + torch.autograd through the reference NCSNpp."""
@@ -122,7 +123,7 @@ def test_config5_adjoint_ode_100_plus_100_steps_vs_reference_golden(precision):
     assert err_g < 5e-3 * scale, (err_g, scale)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16sr"])
 def test_guided_full_vjp_vs_reference_autograd(precision):
     """Input gradient of one forward of the FULL guided UNet (B=1) against torch.autograd through the reference module."""
     g = load_golden("guided_full_vjp.pt")
@@ -137,4 +138,4 @@ def test_guided_full_vjp_vs_reference_autograd(precision):
     scale = g["dx"].abs().max().item()
     err = maxabs(dx, g["dx"])
     print(f"guided full VJP [{precision}]: max-abs {err:.3e} (largest entry {scale:.3f})")
-    assert err < 2e-3 * scale, (err, scale)
+    assert err < (4e-3 if precision == "f16sr" else 2e-3) * scale, (err, scale)

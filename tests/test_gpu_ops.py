@@ -381,6 +381,89 @@ def test_conv2d_h1_fp16_activations(dev, case, passes, monkeypatch):
     assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
 
 
+@pytest.mark.parametrize("case", H1_CASES, ids=[str(c) for c in H1_CASES])
+def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
+    """Plain fp16 activations x plain fp16 weights (w_fmt 1, one MFMA pass - "f16" / "f16sr"): equals the exact
+    convolution of the two fp16-rounded operands to fp32-class accuracy; every tile variant gives the same bits."""
+    from diffpure_amd import ops
+    B, H, W, C, N, k, temb_rows, has_res, scale = case
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(N, C, k, k, seed=3, scale=1.0 / math.sqrt(C * k * k))
+    bias = rnd(N, seed=4).to(dev)
+    table = rnd(B if temb_rows == 2 else 1, N + 8, seed=5).to(dev) if temb_rows else None
+    res = rnd(B, H, W, N, seed=6).to(dev) if has_res else None
+    ref = torch.nn.functional.conv2d(x.half().double().permute(0, 3, 1, 2), w.half().double(), bias.cpu().double(), padding=k // 2).permute(0, 2, 3, 1)
+    if table is not None:
+        ref = ref + table.cpu()[:, 4:4 + N].double().reshape(-1, 1, 1, N)
+    if res is not None:
+        ref = ref + res.cpu().double()
+    ref = (ref * scale).float()
+    xh = _h1_bordered(x, dev)
+    w16 = ops.order_conv_weight_h2(w).half().to(dev)            # [N, K'] plain fp16 in the kernel's reduction order
+
+    def run():
+        y = ops.conv2d_h2(xh, w16, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale,
+                          colstats=True, w_fmt=1)
+        return y.t, y.cols.buf.clone()
+
+    monkeypatch.setenv("DP_H2_PP", "0")
+    base, base_cs = run()
+    close(base, ref, rtol=2e-5, atol=2e-5)
+    # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
+    y1 = ops.conv2d_h2(xh, ops.pack_conv_weight_h2(w, dev), N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N],
+                       res=res, scale=scale, passes=1)
+    assert torch.equal(y1, base)
+    if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
+        monkeypatch.setenv("DP_H2_PP", "1")
+        for _ in range(4):
+            got, got_cs = run()
+            assert torch.equal(got, base)
+            assert torch.equal(got_cs, base_cs)
+    monkeypatch.delenv("DP_H2_PP")
+    got, got_cs = run()
+    assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
+
+
+def test_round_weights_nearest_and_stochastic(dev):
+    """dp_round_weights: round-to-nearest equals torch's .half(); stochastic rounding returns one of the two fp16
+    neighbours, is unbiased (the mean over many keys converges to the fp32 value), reproducible per (seed, key), and
+    independent between keys - through the fp16 subnormal range and at exactly representable values as well."""
+    from diffpure_amd import ops
+    g = torch.Generator().manual_seed(5)
+    w = torch.cat([torch.randn(4096, generator=g) * 0.02, torch.randn(1024, generator=g) * 3e-5, torch.randn(1024, generator=g) * 2e-7,
+                   torch.tensor([0.0, -0.0, 1.0, -2.5, 6.1035e-05, 65504.0, -65504.0, 1e6]), torch.randn(2040, generator=g) * 30.0])
+    pool = ops.WeightPool(dev, stochastic=False)
+    pool.master, pool.work = w.to(dev), torch.empty(w.numel(), dtype=torch.float16, device=dev)
+    pool.round(0)
+    wc = w.clamp(-65504, 65504)
+    assert torch.equal(pool.work.cpu()[:-2040 - 1], w.half()[:-2040 - 1])          # (1e6 -> inf under RTN, as torch)
+    sr = ops.WeightPool(dev, stochastic=True, seed=99)
+    sr.master, sr.work = w.to(dev), torch.empty(w.numel(), dtype=torch.float16, device=dev)
+    lo = torch.where(w.half().float().abs() > wc.abs(), torch.nextafter(w.half(), torch.zeros(()).half()), w.half())   # towards zero
+    lo = torch.where(lo.float().abs() > 65504, torch.sign(w).half() * 65504, lo)
+    hi = torch.nextafter(lo, (torch.sign(w) * float("inf")).half())
+    acc = torch.zeros_like(w, dtype=torch.float64)
+    n_keys = 400
+    first = None
+    for key in range(n_keys):
+        sr.round(key)
+        got = sr.work.cpu()
+        if key == 0:
+            first = got.clone()
+        ok = (got == lo) | (got == hi)
+        assert ok.all(), (w[~ok][:4], got[~ok][:4], lo[~ok][:4], hi[~ok][:4])
+        acc += got.double()
+    mean = (acc / n_keys).float()
+    ulp = (hi.float() - lo.float()).abs().clamp(max=64.0)
+    exact = lo.float() == wc
+    assert torch.equal(mean[exact], wc[exact])                                      # representable values never move
+    assert ((mean - wc).abs() <= 0.12 * ulp + 1e-12)[~exact & (w.abs() < 65504)].all()   # |bias| well under an ulp / sqrt(n)
+    sr.round(0)
+    assert torch.equal(sr.work.cpu(), first)                                        # keyed: reproducible
+    sr.round(1)
+    assert 0.2 < (sr.work.cpu() != first)[~exact].float().mean() < 0.8              # and independent between keys
+
+
 def test_group_norm_h1_output_is_the_fp16_rounding_of_the_fp32_output(dev):
     from diffpure_amd import ops
     x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)

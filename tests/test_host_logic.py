@@ -142,13 +142,13 @@ def test_philox_reference_stream_is_shard_invariant():
     assert not torch.equal(full, other)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16", "f16sr"])
 @pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
 def test_f16x3_mode_engine_wiring(kind, precision):
     """precision="f16x3" / "f16x2" / "f16": GroupNorm emits the convolution operand format of the mode (split-fp16 "h2" or
     plain fp16 "h1") and the 3x3 / qkv convolutions consume it with pre-split weights; on CPU the ops are the torch
     statements of the same contract."""
-    tol = dict(f16x3=(2e-4, 3e-5), f16x2=(2e-3, 2e-3), f16=(1e-2, 1e-2))[precision]
+    tol = dict(f16x3=(2e-4, 3e-5), f16x2=(2e-3, 2e-3), f16=(1e-2, 1e-2), f16sr=(1e-2, 1e-2))[precision]
     if kind == "ncsnpp":
         g = load_golden("ncsnpp_small.pt")
         cfg = pn.parse_config(g["cfg"])
@@ -161,7 +161,17 @@ def test_f16x3_mode_engine_wiring(kind, precision):
         net = pg.GuidedUNet(cfg, "cpu", precision=precision).load_state_dict(synth_state_dict(pg.param_shapes(cfg), g["seed"]))
         out = nchw(net.forward(nhwc(g["x"]), g["t"].float()))
         assert net._out_h2 and net.p["out.w"].dtype == torch.float16
+        if precision in ("f16", "f16sr"):       # plain fp16 panels: views into ONE pool buffer
+            assert net.p["out.w"].untyped_storage().data_ptr() == net._pool.work.untyped_storage().data_ptr()
     torch.testing.assert_close(out, g["out"], rtol=tol[0], atol=tol[1])
+    if precision == "f16sr":                    # a new key re-rounds the weights: same network, different fp16 panels
+        before = net._pool.work.clone()
+        net.reround(5)
+        changed = (net._pool.work != before).float().mean().item()
+        assert 0.2 < changed < 0.8, changed
+        assert (net._pool.work.float() - net._pool.master).abs().max() <= net._pool.master.abs().max() * 2 ** -10
+        net.reround(0)
+        assert torch.equal(net._pool.work, before)      # keyed: reproducible
     if precision != "f16x3":
         assert (out - g["out"]).abs().max() > 1e-6       # the mode really rounds its operands
 
