@@ -24,6 +24,7 @@ struct ConvH2Args {
     int passes;         // MFMA passes per product: 3 = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi ("f16x3"); 2 = a_hi*w_lo + a_hi*w_hi
                         // (activations rounded to fp16, weights to 22 bits); 12 = a_lo*w_hi + a_hi*w_hi (weights rounded);
                         // 1 = a_hi*w_hi (plain fp16 operands, fp32 accumulation)
+    int stagger;        // igemm_h2_pp.hip: cycles per k-tile and phase of the start-up stagger (0 = none)
     int wfmt;           // weight panel: 0 = h2 (hi|lo), 1 = plain fp16 (afmt 1, passes 1 only)
     int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
 };

@@ -117,7 +117,18 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
-
+    // De-phase the CUs.  Every CU runs its tiles back to back, so without this all 256 reach their epilogues - 256 KB of
+    // stores plus the residual reads each - at the same moments and HBM alternates between bursts and idling.  The first
+    // tile of every CU (the first 256 workgroups) starts (b / 8) % 8 eighths of a tile late; the offset persists for the
+    // rest of the launch.  Only for launches of >= 16 rounds of tiles (the start-up / tail cost is a fraction of one tile).
+    // Measured: +1.5 ... +9 % on isolated back-to-back launches of one shape (tests/probes/pp_ablate.py, B=64) but +0.5 % =
+    // noise on the whole purification (bench.py: 2.989 vs 3.004 images/s), where consecutive launches differ in shape and
+    // other kernels sit between them.  OFF by default (DP_H2_PP_STAGGER=200 switches it on).  Results are unaffected.
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const long long delay = (long long)((blockIdx.x >> 3) & 7) * nt * p.stagger;
+        const long long t0 = __builtin_readcyclecounter();
+        while ((long long)__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(16);
+    }
     // ---- staging geometry: a B unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7.
     // An A unit is the rows {blk*128 + unit*64 + 0..63} of every 128-row block blk of the tile.  h2 operand: one piece per
     // block (64 rows x 128 B, lane -> row u, slot tid & 7); h1 operand: one piece per TWO blocks (128 rows x 64 B, lane ->
@@ -527,6 +538,11 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
         else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false, 0, false); \
         else PP_LAUNCH1(BM_, BN_, M_, 3, false, 0, false);                      \
     } while (0)
+    {   // start-up stagger (see the kernel): cycles per k-tile and phase; off unless DP_H2_PP_STAGGER is set
+        const char* st = getenv("DP_H2_PP_STAGGER");
+        const int v = st ? atoi(st) : 0;
+        p.stagger = p.tiles >= 4096 ? v : 0;
+    }
     if (bn == 128) {
         PP_LAUNCH(512, 128, 0);
         return;

@@ -30,21 +30,23 @@ def timeit(fn, iters):
 def main():
     B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 16
     passes = int(sys.argv[sys.argv.index("--passes") + 1]) if "--passes" in sys.argv else 2
+    w16 = "--w16" in sys.argv          # plain fp16 weights, one pass ("f16" / "f16sr")
     for (H, ci, co) in SHAPES:
         x = torch.randn(B, H, H, ci)
         w = torch.randn(co, ci, 3, 3) * (1.0 / (9 * ci)) ** 0.5
-        wh = ops.pack_conv_weight_h2(w, DEV)
+        wh = ops.order_conv_weight_h2(w).half().to(DEV) if w16 else ops.pack_conv_weight_h2(w, DEV)
         xh = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1)).half().contiguous().to(DEV)
         bias = torch.randn(co, device=DEV)
         flop = 2.0 * B * H * H * co * 9 * ci
         iters = max(3, min(30, int(2e12 / flop)))
-        fn = lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, colstats=True, passes=passes)
+        fn = (lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, colstats=True, w_fmt=1)) if w16 else \
+             (lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, colstats=True, passes=passes))
         os.environ["DP_H2_PP"] = "0"
         base = fn()
         tbase = timeit(fn, iters)
         os.environ["DP_H2_PP"] = "1"
         line = f"{H:4d} {ci:5d}->{co:4d} B={B} | 128x128 {flop / tbase / 1e9:6.0f} TF |"
-        for sched in (0, 1):
+        for sched in ((1,) if w16 else (0, 1)):
             os.environ["DP_H2_PP_SCHED"] = str(sched)
             os.environ["DP_H2_PP_MODE"] = "0"
             y = fn()
