@@ -332,11 +332,12 @@ class GuidedUNet:
         xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
-        if tape is None:
-            a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
-        else:
-            a, probs = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout, return_probs=True)
-            tape.append(dict(r=r, x=x, st=st, qkv=qkv, probs=probs, layout=layout))
+        # The taped forward keeps only qkv: the [B*heads, T, T] probabilities (2.1 GB per 32x32 layer at B=64) are
+        # RECOMPUTED per block in the backward pass, as the reference does by checkpointing exactly these blocks
+        # (guided_diffusion/unet.py:305) - so the forward runs the fused flash kernel with or without a tape.
+        a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
+        if tape is not None:
+            tape.append(dict(r=r, x=x, st=st, qkv=qkv, layout=layout))
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True)
 
     def _run(self, blk, h, h2, film, tape=None):
@@ -460,7 +461,10 @@ class GuidedUNet:
         n, c = r["name"], r["ch"]
         b, hh, ww, _ = dout.shape
         da = ops.conv2d(dout, P[n + ".dwproj"], c, 1)
-        dqkv = ops.attention_bwd(t["qkv"].view(b, hh * ww, 3 * c), t["probs"], da.view(b, hh * ww, c), r["heads"], t["layout"])
+        qkv = t["qkv"].view(b, hh * ww, 3 * c)
+        _, probs = ops.attention(qkv, r["heads"], t["layout"], return_probs=True)      # recomputed, freed after this block
+        dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), r["heads"], t["layout"])
+        del probs
         dxn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
         dx, _ = ops.group_norm_bwd(t["x"], self.GN_GROUPS, P[n + ".g"], P[n + ".b"], t["st"], dxn)
         return ops.add(dx, dout)

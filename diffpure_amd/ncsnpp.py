@@ -290,11 +290,10 @@ class NCSNpp:
         st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS)
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
-        if tape is None:
-            a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
-        else:
-            a, probs = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split", return_probs=True)
-            tape.append(dict(r=r, x=x, st=st, qkv=qkv, probs=probs))
+        # the taped forward keeps only qkv; the probabilities are recomputed per block in the backward pass (see GuidedUNet._attn)
+        a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
+        if tape is not None:
+            tape.append(dict(r=r, x=x, st=st, qkv=qkv))
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True)
 
     def time_table(self, labels):
@@ -407,7 +406,10 @@ class NCSNpp:
         n, c = str(r["idx"]), r["ch"]
         b, hh, ww, _ = dout.shape
         da = ops.conv2d(dout, P[n + ".dw3"], c, 1, scale=INV_SQRT2)
-        dqkv = ops.attention_bwd(t["qkv"].view(b, hh * ww, 3 * c), t["probs"], da.view(b, hh * ww, c), 1, "split")
+        qkv = t["qkv"].view(b, hh * ww, 3 * c)
+        _, probs = ops.attention(qkv, 1, "split", return_probs=True)                   # recomputed, freed after this block
+        dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), 1, "split")
+        del probs
         dhn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
         dx, _ = ops.group_norm_bwd(t["x"], self._groups(c), P[n + ".g"], P[n + ".b"], t["st"], dhn)
         return ops.axpby(dx, 1.0, dout, INV_SQRT2)

@@ -139,3 +139,27 @@ def test_guided_full_vjp_vs_reference_autograd(precision):
     err = maxabs(dx, g["dx"])
     print(f"guided full VJP [{precision}]: max-abs {err:.3e} (largest entry {scale:.3f})")
     assert err < (4e-3 if precision == "f16sr" else 2e-3) * scale, (err, scale)
+
+
+def test_guided_full_stochastic_adjoint_runs_at_batch_8():
+    """The adaptive-attack gradient through the SDE runner on the FULL 256x256 guided UNet at B=8: the taped
+    forward keeps no attention probabilities (recomputed per block in the backward pass, as the reference's checkpointed
+    AttentionBlocks do), so the tape is the activations only.  10 of the 100 steps (dt = 1e-2) to keep the suite short; the
+    per-step memory does not depend on the step count."""
+    from diffpure_amd.sde import Purifier
+    pur = Purifier(guided_full("f16sr"), "guided", DEV)
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.rand(8, 3, 256, 256, generator=gen) * 2 - 1
+    cot = torch.randn(8, 3, 256, 256, generator=gen)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    xf = pur.sde(x0, 100, 1e-2, seed=3, sample0=0)
+    g = (pur.sde_vjp(xf, cot, 100, 1e-2, seed=3, sample0=0) * pur.diffuse_scale(100)).cpu()
+    peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
+    print(f"guided stochastic adjoint B=8: dL/dx abs-mean {g.abs().mean():.3e}, peak working set {peak:.1f} GiB above the resident engines")
+    assert g.shape == x0.shape and torch.isfinite(g).all() and g.abs().max() > 0
+    assert peak < 80, peak
+    # deterministic: the Brownian path is regenerated from the Philox key, nothing stored
+    g2 = (pur.sde_vjp(xf, cot, 100, 1e-2, seed=3, sample0=0) * pur.diffuse_scale(100)).cpu()
+    assert torch.equal(g, g2)
