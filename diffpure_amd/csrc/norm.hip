@@ -136,7 +136,51 @@ struct ApplyArgs {
     float* y;
     int C4, cpg, Ho, Wo;
     char* y_raw;     // optional second output (H2 kernels, resample == 0): the UN-normalised input in bordered h2 form
+    float fir[4];    // resample 3 / 4: the 1-D FIR taps k[0..3] (sum 1) of upfirdn2d's separable filter
 };
+
+// FIR resampling of score_sde's `fir: True` networks (up_or_down_sampling.py:203-265 -> upfirdn2d, op/upfirdn2d_kernel.cu:107-207)
+// for a 4-tap separable filter k (sum 1), zero outside the image, evaluated at one output position from an accessor
+// v(y, x) of the (already activated) source pixels:
+//   up x2   (upsample_2d: kernel 2k per axis, zero insertion, pad (2, 1), correlation with the flipped kernel):
+//           out[2i] = 2 (k[3] x[i-1] + k[1] x[i]),  out[2i+1] = 2 (k[2] x[i] + k[0] x[i+1])      per axis
+//   down x2 (downsample_2d: pad (1, 1)):  out[i] = sum_j k[3-j] x[2i + j - 1]                     per axis
+template <class F>
+__device__ __forceinline__ f32x4 fir_up2(const ApplyArgs& p, int oy, int ox, F v) {
+    const int iy = oy >> 1, ix = ox >> 1;
+    const int ya = (oy & 1) ? iy : iy - 1, xa = (ox & 1) ? ix : ix - 1;
+    const float wy[2] = {2.f * ((oy & 1) ? p.fir[2] : p.fir[3]), 2.f * ((oy & 1) ? p.fir[0] : p.fir[1])};
+    const float wx[2] = {2.f * ((ox & 1) ? p.fir[2] : p.fir[3]), 2.f * ((ox & 1) ? p.fir[0] : p.fir[1])};
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int y = ya + dy, x = xa + dx;
+            if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) continue;
+            const f32x4 s = v(y, x);
+            const float w = wy[dy] * wx[dx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(w, s[j], o[j]);
+        }
+    return o;
+}
+template <class F>
+__device__ __forceinline__ f32x4 fir_down2(const ApplyArgs& p, int oy, int ox, F v) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int y = 2 * oy + dy - 1, x = 2 * ox + dx - 1;
+            if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) continue;
+            const f32x4 s = v(y, x);
+            const float w = p.fir[3 - dy] * p.fir[3 - dx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(w, s[j], o[j]);
+        }
+    return o;
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -259,6 +303,10 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
             } else if (p.resample == 1) {
                 raw = gn_load(p, ((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1), c);
                 o = xf(raw);
+            } else if (p.resample >= 3) {
+                auto src = [&](int y, int x) { return xf(gn_load(p, ((size_t)b * p.H + y) * p.W + x, c)); };
+                o = p.resample == 3 ? fir_up2(p, oy, ox, src) : fir_down2(p, oy, ox, src);
+                raw = o;
             } else {
                 const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
                 const f32x4 v00 = xf(gn_load(p, r0, c)), v01 = xf(gn_load(p, r0 + 1, c));
@@ -357,6 +405,9 @@ __global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
                     o[qd] = xf(((size_t)b * p.H + oy) * p.W + ox);
                 } else if (p.resample == 1) {
                     o[qd] = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
+                } else if (p.resample >= 3) {
+                    auto src = [&](int y, int x) { return xf(((size_t)b * p.H + y) * p.W + x); };
+                    o[qd] = p.resample == 3 ? fir_up2(p, oy, ox, src) : fir_down2(p, oy, ox, src);
                 } else {
                     const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
                     const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
@@ -436,22 +487,25 @@ extern "C" int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, con
 extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                            const float* stats, const float* gamma, const float* beta, const float* fscale,
                            const float* fshift, int film_stride, int act, int resample, int out_fmt, void* y,
-                           void* y_raw, void* stream) {
+                           void* y_raw, const float* fir4, void* stream) {
     const int C = C1 + C2;
     DP_REQUIRE(x1 && y && B > 0 && H > 0 && W > 0, "dp_gn_apply: bad args");
     DP_REQUIRE(C2 == 0 || x2, "dp_gn_apply: x2 missing");
     DP_REQUIRE(C % 4 == 0 && C1 % 4 == 0, "dp_gn_apply: channel counts must be multiples of 4");
     DP_REQUIRE(!gamma || (beta && stats && G > 0 && C % (4 * G) == 0), "dp_gn_apply: need beta, stats and C %% (4*G) == 0");
     DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply: FiLM scale and shift come together");
-    DP_REQUIRE(resample >= 0 && resample <= 2, "dp_gn_apply: resample mode %d", resample);
-    DP_REQUIRE(resample != 2 || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply: 2x2 mean needs even H, W");
+    DP_REQUIRE(resample >= 0 && resample <= 4, "dp_gn_apply: resample mode %d", resample);
+    DP_REQUIRE((resample != 2 && resample != 4) || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply: 2x down-sampling needs even H, W");
+    DP_REQUIRE(resample < 3 || fir4, "dp_gn_apply: the FIR resampling modes (3, 4) need the 4 filter taps");
     DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(y), "dp_gn_apply: misaligned tensor");
     DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply: misaligned FiLM rows");
     DP_REQUIRE(out_fmt == 0 || ((out_fmt == 1 || out_fmt == 2) && C % 8 == 0 && C1 % 8 == 0), "dp_gn_apply: out_fmt %d needs channel counts that are multiples of 8", out_fmt);
     DP_REQUIRE(!y_raw || (out_fmt != 0 && resample == 0), "dp_gn_apply: the raw operand output needs out_fmt=1|2 and no resampling");
     ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
-                C / 4, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
-                resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W), (char*)y_raw};
+                C / 4, gamma ? C / G : C, (resample == 1 || resample == 3) ? 2 * H : ((resample == 2 || resample == 4) ? H / 2 : H),
+                (resample == 1 || resample == 3) ? 2 * W : ((resample == 2 || resample == 4) ? W / 2 : W), (char*)y_raw, {0.f, 0.f, 0.f, 0.f}};
+    if (resample >= 3)
+        for (int i = 0; i < 4; ++i) p.fir[i] = fir4[i];
     const int CV = out_fmt ? C / 8 : C / 4;
     const int CVT = CV < 256 ? CV : 256, slots = 256 / CVT;
     const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));

@@ -28,7 +28,7 @@ def parse_config(cfg):
     """cfg: dict with 'model' and 'data' sections (configs/cifar10.yml)."""
     m, d = cfg["model"], cfg["data"]
     ok = (
-        m["name"] == "ncsnpp" and m["resblock_type"].lower() == "biggan" and not m["fir"]
+        m["name"] == "ncsnpp" and m["resblock_type"].lower() == "biggan"
         and m["progressive"].lower() == "none" and m["progressive_input"].lower() == "none"
         and m["embedding_type"].lower() == "positional" and m["conditional"]
         and m["nonlinearity"].lower() == "swish" and not m["scale_by_sigma"] and d["centered"] and m["skip_rescale"]
@@ -45,6 +45,9 @@ def parse_config(cfg):
         sigma_min=float(m["sigma_min"]),
         sigma_max=float(m["sigma_max"]),
         num_scales=int(m["num_scales"]),
+        # fir: True -> the BigGAN blocks resample with upfirdn2d (layerspp.py:245-258) instead of nearest / mean
+        fir=bool(m.get("fir", False)),
+        fir_kernel=tuple(m.get("fir_kernel", (1, 3, 3, 1))),
     )
 
 
@@ -141,6 +144,7 @@ class NCSNpp:
         self.cfg = cfg
         self.precision = precision
         # fp16-matrix-core convolution path: MFMA passes per product and the operand format GroupNorm-apply emits
+        self._fir = ops.fir_taps(cfg["fir_kernel"]) if cfg.get("fir") else None
         self.h2mode = precision in ops.H2_MODES
         passes, ofmt = ops.H2_MODES.get(precision, (3, ops.FMT_H2))
         self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
@@ -243,6 +247,12 @@ class NCSNpp:
                 if isinstance(v, ops.PoolSlot):
                     P[k] = self._pool.view(v.name)
 
+    def _rmode(self, mode):
+        """plan mode (0 / up / down) -> kernel resampling mode: nearest / mean, or upfirdn2d when the config says fir: True"""
+        if not self._fir or not mode:
+            return mode
+        return ops.RESAMPLE_FIR_UP if mode == ops.RESAMPLE_UP else ops.RESAMPLE_FIR_DOWN
+
     def reround(self, key):
         """precision "f16sr": re-round every fp16 weight panel stochastically for this network call (one launch); the
         purification loops pass the step index.  No-op in every other mode."""
@@ -253,14 +263,15 @@ class NCSNpp:
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
         x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
         P, n, co = self.p, str(r["idx"]), r["cout"]
-        mode = r["mode"]
+        mode = self._rmode(r["mode"])
+        fir = self._fir
         conv0 = self._ch2 if r["h2_0"] else ops.conv2d
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
         st0 = ops.group_norm_stats(xa, self._groups(r["cin"]), self.GN_EPS, x2a)
         h2s = r.get("h2_s", False)
         want_raw = h2s and not mode
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
-                           resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw)
+                           resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw, fir=fir)
         if want_raw:
             h, xraw = h
         off = r["dense_off"]
@@ -272,9 +283,9 @@ class NCSNpp:
         h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
         if mode:
             if h2s:
-                skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+                skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
             else:
-                skip = ops.conv2d(ops.resample(x, mode), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+                skip = ops.conv2d(ops.resample(x, mode, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
         elif want_raw:
             skip = self._ch2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
         elif r["cin"] != co:
@@ -415,6 +426,9 @@ class NCSNpp:
         return ops.axpby(dx, 1.0, dout, INV_SQRT2)
 
     def vjp(self, tape, dout):
+        if self._fir is not None:
+            raise NotImplementedError("input gradients through the FIR (fir: True) resamplers are not built: no DiffPure config "
+                                      "sets fir: True (configs/cifar10.yml:24), only the forward purification path covers it")
         """(d out / d x)^T dout for the forward that filled `tape`; dout [B,H,W,channels] fp32."""
         self.enable_grad()
         P = self.p

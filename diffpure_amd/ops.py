@@ -309,6 +309,34 @@ def linear(x, wp, n_out, bias=None):
 # GroupNorm (+FiLM) (+SiLU) (+resample)
 # ---------------------------------------------------------------------------------------------
 RESAMPLE_NONE, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
+RESAMPLE_FIR_UP, RESAMPLE_FIR_DOWN = 3, 4        # score_sde `fir: True`: upfirdn2d with a separable 4-tap filter
+
+
+def _out_hw(h, w, mode):
+    if mode in (RESAMPLE_UP, RESAMPLE_FIR_UP):
+        return h * 2, w * 2
+    if mode in (RESAMPLE_DOWN, RESAMPLE_FIR_DOWN):
+        return h // 2, w // 2
+    return h, w
+
+
+def fir_taps(kernel):
+    """score_sde `fir_kernel` (e.g. [1, 3, 3, 1]) -> the 4 taps normalised to sum 1, as _setup_kernel does per axis
+    (up_or_down_sampling.py:189-200)."""
+    k = [float(v) for v in kernel]
+    if len(k) != 4:
+        raise NotImplementedError(f"FIR resampling is built for 4-tap separable filters, got {kernel}")
+    s = sum(k)
+    return tuple(v / s for v in k)
+
+
+def _fir_arg(mode, fir):
+    if mode not in (RESAMPLE_FIR_UP, RESAMPLE_FIR_DOWN):
+        return None, None
+    if fir is None or len(fir) != 4:
+        raise _lib.DiffpureHipError("FIR resampling needs the 4 filter taps (ops.fir_taps(fir_kernel))")
+    arr = (ctypes.c_float * 4)(*[float(v) for v in fir])
+    return arr, ctypes.addressof(arr)
 
 
 def _nsplit(hw):
@@ -342,7 +370,7 @@ def group_norm_stats(x, groups, eps, x2=None):
 
 
 def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
-               split=False, raw=False):
+               split=False, raw=False, fir=None):
     """y = resample(act(FiLM(GroupNorm(cat(x, x2))))).  film = (scale [R,C], shift [R,C]) with R in
     {1, B}; the two may be column views of one [R, 2C] tensor (row stride is taken from them).
     split=True / "h2" writes the split-fp16 operand format of conv2d_h2 with its one-pixel zero border
@@ -363,8 +391,9 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         assert fh.shape == fs.shape and fh.stride() == fs.stride()
         assert fs.shape[0] in (1, b)
         fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
-    ho, wo = (h * 2, w * 2) if resample == RESAMPLE_UP else ((h // 2, w // 2) if resample == RESAMPLE_DOWN else (h, w))
+    ho, wo = _out_hw(h, w, resample)
     fmt = _fmt_of(split)
+    fkeep, fptr = _fir_arg(resample, fir)
     if fmt:
         y = torch.empty((b, ho + 2, wo + 2, (2 * c) if fmt == FMT_H2 else c), device=x.device, dtype=torch.float16)
     else:
@@ -374,7 +403,7 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         assert fmt and resample == RESAMPLE_NONE
         yr = torch.empty_like(y)
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), _stream())
+              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), fptr, _stream())
     return (y, yr) if raw else y
 
 
@@ -458,16 +487,17 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
     return dx
 
 
-def to_h2(x, mode=RESAMPLE_NONE, fmt="h2"):
+def to_h2(x, mode=RESAMPLE_NONE, fmt="h2", fir=None):
     """fp32 NHWC -> zero-bordered convolution operand without normalisation, optionally through the 2x resampler
     (`mode`): fmt "h2" -> [B, H'+2, W'+2, 2C] fp16 (hi|lo octets), "h1" -> [B, H'+2, W'+2, C] plain fp16."""
     _chk(x, "to_h2.x", 4)
     b, h, w, c = x.shape
     f = _fmt_of(fmt)
     assert f, fmt
-    ho, wo = (h * 2, w * 2) if mode == RESAMPLE_UP else ((h // 2, w // 2) if mode == RESAMPLE_DOWN else (h, w))
+    ho, wo = _out_hw(h, w, mode)
+    fkeep, fptr = _fir_arg(mode, fir)
     y = torch.empty((b, ho + 2, wo + 2, (2 * c) if f == FMT_H2 else c), device=x.device, dtype=torch.float16)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, f, _ptr(y), None, _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, f, _ptr(y), None, fptr, _stream())
     return y
 
 
@@ -481,13 +511,15 @@ def dgrad_weight(w):
     return w.flip(2, 3).transpose(0, 1).contiguous()
 
 
-def resample(x, mode):
-    """Nearest x2 up (mode 1) or 2x2 mean down (mode 2) of an NHWC tensor, no normalisation."""
+def resample(x, mode, fir=None):
+    """Nearest x2 up (mode 1), 2x2 mean down (2) or the FIR x2 up / down of `fir: True` networks (3 / 4, taps `fir`) of an
+    NHWC tensor, no normalisation."""
     _chk(x, "resample.x", 4)
     b, h, w, c = x.shape
-    ho, wo = (h * 2, w * 2) if mode == RESAMPLE_UP else (h // 2, w // 2)
+    ho, wo = _out_hw(h, w, mode)
+    fkeep, fptr = _fir_arg(mode, fir)
     y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), None, _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), None, fptr, _stream())
     return y
 
 

@@ -151,7 +151,10 @@ int dp_softmax_rows(float* x, long long rows, int cols, void* stream);
  *   fscale/fshift: [B][film_stride] rows or NULL (film_stride 0 broadcasts one row).
  *   gamma == NULL skips the normalisation (pure act/resample of x: the x-branch of a
  *   resampling ResBlock, unet.py:249 / layerspp.py:249,256).
- *   act: 0 none, 1 SiLU.  resample: 0 none, 1 nearest x2 (out 2H x 2W), 2 mean 2x2 (out H/2 x W/2).
+ *   act: 0 none, 1 SiLU.  resample: 0 none, 1 nearest x2 (out 2H x 2W), 2 mean 2x2 (out H/2 x W/2),
+ *   3 / 4 = FIR x2 up / down-sampling of score_sde's `fir: True` networks (up_or_down_sampling.py:203-265, i.e.
+ *   upfirdn2d, op/upfirdn2d_kernel.cu:107-207, for a separable 4-tap filter): fir4 = the 1-D taps normalised to sum 1
+ *   (HOST pointer, read at call time; NULL for the other modes), zeros outside the image.
  *   out_fmt: 0 = fp32 NHWC [B][Ho][Wo][C]; 1 = "h2" split-fp16 with a one-pixel zero border,
  *   [B][Ho+2][Wo+2][C] (see dp_conv2d_nhwc_h2); 2 = "h1" plain fp16 with the same border (a_fmt 1 there).
  *   y_raw (optional, out_fmt=1 and resample=0 only): second output = the UN-normalised input
@@ -169,7 +172,7 @@ int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, const float* c
 int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta,
                 const float* fscale, const float* fshift, int film_stride,
-                int act, int resample, int out_fmt, void* y, void* y_raw, void* stream);
+                int act, int resample, int out_fmt, void* y, void* y_raw, const float* fir4, void* stream);
 
 /* ---- small elementwise pieces ----------------------------------------------------------------*/
 /* y = x * sigmoid(x)   (nn.SiLU on the embedding vector, unet.py:211, layerspp.py:265) */

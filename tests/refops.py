@@ -138,7 +138,33 @@ def group_norm_stats(x, groups, eps, x2=None):
     return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).float()
 
 
-def _resample(y, mode):
+def _upfirdn2d(x_nchw, k2d, up, down, pad0, pad1):
+    """torch statement of upfirdn2d (/root/reference/score_sde/op/upfirdn2d.py:167-211, upfirdn2d_native): zero insertion,
+    zero padding, correlation with the flipped kernel, decimation."""
+    n, c, h, w = x_nchw.shape
+    u = x_nchw.new_zeros(n, c, h * up, w * up)
+    u[:, :, ::up, ::up] = x_nchw
+    u = F.pad(u, (pad0, pad1, pad0, pad1))
+    wk = torch.flip(k2d, [0, 1])[None, None].to(u.dtype)
+    out = F.conv2d(u.reshape(n * c, 1, u.shape[2], u.shape[3]), wk)
+    return out[:, :, ::down, ::down].reshape(n, c, out.shape[2] // down + (out.shape[2] % down > 0), -1)
+
+
+def _fir_resample(y, mode, fir):
+    from diffpure_amd import ops
+    k = torch.tensor(fir, dtype=torch.float64)
+    k2 = torch.outer(k, k)
+    x = y.permute(0, 3, 1, 2).double()
+    if mode == ops.RESAMPLE_FIR_UP:        # upsample_2d: k * factor^2, pad ((p+1)//2 + factor-1, p//2), p = 4 - 2
+        out = _upfirdn2d(x, k2 * 4, 2, 1, 2, 1)
+    else:                                  # downsample_2d: pad ((p+1)//2, p//2)
+        out = _upfirdn2d(x, k2, 1, 2, 1, 1)
+    return out.permute(0, 2, 3, 1).to(y.dtype)
+
+
+def _resample(y, mode, fir=None):
+    if mode in (3, 4):
+        return _fir_resample(y, mode, fir)
     if mode == RESAMPLE_UP:
         return y.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
     if mode == RESAMPLE_DOWN:
@@ -148,7 +174,7 @@ def _resample(y, mode):
 
 
 def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
-               split=False, raw=False):
+               split=False, raw=False, fir=None):
     xin = _cat(x, x2)
     y = F.group_norm(xin.permute(0, 3, 1, 2), groups, gamma, beta, eps).permute(0, 2, 3, 1)
     if film is not None:
@@ -156,7 +182,7 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         y = y * (1 + fs.reshape(-1, 1, 1, fs.shape[-1])) + fh.reshape(-1, 1, 1, fh.shape[-1])
     if act:
         y = F.silu(y)
-    y = _resample(y, resample).contiguous()
+    y = _resample(y, resample, fir).contiguous()
     enc = _operand_encoder(split)
     if raw:
         return enc(F.pad(y, (0, 0, 1, 1, 1, 1))), enc(F.pad(xin, (0, 0, 1, 1, 1, 1)))
@@ -170,8 +196,8 @@ def _operand_encoder(split):
     return {ops.FMT_F32: None, ops.FMT_H2: h2_encode, ops.FMT_H1: lambda t: t.half()}[fmt]
 
 
-def resample(x, mode):
-    return _resample(x, mode).contiguous()
+def resample(x, mode, fir=None):
+    return _resample(x, mode, fir).contiguous()
 
 
 def attention(qkv, n_heads, layout, return_probs=False):
@@ -240,8 +266,8 @@ def add(a, b):
     return a + b
 
 
-def to_h2(x, mode=RESAMPLE_NONE, fmt="h2"):
-    return _operand_encoder(fmt)(F.pad(_resample(x, mode), (0, 0, 1, 1, 1, 1)))
+def to_h2(x, mode=RESAMPLE_NONE, fmt="h2", fir=None):
+    return _operand_encoder(fmt)(F.pad(_resample(x, mode, fir), (0, 0, 1, 1, 1, 1)))
 
 
 def silu(x):

@@ -379,3 +379,37 @@ def test_ldsde_runner_loop_vs_oracle(kind):
     xb = torch.rand(4, *x0.shape[1:], generator=torch.Generator().manual_seed(2)) * 2 - 1
     full = pur.ldsde(xb, 100, 0.001, 0.01, 5, seed=9)
     assert torch.equal(full, torch.cat([pur.ldsde(xb[:1], 100, 0.001, 0.01, 5, seed=9), pur.ldsde(xb[1:], 100, 0.001, 0.01, 5, seed=9, sample0=1)]))
+
+
+def test_checkpoint_format_round_trip_on_the_gpu():
+    """The reference-written checkpoint_8.pth-shaped file (tests/golden/make_golden_ckpt.py) through factory.build_ncsnpp on
+    the HIP engine, every precision mode, against the output of the reference module after ITS restore path."""
+    import argparse
+    import os
+    from conftest import GOLDEN
+    from diffpure_amd import factory
+    g = load_golden("ncsnpp_ckpt.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    for precision, tol in (("f32", 1e-4), ("f16x3", 1e-4), ("f16sr", 2e-2)):
+        net, _ = factory.build_ncsnpp(argparse.Namespace(precision=precision), ns(g["cfg"]), DEV, model_dir=os.path.join(GOLDEN, "ckpt"))
+        out = nchw(net.forward(nhwc(g["x"]).to(DEV), g["labels"].to(DEV))).cpu()
+        assert maxabs(out, g["out"]) < tol, (precision, maxabs(out, g["out"]))
+
+
+def test_ncsnpp_fir_forward_vs_reference_golden():
+    """`fir: True` NCSN++ (upfirdn2d resampling in the BigGAN blocks) on the HIP engine against the
+    reference module's forward (tests/golden/make_golden_fir.py)."""
+    from diffpure_amd import ncsnpp as pn
+    g = load_golden("ncsnpp_fir_small.pt")
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    for precision, tol in (("f32", 1e-4), ("f16x3", 1e-4), ("f16sr", 2e-2)):
+        net = pn.NCSNpp(cfg, DEV, precision).load_state_dict(sd)
+        out = nchw(net.forward(nhwc(g["x"]).to(DEV), g["labels"].to(DEV))).cpu()
+        assert maxabs(out, g["out"]) < tol, (precision, maxabs(out, g["out"]))

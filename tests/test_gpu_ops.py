@@ -464,6 +464,29 @@ def test_round_weights_nearest_and_stochastic(dev):
     assert 0.2 < (sr.work.cpu() != first)[~exact].float().mean() < 0.8              # and independent between keys
 
 
+@pytest.mark.parametrize("mode", [3, 4])
+def test_fir_resampling_upfirdn2d(dev, mode):
+    """`fir: True` resampling (upfirdn2d with the separable [1,3,3,1] filter) inside GroupNorm-apply: against the
+    reference's own upsample_2d / downsample_2d (golden fir_ops.pt), and - fused behind GroupNorm + SiLU, every output
+    format, channel-split input - against the torch statement of the same operator."""
+    from conftest import load_golden
+    from diffpure_amd import ops
+    g = load_golden("fir_ops.pt")
+    taps = ops.fir_taps(g["k"])
+    x = g["x"].permute(0, 2, 3, 1).contiguous()
+    got = ops.resample(x.to(dev), mode, fir=taps).cpu().permute(0, 3, 1, 2)
+    close(got, g["up"] if mode == 3 else g["down"], rtol=1e-5, atol=1e-6)
+    x1, x2 = (rnd(2, 8, 12, 96, seed=1) * 2 + 0.5).to(dev), rnd(2, 8, 12, 32, seed=2).to(dev)
+    gamma, beta = (1 + 0.1 * rnd(128, seed=3)).to(dev), (0.1 * rnd(128, seed=4)).to(dev)
+    ref = refops.group_norm(x1.cpu(), 32, 1e-6, gamma.cpu(), beta.cpu(), x2=x2.cpu(), act=True, resample=mode, fir=taps)
+    y32 = ops.group_norm(x1, 32, 1e-6, gamma, beta, x2=x2, act=True, resample=mode, fir=taps)
+    close(y32, ref, rtol=2e-5, atol=2e-5)
+    pad = torch.nn.functional.pad(y32.cpu(), (0, 0, 1, 1, 1, 1))
+    assert torch.equal(ops.group_norm(x1, 32, 1e-6, gamma, beta, x2=x2, act=True, resample=mode, fir=taps, split="h1").cpu(), pad.half())
+    assert torch.equal(ops.group_norm(x1, 32, 1e-6, gamma, beta, x2=x2, act=True, resample=mode, fir=taps, split="h2").cpu(), refops.h2_encode(pad))
+    assert torch.equal(ops.to_h2(x1, mode, fmt="h1", fir=taps).cpu(), torch.nn.functional.pad(ops.resample(x1, mode, fir=taps).cpu(), (0, 0, 1, 1, 1, 1)).half())
+
+
 def test_group_norm_h1_output_is_the_fp16_rounding_of_the_fp32_output(dev):
     from diffpure_amd import ops
     x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)

@@ -381,3 +381,56 @@ def test_sample_offset_separates_ranks_of_an_unsharded_evaluation(monkeypatch):
     assert _common.sample_offset(argparse.Namespace(sample_offset=77)) == 77
     monkeypatch.setattr(_common.ddist, "world", lambda: (3, 8))
     assert _common.sample_offset(argparse.Namespace()) == 3 << 40
+
+
+def test_checkpoint_format_round_trip_through_the_factory():
+    """a checkpoint_8.pth-shaped file written and restored by the REFERENCE's own code
+    (tests/golden/make_golden_ckpt.py: 'model' entry with module.-prefixed keys that strict=False ignores, effective weights =
+    the EMA shadow list in parameters() order) loads through diffpure_amd.factory.build_ncsnpp and gives the reference's output."""
+    import argparse
+    import os
+    from conftest import GOLDEN
+    from diffpure_amd import factory
+    g = load_golden("ncsnpp_ckpt.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    args = argparse.Namespace(precision="f32")          # no synthetic_weights: the file must be found and used
+    net, cfg = factory.build_ncsnpp(args, ns(g["cfg"]), "cpu", model_dir=os.path.join(GOLDEN, "ckpt"))
+    out = nchw(net.forward(nhwc(g["x"]), g["labels"]))
+    torch.testing.assert_close(out, g["out"], rtol=2e-4, atol=2e-5)
+    with pytest.raises(FileNotFoundError):
+        factory.build_ncsnpp(args, ns(g["cfg"]), "cpu", model_dir=os.path.join(GOLDEN, "no_such_dir"))
+    ck = torch.load(os.path.join(GOLDEN, "ckpt", "checkpoint_8.pth"), map_location="cpu")
+    bad = dict(ck, ema=dict(ck["ema"], shadow_params=ck["ema"]["shadow_params"][:-1]))
+    with pytest.raises(ValueError):
+        factory.ncsnpp_state_from_checkpoint(bad, pn.parse_config(g["cfg"]))
+
+
+def test_fir_resamplers_match_the_reference_upfirdn2d():
+    """tests/refops.py's statement of the FIR modes (what the HIP kernels are held to on the GPU) against
+    up_or_down_sampling.upsample_2d / downsample_2d of the reference (golden: tests/golden/make_golden_fir.py)."""
+    from diffpure_amd import ops
+    g = load_golden("fir_ops.pt")
+    taps = ops.fir_taps(g["k"])
+    x = nhwc(g["x"])
+    torch.testing.assert_close(nchw(refops.resample(x, ops.RESAMPLE_FIR_UP, fir=taps)), g["up"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(nchw(refops.resample(x, ops.RESAMPLE_FIR_DOWN, fir=taps)), g["down"], rtol=1e-5, atol=1e-6)
+
+
+def test_ncsnpp_fir_engine_wiring():
+    """`fir: True` NCSN++ (upfirdn2d resampling in the BigGAN blocks) against the reference module's forward."""
+    g = load_golden("ncsnpp_fir_small.pt")
+    cfg = pn.parse_config(g["cfg"])
+    assert cfg["fir"] and cfg["fir_kernel"] == (1, 3, 3, 1)
+    net = pn.NCSNpp(cfg, "cpu").load_state_dict(synth_state_dict(pn.param_shapes(cfg), g["seed"]))
+    out = nchw(net.forward(nhwc(g["x"]), g["labels"]))
+    torch.testing.assert_close(out, g["out"], rtol=2e-4, atol=2e-5)
+    plain = load_golden("ncsnpp_small.pt")
+    assert (g["out"] - plain["out"]).abs().max() > 1e-2 or not torch.equal(g["x"], plain["x"])    # fir changes the function
+    with pytest.raises(NotImplementedError):
+        net.vjp([], torch.zeros(1))
