@@ -195,6 +195,68 @@ def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
                        "oracle = torch-CPU fp32 restatement of the reference modules (pinned to them by tests/golden)")
 
 
+def timed_region(a, world, one_call, fence, before_first=None, after_first=None):
+    """W untimed warm-up calls, then exactly K timed calls bracketed by fence() on both sides; -> (seconds as the MAX over
+    ranks, result of the last call).  Shared by the real bench and the CPU harness test."""
+    for i in range(a.warmup):
+        one_call(i)
+    fence()
+    t0 = time.time()
+    y = None
+    for i in range(a.steps):
+        if i == 0 and before_first:
+            before_first()
+        y = one_call(a.warmup + i)
+        if i == 0 and after_first:
+            after_first()
+    fence()
+    el = time.time() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=y.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    return el, y
+
+
+def stub_main(a, rank, world):
+    """--stub-engine: the distributed harness of this file (rank / world from the launcher's environment, per-rank batch,
+    global sample indices, all_gather of the shards inside the timed region, barrier + MAX-over-ranks timing, one JSON line
+    from rank 0) on CPU ranks over gloo.  The stand-in "purifies" x -> 0.5 x + (global sample index), so the gathered result
+    is checkable."""
+    if world > 1:
+        dist.init_process_group("gloo")
+    B, hw = a.batch or 4, 8
+    gen = torch.Generator().manual_seed(a.seed + rank)
+    x = torch.rand(B, 3, hw, hw, generator=gen) * 2 - 1
+    gathered = torch.empty((world * B, 3, hw, hw)) if world > 1 else None
+
+    def one_call(i):
+        idx = torch.arange(rank * B, rank * B + B, dtype=torch.float32).view(-1, 1, 1, 1)
+        y = x * 0.5 + idx
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y)
+        return y
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    el, y = timed_region(a, world, one_call, fence)
+    ok = True
+    if world > 1:      # every rank sees every shard, in rank order
+        ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], y))
+        for r in range(world):
+            ok = ok and bool((gathered[r * B:(r + 1) * B].mean(dim=(1, 2, 3)) - torch.arange(r * B, r * B + B)).abs().max() < 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (harness test, not a measurement)", "stub": True, "value": world * B * a.steps / el,
+                          "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "stub", "data": "synthetic",
+                          "config": {"workload": "stub", "per_gpu_batch": B, "global_batch": world * B}, "gather_ok": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +273,10 @@ def main():
                          "HIP-graph step of small batches, which is never used while that profiler records")
     ap.add_argument("--precision", default="f16sr", choices=["f32", "f16x3", "f16x2", "f16", "f16sr"],
                     help="f32: fp32-input MFMA; f16x3: split-fp16 3-pass MFMA (fp32-class accuracy)")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="TEST HOOK (tests/test_bench_multirank.py): run the launch / sharding / all_gather / timing harness on CPU "
+                         "ranks over gloo with a stand-in for the purification engine; the line it prints is marked stub and is "
+                         "not a measurement")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,6 +284,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if a.stub_engine:
+        return stub_main(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the purification engine has no CPU path)")
     torch.cuda.set_device(local)
@@ -260,36 +328,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        one_call(i)
-    fence()
     # Instrumentation: per-launch hipEvents on the convolution launches of the FIRST timed step only (sampling: a 100-step
     # purification is 8 600 3x3 launches, the record buffer holds 65 536, and event pairs around every launch of every
     # step would sit inside the timed region for nothing); its GPU window is bracketed by two events on the same stream.
     sample = not a.no_conv_profile
     win0, win1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     clock = SclkSampler(dev)
-    clock.start()
-    t0 = time.time()
-    for i in range(a.steps):
-        if i == 0 and sample:
+
+    def before_first():
+        if sample:
             win0.record()
             ops.prof_enable(True)
-        y = one_call(a.warmup + i)
-        if i == 0 and sample:
+
+    def after_first():
+        if sample:
             ops.prof_enable(False)
             win1.record()
-    fence()
-    el = time.time() - t0
+
+    clock.start()
+    el, y = timed_region(a, world, one_call, fence, before_first, after_first)
     sclk = clock.stop()
     prof = ops.prof_collect() if sample else None
     window_ms = win0.elapsed_time(win1) if sample else None
     assert torch.isfinite(y).all()
 
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = t.item()
     images = world * B * a.steps
     value = images / el
 

@@ -1,0 +1,47 @@
+"""bench.py's multi-rank branch executed for real - the driver's own launch line (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`), two CPU ranks over gloo,
+with `--stub-engine` standing in for the purification engine: rank / world from the launcher's environment, per-rank
+shards keyed by global sample index, the all_gather inside the timed region, barrier + MAX-over-ranks timing, ONE JSON line
+from rank 0.  (No 8-GPU node is available to the builder; the RCCL path differs from this one in the backend name only.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_launch_gather_and_timing_harness(n):
+    if n == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--stub-engine"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+               "--stub-engine"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["stub"] is True and d["n_gpus"] == n and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["global_batch"] == n * d["config"]["per_gpu_batch"]
+    assert d["gather_ok"] is True
+    assert abs(d["value"] - d["config"]["global_batch"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
+
+
+def test_bench_refuses_a_world_size_that_does_not_match_gpus():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
