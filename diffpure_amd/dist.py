@@ -36,8 +36,14 @@ def _gather_rows(local, per, n, ws, group):
     because slices are contiguous)."""
     send = local.new_zeros((per,) + tuple(local.shape[1:]))
     send[: local.shape[0]] = local
-    recv = local.new_empty((ws * per,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo ranks driving GPUs (tests on a single-GPU box: two ranks share the device): stage through the host
+        recv_h = torch.empty((ws * per,) + tuple(local.shape[1:]), dtype=local.dtype)
+        dist.all_gather_into_tensor(recv_h, send.cpu().contiguous(), group=group)
+        recv = recv_h.to(local.device)
+    else:
+        recv = local.new_empty((ws * per,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     return recv if ws * per == n else recv[:n].contiguous()
 
 

@@ -1,0 +1,78 @@
+"""-m gpu: TWO ranks of the REAL engine (one GPU box: both ranks drive cuda:0, gloo carries the all-gather through the
+host).  The batch-sharded runner call must reproduce the single-process result bit for bit - forward (Philox keyed by
+the global sample index) and the gradient an adaptive attack takes through it (per-rank adjoint solve + all-gather)."""
+import argparse
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ns(d):
+    n = argparse.Namespace()
+    for k, v in d.items():
+        setattr(n, k, _ns(v) if isinstance(v, dict) else v)
+    return n
+
+
+def _run(shard, n):
+    from runners.diffpure_sde import RevGuidedDiffusion
+    g = load_golden("ncsnpp_small.pt")
+    config = _ns(g["cfg"])
+    config.device = torch.device("cuda:0")
+    args = argparse.Namespace(t=100, rand_t=True, t_delta=10, use_bm=False, sample_step=1, log_dir=None, score_type="score_sde", seed=4321,
+                              synthetic_weights=True, dt=2e-2, shard_batch=shard)
+    runner = RevGuidedDiffusion(args, config, device=config.device)
+    x = (torch.rand(n, 3, 16, 16, generator=torch.Generator().manual_seed(8)) * 2 - 1).to("cuda:0")
+    with torch.no_grad():
+        out = runner.image_editing_sample(x, bs_id=9)
+    runner._calls = 0
+    xg = x.clone().requires_grad_(True)
+    o2 = runner.image_editing_sample(xg, bs_id=9)
+    cot = torch.randn(o2.shape, generator=torch.Generator().manual_seed(9)).to("cuda:0")
+    (gx,) = torch.autograd.grad((o2 * cot).sum(), xg)
+    return out.cpu(), o2.detach().cpu(), gx.cpu()
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out, o2, gx = _run(True, n)
+        q.put((rank, out, o2, gx))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [4, 3])
+def test_two_rank_sharded_runner_equals_single_process_bitwise(n):
+    ref_out, ref_o2, ref_g = _run(True, n)                # world size 1: shard_batch is a no-op, global indices 0..n-1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out, o2, gx in res:
+        assert torch.equal(out, ref_out), rank           # every rank holds the whole purified batch
+        assert torch.equal(o2, ref_o2), rank
+        assert torch.equal(gx, ref_g), rank              # and the whole dL/dx
