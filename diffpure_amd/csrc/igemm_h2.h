@@ -32,3 +32,8 @@ struct ConvH2Args {
 // 8-wave "ping-pong" variants (igemm_h2_pp.hip): bn = 256 -> 256x256 tiles (needs M % 256 == 0, N % 256 == 0),
 // bn = 128 -> 512x128 tiles (M % 512 == 0, N % 128 == 0); C % 32 == 0.  Fills p.tiles / p.tiles_n itself.
 void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn);
+
+// 2-D halo-tile variant of the 256x256 ping-pong kernel for 3x3 convolutions with fp16 activations and fp16 weights
+// (igemm_h2_halo.hip).  dp_conv_halo_applies: shape / format test; the launcher fills p.tiles / p.tiles_n itself.
+bool dp_conv_halo_applies(const ConvH2Args& p, int min_w);
+void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);

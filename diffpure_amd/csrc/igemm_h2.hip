@@ -500,6 +500,13 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         else if (pp != 0 && p.M % 256 == 0 && N % 256 == 0 && (pp == 1 || fills(256, 256))) bn = 256;
         else if (pp != 0 && p.M % 512 == 0 && N % 128 == 0 && (pp == 1 || fills(512, 128))) bn = 128;
         if (bn) {
+            // 3x3, fp16 x fp16: the halo-tile variant (one activation DMA per channel slice instead of one per tap);
+            // DP_H2_HALO = 0: never (per-tap kernel), 1: whenever the shape allows (W >= 16), unset: where it measured
+            // faster (W >= 32).  Both kernels give identical bits.
+            const char* eh = getenv("DP_H2_HALO");
+            const int hv = eh ? atoi(eh) : 2;
+            if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
+            else
             dp_launch_conv_h2_pp(p, s, bn);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;

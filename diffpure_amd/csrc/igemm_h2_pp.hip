@@ -38,33 +38,15 @@
 #include <stdlib.h>
 
 #include "igemm_h2.h"
+#include "igemm_pp_common.h"
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int NT = 512;
 constexpr int NXCD = 8;
 constexpr int ROWB = 128;               // bytes per LDS row: 32 channels as (hi, lo) fp16 octets
 constexpr int DP_H2_PP_SCHED_DEFAULT = 1;   // measured (tests/probes/pp_ablate.py, B=16): 621-661 vs 495-635 TFLOP/s, bit-identical
-
-// LDS-DMA with (scalar base + 32-bit lane offset) addressing, spelled in asm: the builtin lets the
-// compiler strength-reduce the k-loop addresses back into 64-bit VGPR pointers (two VALU adds and two
-// address VGPRs per DMA).  M0 = LDS destination of lane 0 (wave-uniform); lane l lands at M0 + 16 l.
-// make a wave-uniform 64-bit value provably scalar for the compiler
-__device__ __forceinline__ long long pp_uniform(long long v) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const char* lds_dst) {
-    const unsigned m0v = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :
-                 : "v"(voff), "s"(sbase), "s"(m0v)
-                 : "memory");
-}
-#define PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 // MODE (timing experiments, DP_H2_PP_MODE): bit 0 = no s_setprio; bit 1 = no operand traffic after k-tile 0 (WRONG
 // RESULTS); bit 2 = no barriers in the k-loop (WRONG RESULTS); bit 3 = no ds_reads / bit 4 = no DMA after k-tile 0 / bit 5 = no vmcnt waits (WRONG RESULTS)
@@ -313,8 +295,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     } while (0)
 #define PP_SYNC2(COUNTED, CNT)                                                      \
     do {                                                                            \
-        if (COUNTED) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");     \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+        if constexpr (!(MODE & 32)) {                                               \
+            if (COUNTED) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
+        }                                                                           \
         PP_BARRIER();                                                               \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
         __builtin_amdgcn_sched_barrier(0);                                          \
@@ -448,71 +432,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    const float* __restrict__ resp = p.res;
-    const float* __restrict__ tembp = p.temb;
-    float* __restrict__ outp = p.out;
-    const bool hw32 = HW % 32 == 0;          // a 32-row block lies inside one sample: one temb value per block
-    // One 32-row block at a time, both 32-column blocks inside it: a row's address is formed once and serves both
-    // column blocks (+128 bytes), 32 residual loads are in flight per lane.  (Column block outermost makes the compiler
-    // keep all 64 row addresses = 128 VGPRs live from one column block to the next next to the 128 accumulators: ~110
-    // spilled values and -5 % on the whole kernel.)
-    const int col0 = n0 + wc * 64 + lr;
-    float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
-    float cs[4][2], cq[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
-        float rv[2][16];
-        float tv[2];
-        if (resp) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* rp = resp + (size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col0;
-                rv[0][r] = rp[0];
-                rv[1][r] = rp[32];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
-            cs[i][j] = 0.f;
-            cq[i][j] = 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rowb + (r & 3) + 8 * (r >> 2);
-            float* op = outp + (size_t)row * p.ldo + col0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v = acc[i][j][r] + bv[j];
-                if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
-                if (resp) v += rv[j][r];
-                v *= p.scale;
-                op[j * 32] = v;
-                cs[i][j] += v;
-                cq[i][j] += v * v;
-            }
-        }
-        if (p.colstats) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                cs[i][j] += __shfl_xor(cs[i][j], 32, 64);
-                cq[i][j] += __shfl_xor(cq[i][j], 32, 64);
-            }
-        }
-    }
-    if (p.colstats && lk == 0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float* d = p.colstats + (size_t)(tile_m * (BM / 64) + wr * 2 + q) * 2 * p.N + col0 + j * 32;
-                d[0] = cs[2 * q][j] + cs[2 * q + 1][j];
-                d[p.N] = cq[2 * q][j] + cq[2 * q + 1][j];
-            }
-    }
+    pp_epilogue<BM>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
 }
 
 }  // namespace
@@ -553,6 +473,7 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
         case 6: PP_LAUNCH(256, 256, 6); break;
         case 8: PP_LAUNCH(256, 256, 8); break;
         case 16: PP_LAUNCH(256, 256, 16); break;
+        case 32: PP_LAUNCH(256, 256, 32); break;
         case 256: PP_LAUNCH(256, 256, 256); break;
         default: PP_LAUNCH(256, 256, 0); break;
     }

@@ -52,7 +52,7 @@ std::tuple<Tensor, Tensor> conv2d_nhwc_impl(const Tensor& x, const Tensor& wp, c
     Tensor out = at::empty({B, H, W, n_out}, x.options());
     Tensor cols;
     int tile_rows = 0;
-    if (want_stats) cols = at::empty({(B * H * W + 63) / 64, 2, n_out}, x.options());
+    if (want_stats) cols = at::zeros({(B * H * W + 511) / 512 * 8, 2, n_out}, x.options());   // whole 512-row tiles: see ops._colstats_alloc
     DP_CALL(dp_conv2d_nhwc(x.data_ptr<float>(), (int)x.size(3), nullptr, 0, (int)B, (int)H, (int)W, (int)ksize, (int)ksize,
                            wp.data_ptr<float>(), (int)wp.size(1), (int)n_out, opt_ptr(bias, "bias"), nullptr, 0, nullptr, 0, 1.f,
                            out.data_ptr<float>(), (int)n_out, 0, want_stats ? cols.data_ptr<float>() : nullptr,
@@ -83,7 +83,7 @@ std::tuple<Tensor, Tensor> conv2d_h2_impl(const Tensor& xh, const Tensor& wh, co
     Tensor out = at::empty({B, H, W, n_out}, fopt);
     Tensor cols, work;
     int tile_rows = 0;
-    if (want_stats) cols = at::empty({(B * H * W + 63) / 64, 2, n_out}, fopt);
+    if (want_stats) cols = at::zeros({(B * H * W + 511) / 512 * 8, 2, n_out}, fopt);   // whole 512-row tiles: see ops._colstats_alloc
     const long long wbytes = dp_conv2d_nhwc_h2_workspace((int)B, (int)H, (int)W, (int)ksize, (int)C, (int)n_out);
     if (wbytes) work = at::empty({wbytes / 4}, fopt);
     DP_CALL(dp_conv2d_nhwc_h2(xh.data_ptr(), (int)C, (int)B, (int)H, (int)W, (int)ksize, wh.data_ptr(), (int)n_out,

@@ -193,7 +193,14 @@ def tensor_of(x):
 
 
 def _colstats_alloc(m, n, device):
-    return torch.empty(((m + 63) // 64, 2, n), device=device, dtype=torch.float32), ctypes.c_int(0)
+    """[records][2][n] with one record per 64 output rows.  A tile writes ALL the records of its rows (2 / 4 / 8 per tile of
+    128 / 256 / 512 rows), also those that lie wholly beyond a ragged M: the buffer is rounded up to whole 512-row tiles and
+    the tail beyond ceil(M / 64) is zeroed (round 1 allocated ceil(M / 64) records: a ragged M wrote past the end)."""
+    rec, rec_pad = (m + 63) // 64, (m + 511) // 512 * 8
+    buf = torch.empty((rec_pad, 2, n), device=device, dtype=torch.float32)
+    if rec_pad > rec:
+        buf[rec:].zero_()
+    return buf, ctypes.c_int(0)
 
 
 # precision name -> (MFMA passes per product, activation operand format of the fp16-matrix-core convolutions)

@@ -58,7 +58,8 @@ int dp_prof_collect(double* ms, long long* n, double* flop, double* bytes, long 
  *   bias [N] or NULL; temb [B][temb_stride] or NULL (temb_stride 0 broadcasts one row);
  *   res [M][ldr] or NULL; out [M][ldo].
  * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation).
- * colstats (optional): [ceil(M/64)][2][N] floats; for every record of 64 consecutive output rows the
+ * colstats (optional): [ceil(M/512)*8][2][N] floats (one record per 64 rows, ROUNDED UP to whole 512-row tiles: a tile writes all
+ *   the records of its rows, also those wholly beyond a ragged M); for every record of 64 consecutive output rows the
  *   per-column sum and sum of squares of the FINAL values, reduced inside the epilogue in an order that
  *   does not depend on the tile shape the dispatcher picks (bit-identical for any batch sharding).
  *   *tile_rows returns the record size (64).  dp_gn_finalize_cols turns the records into the GroupNorm

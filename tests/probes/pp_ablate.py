@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from diffpure_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
-SHAPES = [(256, 256, 256), (256, 512, 256), (64, 512, 512), (32, 512, 512)]
+SHAPES = [(256, 256, 256), (256, 512, 256), (128, 256, 256), (64, 512, 512), (32, 512, 512), (16, 1024, 1024)]
 
 
 def timeit(fn, iters):
@@ -46,18 +46,28 @@ def main():
         tbase = timeit(fn, iters)
         os.environ["DP_H2_PP"] = "1"
         line = f"{H:4d} {ci:5d}->{co:4d} B={B} | 128x128 {flop / tbase / 1e9:6.0f} TF |"
+        if w16:     # halo-tile variant against the per-tap kernel
+            os.environ["DP_H2_PP_MODE"] = "0"
+            tt = {}
+            for halo in ("0", "1"):
+                os.environ["DP_H2_HALO"] = halo
+                y = fn()
+                ok = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
+                tt[halo] = (flop / timeit(fn, iters) / 1e9, ok)
+            line += f" per-tap {tt['0'][0]:5.0f} halo {tt['1'][0]:5.0f} [{'ok' if tt['1'][1] and tt['0'][1] else 'DIFF'}] |"
+            os.environ["DP_H2_HALO"] = "0"
         for sched in ((1,) if w16 else (0, 1)):
             os.environ["DP_H2_PP_SCHED"] = str(sched)
             os.environ["DP_H2_PP_MODE"] = "0"
             y = fn()
             same = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
             res = []
-            for mode in (0, 2, 8, 16, 256):
+            for mode in (0, 2, 8, 16, 32, 256):
                 os.environ["DP_H2_PP_MODE"] = str(mode)
                 res.append(f"m{mode}:{flop / timeit(fn, iters) / 1e9:5.0f}")
             line += f" sched{sched} [{'ok' if same else 'DIFF'}] " + " ".join(res) + " |"
         print(line, flush=True)
-    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE"):
+    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO"):
         os.environ.pop(k, None)
 
 
