@@ -37,3 +37,7 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn);
 // (igemm_h2_halo.hip).  dp_conv_halo_applies: shape / format test; the launcher fills p.tiles / p.tiles_n itself.
 bool dp_conv_halo_applies(const ConvH2Args& p, int min_w);
 void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);
+
+// One-wave-per-SIMD software-pipelined variant (igemm_h2_sw.hip): fp16 x fp16, 256x256 tile, 4 waves of 128x128.
+bool dp_conv_sw_applies(const ConvH2Args& p);
+void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s);

@@ -505,7 +505,11 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             // faster (W >= 32).  Both kernels give identical bits.
             const char* eh = getenv("DP_H2_HALO");
             const int hv = eh ? atoi(eh) : 2;
-            if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
+            // fp16 x fp16, N % 256 == 0: the one-wave-per-SIMD software-pipelined kernel (igemm_h2_sw.hip) - measured
+            // fastest on every shape of both networks (tests/probes/pp_ablate.py --w16); DP_H2_SW=0 falls back
+            const char* esw = getenv("DP_H2_SW");
+            if (bn == 256 && (!esw || atoi(esw) != 0) && dp_conv_sw_applies(p)) dp_launch_conv_sw(p, s);
+            else if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
             else
             dp_launch_conv_h2_pp(p, s, bn);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);

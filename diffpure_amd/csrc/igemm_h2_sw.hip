@@ -1,0 +1,272 @@
+// fp16 x fp16 implicit-GEMM convolution, 256x256 tile, ONE WAVE PER SIMD, software-pipelined ("sw").
+//
+// The 8-wave ping-pong kernels (igemm_h2_pp.hip, igemm_h2_halo.hip) are bound, with one MFMA pass per product, by the load
+// segment of a phase: per k-tile a wave has 16 MFMAs (512 cycles) against 12 ds_read_b128, 2-4 LDS-DMA issues and two
+// barrier pairs, and the partner wave's load segment outlasts its own MFMA segment.  This kernel
+// changes the ratio instead of the schedule: 4 waves per workgroup, one per SIMD, each owning a 128 x 128 wave tile
+// (4 x 4 MFMA tiles of 32x32 = 256 accumulator registers of the 512 a lone wave may use).  Per k-tile (32 channels of one
+// tap) a wave issues 32 MFMAs (1024 cycles) and only 16 ds_read_b128 + 8 LDS-DMA, which the compiler interleaves into the
+// MFMA shadows (an MFMA hides up to ~5 single-issue instructions, MI355X_MICROARCH.md); fragments are double-buffered in
+// registers (the reads of k16 step s+1 fly under the MFMAs of step s), operands are staged three k-tiles ahead into a
+// four-stage LDS ring (128 KB), and there is ONE barrier per k-tile:
+//
+//   iteration t:  ds_read fragments (t, s=1) ; then  issue DMA of k-tile t+3 -> stage (t+3) % 4  | 16 MFMA (t, s=0)
+//                 s_waitcnt vmcnt(16)  [k-tile t+1 of THIS wave has landed; t+2, t+3 may fly] ; s_barrier
+//                 ds_read fragments (t+1, s=0)          | 16 MFMA (t, s=1)
+//   RAW: every wave waits for its own share of k-tile t+1 before the barrier of iteration t; the reads follow it.
+//   WAR: stage (t+3) % 4 held k-tile t-1, whose last reads (s=1) precede the barrier of iteration t-1, which the issuing
+//        wave has passed and every other wave has reached.
+// Same operand formats, reduction order and epilogue arithmetic as the other variants: bit-identical output.
+// Needs: fp16 activations and weights (a_fmt 1, w_fmt 1, passes 1), M % 256 == 0, N % 256 == 0, C % 32 == 0.
+#include <stdlib.h>
+
+#include "igemm_h2.h"
+#include "igemm_pp_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NXCD = 8;
+constexpr int NB = 4, DIST = 3;                 // LDS ring stages, prefetch distance in k-tiles
+constexpr int TILE = 256 * 64;                  // one operand tile of a k-tile: 256 rows x 64 bytes (32 fp16)
+constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
+
+#define SW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// MODE (timing ablations, DP_H2_SW_MODE; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait, 4 = no ds_reads
+template <int MODE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    int tile;
+    {   // XCD-aware bijective remap (speed only)
+        const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
+    }
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
+    const int nt = p.K / 32;
+
+    // ---- staging: wave w fills rows [64 w, 64 w + 64) of the A tile and of the B tile, 16 rows per DMA instruction;
+    // lane -> row (lane >> 2) of the group, physical slot lane & 3, logical slot XOR-ed with the row key (row >> 2) & 3
+    const int lrow = lane >> 2;
+    const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
+    const char* actr[4];                        // centre pixel of the lane's A row, + slot
+    const char* bptr[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int m = m0 + wave * 64 + it * 16 + lrow;
+        const int b = m / HW, rem = m - b * HW;
+        const int oy = rem / p.W, ox = rem - oy * p.W;
+        actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
+        bptr[it] = p.w + (size_t)(n0 + wave * 64 + it * 16 + lrow) * p.K * 2 + ls * 16;
+    }
+    int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next k-tile to stage
+    auto issue = [&](int stage) {
+        const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;       // tap / 3 for tap < 9, no division
+        const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
+        char* As = smem + stage * STAGE + wave * 64 * 64;
+        char* Bs = As + TILE;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + off),
+                                             (__attribute__((address_space(3))) void*)(As + it * 16 * 64), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
+                                             (__attribute__((address_space(3))) void*)(Bs + it * 16 * 64), 16, 0, 0);
+            bptr[it] += 64;
+        }
+        if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+    };
+
+    // ---- fragments: lane -> row lr of a 32-row MFMA tile, k-half lk; 64-byte rows, slot (s*2 + lk) ^ key, key = (row >> 2) & 3
+    const int lr = lane & 31, lk = lane >> 5;
+    const int arow = (wr * 128 + lr) * 64;                  // + i * 32 * 64
+    const int brow = TILE + (wc * 128 + lr) * 64;           // + j * 32 * 64
+    int soff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) soff[s] = ((s * 2 + lk) ^ ((lr >> 2) & 3)) << 4;
+    half8 fa[2][4], fb[2][4];                               // [register set = k16 step][tile]
+    auto read_frags = [&](int set, const char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const half8*>(st + arow + i * 32 * 64 + soff[set]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const half8*>(st + brow + j * 32 * 64 + soff[set]);
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfma_rows = [&](int set, int i0, int i1) {           // MFMA tile rows [i0, i1) of k16 step `set`
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: k-tiles 0 .. DIST-1 in flight, k-tile 0 landed, fragments (0, s=0) read
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < nt) issue(d);
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SW_BARRIER();
+    read_frags(0, smem);
+
+    // steady state (one basic block: the compiler interleaves the loads with the MFMAs): k-tile t+DIST exists
+    int t = 0;
+    for (; t + DIST < nt; ++t) {
+        const char* st = smem + (t & (NB - 1)) * STAGE;
+        // Instruction order, pinned with sched_group_barrier (left alone the compiler sinks the fragment reads towards their
+        // use, and the wave then waits for LDS with an idle matrix pipe).  Each half of a k-tile runs 16 MFMAs on one fragment
+        // set and, BEHIND its first MFMA, issues the 8 reads of the other set one per MFMA shadow, then the 8 DMA issues of
+        // k-tile t+3 one per MFMA shadow: the lgkmcnt wait before a half's first MFMA finds reads issued >= 8 MFMAs earlier.
+        if constexpr (!(MODE & 4)) read_frags(1, st);
+        if constexpr (!(MODE & 1)) issue((t + DIST) & (NB - 1));
+        mfma_rows(0, 0, 4);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(MODE & 3)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // k-tile t+1 (this wave's share) has landed; t+2, t+3 may fly
+        if constexpr (!(MODE & 2)) SW_BARRIER();
+        if constexpr (!(MODE & 4)) read_frags(0, smem + ((t + 1) & (NB - 1)) * STAGE);
+        mfma_rows(1, 1, 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // tail: the last DIST k-tiles, nothing left to stage
+    for (; t < nt; ++t) {
+        const char* st = smem + (t & (NB - 1)) * STAGE;
+        mfma_rows(0, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1, st);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(0, 1, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SW_BARRIER();
+        if (t + 1 < nt) read_frags(0, smem + ((t + 1) & (NB - 1)) * STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 1, 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: the arithmetic and the column-record order of pp_epilogue (igemm_pp_common.h) on a 128 x 128 wave tile
+    const float* __restrict__ resp = p.res;
+    const float* __restrict__ tembp = p.temb;
+    float* __restrict__ outp = p.out;
+    const bool hw32 = HW % 32 == 0;
+    const int col0 = n0 + wc * 128 + lr;
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                   // one 64-row column record = two 32-row MFMA tiles
+        float cs[2][4], cq[2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * q + ii;
+            const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
+            float tv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
+                cs[ii][j] = 0.f;
+                cq[ii][j] = 0.f;
+            }
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {        // two column tiles at a time: 32 residual loads in flight per lane
+                float rv[2][16];
+                if (resp) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float* rp = resp + (size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col0 + jh * 64;
+                        rv[0][r] = rp[0];
+                        rv[1][r] = rp[32];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rowb + (r & 3) + 8 * (r >> 2);
+                    float* op = outp + (size_t)row * p.ldo + col0 + jh * 64;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = jh * 2 + jj;
+                        float v = acc[i][j][r] + bv[j];
+                        if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
+                        if (resp) v += rv[jj][r];
+                        v *= p.scale;
+                        op[jj * 32] = v;
+                        cs[ii][j] += v;
+                        cq[ii][j] += v * v;
+                    }
+                }
+            }
+            if (p.colstats) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[ii][j] += __shfl_xor(cs[ii][j], 32, 64);
+                    cq[ii][j] += __shfl_xor(cq[ii][j], 32, 64);
+                }
+            }
+        }
+        if (p.colstats && lk == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col0 + j * 32;
+                d[0] = cs[0][j] + cs[1][j];
+                d[p.N] = cq[0][j] + cq[1][j];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool dp_conv_sw_applies(const ConvH2Args& p) {
+    return p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % 256 == 0 && p.N % 256 == 0 && p.C % 32 == 0;
+}
+
+void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s) {
+    p.tiles_n = p.N / 256;
+    p.tiles = (p.M / 256) * p.tiles_n;
+    const char* e = getenv("DP_H2_SW_MODE");
+    switch (e ? atoi(e) : 0) {
+        case 1: hipLaunchKernelGGL(conv_igemm_sw<1>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(conv_igemm_sw<2>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(conv_igemm_sw<3>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(conv_igemm_sw<4>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
+        case 7: hipLaunchKernelGGL(conv_igemm_sw<7>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
+        default: hipLaunchKernelGGL(conv_igemm_sw<0>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
+    }
+}

@@ -56,18 +56,28 @@ def main():
                 tt[halo] = (flop / timeit(fn, iters) / 1e9, ok)
             line += f" per-tap {tt['0'][0]:5.0f} halo {tt['1'][0]:5.0f} [{'ok' if tt['1'][1] and tt['0'][1] else 'DIFF'}] |"
             os.environ["DP_H2_HALO"] = "0"
+            os.environ["DP_H2_SW"] = "1"          # one wave per SIMD, software-pipelined (igemm_h2_sw.hip)
+            y = fn()
+            ok = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
+            line += f" sw {flop / timeit(fn, iters) / 1e9:5.0f} [{'ok' if ok else 'DIFF'}]"
+            for m in (1, 2, 3, 4, 7):
+                os.environ["DP_H2_SW_MODE"] = str(m)
+                line += f" m{m}:{flop / timeit(fn, iters) / 1e9:5.0f}"
+            os.environ["DP_H2_SW_MODE"] = "0"
+            line += " |"
+            os.environ["DP_H2_SW"] = "0"
         for sched in ((1,) if w16 else (0, 1)):
             os.environ["DP_H2_PP_SCHED"] = str(sched)
             os.environ["DP_H2_PP_MODE"] = "0"
             y = fn()
             same = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
             res = []
-            for mode in (0, 2, 8, 16, 32, 256):
+            for mode in (0,):
                 os.environ["DP_H2_PP_MODE"] = str(mode)
                 res.append(f"m{mode}:{flop / timeit(fn, iters) / 1e9:5.0f}")
             line += f" sched{sched} [{'ok' if same else 'DIFF'}] " + " ".join(res) + " |"
         print(line, flush=True)
-    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO"):
+    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW"):
         os.environ.pop(k, None)
 
 

@@ -414,6 +414,19 @@ def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
     monkeypatch.setenv("DP_H2_PP", "0")
     base, base_cs = run()
     close(base, ref, rtol=2e-5, atol=2e-5)
+    # every 256x256 variant: per-tap ping-pong, halo-tile ping-pong, one-wave-per-SIMD software-pipelined
+    if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64):
+        monkeypatch.setenv("DP_H2_PP", "1")
+        for sw, halo in (("0", "0"), ("0", "1"), ("1", "0")):
+            monkeypatch.setenv("DP_H2_SW", sw)
+            monkeypatch.setenv("DP_H2_HALO", halo)
+            for _ in range(3):
+                got, got_cs = run()
+                assert torch.equal(got, base), (sw, halo)
+                assert torch.equal(got_cs, base_cs), (sw, halo)
+        monkeypatch.delenv("DP_H2_SW")
+        monkeypatch.delenv("DP_H2_HALO")
+        monkeypatch.setenv("DP_H2_PP", "0")
     # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
     y1 = ops.conv2d_h2(xh, ops.pack_conv_weight_h2(w, dev), N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N],
                        res=res, scale=scale, passes=1)
