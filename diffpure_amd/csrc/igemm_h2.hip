@@ -123,8 +123,15 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     for (int it = 0; it < B_IT; ++it) {
         const int n = n0 + r0 + it * RPP;
         const bool ok = n < p.N;
-        bptr[it] = ok ? p.w + (size_t)n * p.K * WSZ + ls * 16 : p.zero + ls * 16;
-        bstep[it] = ok ? ROWB : 0;
+        if constexpr (W16) {    // block layout of the fp16 panels (ops.order_conv_weight_w16): 16-byte piece (n, k'/8 = g) at
+                                // ((n/32 * K/8 + g) * 32 + n%32) * 16; a 32-channel k-tile = 4 groups = 2048 bytes further on
+            static_assert(BKH == 32, "fp16 weight panels are staged one 32-channel k-tile at a time");
+            bptr[it] = ok ? p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512 : p.zero + ls * 16;
+            bstep[it] = ok ? 2048 : 0;
+        } else {
+            bptr[it] = ok ? p.w + (size_t)n * p.K * WSZ + ls * 16 : p.zero + ls * 16;
+            bstep[it] = ok ? ROWB : 0;
+        }
     }
 
     // workgroup-uniform cursor of the k-stage being staged, in weight order: 32-channel slice c32 outermost,

@@ -78,8 +78,11 @@ __global__ __launch_bounds__(NT) void conv_igemm_halo(ConvH2Args p) {
     // ---- weight staging: B unit b = rows {64 wc' + 32 b + 0..31}: one 128-row piece per unit
     unsigned boff[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) boff[b] = (unsigned)((ua >> 5) * 64 + b * 32 + (ua & 31)) * (unsigned)(p.K * 2) + lsa * 16;
-    const char* const bbase = p.w + pp_uniform((long long)n0 * p.K * 2);
+    for (int b = 0; b < 2; ++b) {   // row (ua >> 5) * 64 + b * 32 + (ua & 31) of the tile, block layout of the fp16 panels
+        const int row = (ua >> 5) * 64 + b * 32 + (ua & 31);
+        boff[b] = (unsigned)(row >> 5) * (unsigned)(p.K * 64) + (row & 31) * 16 + lsa * 512;
+    }
+    const char* const bbase = p.w + pp_uniform((long long)(n0 >> 5) * p.K * 64);
     const int bdst = ((ua0 >> 5) * 64 + (ua0 & 31)) * 64;
     auto stage_b = [&](char* buf, int b, long long off) {
         pp_glds(boff[b], bbase + pp_uniform(off), buf + bdst + b * 32 * 64);
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_halo(ConvH2Args p) {
         char* bnxt = bt + ((t + 1) & 1) * TILE_B;
         const bool more1 = t + 1 < nt;
         const bool piece_now = tap < np && c + 1 < nsl;          // halo piece `tap` of the next slice rides with this k-tile
-        const long long offb1 = (long long)(t + 1) * 64;
+        const long long offb1 = (long long)(t + 1) * 2048;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int tsh = ky * Wp + kx;
 

@@ -147,13 +147,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
         for (int i = 0; i < NPB; ++i) {
             if constexpr (W16) {   // 128-row piece, lane -> row ua of the piece (tid >> 2), 4 slots per 64-byte row
                 const int row = BWHOLE ? ua : (ua >> 5) * 64 + b * 32 + (ua & 31);
-                boff[b][i] = (unsigned)row * (unsigned)(p.K * 2) + lsa * 16;     // slot key (row >> 2) & 3 == (ua >> 2) & 3
+                // block layout of the fp16 panels (ops.order_conv_weight_w16); slot key (row >> 2) & 3 == (ua >> 2) & 3
+                boff[b][i] = (unsigned)(row >> 5) * (unsigned)(p.K * 64) + (row & 31) * 16 + lsa * 512;
             } else {
                 boff[b][i] = (unsigned)(i * 128 + (u >> 5) * 64 + b * 32 + (u & 31)) * (unsigned)(p.K * 4) + ls * 16;
             }
         }
     const char* const abase = p.x + pp_uniform(aorg);              // uniform
-    const char* const bbase = p.w + pp_uniform((long long)n0 * p.K * WSZ);   // uniform
+    const char* const bbase = p.w + pp_uniform(W16 ? (long long)(n0 >> 5) * p.K * 64 : (long long)n0 * p.K * WSZ);   // uniform
     const int u0 = wave * 8;                       // first row of this wave inside a 64-row piece (wave-uniform)
     const int ua0 = wave * 16;                     // ... inside a 128-row h1 A piece
     // LDS rows of the A tile are the tile's rows; a wave's DMA instruction fills 1 KB = 8 (h2) / 16 (h1) consecutive rows
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
             const bool traffic = !(MODE & (2 | 8)) || t == 0;
             const bool more1 = (!(MODE & (2 | 16)) || t == 0) && t + 1 < nt;
             const long long offa = tap_off(c1, tap1);
-            const long long offb1 = (long long)(t + 1) * (32 * WSZ);
+            const long long offb1 = (long long)(t + 1) * (W16 ? 2048 : 32 * WSZ);      // fp16 panels: 4 groups of 512 bytes per k-tile
             // phase 0
             if (traffic) {
                 read_a2(cur, 0);

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const int b = m / HW, rem = m - b * HW;
         const int oy = rem / p.W, ox = rem - oy * p.W;
         actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
-        bptr[it] = p.w + (size_t)(n0 + wave * 64 + it * 16 + lrow) * p.K * 2 + ls * 16;
+        const int n = n0 + wave * 64 + it * 16 + lrow;              // block layout of the fp16 panels (ops.order_conv_weight_w16)
+        bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
     int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next k-tile to stage
     auto issue = [&](int stage) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int it = 0; it < 4; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
                                              (__attribute__((address_space(3))) void*)(Bs + it * 16 * 64), 16, 0, 0);
-            bptr[it] += 64;
+            bptr[it] += 2048;
         }
         if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
     };

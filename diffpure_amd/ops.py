@@ -100,6 +100,28 @@ def order_conv_weight_h2(w):
     return w.float().reshape(o, i // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).reshape(o, kh * kw * i).contiguous()
 
 
+def order_conv_weight_w16(w):
+    """OIHW / OI / OIk weight -> the PLAIN-fp16 weight panel layout (w_fmt 1) as an fp32 tensor [N32, K] (N32 = N rounded up
+    to 32 rows, zero rows appended), to be rounded to fp16 element by element.  Flat element order: 32-row blocks outermost,
+    then the 8-element k' groups of the reduction order, then the 32 rows, then the 8 elements -
+        index(n, k') = (((n / 32) * (K / 8) + k' / 8) * 32 + n % 32) * 8 + k' % 8
+    so that the (lane-ordered) B fragment of one 32x32x16 MFMA - 32 rows x 2 groups - is 1 KB of contiguous memory (a wave loads
+    it with one coalesced 16-byte-per-lane instruction, igemm_h2_sw.hip) and a 64-byte LDS row of a 32-channel k-tile is four
+    16-byte pieces 512 bytes apart (the LDS-DMA loaders gather them: every lane has its own address anyway)."""
+    wk = order_conv_weight_h2(w)                        # [N, K] in reduction order
+    n, k = wk.shape
+    n32 = (n + 31) // 32 * 32
+    if n32 != n:
+        wk = torch.cat([wk, wk.new_zeros(n32 - n, k)], dim=0)
+    return wk.reshape(n32 // 32, 32, k // 8, 8).permute(0, 2, 1, 3).reshape(n32, k).contiguous()
+
+
+def unorder_conv_weight_w16(panel, n_out):
+    """inverse of order_conv_weight_w16: [N32, K] panel -> [n_out, K] in plain reduction order (tests / host checks)"""
+    n32, k = panel.shape
+    return panel.reshape(n32 // 32, k // 8, 32, 8).permute(0, 2, 1, 3).reshape(n32, k)[:n_out]
+
+
 class PoolSlot:
     """placeholder of a panel registered with a WeightPool until finalize() hands out the views"""
     __slots__ = ("name",)
@@ -122,7 +144,7 @@ class WeightPool:
 
     def add(self, name, w):
         """register the OIHW / OI / OIk weight `w` under `name`; the panel view is available after finalize()"""
-        self._pending.append((name, order_conv_weight_h2(w.detach())))
+        self._pending.append((name, order_conv_weight_w16(w.detach())))
 
     def finalize(self):
         total = sum(p.numel() for _, p in self._pending)
@@ -229,7 +251,8 @@ def _fmt_of(split):
 
 def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0):
     """conv2d on the fp16 matrix cores; same epilogue contract as conv2d.  wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2),
-    or with w_fmt=1 the plain fp16 panel [N, K] (WeightPool; one pass, h1 activations).
+    or with w_fmt=1 the plain fp16 panel [N32, K] in the block layout of order_conv_weight_w16 (WeightPool; one pass, h1
+    activations).
     x: zero-bordered operand as group_norm(split=...) writes it - h2 [B, H+2, W+2, 2*C] fp16 (three MFMA passes per
     product, `passes` 3, or 12 for the weights-rounded study mode) or h1 [B, H+2, W+2, C] fp16 (`passes` 2 or 1).
     The activation format is read off the shapes; `passes` defaults to the full arithmetic of the formats (3 / 2 / 1)."""
@@ -245,7 +268,10 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
         raise _lib.DiffpureHipError(f"conv2d_h2: operand {tuple(x.shape)} does not match the weight panel {tuple(wh.shape)} (ksize {ksize})")
     if passes is None:
         passes = 1 if w_fmt else (2 if a_fmt else 3)
-    assert wh.shape == (n_out, (1 if w_fmt else 2) * ksize * ksize * c), (wh.shape, n_out, ksize, c)
+    if w_fmt:
+        assert wh.shape == ((n_out + 31) // 32 * 32, ksize * ksize * c), (wh.shape, n_out, ksize, c)
+    else:
+        assert wh.shape == (n_out, 2 * ksize * ksize * c), (wh.shape, n_out, ksize, c)
     if bias is not None:
         _chk(bias, "conv2d_h2.bias", 1)
     ts = 0

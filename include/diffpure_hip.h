@@ -94,8 +94,10 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
  *                                   passes 1  = a_hi*w_hi                           ("f16": the arithmetic of the reference's
  *             own use_fp16 torso, /root/reference/configs/imagenet.yml:18, guided_diffusion/unet.py:626-632, with fp32
  *             accumulation and fp32 GroupNorm)
- *   w_fmt 0 = weights in h2 form (above); w_fmt 1 (with a_fmt 1, passes 1) = PLAIN fp16 weights [N][K'] in the same k'
- *             order: "f16" when rounded to nearest once at load, "f16sr" when the panel is re-rounded STOCHASTICALLY from
+ *   w_fmt 0 = weights in h2 form (above); w_fmt 1 (with a_fmt 1, passes 1) = PLAIN fp16 weights in the same k' order, stored
+ *             in blocks of 32 rows x 8 elements: element (n, k') at index (((n/32) * (K/8) + k'/8) * 32 + n%32) * 8 + k'%8,
+ *             N rounded up to 32 rows (zero rows) - the B fragment of one 32x32x16 MFMA is 1 KB of contiguous memory
+ *             (diffpure_amd/ops.py:order_conv_weight_w16): "f16" when rounded to nearest once at load, "f16sr" when the panel is re-rounded STOCHASTICALLY from
  *             the fp32 masters before every network call (dp_round_weights) - the rounding error of the weights then
  *             changes from call to call and averages out over the solver steps like the activation rounding does,
  *             instead of accumulating coherently as a fixed perturbation of the model.

@@ -34,7 +34,7 @@ def main():
     for (H, ci, co) in SHAPES:
         x = torch.randn(B, H, H, ci)
         w = torch.randn(co, ci, 3, 3) * (1.0 / (9 * ci)) ** 0.5
-        wh = ops.order_conv_weight_h2(w).half().to(DEV) if w16 else ops.pack_conv_weight_h2(w, DEV)
+        wh = ops.order_conv_weight_w16(w).half().to(DEV) if w16 else ops.pack_conv_weight_h2(w, DEV)
         xh = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1)).half().contiguous().to(DEV)
         bias = torch.randn(co, device=DEV)
         flop = 2.0 * B * H * H * co * 9 * ci

@@ -60,6 +60,9 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     operands each mode keeps - f16x3 (h2 activations, passes 3): (hi+lo) x (hi+lo) (the dropped lo*lo term is ~2^-22
     relative, below the test tolerance); passes 12: (hi+lo) x w_hi; h1 activations (plain fp16): passes 2: a x (w_hi+w_lo),
     passes 1: a x w_hi.  x carries a one-pixel zero border."""
+    if w_fmt:
+        from diffpure_amd import ops
+        wh = ops.unorder_conv_weight_w16(wh, n_out)          # block layout of the fp16 panels -> [N, K'] reduction order
     cin = wh.shape[1] // ((1 if w_fmt else 2) * ksize * ksize)
     h1 = x.shape[3] == cin
     if passes is None:

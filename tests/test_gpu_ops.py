@@ -404,7 +404,8 @@ def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
         ref = ref + res.cpu().double()
     ref = (ref * scale).float()
     xh = _h1_bordered(x, dev)
-    w16 = ops.order_conv_weight_h2(w).half().to(dev)            # [N, K'] plain fp16 in the kernel's reduction order
+    w16 = ops.order_conv_weight_w16(w).half().to(dev)           # plain fp16 panel in the kernels' block layout
+    assert torch.equal(ops.unorder_conv_weight_w16(w16.cpu(), N), ops.order_conv_weight_h2(w).half())
 
     def run():
         y = ops.conv2d_h2(xh, w16, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale,
