@@ -33,6 +33,78 @@ constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
 
 #define SW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// ---- epilogue of a 128 x 128 wave tile: the arithmetic and the column-record order of pp_epilogue (igemm_pp_common.h)
+__device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[4][4], int m0, int n0, int tile_m, int wr, int wc, int lr,
+                                            int lk, int HW) {
+    const float* __restrict__ resp = p.res;
+    const float* __restrict__ tembp = p.temb;
+    float* __restrict__ outp = p.out;
+    const bool hw32 = HW % 32 == 0;
+    const int col0 = n0 + wc * 128 + lr;
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                   // one 64-row column record = two 32-row MFMA tiles
+        float cs[2][4], cq[2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * q + ii;
+            const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
+            float tv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
+                cs[ii][j] = 0.f;
+                cq[ii][j] = 0.f;
+            }
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {        // two column tiles at a time: 32 residual loads in flight per lane
+                float rv[2][16];
+                if (resp) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float* rp = resp + (size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col0 + jh * 64;
+                        rv[0][r] = rp[0];
+                        rv[1][r] = rp[32];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rowb + (r & 3) + 8 * (r >> 2);
+                    float* op = outp + (size_t)row * p.ldo + col0 + jh * 64;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = jh * 2 + jj;
+                        float v = acc[i][j][r] + bv[j];
+                        if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
+                        if (resp) v += rv[jj][r];
+                        v *= p.scale;
+                        op[jj * 32] = v;
+                        cs[ii][j] += v;
+                        cq[ii][j] += v * v;
+                    }
+                }
+            }
+            if (p.colstats) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[ii][j] += __shfl_xor(cs[ii][j], 32, 64);
+                    cq[ii][j] += __shfl_xor(cq[ii][j], 32, 64);
+                }
+            }
+        }
+        if (p.colstats && lk == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col0 + j * 32;
+                d[0] = cs[0][j] + cs[1][j];
+                d[p.N] = cq[0][j] + cq[1][j];
+            }
+        }
+    }
+}
+
 // MODE (timing ablations, DP_H2_SW_MODE; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait, 4 = no ds_reads
 template <int MODE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
@@ -182,76 +254,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: the arithmetic and the column-record order of pp_epilogue (igemm_pp_common.h) on a 128 x 128 wave tile
-    const float* __restrict__ resp = p.res;
-    const float* __restrict__ tembp = p.temb;
-    float* __restrict__ outp = p.out;
-    const bool hw32 = HW % 32 == 0;
-    const int col0 = n0 + wc * 128 + lr;
-    float bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {                   // one 64-row column record = two 32-row MFMA tiles
-        float cs[2][4], cq[2][4];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = 2 * q + ii;
-            const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
-            float tv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
-                cs[ii][j] = 0.f;
-                cq[ii][j] = 0.f;
-            }
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {        // two column tiles at a time: 32 residual loads in flight per lane
-                float rv[2][16];
-                if (resp) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float* rp = resp + (size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col0 + jh * 64;
-                        rv[0][r] = rp[0];
-                        rv[1][r] = rp[32];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowb + (r & 3) + 8 * (r >> 2);
-                    float* op = outp + (size_t)row * p.ldo + col0 + jh * 64;
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int j = jh * 2 + jj;
-                        float v = acc[i][j][r] + bv[j];
-                        if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
-                        if (resp) v += rv[jj][r];
-                        v *= p.scale;
-                        op[jj * 32] = v;
-                        cs[ii][j] += v;
-                        cq[ii][j] += v * v;
-                    }
-                }
-            }
-            if (p.colstats) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    cs[ii][j] += __shfl_xor(cs[ii][j], 32, 64);
-                    cq[ii][j] += __shfl_xor(cq[ii][j], 32, 64);
-                }
-            }
-        }
-        if (p.colstats && lk == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col0 + j * 32;
-                d[0] = cs[0][j] + cs[1][j];
-                d[p.N] = cq[0][j] + cq[1][j];
-            }
-        }
-    }
+    sw_epilogue(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
 }
 
+
+// Variants of this kernel that were built, verified bit-identical and measured SLOWER (tests/probes/pp_ablate.py, B=64; removed):
+//   * weight fragments fetched straight from global memory into registers (the block layout of the fp16 panels makes a B
+//     fragment 1 KB of contiguous memory): no LDS write / read / barrier dependence for B, but the two waves that share a column
+//     block fetch the same bytes - 48 KB instead of 32 KB per k-tile through the vector-memory path: 891-972 vs 918-1003 TFLOP/s;
+//   * activation operand as a 2-D halo tile (as igemm_h2_halo.hip; 21.5 KB instead of 32 KB per k-tile): 885-1022 vs 946-1131
+//     TFLOP/s - the per-tap address arithmetic, the data-dependent vmcnt variants and the 160 KB of LDS cost more than the
+//     bytes save (its no-loads-at-all ablation is already slower than this kernel's: 1277-1599 vs 1498-1880).
 }  // namespace
 
 bool dp_conv_sw_applies(const ConvH2Args& p) {

@@ -77,7 +77,7 @@ def main():
                 res.append(f"m{mode}:{flop / timeit(fn, iters) / 1e9:5.0f}")
             line += f" sched{sched} [{'ok' if same else 'DIFF'}] " + " ".join(res) + " |"
         print(line, flush=True)
-    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW"):
+    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW", "DP_H2_SW_MODE"):
         os.environ.pop(k, None)
 
 
