@@ -97,8 +97,9 @@ struct FlashArgs {
     const char* qh;
     const char* kh;
     const char* vt;
-    float* out;         // [B][T][C]
+    float* out;         // [B][T][C] fp32, or (out16) the zero-bordered "h1" operand [B][T/W + 2][W + 2][C] fp16 (border pre-zeroed)
     int T, C, NH;
+    int out16, W;
 };
 
 #define AT_GLDS(src, dst)                                                                      \
@@ -238,6 +239,20 @@ __global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
     // ---- O^T tile t: rows = d (t*32 + (r&3) + 8*(r>>2) + 4*lk), column = query lr -> out[b][q0 + lr][h*D + d]
     const int b = z / p.NH, h = z - b * p.NH;
     const float inv = 1.f / l_run;
+    if (p.out16) {      // token (ty, tx) -> interior pixel (ty + 1, tx + 1) of the bordered fp16 operand of proj_out
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const int tok = q0 + lr, ty = tok / p.W, tx = tok - ty * p.W;
+        _Float16* orow = reinterpret_cast<_Float16*>(p.out) + (((size_t)b * (p.T / p.W + 2) + ty + 1) * (p.W + 2) + tx + 1) * p.C + h * D;
+#pragma unroll
+        for (int t = 0; t < D / 32; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half4 v = {(_Float16)(o[t][g * 4] * inv), (_Float16)(o[t][g * 4 + 1] * inv), (_Float16)(o[t][g * 4 + 2] * inv),
+                                 (_Float16)(o[t][g * 4 + 3] * inv)};
+                *reinterpret_cast<half4*>(orow + t * 32 + g * 8 + lk * 4) = v;
+            }
+        return;
+    }
     float* orow = p.out + ((size_t)b * p.T + q0 + lr) * p.C + h * D;
 #pragma unroll
     for (int t = 0; t < D / 32; ++t)
@@ -250,13 +265,14 @@ __global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
 
 }  // namespace
 
-extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, float* out, void* work,
-                                  void* stream) {
+extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, void* out, int out_fmt, int W,
+                                  void* work, void* stream) {
     DP_REQUIRE(qkv && out && work && B > 0 && T > 0 && C > 0 && n_heads > 0, "dp_attention_fused: bad args");
     DP_REQUIRE(C % n_heads == 0 && C / n_heads == D, "dp_attention_fused: head dimension must be %d (got %d)", D,
                n_heads ? C / n_heads : 0);
     DP_REQUIRE(T % 64 == 0, "dp_attention_fused: token count must be a multiple of 64 (got %d)", T);
     DP_REQUIRE(layout == 0 || layout == 1, "dp_attention_fused: layout %d", layout);
+    DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && W > 0 && T % W == 0), "dp_attention_fused: out_fmt 1 (bordered fp16 operand) needs the image width W | T (got %d, W=%d)", out_fmt, W);
     DP_REQUIRE(dp_aligned16(qkv) && dp_aligned16(out) && dp_aligned16(work), "dp_attention_fused: misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
     const size_t part = (size_t)B * T * C * 4;
@@ -269,7 +285,7 @@ extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_h
     const int Z = B * n_heads;
     hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
     DP_LAUNCH_CHECK("attn_pack");
-    FlashArgs fa{pa.qh, pa.kh, pa.vt, out, T, C, n_heads};
+    FlashArgs fa{pa.qh, pa.kh, pa.vt, static_cast<float*>(out), T, C, n_heads, out_fmt, out_fmt ? W : 1};
     if (T % 128 == 0) hipLaunchKernelGGL(attn_flash_kernel<4>, dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
     else hipLaunchKernelGGL(attn_flash_kernel<2>, dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
     DP_LAUNCH_CHECK("attn_flash");

@@ -14,7 +14,7 @@ void dp_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dp_last_error(void) { return g_dp_err; }
-extern "C" int dp_abi_version(void) { return 2; }
+extern "C" int dp_abi_version(void) { return 3; }
 
 namespace {
 

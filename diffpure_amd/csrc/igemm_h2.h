@@ -27,7 +27,18 @@ struct ConvH2Args {
     int stagger;        // igemm_h2_pp.hip: cycles per k-tile and phase of the start-up stagger (0 = none)
     int wfmt;           // weight panel: 0 = h2 (hi|lo), 1 = plain fp16 (afmt 1, passes 1 only)
     int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
+    int ofmt;           // output: 0 = fp32 [M][ldo]; 1 = plain fp16 [M][ldo] (the final fp32 value rounded to nearest; `out` then
+                        // points at fp16 elements).  Column statistics are those of the UNROUNDED values in both cases.
 };
+
+typedef _Float16 dp_half2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dp_half4 __attribute__((ext_vector_type(4)));
+
+// one output element in the format p.ofmt names (the generic, one-element-per-lane path of the tile variants)
+__device__ __forceinline__ void dp_conv_store(const ConvH2Args& p, size_t row, int col, float v) {
+    if (p.ofmt) reinterpret_cast<_Float16*>(p.out)[row * p.ldo + col] = (_Float16)v;
+    else p.out[row * p.ldo + col] = v;
+}
 
 // 8-wave "ping-pong" variants (igemm_h2_pp.hip): bn = 256 -> 256x256 tiles (needs M % 256 == 0, N % 256 == 0),
 // bn = 128 -> 512x128 tiles (M % 512 == 0, N % 128 == 0); C % 32 == 0.  Fills p.tiles / p.tiles_n itself.
@@ -41,3 +52,8 @@ void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);
 // One-wave-per-SIMD software-pipelined variant (igemm_h2_sw.hip): fp16 x fp16, 256x256 tile, 4 waves of 128x128.
 bool dp_conv_sw_applies(const ConvH2Args& p);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s);
+
+// The same kernel with the three kx taps of a (channel slice, ky) pair served by ONE activation halo run in LDS
+// (igemm_h2_sx.hip): 3x3 only, 32 <= W, image rows that tile 256-pixel blocks.
+bool dp_conv_sx_applies(const ConvH2Args& p);
+void dp_launch_conv_sx(ConvH2Args& p, hipStream_t s);

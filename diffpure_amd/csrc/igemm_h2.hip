@@ -45,6 +45,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int NT = 256;
 constexpr int NXCD = 8;
 constexpr int DP_H2_PP_DEFAULT = 2;   // see the dispatcher
+constexpr int DP_H2_SX_DEFAULT = 0;   // see the dispatcher
 
 
 // Tile variants of THIS file (256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS stages, two
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     const float* __restrict__ resp = p.res;
     const float* __restrict__ tembp = p.temb;
     float* __restrict__ outp = p.out;
+    _Float16* __restrict__ outh = reinterpret_cast<_Float16*>(p.out);      // p.ofmt 1: fp16 output
     const bool hw32 = HW % 32 == 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -292,7 +294,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
                 if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
                 if (resp) v += rv[i][r];
                 v *= p.scale;
-                outp[(size_t)row * p.ldo + col] = v;
+                if (p.ofmt) outh[(size_t)row * p.ldo + col] = (_Float16)v;
+                else outp[(size_t)row * p.ldo + col] = v;
                 cs += v;
                 cq += v * v;
             }
@@ -364,7 +367,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvH2Args p) {
             cs[j] += v[j];
             cq[j] += v[j] * v[j];
         }
-        *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col0) = v;
+        if (p.ofmt) {
+            const dp_half4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<dp_half4*>(reinterpret_cast<_Float16*>(p.out) + (size_t)row * p.ldo + col0) = h;
+        } else {
+            *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col0) = v;
+        }
     }
     if (!p.colstats) return;
 #pragma unroll
@@ -440,8 +448,8 @@ extern "C" long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, in
 
 extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
                                  const float* bias, const float* temb, int temb_stride, const float* res, int ldr,
-                                 float scale, float* out, int ldo, float* colstats, int* tile_rows, void* work,
-                                 long long work_bytes, int passes, int a_fmt, int w_fmt, void* stream) {
+                                 float scale, void* out, int ldo, float* colstats, int* tile_rows, void* work,
+                                 long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, void* stream) {
     DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
     DP_REQUIRE(KS == 1 || KS == 3, "dp_conv2d_nhwc_h2: kernel size %d unsupported", KS);
     DP_REQUIRE((a_fmt == 0 && (passes == 3 || passes == 12)) || (a_fmt == 1 && (passes == 2 || passes == 1)),
@@ -449,6 +457,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
                a_fmt, passes);
     DP_REQUIRE(w_fmt == 0 || (w_fmt == 1 && a_fmt == 1 && passes == 1),
                "dp_conv2d_nhwc_h2: plain fp16 weights (w_fmt 1) go with plain fp16 activations and one pass (got a_fmt %d, passes %d)", a_fmt, passes);
+    DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && ldo % 2 == 0 && N % 4 == 0), "dp_conv2d_nhwc_h2: out_fmt must be 0 (fp32) or 1 (fp16; even row stride, N %% 4 == 0), got %d", out_fmt);
     DP_REQUIRE(C > 0 && C % 32 == 0, "dp_conv2d_nhwc_h2: channel count must be a multiple of 32 (got %d)", C);
     DP_REQUIRE(dp_aligned16(x) && dp_aligned16(w), "dp_conv2d_nhwc_h2: misaligned operand");
     DP_REQUIRE(B > 0 && H > 0 && W > 0 && N > 0 && (long long)B * H * W < (1ll << 31), "dp_conv2d_nhwc_h2: bad shape");
@@ -456,7 +465,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.x = (const char*)x; p.C = C;
     p.B = B; p.H = H; p.W = W; p.KS = KS; p.pad = KS / 2;
     p.w = (const char*)w; p.bias = bias; p.temb = temb; p.temb_stride = temb_stride;
-    p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo;
+    p.res = res; p.ldr = ldr; p.out = static_cast<float*>(out); p.ldo = ldo;
     p.M = B * H * W; p.N = N; p.K = KS * KS * C; p.scale = scale;
     p.zero = zero_page();
     DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
@@ -464,6 +473,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.passes = passes;
     p.afmt = a_fmt;
     p.wfmt = w_fmt;
+    p.ofmt = out_fmt;
     p.stagger = 0;
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
@@ -477,7 +487,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     // algorithmic HBM bytes: the activation operand once (4 or 2 bytes per element), the h2 weights once, the residual and
     // the fp32 output once
     dp_prof_begin(KS == 3 ? DP_PROF_3X3_OTHER : DP_PROF_1X1, 2.0 * p.M * (double)p.N * p.K,
-                  (double)p.M * C * (a_fmt ? 2 : 4) + (w_fmt ? 2.0 : 4.0) * p.K * N + 4.0 * (double)p.M * N * (res ? 2 : 1), s, &rec);
+                  (double)p.M * C * (a_fmt ? 2 : 4) + (w_fmt ? 2.0 : 4.0) * p.K * N + (double)p.M * N * ((res ? 4 : 0) + (out_fmt ? 2 : 4)), s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
 #define DP_H2_LAUNCH(BM_, BN_, BK_, ABL_)                                                                  \
     do {                                                                                                   \
@@ -515,7 +525,12 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             // fp16 x fp16, N % 256 == 0: the one-wave-per-SIMD software-pipelined kernel (igemm_h2_sw.hip) - measured
             // fastest on every shape of both networks (tests/probes/pp_ablate.py --w16); DP_H2_SW=0 falls back
             const char* esw = getenv("DP_H2_SW");
-            if (bn == 256 && (!esw || atoi(esw) != 0) && dp_conv_sw_applies(p)) dp_launch_conv_sw(p, s);
+            // ... and its x-halo form (igemm_h2_sx.hip: the three kx taps read one activation run) for 3x3 layers with W >= 32;
+            // DP_H2_SX = 0 never, 1 whenever the shape allows, unset = DP_H2_SX_DEFAULT.  Identical bits either way.
+            const char* esx = getenv("DP_H2_SX");
+            const bool sw_on = bn == 256 && (!esw || atoi(esw) != 0);
+            if (sw_on && (esx ? atoi(esx) != 0 : DP_H2_SX_DEFAULT != 0) && dp_conv_sx_applies(p)) dp_launch_conv_sx(p, s);
+            else if (sw_on && dp_conv_sw_applies(p)) dp_launch_conv_sw(p, s);
             else if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
             else
             dp_launch_conv_h2_pp(p, s, bn);

@@ -21,7 +21,7 @@
 #include <stdlib.h>
 
 #include "igemm_h2.h"
-#include "igemm_pp_common.h"
+#include "igemm_sw_common.h"
 
 namespace {
 
@@ -30,80 +30,6 @@ constexpr int NXCD = 8;
 constexpr int NB = 4, DIST = 3;                 // LDS ring stages, prefetch distance in k-tiles
 constexpr int TILE = 256 * 64;                  // one operand tile of a k-tile: 256 rows x 64 bytes (32 fp16)
 constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
-
-#define SW_BARRIER() asm volatile("s_barrier" ::: "memory")
-
-// ---- epilogue of a 128 x 128 wave tile: the arithmetic and the column-record order of pp_epilogue (igemm_pp_common.h)
-__device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[4][4], int m0, int n0, int tile_m, int wr, int wc, int lr,
-                                            int lk, int HW) {
-    const float* __restrict__ resp = p.res;
-    const float* __restrict__ tembp = p.temb;
-    float* __restrict__ outp = p.out;
-    const bool hw32 = HW % 32 == 0;
-    const int col0 = n0 + wc * 128 + lr;
-    float bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {                   // one 64-row column record = two 32-row MFMA tiles
-        float cs[2][4], cq[2][4];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = 2 * q + ii;
-            const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
-            float tv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
-                cs[ii][j] = 0.f;
-                cq[ii][j] = 0.f;
-            }
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {        // two column tiles at a time: 32 residual loads in flight per lane
-                float rv[2][16];
-                if (resp) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float* rp = resp + (size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col0 + jh * 64;
-                        rv[0][r] = rp[0];
-                        rv[1][r] = rp[32];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowb + (r & 3) + 8 * (r >> 2);
-                    float* op = outp + (size_t)row * p.ldo + col0 + jh * 64;
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int j = jh * 2 + jj;
-                        float v = acc[i][j][r] + bv[j];
-                        if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
-                        if (resp) v += rv[jj][r];
-                        v *= p.scale;
-                        op[jj * 32] = v;
-                        cs[ii][j] += v;
-                        cq[ii][j] += v * v;
-                    }
-                }
-            }
-            if (p.colstats) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    cs[ii][j] += __shfl_xor(cs[ii][j], 32, 64);
-                    cq[ii][j] += __shfl_xor(cq[ii][j], 32, 64);
-                }
-            }
-        }
-        if (p.colstats && lk == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col0 + j * 32;
-                d[0] = cs[0][j] + cs[1][j];
-                d[p.N] = cq[0][j] + cq[1][j];
-            }
-        }
-    }
-}
 
 // MODE (timing ablations, DP_H2_SW_MODE; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait, 4 = no ds_reads
 template <int MODE>
@@ -254,7 +180,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    sw_epilogue(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
+    sw_epilogue_any(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
 }
 
 

@@ -36,6 +36,7 @@ __device__ __forceinline__ void pp_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
     const float* __restrict__ resp = p.res;
     const float* __restrict__ tembp = p.temb;
     float* __restrict__ outp = p.out;
+    _Float16* __restrict__ outh = reinterpret_cast<_Float16*>(p.out);      // p.ofmt 1: fp16 output
     const bool hw32 = HW % 32 == 0;          // a 32-row block lies inside one sample: one temb value per block
     // One 32-row block at a time, both 32-column blocks inside it: a row's address is formed once and serves both
     // column blocks (+128 bytes), 32 residual loads are in flight per lane.  (Column block outermost makes the compiler
@@ -68,14 +69,14 @@ __device__ __forceinline__ void pp_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rowb + (r & 3) + 8 * (r >> 2);
-            float* op = outp + (size_t)row * p.ldo + col0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float v = acc[i][j][r] + bv[j];
                 if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
                 if (resp) v += rv[j][r];
                 v *= p.scale;
-                op[j * 32] = v;
+                if (p.ofmt) outh[(size_t)row * p.ldo + col0 + j * 32] = (_Float16)v;
+                else outp[(size_t)row * p.ldo + col0 + j * 32] = v;
                 cs[i][j] += v;
                 cq[i][j] += v * v;
             }

@@ -444,6 +444,96 @@ __global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
     }
 }
 
+// fp16 in -> "h1" operand out: GroupNorm-apply over a tensor the producing convolution stored as plain fp16 (dp_conv2d_nhwc_h2
+// out_fmt 1: [B][H][W][C] fp16, no border) - the second GroupNorm of a ResBlock (FiLM + SiLU, no resampling, one source).
+// 4 HBM bytes per element instead of 6.  A thread owns one channel OCTET: 16-byte loads, 16-byte stores, lanes along the
+// channels.  Per element the arithmetic is gn_apply_h2q_kernel's on the (exactly representable) fp32 value of the fp16
+// input: identical bytes to dp_gn_apply(out_fmt 2) of the up-converted tensor.
+struct Apply16Args {
+    const _Float16* x;
+    int C, B, H, W, G;
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    const float* fscale;
+    const float* fshift;
+    int film_stride;
+    char* y;
+    int cpg;
+};
+
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_apply_f16in_kernel(Apply16Args p, int COT, int slots) {
+    const int CO = p.C / 8;
+    const int Hq = p.H + 2, Wq = p.W + 2;
+    const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
+    const int oy = qy - 1;
+    const bool zrow = (unsigned)oy >= (unsigned)p.H;
+    const int slot = threadIdx.x / COT;
+    const size_t orow = ((size_t)b * Hq + qy) * Wq;
+    half8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.f;
+    for (int co = threadIdx.x - slot * COT; co < CO; co += COT) {
+        float a[8], d[8];                                  // y = x*a + d before act
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+            const int c = co * 8 + qd * 4;
+            const int g = c / p.cpg;
+            const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[qd * 4 + j] = rstd * ga[j];
+                d[qd * 4 + j] = be[j] - mean * a[qd * 4 + j];
+            }
+            if (p.fscale) {
+                const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
+                const f32x4 fh = *reinterpret_cast<const f32x4*>(p.fshift + (size_t)b * p.film_stride + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float m = 1.f + fs[j];
+                    a[qd * 4 + j] *= m;
+                    d[qd * 4 + j] = d[qd * 4 + j] * m + fh[j];
+                }
+            }
+        }
+        auto xf = [&](half8 v) {
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float u = (float)v[j] * a[j] + d[j];
+                o[j] = (_Float16)(ACT ? dp_silu_f(u) : u);
+            }
+            return o;
+        };
+        half8* yrow = reinterpret_cast<half8*>(p.y) + orow * CO + co;
+        if (zrow) {
+            for (int qx = slot; qx < Wq; qx += slots) yrow[(size_t)qx * CO] = zero8;
+            continue;
+        }
+        const half8* xrow = reinterpret_cast<const half8*>(p.x) + ((size_t)b * p.H + oy) * p.W * CO + co;
+        int qx = slot;
+        for (; qx + 3 * slots < Wq; qx += 4 * slots) {       // four pixels at a time: all loads issued before the first use
+            half8 rv[4];
+            bool in[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ox = qx + k * slots - 1;
+                in[k] = (unsigned)ox < (unsigned)p.W;
+                rv[k] = in[k] ? xrow[(size_t)ox * CO] : zero8;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yrow[(size_t)(qx + k * slots) * CO] = in[k] ? xf(rv[k]) : zero8;
+        }
+        for (; qx < Wq; qx += slots) {
+            const int ox = qx - 1;
+            yrow[(size_t)qx * CO] = (unsigned)ox < (unsigned)p.W ? xf(xrow[(size_t)ox * CO]) : zero8;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dp_gn_stats(const float* x1, int C1, const float* x2, int C2, int B, int HW, int G, int nsplit,
@@ -530,5 +620,22 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     }
 #undef GN_APPLY_LAUNCH
     DP_LAUNCH_CHECK("gn_apply");
+    return 0;
+}
+
+extern "C" int dp_gn_apply_f16in(const void* x16, int C, int B, int H, int W, int G, const float* stats, const float* gamma,
+                                 const float* beta, const float* fscale, const float* fshift, int film_stride, int act, void* y,
+                                 void* stream) {
+    DP_REQUIRE(x16 && y && stats && gamma && beta && B > 0 && H > 0 && W > 0 && G > 0, "dp_gn_apply_f16in: bad args");
+    DP_REQUIRE(C % 8 == 0 && C % (4 * G) == 0, "dp_gn_apply_f16in: need C %% 8 == 0 and C %% (4*G) == 0 (C=%d, G=%d)", C, G);
+    DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply_f16in: FiLM scale and shift come together");
+    DP_REQUIRE(dp_aligned16(x16) && dp_aligned16(y) && dp_aligned16(gamma) && dp_aligned16(beta), "dp_gn_apply_f16in: misaligned tensor");
+    DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply_f16in: misaligned FiLM rows");
+    Apply16Args p{(const _Float16*)x16, C, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, (char*)y, C / G};
+    const int CO = C / 8, COT = CO < 256 ? CO : 256, slots = 256 / COT;
+    const unsigned rows = (unsigned)(B * (H + 2));
+    if (act) hipLaunchKernelGGL((gn_apply_f16in_kernel<true>), dim3(rows), dim3(COT * slots), 0, (hipStream_t)stream, p, COT, slots);
+    else hipLaunchKernelGGL((gn_apply_f16in_kernel<false>), dim3(rows), dim3(COT * slots), 0, (hipStream_t)stream, p, COT, slots);
+    DP_LAUNCH_CHECK("gn_apply_f16in");
     return 0;
 }

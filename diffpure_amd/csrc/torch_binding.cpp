@@ -89,7 +89,7 @@ std::tuple<Tensor, Tensor> conv2d_h2_impl(const Tensor& xh, const Tensor& wh, co
     DP_CALL(dp_conv2d_nhwc_h2(xh.data_ptr(), (int)C, (int)B, (int)H, (int)W, (int)ksize, wh.data_ptr(), (int)n_out,
                               opt_ptr(bias, "bias"), nullptr, 0, nullptr, 0, 1.f, out.data_ptr<float>(), (int)n_out,
                               want_stats ? cols.data_ptr<float>() : nullptr, want_stats ? &tile_rows : nullptr,
-                              wbytes ? work.data_ptr() : nullptr, wbytes, (int)passes, a_fmt, (int)w_fmt, cur_stream(xh)));
+                              wbytes ? work.data_ptr() : nullptr, wbytes, (int)passes, a_fmt, (int)w_fmt, /*out_fmt=*/0, cur_stream(xh)));
     return {out, cols};
 }
 Tensor conv2d_h2(const Tensor& xh, const Tensor& wh, const c10::optional<Tensor>& bias, int64_t n_out, int64_t ksize, int64_t passes,
@@ -150,7 +150,7 @@ Tensor attention(const Tensor& qkv, int64_t n_heads, bool legacy_layout) {
     if (d == 64 && T % 64 == 0) {       // flash-style kernel: the T x T scores never leave the registers
         Tensor work = at::empty({3 * B * T * C}, qkv.options());
         DP_CALL(dp_attention_fused(qkv.data_ptr<float>(), (int)B, (int)T, (int)C, (int)n_heads, legacy_layout ? 0 : 1,
-                                   out.data_ptr<float>(), work.data_ptr(), s));
+                                   out.data_ptr<float>(), /*out_fmt=*/0, /*W=*/0, work.data_ptr(), s));
         return out;
     }
     const int64_t oq = 0, ok = legacy_layout ? d : C, ov = legacy_layout ? 2 * d : 2 * C, sh = legacy_layout ? 3 * d : d;

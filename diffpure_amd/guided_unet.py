@@ -20,6 +20,7 @@ import math
 from collections import OrderedDict
 
 import functools
+import os
 
 import torch
 
@@ -188,6 +189,9 @@ class GuidedUNet:
         self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
         self._pool = ops.WeightPool(torch.device(device), stochastic=precision == "f16sr") if precision in ops.W16_MODES else None
         self._ch2 = functools.partial(ops.conv2d_h2, passes=passes, w_fmt=1 if self._pool is not None else 0)
+        # fp16 x fp16 modes: a ResBlock's first convolution stores its output as fp16 (its only reader is the GroupNorm-apply
+        # that emits the fp16 operand of the second one) and the attention output reaches proj_out as an fp16 operand
+        self._lean = self._pool is not None and os.environ.get("DIFFPURE_LEAN", "1") != "0"
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -257,6 +261,10 @@ class GuidedUNet:
                 P[n + ".wqkv"], r["h2"] = conv_w(n + ".qkv.weight", r["ch"])
                 P[n + ".cqkv"] = vec(n + ".qkv.bias")
                 P[n + ".wproj"] = ops.pack_conv_weight(sd[n + ".proj_out.weight"].detach()).to(dev)
+                # lean fp16 x fp16 modes: proj_out runs on the fp16 matrix path too, fed by the attention kernel's fp16 operand
+                r["proj16"] = self._lean and r["h2"] and r["ch"] // r["heads"] == 64
+                if r["proj16"]:
+                    P[n + ".wproj16"] = self._pack_h2w(sd[n + ".proj_out.weight"].detach())
                 P[n + ".cproj"] = vec(n + ".proj_out.bias")
         # one packed [emb_dim, sum(2*cout)] panel for every block's emb_layers Linear
         P["emb.w"] = ops.pack_linear_weight(torch.cat(emb_w, dim=0)).to(dev)
@@ -306,14 +314,18 @@ class GuidedUNet:
                            raw=want_raw)
         if want_raw:
             h, xraw = h
-        h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True)
+        mid16 = self._lean and tape is None and r["h2_1"] and r["h2_2"]      # the taped forward keeps fp32 for the backward pass
+        h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True, **({"out_f16": True} if mid16 else {}))
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
         st2 = ops.group_norm_stats(h, G, eps)
         h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
-        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
+        if mid16:
+            h = ops.group_norm_f16in(h, G, P[n + ".g2"], P[n + ".b2"], st2, film=film, act=True)
+        else:
+            h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
         if mode:
             skip = ops.resample(x, mode)
         elif want_raw:
@@ -335,9 +347,12 @@ class GuidedUNet:
         # The taped forward keeps only qkv: the [B*heads, T, T] probabilities (2.1 GB per 32x32 layer at B=64) are
         # RECOMPUTED per block in the backward pass, as the reference does by checkpointing exactly these blocks
         # (guided_diffusion/unet.py:305) - so the forward runs the fused flash kernel with or without a tape.
-        a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
         if tape is not None:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv, layout=layout))
+        if r.get("proj16") and ops.attention_fused_ok(hh * ww, c // r["heads"]):
+            ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), r["heads"], layout, operand_hw=(hh, ww))
+            return self._ch2(ah, P[n + ".wproj16"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True)
+        a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True)
 
     def _run(self, blk, h, h2, film, tape=None):

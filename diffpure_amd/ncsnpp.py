@@ -16,6 +16,7 @@ import math
 from collections import OrderedDict
 
 import functools
+import os
 
 import torch
 
@@ -150,6 +151,8 @@ class NCSNpp:
         self._ofmt = "h1" if ofmt == ops.FMT_H1 else "h2"
         self._pool = ops.WeightPool(torch.device(device), stochastic=precision == "f16sr") if precision in ops.W16_MODES else None
         self._ch2 = functools.partial(ops.conv2d_h2, passes=passes, w_fmt=1 if self._pool is not None else 0)
+        # fp16 x fp16 modes: the first convolution of a ResBlock stores its output as fp16 (see GuidedUNet)
+        self._lean = self._pool is not None and os.environ.get("DIFFPURE_LEAN", "1") != "0"
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -275,12 +278,16 @@ class NCSNpp:
         if want_raw:
             h, xraw = h
         off = r["dense_off"]
-        h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True)
+        mid16 = self._lean and tape is None and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0
+        h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True, **({"out_f16": True} if mid16 else {}))
         st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
         h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
-        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
+        if mid16:
+            h = ops.group_norm_f16in(h, self._groups(co), P[n + ".g1"], P[n + ".b1"], st1, act=True)
+        else:
+            h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
         if mode:
             if h2s:
                 skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"])

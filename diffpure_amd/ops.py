@@ -249,13 +249,15 @@ def _fmt_of(split):
     raise ValueError(f"unknown operand format {split!r}")
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False):
     """conv2d on the fp16 matrix cores; same epilogue contract as conv2d.  wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2),
     or with w_fmt=1 the plain fp16 panel [N32, K] in the block layout of order_conv_weight_w16 (WeightPool; one pass, h1
     activations).
     x: zero-bordered operand as group_norm(split=...) writes it - h2 [B, H+2, W+2, 2*C] fp16 (three MFMA passes per
     product, `passes` 3, or 12 for the weights-rounded study mode) or h1 [B, H+2, W+2, C] fp16 (`passes` 2 or 1).
-    The activation format is read off the shapes; `passes` defaults to the full arithmetic of the formats (3 / 2 / 1)."""
+    The activation format is read off the shapes; `passes` defaults to the full arithmetic of the formats (3 / 2 / 1).
+    out_f16=True: the result is stored as PLAIN fp16 [B, H, W, N] (rounded to nearest; the column statistics are those of
+    the unrounded values) - for a tensor whose only consumer is `group_norm_f16in` (the first convolution of a ResBlock)."""
     _chk_h2(x, "conv2d_h2.x")
     _chk_h2(wh, "conv2d_h2.w")
     b, h, w = x.shape[0], x.shape[1] - 2, x.shape[2] - 2
@@ -279,7 +281,7 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
         assert temb.is_cuda and temb.dtype == torch.float32 and temb.dim() == 2 and temb.stride(1) == 1
         assert temb.shape[0] in (1, b) and temb.shape[1] >= n_out
         ts = 0 if temb.shape[0] == 1 else temb.stride(0)
-    out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float32)
+    out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
     ldr = 0
     if res is not None:
         _chk(res, "conv2d_h2.res", 4)
@@ -291,7 +293,7 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     work = torch.empty((wbytes // 4,), device=x.device, dtype=torch.float32) if wbytes else None
     _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
               ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _ptr(work), wbytes,
-              int(passes), a_fmt, int(w_fmt), _stream())
+              int(passes), a_fmt, int(w_fmt), 1 if out_f16 else 0, _stream())
     return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
 
@@ -384,7 +386,12 @@ def group_norm_stats(x, groups, eps, x2=None):
     k1 = x.cols if isinstance(x, Act) else None
     k2 = x2.cols if isinstance(x2, Act) else None
     x, x2 = tensor_of(x), tensor_of(x2)
-    _chk(x, "gn.x", 4)
+    if x.dtype == torch.float16 and x2 is None:
+        # a convolution's fp16 output (conv2d_h2 out_f16): its statistics exist only as the epilogue's column records
+        if k1 is None or not x.is_cuda or x.dim() != 4 or (x.shape[1] * x.shape[2]) % k1.tile_rows != 0:
+            raise _lib.DiffpureHipError("gn.x: an fp16 activation needs the column records of its producing convolution")
+    else:
+        _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else _chk(x2, "gn.x2", 4).shape[3]
     hw = h * w
@@ -438,6 +445,27 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
               _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), fptr, _stream())
     return (y, yr) if raw else y
+
+
+def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
+    """GroupNorm-apply (+FiLM) (+SiLU) of a tensor its producing convolution stored as plain fp16 (conv2d_h2 out_f16=True):
+    x16 [B, H, W, C] fp16 -> the zero-bordered "h1" operand [B, H+2, W+2, C] fp16 of the next convolution.  Same values as
+    group_norm(x16.float(), ..., split="h1") at 4 instead of 6 HBM bytes per element."""
+    if not isinstance(x16, torch.Tensor) or not x16.is_cuda or x16.dtype != torch.float16 or not x16.is_contiguous() or x16.dim() != 4:
+        raise _lib.DiffpureHipError("group_norm_f16in.x16: expected a contiguous fp16 GPU tensor [B, H, W, C]")
+    b, h, w, c = x16.shape
+    fs = fh = None
+    fstride = 0
+    if film is not None:
+        fs, fh = film
+        assert fs.is_cuda and fs.dtype == torch.float32 and fs.shape[-1] == c and fs.stride(-1) == 1
+        assert fh.shape == fs.shape and fh.stride() == fs.stride()
+        assert fs.shape[0] in (1, b)
+        fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
+    y = torch.empty((b, h + 2, w + 2, c), device=x16.device, dtype=torch.float16)
+    _lib.call("dp_gn_apply_f16in", _ptr(x16), c, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh), fstride,
+              1 if act else 0, _ptr(y), _stream())
+    return y
 
 
 def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False):
@@ -572,14 +600,22 @@ def attention_fused_ok(t, d):
     return d == 64 and t % 64 == 0 and os.environ.get("DIFFPURE_ATTN_FUSED", "1") != "0"
 
 
-def attention_fused(qkv, n_heads, layout):
-    """softmax(q k^T / sqrt(d)) v without materialising the scores (csrc/attention.hip); inference path only."""
+def attention_fused(qkv, n_heads, layout, operand_hw=None):
+    """softmax(q k^T / sqrt(d)) v without materialising the scores (csrc/attention.hip).  operand_hw=(H, W) (H * W tokens):
+    the result is written as the zero-bordered fp16 operand [B, H+2, W+2, C] of the following 1x1 convolution
+    (conv2d_h2, "h1" format) instead of fp32 [B, T, C]."""
     _chk(qkv, "attention_fused.qkv", 3)
     b, t, c3 = qkv.shape
     c = c3 // 3
-    out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
     work = torch.empty((3 * b * t * c,), device=qkv.device, dtype=torch.float32)
-    _lib.call("dp_attention_fused", _ptr(qkv), b, t, c, n_heads, 0 if layout == "legacy" else 1, _ptr(out), _ptr(work), _stream())
+    if operand_hw is not None:
+        hh, ww = operand_hw
+        assert hh * ww == t, (operand_hw, t)
+        out = torch.zeros((b, hh + 2, ww + 2, c), device=qkv.device, dtype=torch.float16)       # the border stays zero
+        _lib.call("dp_attention_fused", _ptr(qkv), b, t, c, n_heads, 0 if layout == "legacy" else 1, _ptr(out), 1, ww, _ptr(work), _stream())
+        return out
+    out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
+    _lib.call("dp_attention_fused", _ptr(qkv), b, t, c, n_heads, 0 if layout == "legacy" else 1, _ptr(out), 0, 0, _ptr(work), _stream())
     return out
 
 

@@ -105,13 +105,18 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
  *   fp32 engine): f16x3 3.9e-6, f16x2 1.3e-4, f16x2w 1.0e-3, f16 1.0e-3 (guided 256^2); 2.3e-6 / 9.4e-5 / 8.6e-4 / 8.6e-4
  *   (NCSN++): rounding the WEIGHTS is what costs accuracy (a fixed perturbation of the model, coherent over the steps),
  *   rounding the activations averages out; "f16sr": 2.2e-4 (guided) / 1.6e-4 (NCSN++) against the reference modules
- *   (tests/probes/sr_weights_probe.py, tests/test_gpu_loops.py). */
+ *   (tests/probes/sr_weights_probe.py, tests/test_gpu_loops.py).
+ *   out_fmt 0 = `out` is fp32 [M][ldo]; out_fmt 1 = `out` is PLAIN fp16 [M][ldo] (the final fp32 value - bias, temb, residual
+ *             and scale applied - rounded to nearest even; ldo even, N % 4 == 0).  For a tensor whose only consumer is a
+ *             GroupNorm-apply pass that emits an fp16 operand anyway (the first convolution of every ResBlock:
+ *             guided_diffusion/unet.py:244-264 in_layers -> out_layers[0]): half the store bytes here, half the load bytes
+ *             there (dp_gn_apply_f16in).  `colstats` are the sums of the UNROUNDED values in both formats. */
 int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
                       const float* res, int ldr, float scale,
-                      float* out, int ldo, float* colstats, int* tile_rows,
-                      void* work, long long work_bytes, int passes, int a_fmt, int w_fmt, void* stream);
+                      void* out, int ldo, float* colstats, int* tile_rows,
+                      void* work, long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, void* stream);
 /* Scratch the call above needs for this layer shape (0 for most): low-resolution levels (H*W <= 64) are reduced with
  * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
  * layer shape only, never on B, so that results do not depend on how a batch is sharded. */
@@ -176,6 +181,14 @@ int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, 
                 const float* stats, const float* gamma, const float* beta,
                 const float* fscale, const float* fshift, int film_stride,
                 int act, int resample, int out_fmt, void* y, void* y_raw, const float* fir4, void* stream);
+/* Step 3 for a tensor its producing convolution stored as plain fp16 (dp_conv2d_nhwc_h2 out_fmt 1): x16 is [B][H][W][C] fp16
+ * (no border), y the zero-bordered "h1" operand [B][H+2][W+2][C] fp16; one source, no resampling - the out_layers GroupNorm
+ * of a ResBlock (guided_diffusion/unet.py:251-258 scale-shift norm + SiLU; score_sde layerspp.py:246 GroupNorm_1 + act).
+ * Same arithmetic per element as dp_gn_apply(out_fmt 2) on the up-converted tensor (identical bytes), 4 HBM bytes per element
+ * instead of 6. */
+int dp_gn_apply_f16in(const void* x16, int C, int B, int H, int W, int G, const float* stats, const float* gamma,
+                      const float* beta, const float* fscale, const float* fshift, int film_stride, int act, void* y,
+                      void* stream);
 
 /* ---- small elementwise pieces ----------------------------------------------------------------*/
 /* y = x * sigmoid(x)   (nn.SiLU on the embedding vector, unet.py:211, layerspp.py:265) */
@@ -244,9 +257,13 @@ int dp_add(const float* a, const float* b, float* out, long long n, void* stream
  * head on the fp16 matrix cores with split-fp16 operands (fp32-class accuracy), flash-style (the T x T scores stay
  * in registers).  Same operand conventions as dp_gemm_strided-based attention: qkv [B,T,3C] fp32, layout 0 =
  * 'legacy' (heads x [q|k|v], QKVAttentionLegacy unet.py:345-362), 1 = 'split' ([Q|K|V]); head dimension 64,
- * T % 64 == 0.  work: 3 * B * T * C * 4 bytes of 16-byte-aligned scratch (packed Q, K and transposed V). */
-int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, float* out, void* work,
-                       void* stream);
+ * T % 64 == 0.  work: 3 * B * T * C * 4 bytes of 16-byte-aligned scratch (packed Q, K and transposed V).
+ * out_fmt 0: out is fp32 [B][T][C].  out_fmt 1: the tokens are the pixels of an image of width W (T % W == 0) and out is the
+ * zero-bordered plain-fp16 operand [B][T/W + 2][W + 2][C] of the proj_out 1x1 convolution (a_fmt 1 of dp_conv2d_nhwc_h2;
+ * AttentionBlock.proj_out, unet.py:312): the kernel writes the interior pixels (rounded to nearest), the CALLER zeroes
+ * the border. */
+int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, void* out, int out_fmt, int W,
+                       void* work, void* stream);
 
 /* ---- the steps either side of the purifier ---------------------------------------
  * y = (bilinear(x) + shift) * scale, PyTorch semantics of F.interpolate(mode='bilinear',

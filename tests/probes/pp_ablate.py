@@ -65,6 +65,18 @@ def main():
                 line += f" m{m}:{flop / timeit(fn, iters) / 1e9:5.0f}"
             os.environ["DP_H2_SW_MODE"] = "0"
             line += " |"
+            os.environ["DP_H2_SX"] = "1"          # its x-halo form (igemm_h2_sx.hip)
+            y = fn()
+            ok = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
+            line += f" sx {flop / timeit(fn, iters) / 1e9:5.0f} [{'ok' if ok else 'DIFF'}]"
+            for m in (1, 2, 4, 7):
+                os.environ["DP_H2_SX_MODE"] = str(m)
+                line += f" m{m}:{flop / timeit(fn, iters) / 1e9:5.0f}"
+            os.environ["DP_H2_SX_MODE"] = "0"
+            fn16 = lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, colstats=True, w_fmt=1, out_f16=True)
+            line += f" sx+fp16out {flop / timeit(fn16, iters) / 1e9:5.0f}"
+            os.environ["DP_H2_SX"] = "0"
+            line += f" sw+fp16out {flop / timeit(fn16, iters) / 1e9:5.0f} |"
             os.environ["DP_H2_SW"] = "0"
         for sched in ((1,) if w16 else (0, 1)):
             os.environ["DP_H2_PP_SCHED"] = str(sched)
@@ -77,7 +89,7 @@ def main():
                 res.append(f"m{mode}:{flop / timeit(fn, iters) / 1e9:5.0f}")
             line += f" sched{sched} [{'ok' if same else 'DIFF'}] " + " ".join(res) + " |"
         print(line, flush=True)
-    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW", "DP_H2_SW_MODE"):
+    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW", "DP_H2_SW_MODE", "DP_H2_SX", "DP_H2_SX_MODE"):
         os.environ.pop(k, None)
 
 

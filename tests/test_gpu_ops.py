@@ -342,7 +342,10 @@ H1_CASES = H2_CASES + PP_CASES + [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (8, 64
                                   # three channel slices (halo buffer swaps), several tile rows per image, images per tile boundary
                                   (1, 128, 128, 64, 256, 3, 1, True, 0.5), (1, 256, 256, 32, 256, 3, 0, False, 1.0),
                                   (2, 256, 256, 64, 256, 3, 2, True, 1.0), (3, 64, 64, 96, 512, 3, 0, True, 1.0),
-                                  (5, 16, 16, 160, 256, 3, 2, False, 1.0)]
+                                  (5, 16, 16, 160, 256, 3, 2, False, 1.0),
+                                  # x-halo kernel (igemm_h2_sx.hip): one / several image rows per 256-pixel tile, 1 .. 3 channel slices,
+                                  # two column tiles, tiles that end at the last pixel of the tensor
+                                  (1, 256, 256, 96, 512, 3, 1, True, 1.0), (4, 32, 32, 32, 256, 3, 2, True, 0.5), (1, 8, 512, 64, 256, 3, 0, False, 1.0)]
 
 
 @pytest.mark.parametrize("passes", [2, 1])
@@ -418,15 +421,18 @@ def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
     # every 256x256 variant: per-tap ping-pong, halo-tile ping-pong, one-wave-per-SIMD software-pipelined
     if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64):
         monkeypatch.setenv("DP_H2_PP", "1")
-        for sw, halo in (("0", "0"), ("0", "1"), ("1", "0")):
+        # ... and its x-halo form (igemm_h2_sx.hip; 3x3 layers with W >= 32)
+        for sw, halo, sx in (("0", "0", "0"), ("0", "1", "0"), ("1", "0", "0"), ("1", "0", "1")):
             monkeypatch.setenv("DP_H2_SW", sw)
             monkeypatch.setenv("DP_H2_HALO", halo)
+            monkeypatch.setenv("DP_H2_SX", sx)
             for _ in range(3):
                 got, got_cs = run()
-                assert torch.equal(got, base), (sw, halo)
-                assert torch.equal(got_cs, base_cs), (sw, halo)
+                assert torch.equal(got, base), (sw, halo, sx)
+                assert torch.equal(got_cs, base_cs), (sw, halo, sx)
         monkeypatch.delenv("DP_H2_SW")
         monkeypatch.delenv("DP_H2_HALO")
+        monkeypatch.delenv("DP_H2_SX")
         monkeypatch.setenv("DP_H2_PP", "0")
     # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
     y1 = ops.conv2d_h2(xh, ops.pack_conv_weight_h2(w, dev), N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N],
@@ -652,3 +658,75 @@ def test_torch_ops_namespace_runs_the_hip_kernels(dev):
                        ops.em_step(xs, eps, -0.5, 1.1, -2.0, False, 1e-3, 1.05, 0.0316, seed=77, sample0=5, step=3))
     with pytest.raises(RuntimeError):
         T.conv2d_nhwc(x, wp[:, :8].contiguous(), bias, 96, 3)     # TORCH_CHECK -> RuntimeError with the library's message
+
+
+FP16_OUT_CASES = [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (1, 128, 128, 64, 256, 3, 1, False, 0.5), (4, 16, 16, 128, 128, 3, 0, False, 1.0),
+                  (8, 8, 8, 256, 256, 3, 1, True, 1.0), (3, 16, 16, 96, 72, 3, 0, False, 1.0), (2, 64, 64, 64, 512, 1, 0, True, 1.0)]
+
+
+@pytest.mark.parametrize("case", FP16_OUT_CASES, ids=[str(c) for c in FP16_OUT_CASES])
+def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
+    """dp_conv2d_nhwc_h2 out_fmt 1: the tensor is stored as plain fp16 = the fp32 result rounded to nearest, bit for bit, in
+    every tile variant (generic 128 / 64 tiles, split-K level, ping-pong, halo, one-wave-per-SIMD with the paired-lane
+    packed stores, x-halo); the column records stay those of the unrounded values."""
+    from diffpure_amd import ops
+    B, H, W, C, N, k, temb_rows, has_res, scale = case
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(N, C, k, k, seed=3, scale=1.0 / math.sqrt(C * k * k))
+    bias = rnd(N, seed=4).to(dev)
+    table = rnd(B if temb_rows == 2 else 1, N + 8, seed=5).to(dev) if temb_rows else None
+    res = rnd(B, H, W, N, seed=6).to(dev) if has_res else None
+    xh = _h1_bordered(x, dev)
+    w16 = ops.order_conv_weight_w16(w).half().to(dev)
+
+    def run(f16):
+        y = ops.conv2d_h2(xh, w16, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale,
+                          colstats=True, w_fmt=1, out_f16=f16)
+        return y.t, y.cols.buf.clone()
+
+    combos = [("0", None, None, None)]
+    if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
+        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"), ("1", "1", "0", "1")]
+    for pp, sw, halo, sx in combos:
+        monkeypatch.setenv("DP_H2_PP", pp)
+        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo), ("DP_H2_SX", sx)):
+            if val is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, val)
+        y32, cs32 = run(False)
+        y16, cs16 = run(True)
+        assert y16.dtype == torch.float16 and y16.shape == y32.shape
+        assert torch.equal(y16, y32.half()), (pp, sw, halo, sx)
+        assert torch.equal(cs16, cs32), (pp, sw, halo, sx)
+
+
+def test_group_norm_f16in_equals_group_norm_of_the_upconverted_tensor(dev):
+    """dp_gn_apply_f16in (fp16 NHWC in -> bordered fp16 operand out) gives the bytes of dp_gn_apply(out_fmt 2) on the same
+    values held as fp32: with FiLM rows per sample / broadcast / absent, with and without SiLU, narrow and wide channel counts."""
+    from diffpure_amd import ops
+    for (B, H, W, C, G) in ((2, 8, 8, 256, 32), (3, 5, 7, 64, 16), (1, 16, 16, 1024, 32), (2, 4, 4, 384, 32), (1, 3, 260, 128, 32)):
+        x16 = (rnd(B, H, W, C, seed=1) * 2 + 0.5).half().to(dev)
+        gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
+        stats = ops.group_norm_stats(x16.float(), G, 1e-5)
+        for film_rows in (0, 1, B):
+            table = rnd(film_rows, 2 * C + 8, seed=7).to(dev) if film_rows else None
+            film = None if table is None else (table[:, 4:4 + C], table[:, 4 + C:4 + 2 * C])
+            for act in (True, False):
+                ref = ops.group_norm(x16.float(), G, 1e-5, gamma, beta, film=film, act=act, split="h1", stats=stats)
+                got = ops.group_norm_f16in(x16, G, gamma, beta, stats, film=film, act=act)
+                assert got.dtype == torch.float16 and got.shape == ref.shape
+                assert torch.equal(got, ref), (B, H, W, C, film_rows, act)
+
+
+def test_attention_fused_operand_output(dev):
+    """dp_attention_fused out_fmt 1: the attention output lands as the zero-bordered fp16 operand of proj_out - the fp32
+    result rounded to nearest in the interior pixels, zeros on the border."""
+    from diffpure_amd import ops
+    for (B, hh, ww, heads, layout) in ((2, 8, 8, 4, "legacy"), (1, 16, 16, 8, "legacy"), (2, 8, 16, 2, "split")):
+        c = heads * 64
+        qkv = rnd(B, hh * ww, 3 * c, seed=11).to(dev)
+        ref = ops.attention_fused(qkv, heads, layout)
+        got = ops.attention_fused(qkv, heads, layout, operand_hw=(hh, ww))
+        want = torch.nn.functional.pad(ref.view(B, hh, ww, c), (0, 0, 1, 1, 1, 1)).half()
+        assert got.dtype == torch.float16 and torch.equal(got, want), (B, hh, ww, heads, layout)
