@@ -55,11 +55,11 @@ def _h2_hi(t):
     return t.reshape(-1, shp[-1] // 16, 2, 8).double()[:, :, 0].reshape(*shp[:-1], shp[-1] // 2)
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False):
     """Statement of the fp16-matrix-core contract (include/diffpure_hip.h, dp_conv2d_nhwc_h2): exact products of the
     operands each mode keeps - f16x3 (h2 activations, passes 3): (hi+lo) x (hi+lo) (the dropped lo*lo term is ~2^-22
     relative, below the test tolerance); passes 12: (hi+lo) x w_hi; h1 activations (plain fp16): passes 2: a x (w_hi+w_lo),
-    passes 1: a x w_hi.  x carries a one-pixel zero border."""
+    passes 1: a x w_hi.  x carries a one-pixel zero border.  out_f16: the result rounded to fp16 (out_fmt 1)."""
     if w_fmt:
         from diffpure_amd import ops
         wh = ops.unorder_conv_weight_w16(wh, n_out)          # block layout of the fp16 panels -> [N, K'] reduction order
@@ -81,7 +81,35 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     if res is not None:
         y = y + res
     y = (y * scale).float().contiguous()
+    if out_f16:
+        y = y.half()
     return _act(y) if colstats else y
+
+
+def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
+    """dp_gn_apply_f16in: GroupNorm-apply of the fp16 tensor (statistics as given) -> bordered "h1" operand"""
+    b, h, w, c = x16.shape
+    mean, rstd = stats[:, :, 0], stats[:, :, 1]
+    y = (x16.float().reshape(b, h * w, groups, c // groups) - mean[:, None, :, None]) * rstd[:, None, :, None]
+    y = y.reshape(b, h, w, c) * gamma + beta
+    if film is not None:
+        fs, fh = film
+        y = y * (1 + fs.reshape(-1, 1, 1, fs.shape[-1])) + fh.reshape(-1, 1, 1, fh.shape[-1])
+    if act:
+        y = F.silu(y)
+    return F.pad(y, (0, 0, 1, 1, 1, 1)).half().contiguous()
+
+
+def attention_fused_ok(t, d):
+    return d == 64 and t % 64 == 0
+
+
+def attention_fused(qkv, n_heads, layout, operand_hw=None):
+    out = attention(qkv, n_heads, layout)
+    if operand_hw is None:
+        return out
+    hh, ww = operand_hw
+    return F.pad(out.reshape(out.shape[0], hh, ww, out.shape[2]), (0, 0, 1, 1, 1, 1)).half().contiguous()
 
 
 def round_weights(master, work, stochastic, seed, key):
@@ -385,7 +413,8 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
 
 
 PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd",
-           "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "resample", "attention", "silu", "axpby",
+           "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "group_norm_f16in", "resample", "attention", "attention_fused",
+           "attention_fused_ok", "silu", "axpby",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
 
 
