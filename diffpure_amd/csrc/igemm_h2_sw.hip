@@ -28,13 +28,17 @@ namespace {
 constexpr int NT = 256;
 constexpr int NXCD = 8;
 constexpr int NB = 4, DIST = 3;                 // LDS ring stages, prefetch distance in k-tiles
+constexpr int DP_H2_SW_VAR_DEFAULT = 0;         // DP_H2_SW_VAR: 0 = DMA issues back to back, 1 = spread (see the kernel)
 constexpr int TILE = 256 * 64;                  // one operand tile of a k-tile: 256 rows x 64 bytes (32 fp16)
 constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
 
 // MODE (timing ablations, DP_H2_SW_MODE; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait, 4 = no ds_reads
-template <int MODE>
+// VAR 1: the 8 DMA issues of a k-tile are SPREAD - one behind every second fragment read, the activation pieces in the first half
+// of the k-tile and the weight pieces in the second - instead of back to back in 8 consecutive MFMA shadows (an LDS-DMA issue
+// costs more than one 32-cycle shadow; consecutive ones queue up in front of the next MFMA).
+template <int MODE, int VAR>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
-    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE];
+    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE + 1024];      // + 256 bytes per wave: landing zone of the residual prefetch
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,23 +69,54 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
     int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next k-tile to stage
-    auto issue = [&](int stage) {
+    auto issueA = [&](int stage) {
         const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;       // tap / 3 for tap < 9, no division
         const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
         char* As = smem + stage * STAGE + wave * 64 * 64;
-        char* Bs = As + TILE;
 #pragma unroll
         for (int it = 0; it < 4; ++it)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + off),
                                              (__attribute__((address_space(3))) void*)(As + it * 16 * 64), 16, 0, 0);
+        if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+    };
+    auto issueB = [&](int stage) {
+        char* Bs = smem + stage * STAGE + wave * 64 * 64 + TILE;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
                                              (__attribute__((address_space(3))) void*)(Bs + it * 16 * 64), 16, 0, 0);
             bptr[it] += 2048;
         }
-        if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
     };
+    auto issue = [&](int stage) {
+        issueA(stage);
+        issueB(stage);
+    };
+    // VAR 1: one piece at a time, in PROGRAM order between the fragment reads (an LDS-DMA write and a ds_read may alias as far
+    // as the scheduler knows: it never moves one across the other, so the interleave has to be written)
+    long long a_off = 0;
+    auto pieceA = [&](int stage, int it) {
+        if (it == 0) {
+            const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;
+            a_off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + a_off),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + wave * 64 * 64 + it * 16 * 64), 16, 0, 0);
+        if (it == 3 && ++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+    };
+    auto pieceB = [&](int stage, int it) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + wave * 64 * 64 + TILE + it * 16 * 64), 16, 0, 0);
+        bptr[it] += 2048;
+    };
+    // Residual prefetch (p.pf): the epilogue's residual reads (256 KB per tile) otherwise start when every CU of the chip has
+    // reached its epilogue at the same moment.  During the last 8 steady k-tiles one instruction per k-tile touches 64 of the
+    // wave tile's 512 cache lines (one dword per lane, landed in a scratch corner of LDS and never read): the lines are in
+    // L2 / MALL when the epilogue asks for them, fetched while HBM was idle under the MFMA phase.
+    const char* pfp = nullptr;
+    if (p.pf && p.res)
+        pfp = reinterpret_cast<const char*>(p.res) + ((size_t)(m0 + wr * 128 + (lane >> 2)) * p.ldr + n0 + wc * 128) * 4 + (lane & 3) * 128;
+    char* pf_lds = smem + NB * STAGE + wave * 256;
 
     // ---- fragments: lane -> row lr of a 32-row MFMA tile, k-half lk; 64-byte rows, slot (s*2 + lk) ^ key, key = (row >> 2) & 3
     const int lr = lane & 31, lk = lane >> 5;
@@ -96,6 +131,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const half8*>(st + arow + i * 32 * 64 + soff[set]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const half8*>(st + brow + j * 32 * 64 + soff[set]);
+    };
+    // fragment reads of one k16 step, two at a time: pair q = 0, 1 -> A tiles (2q, 2q+1); q = 2, 3 -> B tiles (2q-4, 2q-3)
+    auto read_pair = [&](int set, const char* st, int q) {
+        if (q < 2) {
+            fa[set][2 * q] = *reinterpret_cast<const half8*>(st + arow + (2 * q) * 32 * 64 + soff[set]);
+            fa[set][2 * q + 1] = *reinterpret_cast<const half8*>(st + arow + (2 * q + 1) * 32 * 64 + soff[set]);
+        } else {
+            fb[set][2 * q - 4] = *reinterpret_cast<const half8*>(st + brow + (2 * q - 4) * 32 * 64 + soff[set]);
+            fb[set][2 * q - 3] = *reinterpret_cast<const half8*>(st + brow + (2 * q - 3) * 32 * 64 + soff[set]);
+        }
     };
 
     f32x16 acc[4][4];
@@ -130,35 +175,85 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // use, and the wave then waits for LDS with an idle matrix pipe).  Each half of a k-tile runs 16 MFMAs on one fragment
         // set and, BEHIND its first MFMA, issues the 8 reads of the other set one per MFMA shadow, then the 8 DMA issues of
         // k-tile t+3 one per MFMA shadow: the lgkmcnt wait before a half's first MFMA finds reads issued >= 8 MFMAs earlier.
-        if constexpr (!(MODE & 4)) read_frags(1, st);
-        if constexpr (!(MODE & 1)) issue((t + DIST) & (NB - 1));
-        mfma_rows(0, 0, 4);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (pfp) {
+            const int q = t - (nt - DIST - 8);          // 0 .. 7 in the last 8 steady k-tiles (wave-uniform)
+            if (q >= 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pfp + (size_t)q * 16 * p.ldr * 4),
+                                                 (__attribute__((address_space(3))) void*)pf_lds, 4, 0, 0);
         }
+        if constexpr (VAR == 0) {
+            if constexpr (!(MODE & 4)) read_frags(1, st);
+            if constexpr (!(MODE & 1)) issue((t + DIST) & (NB - 1));
+            mfma_rows(0, 0, 4);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
+            for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_rows(1, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(MODE & 3)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // k-tile t+1 (this wave's share) has landed; t+2, t+3 may fly
-        if constexpr (!(MODE & 2)) SW_BARRIER();
-        if constexpr (!(MODE & 4)) read_frags(0, smem + ((t + 1) & (NB - 1)) * STAGE);
-        mfma_rows(1, 1, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_rows(1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(MODE & 3)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // k-tile t+1 (this wave's share) has landed; t+2, t+3 may fly
+            if constexpr (!(MODE & 2)) SW_BARRIER();
+            if constexpr (!(MODE & 4)) read_frags(0, smem + ((t + 1) & (NB - 1)) * STAGE);
+            mfma_rows(1, 1, 4);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // first half: 16 MFMAs | 8 reads and the 4 activation pieces of k-tile t+3 as (read, read, DMA) x 4, one per MFMA shadow
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (!(MODE & 4)) read_pair(1, st, q);
+                if constexpr (!(MODE & 1)) pieceA((t + DIST) & (NB - 1), q);
+            }
+            mfma_rows(0, 0, 4);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_rows(1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // in flight at most: the activation pieces of t+3 (just issued), the weight pieces of t+2, the activation pieces of t+2
+            if constexpr (!(MODE & 3)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if constexpr (!(MODE & 2)) SW_BARRIER();
+            // second half after the barrier: 12 MFMAs | 8 reads and the 4 weight pieces of k-tile t+3 in the same pattern
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (!(MODE & 4)) read_pair(0, smem + ((t + 1) & (NB - 1)) * STAGE, q);
+                if constexpr (!(MODE & 1)) pieceB((t + DIST) & (NB - 1), q);
+            }
+            mfma_rows(1, 1, 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-        __builtin_amdgcn_sched_barrier(0);
     }
     // tail: the last DIST k-tiles, nothing left to stage
     for (; t < nt; ++t) {
@@ -201,12 +296,21 @@ void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s) {
     p.tiles_n = p.N / 256;
     p.tiles = (p.M / 256) * p.tiles_n;
     const char* e = getenv("DP_H2_SW_MODE");
+    const char* ev = getenv("DP_H2_SW_VAR");
+    const int var = ev ? atoi(ev) : DP_H2_SW_VAR_DEFAULT;
+    const dim3 g((unsigned)p.tiles), b(NT);
+#define SW_LAUNCH(M_)                                                                  \
+    do {                                                                               \
+        if (var == 1) hipLaunchKernelGGL((conv_igemm_sw<M_, 1>), g, b, 0, s, p);       \
+        else hipLaunchKernelGGL((conv_igemm_sw<M_, 0>), g, b, 0, s, p);                \
+    } while (0)
     switch (e ? atoi(e) : 0) {
-        case 1: hipLaunchKernelGGL(conv_igemm_sw<1>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
-        case 2: hipLaunchKernelGGL(conv_igemm_sw<2>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
-        case 3: hipLaunchKernelGGL(conv_igemm_sw<3>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
-        case 4: hipLaunchKernelGGL(conv_igemm_sw<4>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
-        case 7: hipLaunchKernelGGL(conv_igemm_sw<7>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
-        default: hipLaunchKernelGGL(conv_igemm_sw<0>, dim3((unsigned)p.tiles), dim3(NT), 0, s, p); break;
+        case 1: SW_LAUNCH(1); break;
+        case 2: SW_LAUNCH(2); break;
+        case 3: SW_LAUNCH(3); break;
+        case 4: SW_LAUNCH(4); break;
+        case 7: SW_LAUNCH(7); break;
+        default: SW_LAUNCH(0); break;
     }
+#undef SW_LAUNCH
 }

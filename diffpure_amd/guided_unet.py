@@ -314,7 +314,9 @@ class GuidedUNet:
                            raw=want_raw)
         if want_raw:
             h, xraw = h
-        mid16 = self._lean and tape is None and r["h2_1"] and r["h2_2"]      # the taped forward keeps fp32 for the backward pass
+        # (the taped forward keeps fp32 for the backward pass; below 64 pixels per sample the column records straddle samples and
+        #  GroupNorm reduces the tensor itself, which it reads as fp32)
+        mid16 = self._lean and tape is None and r["h2_1"] and r["h2_2"] and ((h.shape[1] - 2) * (h.shape[2] - 2)) % 64 == 0
         h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True, **({"out_f16": True} if mid16 else {}))
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])

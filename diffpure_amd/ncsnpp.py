@@ -278,7 +278,10 @@ class NCSNpp:
         if want_raw:
             h, xraw = h
         off = r["dense_off"]
-        mid16 = self._lean and tape is None and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0
+        # (the taped forward keeps fp32 for the backward pass; below 64 pixels per sample the column records straddle samples and
+        #  GroupNorm reduces the tensor itself, which it reads as fp32)
+        mid16 = (self._lean and tape is None and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0
+                 and ((h.shape[1] - 2) * (h.shape[2] - 2)) % 64 == 0)
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True, **({"out_f16": True} if mid16 else {}))
         st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
         h = h.t

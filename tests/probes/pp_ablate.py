@@ -65,6 +65,29 @@ def main():
                 line += f" m{m}:{flop / timeit(fn, iters) / 1e9:5.0f}"
             os.environ["DP_H2_SW_MODE"] = "0"
             line += " |"
+            os.environ["DP_H2_SW_VAR"] = "1"      # DMA issues spread between the fragment reads
+            y = fn()
+            ok = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
+            line += f" sw.var1 {flop / timeit(fn, iters) / 1e9:5.0f} [{'ok' if ok else 'DIFF'}]"
+            for m in (1, 4, 7):
+                os.environ["DP_H2_SW_MODE"] = str(m)
+                line += f" m{m}:{flop / timeit(fn, iters) / 1e9:5.0f}"
+            os.environ["DP_H2_SW_MODE"] = "0"
+            # with a residual (the second convolution of a ResBlock): prefetch of the residual tile on / off, both schedules
+            rs = torch.randn(B, H, H, co, device=DEV)
+            fnr = lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, res=rs, colstats=True, w_fmt=1)
+            os.environ["DP_H2_SW_VAR"] = "0"
+            os.environ["DP_H2_SW_PF"] = "0"
+            yr0 = fnr()
+            line += " | +res"
+            for var, pf in (("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")):
+                os.environ["DP_H2_SW_VAR"], os.environ["DP_H2_SW_PF"] = var, pf
+                y = fnr()
+                ok = torch.equal(y.t, yr0.t) and torch.equal(y.cols.buf, yr0.cols.buf)
+                line += f" v{var}pf{pf} {flop / timeit(fnr, iters) / 1e9:5.0f}{'' if ok else ' DIFF'}"
+            os.environ["DP_H2_SW_VAR"], os.environ["DP_H2_SW_PF"] = "0", "0"
+            del rs, yr0
+            line += " |"
             os.environ["DP_H2_SX"] = "1"          # its x-halo form (igemm_h2_sx.hip)
             y = fn()
             ok = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
@@ -89,7 +112,7 @@ def main():
                 res.append(f"m{mode}:{flop / timeit(fn, iters) / 1e9:5.0f}")
             line += f" sched{sched} [{'ok' if same else 'DIFF'}] " + " ".join(res) + " |"
         print(line, flush=True)
-    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW", "DP_H2_SW_MODE", "DP_H2_SX", "DP_H2_SX_MODE"):
+    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW", "DP_H2_SW_MODE", "DP_H2_SX", "DP_H2_SX_MODE", "DP_H2_SW_VAR", "DP_H2_SW_PF"):
         os.environ.pop(k, None)
 
 
