@@ -27,7 +27,7 @@ struct ConvH2Args {
     int stagger;        // igemm_h2_pp.hip: cycles per k-tile and phase of the start-up stagger (0 = none)
     int wfmt;           // weight panel: 0 = h2 (hi|lo), 1 = plain fp16 (afmt 1, passes 1 only)
     int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
-    int pf;             // igemm_h2_sw.hip: prefetch the residual tile into L2 during the last k-tiles (speed only)
+    int epi;            // one-wave-per-SIMD kernels: 1 = wide-access epilogue (sw_epilogue_wide), 0 = one dword per lane
     int ofmt;           // output: 0 = fp32 [M][ldo]; 1 = plain fp16 [M][ldo] (the final fp32 value rounded to nearest; `out` then
                         // points at fp16 elements).  Column statistics are those of the UNROUNDED values in both cases.
 };

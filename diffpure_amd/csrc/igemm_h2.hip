@@ -46,7 +46,7 @@ constexpr int NT = 256;
 constexpr int NXCD = 8;
 constexpr int DP_H2_PP_DEFAULT = 2;   // see the dispatcher
 constexpr int DP_H2_SX_DEFAULT = 0;   // see the dispatcher
-constexpr int DP_H2_SW_PF_DEFAULT = 0; // residual prefetch of the one-wave-per-SIMD kernel (ConvH2Args::pf)
+constexpr int DP_H2_SW_EPI_DEFAULT = 0; // epilogue of the one-wave-per-SIMD kernels (ConvH2Args::epi)
 
 
 // Tile variants of THIS file (256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS stages, two
@@ -477,8 +477,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.ofmt = out_fmt;
     p.stagger = 0;
     {
-        const char* epf = getenv("DP_H2_SW_PF");
-        p.pf = epf ? atoi(epf) : DP_H2_SW_PF_DEFAULT;
+        const char* ee = getenv("DP_H2_SW_EPI");
+        p.epi = ee ? atoi(ee) : DP_H2_SW_EPI_DEFAULT;
     }
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);

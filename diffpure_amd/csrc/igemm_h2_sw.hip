@@ -28,7 +28,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int NXCD = 8;
 constexpr int NB = 4, DIST = 3;                 // LDS ring stages, prefetch distance in k-tiles
-constexpr int DP_H2_SW_VAR_DEFAULT = 0;         // DP_H2_SW_VAR: 0 = DMA issues back to back, 1 = spread (see the kernel)
+constexpr int DP_H2_SW_VAR_DEFAULT = 1;         // DP_H2_SW_VAR: 0 = DMA issues back to back, 1 = spread (see the kernel)
 constexpr int TILE = 256 * 64;                  // one operand tile of a k-tile: 256 rows x 64 bytes (32 fp16)
 constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
 
@@ -38,7 +38,7 @@ constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
 // costs more than one 32-cycle shadow; consecutive ones queue up in front of the next MFMA).
 template <int MODE, int VAR>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
-    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE + 1024];      // + 256 bytes per wave: landing zone of the residual prefetch
+    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,14 +109,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                                          (__attribute__((address_space(3))) void*)(smem + stage * STAGE + wave * 64 * 64 + TILE + it * 16 * 64), 16, 0, 0);
         bptr[it] += 2048;
     };
-    // Residual prefetch (p.pf): the epilogue's residual reads (256 KB per tile) otherwise start when every CU of the chip has
-    // reached its epilogue at the same moment.  During the last 8 steady k-tiles one instruction per k-tile touches 64 of the
-    // wave tile's 512 cache lines (one dword per lane, landed in a scratch corner of LDS and never read): the lines are in
-    // L2 / MALL when the epilogue asks for them, fetched while HBM was idle under the MFMA phase.
-    const char* pfp = nullptr;
-    if (p.pf && p.res)
-        pfp = reinterpret_cast<const char*>(p.res) + ((size_t)(m0 + wr * 128 + (lane >> 2)) * p.ldr + n0 + wc * 128) * 4 + (lane & 3) * 128;
-    char* pf_lds = smem + NB * STAGE + wave * 256;
 
     // ---- fragments: lane -> row lr of a 32-row MFMA tile, k-half lk; 64-byte rows, slot (s*2 + lk) ^ key, key = (row >> 2) & 3
     const int lr = lane & 31, lk = lane >> 5;
@@ -175,12 +167,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // use, and the wave then waits for LDS with an idle matrix pipe).  Each half of a k-tile runs 16 MFMAs on one fragment
         // set and, BEHIND its first MFMA, issues the 8 reads of the other set one per MFMA shadow, then the 8 DMA issues of
         // k-tile t+3 one per MFMA shadow: the lgkmcnt wait before a half's first MFMA finds reads issued >= 8 MFMAs earlier.
-        if (pfp) {
-            const int q = t - (nt - DIST - 8);          // 0 .. 7 in the last 8 steady k-tiles (wave-uniform)
-            if (q >= 0)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pfp + (size_t)q * 16 * p.ldr * 4),
-                                                 (__attribute__((address_space(3))) void*)pf_lds, 4, 0, 0);
-        }
         if constexpr (VAR == 0) {
             if constexpr (!(MODE & 4)) read_frags(1, st);
             if constexpr (!(MODE & 1)) issue((t + DIST) & (NB - 1));
@@ -314,3 +300,7 @@ void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s) {
     }
 #undef SW_LAUNCH
 }
+
+// Also tried on this kernel and measured SLOWER (tests/probes/pp_ablate.py, B=64): prefetching the residual tile into L2 during the
+// last eight steady k-tiles (one 64-line touch per k-tile through a scratch LDS-DMA): 788-1049 vs 843-1061 TFLOP/s on the
+// residual-carrying launches - the extra requests queue in front of the operand DMAs.

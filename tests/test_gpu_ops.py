@@ -423,18 +423,19 @@ def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
         monkeypatch.setenv("DP_H2_PP", "1")
         # ... and its x-halo form (igemm_h2_sx.hip; 3x3 layers with W >= 32)
         # (last entry: the spread-DMA schedule of the one-wave-per-SIMD kernel with the residual prefetch on)
-        for sw, halo, sx, var, pf in (("0", "0", "0", "0", "0"), ("0", "1", "0", "0", "0"), ("1", "0", "0", "0", "0"), ("1", "0", "1", "0", "0"),
-                                      ("1", "0", "0", "1", "1"), ("1", "0", "0", "0", "1")):
+        # (var: DMA issues back to back / spread between the fragment reads; epi: dword / wide-access epilogue)
+        for sw, halo, sx, var, epi in (("0", "0", "0", "0", "0"), ("0", "1", "0", "0", "0"), ("1", "0", "0", "0", "0"), ("1", "0", "1", "0", "0"),
+                                       ("1", "0", "0", "1", "0"), ("1", "0", "0", "1", "1"), ("1", "0", "1", "0", "1")):
             monkeypatch.setenv("DP_H2_SW", sw)
             monkeypatch.setenv("DP_H2_HALO", halo)
             monkeypatch.setenv("DP_H2_SX", sx)
             monkeypatch.setenv("DP_H2_SW_VAR", var)
-            monkeypatch.setenv("DP_H2_SW_PF", pf)
+            monkeypatch.setenv("DP_H2_SW_EPI", epi)
             for _ in range(3):
                 got, got_cs = run()
-                assert torch.equal(got, base), (sw, halo, sx, var, pf)
-                assert torch.equal(got_cs, base_cs), (sw, halo, sx, var, pf)
-        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_SX", "DP_H2_SW_VAR", "DP_H2_SW_PF"):
+                assert torch.equal(got, base), (sw, halo, sx, var, epi)
+                assert torch.equal(got_cs, base_cs), (sw, halo, sx, var, epi)
+        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_SX", "DP_H2_SW_VAR", "DP_H2_SW_EPI"):
             monkeypatch.delenv(name)
         monkeypatch.setenv("DP_H2_PP", "0")
     # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
@@ -687,12 +688,14 @@ def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
                           colstats=True, w_fmt=1, out_f16=f16)
         return y.t, y.cols.buf.clone()
 
-    combos = [("0", None, None, None)]
+    base32 = basecs = None
+    combos = [("0", None, None, None, None)]
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
-        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"), ("1", "1", "0", "1")]
-    for pp, sw, halo, sx in combos:
+        combos += [("1", "0", "0", "0", "0"), ("1", "0", "1", "0", "0"), ("1", "1", "0", "0", "0"), ("1", "1", "0", "1", "0"), ("1", "1", "0", "0", "1"),
+                   ("1", "1", "0", "1", "1")]
+    for pp, sw, halo, sx, epi in combos:
         monkeypatch.setenv("DP_H2_PP", pp)
-        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo), ("DP_H2_SX", sx)):
+        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo), ("DP_H2_SX", sx), ("DP_H2_SW_EPI", epi)):
             if val is None:
                 monkeypatch.delenv(name, raising=False)
             else:
@@ -700,8 +703,11 @@ def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
         y32, cs32 = run(False)
         y16, cs16 = run(True)
         assert y16.dtype == torch.float16 and y16.shape == y32.shape
-        assert torch.equal(y16, y32.half()), (pp, sw, halo, sx)
-        assert torch.equal(cs16, cs32), (pp, sw, halo, sx)
+        assert torch.equal(y16, y32.half()), (pp, sw, halo, sx, epi)
+        assert torch.equal(cs16, cs32), (pp, sw, halo, sx, epi)
+        if base32 is None:
+            base32, basecs = y32, cs32
+        assert torch.equal(y32, base32) and torch.equal(cs32, basecs), (pp, sw, halo, sx, epi)
 
 
 def test_group_norm_f16in_equals_group_norm_of_the_upconverted_tensor(dev):
@@ -733,6 +739,11 @@ def test_attention_fused_operand_output(dev):
         got = ops.attention_fused(qkv, heads, layout, operand_hw=(hh, ww))
         want = torch.nn.functional.pad(ref.view(B, hh, ww, c), (0, 0, 1, 1, 1, 1)).half()
         assert got.dtype == torch.float16 and got.shape == want.shape
-        bad = (got != want).nonzero()
-        assert bad.numel() == 0, ((B, hh, ww, heads, layout), f"{bad.shape[0]} of {got.numel()} elements differ; first {bad[:6].tolist()}",
-                                  got[tuple(bad[0])].item(), want[tuple(bad[0])].item(), (got.float() - want.float()).abs().max().item())
+        # the kernel converts o * (1 / l) to fp16 in ONE rounding (v_fma_mixlo_f16); rounding the fp32 product again may differ by
+        # one fp16 ulp in a few elements per 10^5 (measured: 6 of 165 888): equal up to that, exact zeros on the border
+        diff = (got.float() - want.float()).abs()
+        assert (diff <= want.float().abs() * 2.0 ** -10 + 1e-7).all(), ((B, hh, ww, heads, layout), diff.max().item())
+        assert (got != want).float().mean().item() < 1e-3
+        border = torch.ones_like(got, dtype=torch.bool)
+        border[:, 1:-1, 1:-1, :] = False
+        assert (got[border] == 0).all()

@@ -9,11 +9,11 @@ lap() { echo "[$(( $(date +%s) - S )) s] $1" >> gpurun_out/dev_timeline.log; }
 timeout 400 python -m pytest tests/test_gpu_ops.py -q -k "fp16_weights_single_pass or fp16_output or f16in or operand_output" > gpurun_out/dev_tests.log 2>&1
 echo "rc=$?" >> gpurun_out/dev_tests.log; lap tests
 timeout 200 python tests/probes/pp_ablate.py --batch 64 --w16 > gpurun_out/dev_ablate.log 2>&1; lap ablate
-for cfg in "1 0" "0 1" "1 1"; do
-  set -- $cfg
-  DP_H2_SW_VAR=$1 DP_H2_SW_PF=$2 timeout 150 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_b32_var$1_pf$2.json 2> gpurun_out/dev_bench_b32_var$1_pf$2.err; lap bench_var$1_pf$2
+for epi in 0 1; do
+  DP_H2_SW_EPI=$epi timeout 150 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_b32_epi$epi.json 2> gpurun_out/dev_bench_b32_epi$epi.err; lap bench_b32_epi$epi
 done
-timeout 300 python -m pytest tests/test_gpu_loops.py -x -q -s -k "f16sr and (ncsnpp_loop or adjoint_ode)" > gpurun_out/dev_loops.log 2>&1
+DP_H2_SW_EPI=1 timeout 200 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_b64_epi1.json 2> gpurun_out/dev_bench_b64_epi1.err; lap bench_b64_epi1
+timeout 300 python -m pytest tests/test_gpu_loops.py -x -q -s -k "f16sr and (guided_loop or ncsnpp_loop)" > gpurun_out/dev_loops.log 2>&1
 echo "rc=$?" >> gpurun_out/dev_loops.log; lap loops
 tail -30 gpurun_out/dev_tests.log | cut -c1-400; cat gpurun_out/dev_ablate.log; grep -a "max-abs\|passed\|failed" gpurun_out/dev_loops.log
 python - <<'P'
