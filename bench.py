@@ -362,15 +362,14 @@ def main():
         unet_tflops = value / world * wl["gflop"] * n_steps / 1e3
         roof = {"bound": "mfma",
                 "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
-                          (f"conv_igemm_sx / conv_igemm_sw (3x3 implicit GEMM, 256x256 tile, one wave per SIMD with 128x128 wave tiles, "
-                           f"software-pipelined; sx = the three kx taps read one activation halo run; {passes} x v_mfma_f32_32x32x16_f16 "
-                           f"per product)" if a.precision in ("f16", "f16sr") else
+                          (f"conv_igemm_sw (3x3 implicit GEMM, 256x256 tile, one wave per SIMD with 128x128 wave tiles, software-pipelined "
+                           f"4-stage LDS ring; {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
                            f"conv_igemm_h2_pp (3x3 implicit GEMM on the 8-wave ping-pong kernel; {passes} x v_mfma_f32_32x32x16_f16 per "
                            f"product; executed MFMA flops = {passes} x achieved)"),
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "peak_note": "dense fp16 MFMA peak at the 2.4 GHz nominal clock (MI355X_MICROARCH.md); see sclk_mhz for the clock this run held",
                 "mfma_passes": passes, "sclk_mhz": sclk, "end_to_end_unet_tflops_per_gpu": unet_tflops,
-                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DP_H2_SX", "DP_H2_SW", "DP_H2_HALO", "DP_H2_PP") if k in os.environ}}
+                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DP_H2_SW", "DP_H2_SW_VAR", "DP_H2_HALO", "DP_H2_PP") if k in os.environ}}
         if prof is not None:
             dom = prof["pp3x3"] if prof["pp3x3"]["n"] else prof["other3x3"]      # f32 / tiny shapes never reach the ping-pong kernel
             if dom["ms"] > 0:

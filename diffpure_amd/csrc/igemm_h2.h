@@ -27,7 +27,6 @@ struct ConvH2Args {
     int stagger;        // igemm_h2_pp.hip: cycles per k-tile and phase of the start-up stagger (0 = none)
     int wfmt;           // weight panel: 0 = h2 (hi|lo), 1 = plain fp16 (afmt 1, passes 1 only)
     int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
-    int epi;            // one-wave-per-SIMD kernels: 1 = wide-access epilogue (sw_epilogue_wide), 0 = one dword per lane
     int ofmt;           // output: 0 = fp32 [M][ldo]; 1 = plain fp16 [M][ldo] (the final fp32 value rounded to nearest; `out` then
                         // points at fp16 elements).  Column statistics are those of the UNROUNDED values in both cases.
 };
@@ -54,7 +53,3 @@ void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);
 bool dp_conv_sw_applies(const ConvH2Args& p);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s);
 
-// The same kernel with the three kx taps of a (channel slice, ky) pair served by ONE activation halo run in LDS
-// (igemm_h2_sx.hip): 3x3 only, 32 <= W, image rows that tile 256-pixel blocks.
-bool dp_conv_sx_applies(const ConvH2Args& p);
-void dp_launch_conv_sx(ConvH2Args& p, hipStream_t s);

@@ -45,8 +45,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int NT = 256;
 constexpr int NXCD = 8;
 constexpr int DP_H2_PP_DEFAULT = 2;   // see the dispatcher
-constexpr int DP_H2_SX_DEFAULT = 0;   // see the dispatcher
-constexpr int DP_H2_SW_EPI_DEFAULT = 0; // epilogue of the one-wave-per-SIMD kernels (ConvH2Args::epi)
 
 
 // Tile variants of THIS file (256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS stages, two
@@ -476,10 +474,6 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.wfmt = w_fmt;
     p.ofmt = out_fmt;
     p.stagger = 0;
-    {
-        const char* ee = getenv("DP_H2_SW_EPI");
-        p.epi = ee ? atoi(ee) : DP_H2_SW_EPI_DEFAULT;
-    }
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
@@ -530,12 +524,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             // fp16 x fp16, N % 256 == 0: the one-wave-per-SIMD software-pipelined kernel (igemm_h2_sw.hip) - measured
             // fastest on every shape of both networks (tests/probes/pp_ablate.py --w16); DP_H2_SW=0 falls back
             const char* esw = getenv("DP_H2_SW");
-            // ... and its x-halo form (igemm_h2_sx.hip: the three kx taps read one activation run) for 3x3 layers with W >= 32;
-            // DP_H2_SX = 0 never, 1 whenever the shape allows, unset = DP_H2_SX_DEFAULT.  Identical bits either way.
-            const char* esx = getenv("DP_H2_SX");
-            const bool sw_on = bn == 256 && (!esw || atoi(esw) != 0);
-            if (sw_on && (esx ? atoi(esx) != 0 : DP_H2_SX_DEFAULT != 0) && dp_conv_sx_applies(p)) dp_launch_conv_sx(p, s);
-            else if (sw_on && dp_conv_sw_applies(p)) dp_launch_conv_sw(p, s);
+            if (bn == 256 && (!esw || atoi(esw) != 0) && dp_conv_sw_applies(p)) dp_launch_conv_sw(p, s);
             else if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
             else
             dp_launch_conv_h2_pp(p, s, bn);

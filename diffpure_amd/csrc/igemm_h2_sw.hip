@@ -271,7 +271,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 //     block fetch the same bytes - 48 KB instead of 32 KB per k-tile through the vector-memory path: 891-972 vs 918-1003 TFLOP/s;
 //   * activation operand as a 2-D halo tile (as igemm_h2_halo.hip; 21.5 KB instead of 32 KB per k-tile): 885-1022 vs 946-1131
 //     TFLOP/s - the per-tap address arithmetic, the data-dependent vmcnt variants and the 160 KB of LDS cost more than the
-//     bytes save (its no-loads-at-all ablation is already slower than this kernel's: 1277-1599 vs 1498-1880).
+//     bytes save (its no-loads-at-all ablation is already slower than this kernel's: 1277-1599 vs 1498-1880);
+//   * the x-halo form (one activation run of R x (W + 2) pixels per (channel slice, ky) serves the three kx taps: 65 DMA pieces
+//     per three k-tiles instead of 96; super-tiles of three k-tiles, two 68 KB LDS stages, ONE barrier per 96 MFMAs, the 24
+//     shifted fragment offsets precomputed): 876-1041 vs 907-1038 TFLOP/s - a third fewer operand bytes buy nothing, the L2 ->
+//     LDS path is not the bound either, and the one-super-tile prefetch distance exposes DMA latency (its no-wait ablation
+//     gains 9 %, this kernel's 3 %).
 }  // namespace
 
 bool dp_conv_sw_applies(const ConvH2Args& p) {

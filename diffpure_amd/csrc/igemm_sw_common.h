@@ -1,5 +1,5 @@
-// Pieces shared by the one-wave-per-SIMD convolution kernels (igemm_h2_sw.hip, igemm_h2_sx.hip): 4 waves per workgroup,
-// each owning a 128 x 128 wave tile = 4 x 4 MFMA tiles of 32 x 32 (256 accumulator registers).
+// Epilogue of the one-wave-per-SIMD convolution kernel (igemm_h2_sw.hip): 4 waves per workgroup, each owning a 128 x 128 wave
+// tile = 4 x 4 MFMA tiles of 32 x 32 (256 accumulator registers).
 #pragma once
 #include "igemm_h2.h"
 
@@ -108,153 +108,14 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
     }
 }
 
-// value of lane ^ 2 (quad_perm [2, 3, 0, 1])
-__device__ __forceinline__ float sw_swap2(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-}
-
-// 4 x 4 transpose across the four lanes of a quad (q = lane & 3): in x[rho] = M[rho][q], out x[c] = M[q][c].  An involution.
-// Two exchange stages through the DPP crossbar (4 moves + 8 selects), no LDS.
-__device__ __forceinline__ void sw_transpose4(float (&x)[4], int q) {
-    const bool o = q & 1, hi = q & 2;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float recv = sw_swap1(o ? x[2 * k] : x[2 * k + 1]);
-        if (o) x[2 * k] = recv;
-        else x[2 * k + 1] = recv;
-    }
-    const float ra = sw_swap2(hi ? x[0] : x[2]), rb = sw_swap2(hi ? x[1] : x[3]);
-    if (hi) {
-        x[0] = ra;
-        x[1] = rb;
-    } else {
-        x[2] = ra;
-        x[3] = rb;
-    }
-}
-
-// ---- the same epilogue with WIDE memory instructions.  The per-CU store path retires about one wave-instruction per ~27
-// cycles whatever its width (the 256 dword stores per lane of sw_epilogue take ~15 us per tile, the guide's "store-issue-bound"
-// tail), so the accumulator blocks are transposed inside each lane quad first: a lane then owns FOUR ADJACENT COLUMNS of one
-// row - one 16-byte store (8-byte for fp16 output) instead of four dword stores, 8 rows x 128 contiguous bytes per
-// wave-instruction.  The residual is fetched the same way (16-byte loads) and transposed back INTO the accumulator layout, so
-// every value, the order of every sum and the column records are those of sw_epilogue: identical bits, a quarter of the
-// memory instructions.
-template <bool OUT16>
-__device__ __forceinline__ void sw_epilogue_wide(const ConvH2Args& p, f32x16 (&acc)[4][4], int m0, int n0, int tile_m, int wr, int wc, int lr,
-                                                 int lk, int HW) {
-    const float* __restrict__ resp = p.res;
-    const float* __restrict__ tembp = p.temb;
-    const bool hw32 = HW % 32 == 0;
-    const int col0 = n0 + wc * 128 + lr;                // the lane's column in the accumulator layout (+ 32 j)
-    const int colq = n0 + wc * 128 + (lr & ~3);         // first of its four columns in the transposed layout (+ 32 j)
-    const int q4 = lr & 3;
-    // wide accesses are indexed in units of their own width from the (16-byte aligned) tensor base, so that the compiler keeps them
-    // as single instructions (indexed in floats it splits the 16-byte loads into four dword loads)
-    // (explicitly a GLOBAL pointer: left generic, the residual loads come out as flat_load, which also ticks lgkmcnt)
-    const __attribute__((address_space(1))) f32x4* __restrict__ res4 = (const __attribute__((address_space(1))) f32x4*)p.res;
-    f32x4* __restrict__ out4 = reinterpret_cast<f32x4*>(p.out);
-    dp_half4* __restrict__ outh4 = reinterpret_cast<dp_half4*>(p.out);
-    const size_t ldr4 = (size_t)(p.ldr >> 2), ldo4 = (size_t)(p.ldo >> 2);
-    float bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {                   // one 64-row column record = two 32-row MFMA tiles
-        float cs[2][4], cq[2][4];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = 2 * q + ii;
-            const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
-            const size_t rowt = (size_t)(rowb + q4);                    // transposed layout: row of block g is rowt + 8 g
-            float tv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
-                cs[ii][j] = 0.f;
-                cq[ii][j] = 0.f;
-            }
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {        // two column tiles at a time: 8 residual loads of 16 bytes in flight per lane
-                float rv[2][16];
-                if (resp) {
-                    f32x4 rt[2][4];
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            rt[jj][g] = res4[(rowt + 8 * g) * ldr4 + (colq >> 2) + (jh * 2 + jj) * 8];   // 16-byte units: alignment stays visible
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            float x[4] = {rt[jj][g][0], rt[jj][g][1], rt[jj][g][2], rt[jj][g][3]};
-                            sw_transpose4(x, q4);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) rv[jj][4 * g + c] = x[c];
-                        }
-                }
-                float vv[2][16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowb + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int j = jh * 2 + jj;
-                        float v = acc[i][j][r] + bv[j];
-                        if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
-                        if (resp) v += rv[jj][r];
-                        v *= p.scale;
-                        vv[jj][r] = v;
-                        cs[ii][j] += v;
-                        cq[ii][j] += v * v;
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float x[4] = {vv[jj][4 * g], vv[jj][4 * g + 1], vv[jj][4 * g + 2], vv[jj][4 * g + 3]};
-                        sw_transpose4(x, q4);
-                        const size_t at4 = (rowt + 8 * g) * ldo4 + (colq >> 2) + (jh * 2 + jj) * 8;     // in units of 4 elements
-                        if constexpr (OUT16) {
-                            const dp_half4 h = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
-                            outh4[at4] = h;
-                        } else {
-                            const f32x4 o = {x[0], x[1], x[2], x[3]};
-                            out4[at4] = o;
-                        }
-                    }
-            }
-            if (p.colstats) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    cs[ii][j] += __shfl_xor(cs[ii][j], 32, 64);
-                    cq[ii][j] += __shfl_xor(cq[ii][j], 32, 64);
-                }
-            }
-        }
-        if (p.colstats && lk == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col0 + j * 32;
-                d[0] = cs[0][j] + cs[1][j];
-                d[p.N] = cq[0][j] + cq[1][j];
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ void sw_epilogue_any(const ConvH2Args& p, f32x16 (&acc)[4][4], int m0, int n0, int tile_m, int wr, int wc,
                                                 int lr, int lk, int HW) {
-    // wide form: 16-byte accesses need row strides that are multiples of 4 elements (always true for N % 256 == 0 tensors)
-    if (p.epi && p.ldo % 4 == 0 && (!p.res || p.ldr % 4 == 0)) {
-        if (p.ofmt) sw_epilogue_wide<true>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
-        else sw_epilogue_wide<false>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
-        return;
-    }
     if (p.ofmt) sw_epilogue<true>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
     else sw_epilogue<false>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
 }
 
+// Measured on this epilogue and NOT kept (tests/probes/pp_ablate.py, B=64, bit-identical results):
+//   * 16-byte stores and residual loads after a 4 x 4 transpose inside each lane quad (two DPP exchange stages): a quarter of the
+//     memory instructions, +0.7 % without a residual, -3 % with one, -2.5 % with fp16 output - the tile's fixed cost (~18 us of
+//     an 84 us K = 2304 tile) is not the number of store instructions.
 }  // namespace

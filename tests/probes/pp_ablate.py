@@ -58,7 +58,6 @@ def main():
             os.environ["DP_H2_HALO"] = "0"
             os.environ["DP_H2_SW"] = "1"          # one wave per SIMD, software-pipelined (igemm_h2_sw.hip)
             os.environ["DP_H2_SW_VAR"] = "0"
-            os.environ["DP_H2_SW_EPI"] = "0"
             y = fn()
             ok = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
             line += f" sw {flop / timeit(fn, iters) / 1e9:5.0f} [{'ok' if ok else 'DIFF'}]"
@@ -75,35 +74,12 @@ def main():
                 os.environ["DP_H2_SW_MODE"] = str(m)
                 line += f" m{m}:{flop / timeit(fn, iters) / 1e9:5.0f}"
             os.environ["DP_H2_SW_MODE"] = "0"
-            # epilogue variants (dword / wide accesses), without and with a residual, fp32 and fp16 output
+            # with a residual (the second convolution of a ResBlock) and with fp16 output (the first)
             rs = torch.randn(B, H, H, co, device=DEV)
             fnr = lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, res=rs, colstats=True, w_fmt=1)
             fn16 = lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, colstats=True, w_fmt=1, out_f16=True)
-            os.environ["DP_H2_SW_EPI"] = "0"
-            yr0, y160 = fnr(), fn16()
-            line += " | epi"
-            for epi in ("0", "1"):
-                os.environ["DP_H2_SW_EPI"] = epi
-                y, yr, y16 = fn(), fnr(), fn16()
-                ok = (torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf) and torch.equal(yr.t, yr0.t) and
-                      torch.equal(yr.cols.buf, yr0.cols.buf) and torch.equal(y16.t, y160.t))
-                line += (f" e{epi}: {flop / timeit(fn, iters) / 1e9:5.0f} +res {flop / timeit(fnr, iters) / 1e9:5.0f} f16out "
-                         f"{flop / timeit(fn16, iters) / 1e9:5.0f}{'' if ok else ' DIFF'}")
-            os.environ.pop("DP_H2_SW_EPI")
-            del rs, yr0, y160
-            line += " |"
-            os.environ["DP_H2_SX"] = "1"          # its x-halo form (igemm_h2_sx.hip)
-            y = fn()
-            ok = torch.equal(y.t, base.t) and torch.equal(y.cols.buf, base.cols.buf)
-            line += f" sx {flop / timeit(fn, iters) / 1e9:5.0f} [{'ok' if ok else 'DIFF'}]"
-            for m in (1, 2, 4, 7):
-                os.environ["DP_H2_SX_MODE"] = str(m)
-                line += f" m{m}:{flop / timeit(fn, iters) / 1e9:5.0f}"
-            os.environ["DP_H2_SX_MODE"] = "0"
-            fn16 = lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, colstats=True, w_fmt=1, out_f16=True)
-            line += f" sx+fp16out {flop / timeit(fn16, iters) / 1e9:5.0f}"
-            os.environ["DP_H2_SX"] = "0"
-            line += f" sw+fp16out {flop / timeit(fn16, iters) / 1e9:5.0f} |"
+            line += f" +res {flop / timeit(fnr, iters) / 1e9:5.0f} f16out {flop / timeit(fn16, iters) / 1e9:5.0f} |"
+            del rs
             os.environ["DP_H2_SW"] = "0"
         for sched in ((1,) if w16 else (0, 1)):
             os.environ["DP_H2_PP_SCHED"] = str(sched)
@@ -116,7 +92,7 @@ def main():
                 res.append(f"m{mode}:{flop / timeit(fn, iters) / 1e9:5.0f}")
             line += f" sched{sched} [{'ok' if same else 'DIFF'}] " + " ".join(res) + " |"
         print(line, flush=True)
-    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW", "DP_H2_SW_MODE", "DP_H2_SX", "DP_H2_SX_MODE", "DP_H2_SW_VAR", "DP_H2_SW_EPI"):
+    for k in ("DP_H2_PP", "DP_H2_PP_SCHED", "DP_H2_PP_MODE", "DP_H2_HALO", "DP_H2_SW", "DP_H2_SW_MODE", "DP_H2_SW_VAR"):
         os.environ.pop(k, None)
 
 

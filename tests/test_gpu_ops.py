@@ -343,8 +343,7 @@ H1_CASES = H2_CASES + PP_CASES + [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (8, 64
                                   (1, 128, 128, 64, 256, 3, 1, True, 0.5), (1, 256, 256, 32, 256, 3, 0, False, 1.0),
                                   (2, 256, 256, 64, 256, 3, 2, True, 1.0), (3, 64, 64, 96, 512, 3, 0, True, 1.0),
                                   (5, 16, 16, 160, 256, 3, 2, False, 1.0),
-                                  # x-halo kernel (igemm_h2_sx.hip): one / several image rows per 256-pixel tile, 1 .. 3 channel slices,
-                                  # two column tiles, tiles that end at the last pixel of the tensor
+                                  # one / several image rows per 256-pixel tile, 1 .. 3 channel slices, two column tiles, a wide image
                                   (1, 256, 256, 96, 512, 3, 1, True, 1.0), (4, 32, 32, 32, 256, 3, 2, True, 0.5), (1, 8, 512, 64, 256, 3, 0, False, 1.0)]
 
 
@@ -421,21 +420,17 @@ def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
     # every 256x256 variant: per-tap ping-pong, halo-tile ping-pong, one-wave-per-SIMD software-pipelined
     if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64):
         monkeypatch.setenv("DP_H2_PP", "1")
-        # ... and its x-halo form (igemm_h2_sx.hip; 3x3 layers with W >= 32)
         # (last entry: the spread-DMA schedule of the one-wave-per-SIMD kernel with the residual prefetch on)
-        # (var: DMA issues back to back / spread between the fragment reads; epi: dword / wide-access epilogue)
-        for sw, halo, sx, var, epi in (("0", "0", "0", "0", "0"), ("0", "1", "0", "0", "0"), ("1", "0", "0", "0", "0"), ("1", "0", "1", "0", "0"),
-                                       ("1", "0", "0", "1", "0"), ("1", "0", "0", "1", "1"), ("1", "0", "1", "0", "1")):
+        # (var: the one-wave-per-SIMD kernel with its DMA issues back to back / spread between the fragment reads)
+        for sw, halo, var in (("0", "0", "0"), ("0", "1", "0"), ("1", "0", "0"), ("1", "0", "1")):
             monkeypatch.setenv("DP_H2_SW", sw)
             monkeypatch.setenv("DP_H2_HALO", halo)
-            monkeypatch.setenv("DP_H2_SX", sx)
             monkeypatch.setenv("DP_H2_SW_VAR", var)
-            monkeypatch.setenv("DP_H2_SW_EPI", epi)
             for _ in range(3):
                 got, got_cs = run()
-                assert torch.equal(got, base), (sw, halo, sx, var, epi)
-                assert torch.equal(got_cs, base_cs), (sw, halo, sx, var, epi)
-        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_SX", "DP_H2_SW_VAR", "DP_H2_SW_EPI"):
+                assert torch.equal(got, base), (sw, halo, var)
+                assert torch.equal(got_cs, base_cs), (sw, halo, var)
+        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_SW_VAR"):
             monkeypatch.delenv(name)
         monkeypatch.setenv("DP_H2_PP", "0")
     # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
@@ -672,7 +667,7 @@ FP16_OUT_CASES = [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (1, 128, 128, 64, 256,
 def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
     """dp_conv2d_nhwc_h2 out_fmt 1: the tensor is stored as plain fp16 = the fp32 result rounded to nearest, bit for bit, in
     every tile variant (generic 128 / 64 tiles, split-K level, ping-pong, halo, one-wave-per-SIMD with the paired-lane
-    packed stores, x-halo); the column records stay those of the unrounded values."""
+    packed stores); the column records stay those of the unrounded values."""
     from diffpure_amd import ops
     B, H, W, C, N, k, temb_rows, has_res, scale = case
     x = rnd(B, H, W, C, seed=1)
@@ -689,13 +684,12 @@ def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
         return y.t, y.cols.buf.clone()
 
     base32 = basecs = None
-    combos = [("0", None, None, None, None)]
+    combos = [("0", None, None, None)]
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
-        combos += [("1", "0", "0", "0", "0"), ("1", "0", "1", "0", "0"), ("1", "1", "0", "0", "0"), ("1", "1", "0", "1", "0"), ("1", "1", "0", "0", "1"),
-                   ("1", "1", "0", "1", "1")]
-    for pp, sw, halo, sx, epi in combos:
+        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"), ("1", "1", "0", "1")]
+    for pp, sw, halo, var in combos:
         monkeypatch.setenv("DP_H2_PP", pp)
-        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo), ("DP_H2_SX", sx), ("DP_H2_SW_EPI", epi)):
+        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo), ("DP_H2_SW_VAR", var)):
             if val is None:
                 monkeypatch.delenv(name, raising=False)
             else:
@@ -703,11 +697,11 @@ def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
         y32, cs32 = run(False)
         y16, cs16 = run(True)
         assert y16.dtype == torch.float16 and y16.shape == y32.shape
-        assert torch.equal(y16, y32.half()), (pp, sw, halo, sx, epi)
-        assert torch.equal(cs16, cs32), (pp, sw, halo, sx, epi)
+        assert torch.equal(y16, y32.half()), (pp, sw, halo, var)
+        assert torch.equal(cs16, cs32), (pp, sw, halo, var)
         if base32 is None:
             base32, basecs = y32, cs32
-        assert torch.equal(y32, base32) and torch.equal(cs32, basecs), (pp, sw, halo, sx, epi)
+        assert torch.equal(y32, base32) and torch.equal(cs32, basecs), (pp, sw, halo, var)
 
 
 def test_group_norm_f16in_equals_group_norm_of_the_upconverted_tensor(dev):
