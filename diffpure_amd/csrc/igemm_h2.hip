@@ -35,6 +35,7 @@
 // one L2.
 #include <mutex>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "igemm_h2.h"
 
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     float* __restrict__ outp = p.out;
     _Float16* __restrict__ outh = reinterpret_cast<_Float16*>(p.out);      // p.ofmt 1: fp16 output
     const bool hw32 = HW % 32 == 0;
+    // the output format is a compile-time flag of the store loop (tested per store it costs a branch per element)
+    auto store_tile = [&](auto out16) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + j * 32 + lr;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
                 if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
                 if (resp) v += rv[i][r];
                 v *= p.scale;
-                if (p.ofmt) outh[(size_t)row * p.ldo + col] = (_Float16)v;
+                if constexpr (decltype(out16)::value) outh[(size_t)row * p.ldo + col] = (_Float16)v;
                 else outp[(size_t)row * p.ldo + col] = v;
                 cs += v;
                 cq += v * v;
@@ -309,6 +312,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
             }
         }
     }
+    };
+    if (p.ofmt) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
     if (p.colstats) {
         __syncthreads();
         constexpr int REC = BM / 64;

@@ -30,9 +30,11 @@ __device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const 
 // bias / temb / residual / scale, store, per-column (sum, sumsq) of every 64 output rows.
 // 32-row sub-sums (16 values per lane in r order, then the partner half-wave) paired even+odd: the
 // tile-shape-independent order of igemm.hip.  Both sub-sums of a record live in this wave: no LDS.
-template <int BM>
-__device__ __forceinline__ void pp_epilogue(const ConvH2Args& p, f32x16 (&acc)[4][2], int m0, int n0, int tile_m, int wr, int wc, int lr,
-                                            int lk, int HW) {
+// OUT16 (p.ofmt 1): the tensor is stored as plain fp16 (one 2-byte store per value; the packed form lives in igemm_sw_common.h).  A
+// template parameter, chosen once per kernel by pp_epilogue: tested per store it costs a branch per element.
+template <int BM, bool OUT16>
+__device__ __forceinline__ void pp_epilogue_t(const ConvH2Args& p, f32x16 (&acc)[4][2], int m0, int n0, int tile_m, int wr, int wc, int lr,
+                                              int lk, int HW) {
     const float* __restrict__ resp = p.res;
     const float* __restrict__ tembp = p.temb;
     float* __restrict__ outp = p.out;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void pp_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
                 if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
                 if (resp) v += rv[j][r];
                 v *= p.scale;
-                if (p.ofmt) outh[(size_t)row * p.ldo + col0 + j * 32] = (_Float16)v;
+                if constexpr (OUT16) outh[(size_t)row * p.ldo + col0 + j * 32] = (_Float16)v;
                 else outp[(size_t)row * p.ldo + col0 + j * 32] = v;
                 cs[i][j] += v;
                 cq[i][j] += v * v;
@@ -99,6 +101,13 @@ __device__ __forceinline__ void pp_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
                 d[p.N] = cq[2 * q][j] + cq[2 * q + 1][j];
             }
     }
+}
+
+template <int BM>
+__device__ __forceinline__ void pp_epilogue(const ConvH2Args& p, f32x16 (&acc)[4][2], int m0, int n0, int tile_m, int wr, int wc, int lr,
+                                            int lk, int HW) {
+    if (p.ofmt) pp_epilogue_t<BM, true>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
+    else pp_epilogue_t<BM, false>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
 }
 
 }  // namespace

@@ -1,21 +1,18 @@
 #!/bin/bash
-# One-shot development check on the GPU box (gpurun): new-kernel tests, ablation probes, A/B bench lines.  Writes gpurun_out/dev_*.
+# Short development check on the GPU box (gpurun): kernel tests of the convolution variants, smoke, the two CIFAR bench lines.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 S=$(date +%s)
 lap() { echo "[$(( $(date +%s) - S )) s] $1" >> gpurun_out/dev_timeline.log; }
 : > gpurun_out/dev_timeline.log
-timeout 400 python -m pytest tests/test_gpu_ops.py -q -k "fp16_weights_single_pass or fp16_output or f16in or operand_output" > gpurun_out/dev_tests.log 2>&1
+timeout 400 python -m pytest tests/test_gpu_ops.py -q -k "conv2d" > gpurun_out/dev_tests.log 2>&1
 echo "rc=$?" >> gpurun_out/dev_tests.log; lap tests
-timeout 200 python tests/probes/pp_ablate.py --batch 64 --w16 > gpurun_out/dev_ablate.log 2>&1; lap ablate
-for epi in 0 1; do
-  DP_H2_SW_EPI=$epi timeout 150 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_b32_epi$epi.json 2> gpurun_out/dev_bench_b32_epi$epi.err; lap bench_b32_epi$epi
-done
-DP_H2_SW_EPI=1 timeout 200 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_b64_epi1.json 2> gpurun_out/dev_bench_b64_epi1.err; lap bench_b64_epi1
-timeout 300 python -m pytest tests/test_gpu_loops.py -x -q -s -k "f16sr and (guided_loop or ncsnpp_loop)" > gpurun_out/dev_loops.log 2>&1
-echo "rc=$?" >> gpurun_out/dev_loops.log; lap loops
-tail -30 gpurun_out/dev_tests.log | cut -c1-400; cat gpurun_out/dev_ablate.log; grep -a "max-abs\|passed\|failed" gpurun_out/dev_loops.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/dev_smoke.log 2>&1; echo "rc=$?" >> gpurun_out/dev_smoke.log; lap smoke
+timeout 200 python bench.py --workload cifar32_ncsnpp --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_cifar.json 2> gpurun_out/dev_bench_cifar.err; lap cifar
+DIFFPURE_LEAN=0 timeout 200 python bench.py --workload cifar32_ncsnpp --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_cifar_nolean.json 2> gpurun_out/dev_bench_cifar_nolean.err; lap cifar_nolean
+timeout 200 python bench.py --workload cifar32_ncsnpp_adjoint --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/dev_bench_adjoint.json 2> gpurun_out/dev_bench_adjoint.err; lap adjoint
+tail -3 gpurun_out/dev_tests.log; tail -2 gpurun_out/dev_smoke.log
 python - <<'P'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/dev_bench_*.json")):
