@@ -53,3 +53,7 @@ void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);
 bool dp_conv_sw_applies(const ConvH2Args& p);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s);
 
+// Few output channels (N <= 32: the 6-channel head), 3x3, fp16 x fp16: 256 x 32 tiles over x-halo activation runs (igemm_h2_nn.hip).
+bool dp_conv_nn_applies(const ConvH2Args& p);
+void dp_launch_conv_nn(ConvH2Args& p, hipStream_t s);
+

@@ -541,6 +541,15 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             return 0;
         }
     }
+    {   // few output channels (the 6-channel head): 256 x 32 tiles over x-halo runs; DP_H2_NN=0 falls back to the generic tiles
+        const char* enn = getenv("DP_H2_NN");
+        if ((!enn || atoi(enn) != 0) && dp_conv_nn_applies(p)) {
+            dp_launch_conv_nn(p, s);
+            dp_prof_end(rec, s);
+            DP_LAUNCH_CHECK("conv_igemm_nn");
+            return 0;
+        }
+    }
     // (thresholds 256 / 512 / 1024, a <128,64,32> middle variant and wide 4-wave tiles <128,256,16> / <256,128,16> were
     //  tried on these shapes: all within run-to-run noise or slower; the wide ones are superseded by igemm_h2_pp.hip)
     if (N <= 64 || tiles(128, 128) * p.ksplit < 256) DP_H2_LAUNCH(64, 64, 32, 0);

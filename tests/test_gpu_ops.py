@@ -741,3 +741,32 @@ def test_attention_fused_operand_output(dev):
         border = torch.ones_like(got, dtype=torch.bool)
         border[:, 1:-1, 1:-1, :] = False
         assert (got[border] == 0).all()
+
+
+NN_CASES = [(2, 32, 32, 64, 6), (1, 256, 256, 32, 6), (3, 64, 64, 96, 3), (1, 128, 128, 64, 32), (1, 8, 512, 32, 16), (4, 16, 64, 64, 6)]
+
+
+@pytest.mark.parametrize("case", NN_CASES, ids=[str(c) for c in NN_CASES])
+def test_conv2d_few_output_channels_kernel(dev, case, monkeypatch):
+    """igemm_h2_nn.hip (3x3, fp16 x fp16, N <= 32: the 6-channel head): identical bits to the generic tile kernel it replaces, and the
+    exact convolution of the fp16-rounded operands to fp32-class accuracy; one to three channel slices, one / several image rows
+    per 256-pixel tile, a wide image, the last tile of the tensor."""
+    from diffpure_amd import ops
+    B, H, W, C, N = case
+    x = rnd(B, H, W, C, seed=1)
+    w = rnd(N, C, 3, 3, seed=3, scale=1.0 / math.sqrt(C * 9))
+    bias = rnd(N, seed=4).to(dev)
+    ref = torch.nn.functional.conv2d(x.half().double().permute(0, 3, 1, 2), w.half().double(), bias.cpu().double(), padding=1).permute(0, 2, 3, 1)
+    ref = (ref * 0.5).float()
+    xh = _h1_bordered(x, dev)
+    w16 = ops.order_conv_weight_w16(w).half().to(dev)
+    monkeypatch.setenv("DP_H2_NN", "0")
+    base = ops.conv2d_h2(xh, w16, N, 3, bias=bias, scale=0.5, w_fmt=1)
+    close(base, ref, rtol=2e-5, atol=2e-5)
+    monkeypatch.setenv("DP_H2_NN", "1")
+    for _ in range(3):
+        got = ops.conv2d_h2(xh, w16, N, 3, bias=bias, scale=0.5, w_fmt=1)
+        assert torch.equal(got, base)
+    # the epilogues this kernel does not carry go to the generic tiles, whatever the switch says
+    y = ops.conv2d_h2(xh, w16, N, 3, bias=bias, scale=0.5, w_fmt=1, colstats=True)
+    assert torch.equal(y.t, base)
