@@ -413,3 +413,39 @@ def test_ncsnpp_fir_forward_vs_reference_golden():
         net = pn.NCSNpp(cfg, DEV, precision).load_state_dict(sd)
         out = nchw(net.forward(nhwc(g["x"]).to(DEV), g["labels"].to(DEV))).cpu()
         assert maxabs(out, g["out"]) < tol, (precision, maxabs(out, g["out"]))
+
+
+@pytest.mark.parametrize("kind", ["guided", "ncsnpp"])
+def test_lean_fp16_mid_tensors_agree_with_fp32_mid_tensors(kind, monkeypatch):
+    """DESIGN.md section 3 "lean": in the fp16 x fp16 modes the tensor between a ResBlock's two convolutions (and the attention output
+    on its way to proj_out) travels as fp16.  Same network, same round-to-nearest fp16 weights ("f16"), both settings: the two
+    forwards differ (the path is really taken) by no more than the extra fp16 rounding of an activation explains, both sit inside
+    the f16 tolerance of the reference golden, and a taped forward (which keeps fp32 for the backward pass) equals the fp32-mid one."""
+    from diffpure_amd import guided_unet as pg
+    from diffpure_amd import ncsnpp as pn
+    if kind == "guided":
+        g = load_golden("guided_small.pt")
+        cfg, mod, cls = pg.parse_config(g["cfg"]), pg, pg.GuidedUNet
+        args = (nhwc(g["x"]).to(DEV), g["t"].float().to(DEV))
+    else:
+        g = load_golden("ncsnpp_small.pt")
+        cfg, mod, cls = pn.parse_config(g["cfg"]), pn, pn.NCSNpp
+        args = (nhwc(g["x"]).to(DEV), g["labels"].to(DEV))
+    sd = synth_state_dict(mod.param_shapes(cfg), g["seed"])
+    outs = {}
+    for lean in ("1", "0"):
+        monkeypatch.setenv("DIFFPURE_LEAN", lean)
+        net = cls(cfg, DEV, "f16").load_state_dict(sd)
+        assert net._lean == (lean == "1")
+        outs[lean] = nchw(net.forward(*args)).cpu()
+        if lean == "1":
+            tape = []
+            outs["taped"] = nchw(net.forward(*args, tape=tape)).cpu()
+            assert tape
+    scale = g["out"].abs().max().item()
+    d = maxabs(outs["1"], outs["0"])
+    print(f"lean vs fp32-mid [{kind}]: max-abs {d:.3e} (largest output {scale:.3f}); vs golden {maxabs(outs['1'], g['out']):.3e} / {maxabs(outs['0'], g['out']):.3e}")
+    assert 0 < d < 1e-2 * scale, (d, scale)
+    assert maxabs(outs["1"], g["out"]) < 2e-2 * max(1.0, scale) and maxabs(outs["0"], g["out"]) < 2e-2 * max(1.0, scale)
+    if kind == "ncsnpp":            # no attention operand in the way: the taped forward of the lean engine IS the fp32-mid forward
+        assert torch.equal(outs["taped"], outs["0"])
