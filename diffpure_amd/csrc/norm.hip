@@ -123,45 +123,11 @@ __global__ void gn_finalize_cols_kernel(const float* cs1, int C1, int tr1, const
     }
 }
 
-// The same statistics for ONE source whose groups are at most 32 channels wide (every GroupNorm of the networks but the ones over a
-// channel concatenation): one workgroup per (sample, 32-channel block) - the lanes of a wave run along 32 consecutive channels of
-// two records, so every 128-byte line of the record array is used whole (the kernel above reads a group's 8 .. 16 floats out of
-// each line: 92 us per launch at 256^2, a quarter of the fetched bytes used).  256 threads = 32 channels x 8 record slots; per
-// group the partial sums are combined in a fixed order (channels outer, slots inner), in double like above.
-__global__ __launch_bounds__(256) void gn_finalize_cols32_kernel(const float* cs, int C, int tr, int HW, int G, float eps, float* stats) {
-    __shared__ double rs[8][32];
-    __shared__ double rq[8][32];
-    const int nb = C / 32, cpg = C / G, gq = 32 / cpg;
-    const int b = blockIdx.x / nb, cb = blockIdx.x - b * nb;
-    const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
-    const int tps = HW / tr;
-    const float* rec0 = cs + (size_t)b * tps * 2 * C + cb * 32 + c;
-    double s = 0.0, q = 0.0;
-    for (int t = slot; t < tps; t += 8) {
-        const float* rec = rec0 + (size_t)t * 2 * C;
-        s += rec[0];
-        q += rec[C];
-    }
-    rs[slot][c] = s;
-    rq[slot][c] = q;
-    __syncthreads();
-    if ((int)threadIdx.x < gq) {
-        double S = 0.0, Q = 0.0;
-        for (int ch = threadIdx.x * cpg; ch < ((int)threadIdx.x + 1) * cpg; ++ch)
-            for (int sl = 0; sl < 8; ++sl) {
-                S += rs[sl][ch];
-                Q += rq[sl][ch];
-            }
-        const double inv = 1.0 / ((double)HW * cpg);
-        const double mean = S * inv;
-        double var = Q * inv - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const int g = cb * gq + threadIdx.x;
-        stats[(b * G + g) * 2] = (float)mean;
-        stats[(b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-}
-
+// Measured and not kept: a line-wide form of the kernel above for single-source statistics (one workgroup per (sample, 32-channel
+// block), the lanes of a wave along 32 consecutive channels of two records, so that every 128-byte line of the record array is
+// used whole instead of 32 .. 64 bytes of it).  Isolated, back to back at 256^2 x 256, B=64: 45 us instead of 82 us per launch; in
+// the purification itself (rocprofv3, 10 100 launches) 20.7 us average instead of 18.9 us: a quarter of the workgroups, each with
+// a four times longer dependent sweep - the launch is latency-bound, not byte-bound.
 struct ApplyArgs {
     const float* x1;
     const float* x2;
@@ -607,15 +573,8 @@ extern "C" int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, con
     DP_REQUIRE((C1 + C2) % G == 0, "dp_gn_finalize_cols: C must be a multiple of G");
     DP_REQUIRE(tile_rows1 > 0 && HW % tile_rows1 == 0 && (C2 == 0 || (tile_rows2 > 0 && HW % tile_rows2 == 0)),
                "dp_gn_finalize_cols: a convolution tile must not straddle two samples (HW %% tile_rows != 0)");
-    const int cpg = (C1 + C2) / G;
-    const char* e32 = getenv("DP_GN_FINALIZE32");       // A/B switch, read per call
-    const bool wide = !e32 || atoi(e32) != 0;
-    if (wide && C2 == 0 && C1 % 32 == 0 && cpg <= 32 && 32 % cpg == 0)       // one source, groups inside 32-channel blocks: whole cache lines
-        hipLaunchKernelGGL(gn_finalize_cols32_kernel, dim3((unsigned)(B * (C1 / 32))), dim3(256), 0, (hipStream_t)stream, cs1, C1, tile_rows1, HW, G,
-                           eps, stats);
-    else
-        hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3((unsigned)(B * G)), dim3(256), 0, (hipStream_t)stream, cs1, C1, tile_rows1,
-                           cs2, C2, C2 ? tile_rows2 : 1, HW, G, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3((unsigned)(B * G)), dim3(256), 0, (hipStream_t)stream, cs1, C1, tile_rows1,
+                       cs2, C2, C2 ? tile_rows2 : 1, HW, G, eps, stats);
     DP_LAUNCH_CHECK("gn_finalize_cols");
     return 0;
 }

@@ -771,32 +771,3 @@ def test_conv2d_few_output_channels_kernel(dev, case, monkeypatch):
     y = ops.conv2d_h2(xh, w16, N, 3, bias=bias, scale=0.5, w_fmt=1, colstats=True)
     assert torch.equal(y.t, base)
 
-
-def test_gn_finalize_cols_line_wide_kernel_equals_the_per_group_kernel(dev, monkeypatch):
-    """gn_finalize_cols32 (one workgroup per 32-channel block, whole cache lines of the record array) against the per-group kernel
-    and against the statistics pass over the tensor: groups of 4 / 8 / 16 / 32 channels, 1 .. 1024 records per sample."""
-    import time
-    from diffpure_amd import ops
-    for (B, H, W, C, G) in ((2, 16, 16, 128, 32), (3, 8, 8, 256, 32), (2, 32, 32, 512, 32), (1, 64, 64, 1024, 32), (2, 256, 256, 256, 32)):
-        x = (rnd(B, H, W, C, seed=2) * 1.5 + 0.3).to(dev)
-        w = rnd(C, C, 1, 1, seed=3, scale=1.0 / math.sqrt(C))
-        y = ops.conv2d(x, ops.pack_conv_weight(w).to(dev), C, 1, colstats=True)
-        monkeypatch.setenv("DP_GN_FINALIZE32", "0")
-        old = ops.group_norm_stats(y, G, 1e-5)
-        monkeypatch.setenv("DP_GN_FINALIZE32", "1")
-        new = ops.group_norm_stats(y, G, 1e-5)
-        plain = ops.group_norm_stats(y.t, G, 1e-5)
-        close(new, old.cpu(), rtol=1e-6, atol=1e-7)
-        close(new, plain.cpu(), rtol=2e-5, atol=2e-6)
-        assert torch.equal(new, ops.group_norm_stats(y, G, 1e-5))
-    # the 256^2 x 256 case at B=64: time of one launch, either kernel
-    y = ops.conv2d(torch.randn(64, 256, 256, 32, device=dev), ops.pack_conv_weight(rnd(256, 32, 1, 1, seed=5)).to(dev), 256, 1, colstats=True)
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DP_GN_FINALIZE32", flag)
-        ops.group_norm_stats(y, 32, 1e-5)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(20):
-            ops.group_norm_stats(y, 32, 1e-5)
-        torch.cuda.synchronize()
-        print(f"gn_finalize_cols 256^2 x 256 B=64, DP_GN_FINALIZE32={flag}: {(time.time() - t0) / 20 * 1e6:.1f} us per launch")
