@@ -25,6 +25,42 @@ def test_library_exports_every_declared_symbol():
     assert lib.dp_abi_version() == 3
 
 
+def test_ctypes_table_matches_the_header_prototypes():
+    """Every prototype of include/diffpure_hip.h against diffpure_amd/_lib.py::SIGNATURES: the same number of parameters, and
+    per parameter the same class (pointer / float / 32-bit int / 64-bit int) - the ABI is bound by hand on the Python side, an
+    added or re-ordered parameter must not go unnoticed until a kernel reads garbage."""
+    import ctypes as C
+    from diffpure_amd import _lib
+    text = open(os.path.join(ROOT, "include", "diffpure_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = dict(re.findall(r"\b(dp_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text))
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+
+    def klass_c(param):
+        param = " ".join(param.split())
+        if param in ("void", ""):
+            return None
+        if "*" in param:
+            return "ptr"
+        base = param.rsplit(" ", 1)[0] if " " in param else param
+        if base in ("float",):
+            return "f32"
+        if base in ("double",):
+            return "f64"
+        if base in ("long long", "unsigned long long", "int64_t", "uint64_t", "size_t"):
+            return "i64"
+        if base in ("int", "unsigned", "unsigned int", "int32_t", "uint32_t"):
+            return "i32"
+        raise AssertionError(f"unclassified C parameter {param!r}")
+
+    klass_py = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_float: "f32", C.c_double: "f64", C.c_int: "i32", C.c_uint: "i32",
+                C.c_longlong: "i64", C.c_ulonglong: "i64"}
+    for name, plist in protos.items():
+        want = [k for k in (klass_c(q) for q in plist.split(",")) if k is not None]
+        got = [klass_py[t] for t in _lib.SIGNATURES[name]]
+        assert got == want, f"{name}: header {want} vs ctypes {got}"
+
+
 def test_argument_validation_reports_errors_without_a_gpu():
     from diffpure_amd import _lib
     lib = _lib.load()
