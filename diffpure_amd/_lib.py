@@ -20,6 +20,8 @@ _p = C.c_void_p
 SIGNATURES = {
     "dp_abi_version": [],
     "dp_last_error": [],
+    "dp_set_tuning": [C.c_char_p, _i],
+    "dp_get_tuning": [C.c_char_p, _p],
     "dp_prof_enable": [_i],
     "dp_prof_collect": [_p, _p, _p, _p, _p],
     "dp_conv2d_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _p, _p, _p],

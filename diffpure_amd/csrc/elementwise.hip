@@ -2,8 +2,13 @@
 // diffusion + in-kernel Philox noise), SiLU, axpby, sinusoidal embedding, row softmax.
 // All are float4-vectorised, grid-stride, and sized to ~2048 workgroups (256 CUs x 8).
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
 
 #include "dp_common.h"
+#include "dp_tune.h"
 
 // ---- error plumbing (shared by every translation unit) ----------------------------------------
 static thread_local char g_dp_err[512] = "";
@@ -14,7 +19,49 @@ void dp_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dp_last_error(void) { return g_dp_err; }
-extern "C" int dp_abi_version(void) { return 3; }
+extern "C" int dp_abi_version(void) { return 4; }
+
+// ---- tuning switches (dp_tune.h): environment read once, then only dp_set_tuning() changes a value -----------------
+namespace {
+struct TuneEntry { const char* name; int def; };
+const TuneEntry kTune[DP_T_COUNT] = {
+    {"DP_H2_PP", 2}, {"DP_H2_HALO", 2}, {"DP_H2_SW", 1}, {"DP_H2_NN", 1}, {"DP_H2_PP_SCHED", 1},
+    {"DP_H2_PP_STAGGER", 0}, {"DP_GN_APPLY_QUAD", 1}, {"DP_H2_DW", 0}, {"DP_H2_DW_STAGGER", 550}, {"DP_H2_DW_MINROUNDS", 12},
+    {"DP_H2_DW_ADEPTH", 3}, {"DP_GN_FOLD", 0},
+};
+int g_tune[DP_T_COUNT];
+std::once_flag g_tune_once;
+void tune_load() {
+    for (int k = 0; k < DP_T_COUNT; ++k) {
+        const char* e = getenv(kTune[k].name);
+        g_tune[k] = e ? atoi(e) : kTune[k].def;
+    }
+}
+}  // namespace
+int dp_tune(DpTune k) {
+    std::call_once(g_tune_once, tune_load);
+    return g_tune[k];
+}
+extern "C" int dp_set_tuning(const char* name, int value) {
+    std::call_once(g_tune_once, tune_load);
+    for (int k = 0; k < DP_T_COUNT; ++k)
+        if (name && strcmp(name, kTune[k].name) == 0) {
+            g_tune[k] = value;
+            return 0;
+        }
+    dp_set_error("dp_set_tuning: unknown switch '%s'", name ? name : "(null)");
+    return 1;
+}
+extern "C" int dp_get_tuning(const char* name, int* value) {
+    std::call_once(g_tune_once, tune_load);
+    for (int k = 0; k < DP_T_COUNT; ++k)
+        if (name && value && strcmp(name, kTune[k].name) == 0) {
+            *value = g_tune[k];
+            return 0;
+        }
+    dp_set_error("dp_get_tuning: unknown switch '%s'", name ? name : "(null)");
+    return 1;
+}
 
 namespace {
 

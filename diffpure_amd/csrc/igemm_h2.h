@@ -24,7 +24,7 @@ struct ConvH2Args {
     int passes;         // MFMA passes per product: 3 = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi ("f16x3"); 2 = a_hi*w_lo + a_hi*w_hi
                         // (activations rounded to fp16, weights to 22 bits); 12 = a_lo*w_hi + a_hi*w_hi (weights rounded);
                         // 1 = a_hi*w_hi (plain fp16 operands, fp32 accumulation)
-    int stagger;        // igemm_h2_pp.hip: cycles per k-tile and phase of the start-up stagger (0 = none)
+    int stagger;        // igemm_h2_pp.hip / igemm_h2_dw.hip: cycles per k-tile of the start-up stagger (0 = none)
     int wfmt;           // weight panel: 0 = h2 (hi|lo), 1 = plain fp16 (afmt 1, passes 1 only)
     int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
     int ofmt;           // output: 0 = fp32 [M][ldo]; 1 = plain fp16 [M][ldo] (the final fp32 value rounded to nearest; `out` then
@@ -52,6 +52,10 @@ void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);
 // One-wave-per-SIMD software-pipelined variant (igemm_h2_sw.hip): fp16 x fp16, 256x256 tile, 4 waves of 128x128.
 bool dp_conv_sw_applies(const ConvH2Args& p);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s);
+
+// Two workgroups per CU, 128x256 tiles, 4 waves of 64x128 (igemm_h2_dw.hip): fp16 x fp16; the launcher fills p.tiles / p.stagger.
+bool dp_conv_dw_applies(const ConvH2Args& p);
+void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s);
 
 // Few output channels (N <= 32: the 6-channel head), 3x3, fp16 x fp16: 256 x 32 tiles over x-halo activation runs (igemm_h2_nn.hip).
 bool dp_conv_nn_applies(const ConvH2Args& p);

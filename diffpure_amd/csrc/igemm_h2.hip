@@ -37,6 +37,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include "dp_tune.h"
 #include "igemm_h2.h"
 
 namespace {
@@ -45,7 +46,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int NT = 256;
 constexpr int NXCD = 8;
-constexpr int DP_H2_PP_DEFAULT = 2;   // see the dispatcher
 
 
 // Tile variants of THIS file (256 threads = 2x2 waves, wave tile (BM/2) x (BN/2) of 32x32 MFMA tiles, two LDS stages, two
@@ -505,12 +505,22 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         else if (p.passes == 12) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 12, false, false>), g_, dim3(NT), 0, s, p);        \
         else hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 3, false, false>), g_, dim3(NT), 0, s, p);                             \
     } while (0)
+    {   // fp16 x fp16: two workgroups per CU on 128x256 tiles (igemm_h2_dw.hip); DP_H2_DW = 0 never, 1 when the launch fills
+        // every CU twice, 2 wherever the shape allows.  Bit-identical to the other variants.
+        const int dw = dp_tune(DP_T_H2_DW);
+        if (dw != 0 && dp_conv_dw_applies(p) && (dw == 2 || tiles(128, 256) >= 512)) {
+            dp_launch_conv_dw(p, s);
+            dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
+            if (tile_rows) *tile_rows = 64;
+            dp_prof_end(rec, s);
+            DP_LAUNCH_CHECK("conv_igemm_dw");
+            return 0;
+        }
+    }
     // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
-    // also fills the chip (>= one tile per CU); unset = DP_H2_PP_DEFAULT.  Read per call so that a probe can
-    // flip it inside one process.
+    // also fills the chip (>= one tile per CU); default 2 (dp_tune.h: read once; probes flip it with dp_set_tuning).
     {
-        const char* e = getenv("DP_H2_PP");
-        const int pp = e ? atoi(e) : DP_H2_PP_DEFAULT;
+        const int pp = dp_tune(DP_T_H2_PP);
         // one workgroup per CU: the grid runs in rounds of 256 tiles; take the variant when the last round is not
         // mostly empty (measured at B=16: 407-450 TFLOP/s vs 326-375 on full rounds, 262 vs 350 on half a round)
         auto fills = [&](int bm, int bn) {
@@ -525,12 +535,10 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             // 3x3, fp16 x fp16: the halo-tile variant (one activation DMA per channel slice instead of one per tap);
             // DP_H2_HALO = 0: never (per-tap kernel), 1: whenever the shape allows (W >= 16), unset: where it measured
             // faster (W >= 32).  Both kernels give identical bits.
-            const char* eh = getenv("DP_H2_HALO");
-            const int hv = eh ? atoi(eh) : 2;
+            const int hv = dp_tune(DP_T_H2_HALO);
             // fp16 x fp16, N % 256 == 0: the one-wave-per-SIMD software-pipelined kernel (igemm_h2_sw.hip) - measured
             // fastest on every shape of both networks (tests/probes/pp_ablate.py --w16); DP_H2_SW=0 falls back
-            const char* esw = getenv("DP_H2_SW");
-            if (bn == 256 && (!esw || atoi(esw) != 0) && dp_conv_sw_applies(p)) dp_launch_conv_sw(p, s);
+            if (bn == 256 && dp_tune(DP_T_H2_SW) != 0 && dp_conv_sw_applies(p)) dp_launch_conv_sw(p, s);
             else if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
             else
             dp_launch_conv_h2_pp(p, s, bn);
@@ -542,8 +550,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         }
     }
     {   // few output channels (the 6-channel head): 256 x 32 tiles over x-halo runs; DP_H2_NN=0 falls back to the generic tiles
-        const char* enn = getenv("DP_H2_NN");
-        if ((!enn || atoi(enn) != 0) && dp_conv_nn_applies(p)) {
+        if (dp_tune(DP_T_H2_NN) != 0 && dp_conv_nn_applies(p)) {
             dp_launch_conv_nn(p, s);
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("conv_igemm_nn");

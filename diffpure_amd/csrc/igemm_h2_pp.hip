@@ -37,6 +37,7 @@
 // sched_barrier(0) keeps each MFMA cluster inside its interval.
 #include <stdlib.h>
 
+#include "dp_tune.h"
 #include "igemm_h2.h"
 #include "igemm_pp_common.h"
 
@@ -46,7 +47,7 @@ namespace {
 constexpr int NT = 512;
 constexpr int NXCD = 8;
 constexpr int ROWB = 128;               // bytes per LDS row: 32 channels as (hi, lo) fp16 octets
-constexpr int DP_H2_PP_SCHED_DEFAULT = 1;   // measured (tests/probes/pp_ablate.py, B=16): 621-661 vs 495-635 TFLOP/s, bit-identical
+// DP_H2_PP_SCHED default 1 (dp_tune.h): measured (tests/probes/pp_ablate.py, B=16): 621-661 vs 495-635 TFLOP/s, bit-identical
 
 // MODE (timing experiments, DP_H2_PP_MODE): bit 0 = no s_setprio; bit 1 = no operand traffic after k-tile 0 (WRONG
 // RESULTS); bit 2 = no barriers in the k-loop (WRONG RESULTS); bit 3 = no ds_reads / bit 4 = no DMA after k-tile 0 / bit 5 = no vmcnt waits (WRONG RESULTS)
@@ -442,13 +443,14 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
     const int bm = bn == 256 ? 256 : 512;
     p.tiles_n = p.N / bn;
     p.tiles = (p.M / bm) * p.tiles_n;
+#ifdef DP_ABLATE   // timing ablations (WRONG RESULTS): only in libdiffpure_hip_ablate.so (tests/probes/build_ablate.py)
     const char* e = getenv("DP_H2_PP_MODE");
     const int mode = e ? atoi(e) : 0;
+#endif
 #define PP_LAUNCH1(BM_, BN_, M_, P_, A_, S_, W_) \
     hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_, P_, A_, S_, W_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
     // DP_H2_PP_SCHED: schedule of the fp16-operand kernels (0 = four phases per k-tile, 1 = two); A/B switch
-    const char* es = getenv("DP_H2_PP_SCHED");
-    const int sched = es ? atoi(es) : DP_H2_PP_SCHED_DEFAULT;
+    const int sched = dp_tune(DP_T_H2_PP_SCHED);
 #define PP_LAUNCH(BM_, BN_, M_)                                          \
     do {                                                                 \
         if (p.wfmt == 1) PP_LAUNCH1(BM_, BN_, M_, 1, true, 1, true);     \
@@ -459,25 +461,25 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
         else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false, 0, false); \
         else PP_LAUNCH1(BM_, BN_, M_, 3, false, 0, false);                      \
     } while (0)
-    {   // start-up stagger (see the kernel): cycles per k-tile and phase; off unless DP_H2_PP_STAGGER is set
-        const char* st = getenv("DP_H2_PP_STAGGER");
-        const int v = st ? atoi(st) : 0;
-        p.stagger = p.tiles >= 4096 ? v : 0;
-    }
+    // start-up stagger (see the kernel): cycles per k-tile and phase; off unless DP_H2_PP_STAGGER is set
+    p.stagger = p.tiles >= 4096 ? dp_tune(DP_T_H2_PP_STAGGER) : 0;
     if (bn == 128) {
         PP_LAUNCH(512, 128, 0);
         return;
     }
+#ifdef DP_ABLATE
     switch (mode) {     // timing experiments (see MODE)
-        case 1: PP_LAUNCH(256, 256, 1); break;
-        case 2: PP_LAUNCH(256, 256, 2); break;
-        case 6: PP_LAUNCH(256, 256, 6); break;
-        case 8: PP_LAUNCH(256, 256, 8); break;
-        case 16: PP_LAUNCH(256, 256, 16); break;
-        case 32: PP_LAUNCH(256, 256, 32); break;
-        case 256: PP_LAUNCH(256, 256, 256); break;
-        default: PP_LAUNCH(256, 256, 0); break;
+        case 1: PP_LAUNCH(256, 256, 1); return;
+        case 2: PP_LAUNCH(256, 256, 2); return;
+        case 6: PP_LAUNCH(256, 256, 6); return;
+        case 8: PP_LAUNCH(256, 256, 8); return;
+        case 16: PP_LAUNCH(256, 256, 16); return;
+        case 32: PP_LAUNCH(256, 256, 32); return;
+        case 256: PP_LAUNCH(256, 256, 256); return;
+        default: break;
     }
+#endif
+    PP_LAUNCH(256, 256, 0);
 #undef PP_LAUNCH
 #undef PP_LAUNCH1
 }

@@ -1,5 +1,6 @@
-// Epilogue of the one-wave-per-SIMD convolution kernel (igemm_h2_sw.hip): 4 waves per workgroup, each owning a 128 x 128 wave
-// tile = 4 x 4 MFMA tiles of 32 x 32 (256 accumulator registers).
+// Epilogue of the 4-wave fp16 x fp16 convolution kernels: igemm_h2_sw.hip (one workgroup per CU, 128 x 128 wave tiles = 4 x 4
+// MFMA tiles of 32 x 32, NQ = 2 column records of 64 rows per wave) and igemm_h2_dw.hip (two workgroups per CU, 64 x 128 wave
+// tiles = 2 x 4 MFMA tiles, NQ = 1).
 #pragma once
 #include "igemm_h2.h"
 
@@ -19,56 +20,80 @@ __device__ __forceinline__ float sw_swap1(float v) {
 // its own output to fp16), at half the bytes for this kernel's stores and for that pass's loads.  The MFMA accumulator
 // layout gives a lane ONE column (lr) of 16 rows; two neighbouring lanes exchange half of their values (rows r odd <-> r
 // even) so that each stores two ADJACENT columns of 8 rows as one dword: 8 stores per 32 x 32 tile instead of 16.
-template <bool OUT16>
-__device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[4][4], int m0, int n0, int tile_m, int wr, int wc, int lr,
-                                            int lk, int HW) {
-    const __attribute__((address_space(1))) float* __restrict__ resp = (const __attribute__((address_space(1))) float*)p.res;
+// row0: first output row of the wave tile; colw: its first column; rec0: index of its first 64-row column record
+// JP: column tiles handled per pass (16 JP residual loads in flight per lane)
+// Addressing: every global access is (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): the lane offsets of
+// the 16 rows a lane owns in a 32-row MFMA tile are computed ONCE (16 registers) and serve every tile of the wave; the
+// per-element 64-bit multiply-adds of the first version of this epilogue (two VALU instructions and a register pair per
+// element) are gone - which is also what lets the 256-register kernel keep its accumulators out of scratch.
+template <bool OUT16, int NQ, int JP>
+__device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2 * NQ][4], int row0, int colw, int rec0, int lr, int lk,
+                                            int HW) {
+    // Every tile variant must produce the SAME bits, column records included: products and sums stay separate instructions
+    // here as in the other epilogues (left to itself the vectoriser pairs `cq += v * v` into v_pk_fma_f32, which skips the
+    // rounding of v * v and changes the records in the last bit).
+#pragma clang fp contract(off)
+    typedef const __attribute__((address_space(1))) char* gptr;
     const float* __restrict__ tembp = p.temb;
-    float* __restrict__ outp = p.out;
-    _Float16* __restrict__ outh = reinterpret_cast<_Float16*>(p.out);
-    const bool hw32 = HW % 32 == 0;
-    const int col0 = n0 + wc * 128 + lr;
-    const bool odd = lr & 1;
+    // time-embedding rows: the callers (dp_conv_sw_applies / dp_conv_dw_applies) admit a temb only when H * W % 32 == 0,
+    // i.e. when the 32 rows of an MFMA tile belong to ONE sample
+    const int col0 = colw + lr;
+    const int odd = lr & 1;
     float bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
+    // lane offsets (bytes) inside a 32-row tile: row 4 lk + (r & 3) + 8 (r >> 2), column lr
+    unsigned vo[OUT16 ? 8 : 16], vr[16];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {                   // one 64-row column record = two 32-row MFMA tiles
+    for (int r = 0; r < 16; ++r) {
+        const int rr = 4 * lk + (r & 3) + 8 * (r >> 2);
+        vr[r] = ((unsigned)rr * (unsigned)p.ldr + (unsigned)lr) * 4u;
+        if constexpr (!OUT16) vo[r] = ((unsigned)rr * (unsigned)p.ldo + (unsigned)lr) * 4u;
+    }
+    if constexpr (OUT16) {
+        // pair store: the even lane keeps row r = 2k and stores columns (lr, lr + 1); the odd lane keeps row 2k + 1, columns (lr - 1, lr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rr = 4 * lk + ((2 * k) & 3) + 8 * ((2 * k) >> 2) + odd;
+            vo[k] = ((unsigned)rr * (unsigned)p.ldo + (unsigned)(lr - odd)) * 2u;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {                  // one 64-row column record = two 32-row MFMA tiles
         float cs[2][4], cq[2][4];
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * q + ii;
-            const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
+            const int rowt = row0 + i * 32;         // wave-uniform
             float tv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
+                tv[j] = tembp ? tembp[(size_t)(rowt / HW) * p.temb_stride + col0 + j * 32] : 0.f;
                 cs[ii][j] = 0.f;
                 cq[ii][j] = 0.f;
             }
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {        // two column tiles at a time: 32 residual loads in flight per lane
-                float rv[2][16];
-                if (resp) {
+            for (int jh = 0; jh < 4 / JP; ++jh) {   // JP column tiles at a time
+                float rv[JP][16];
+                if (p.res) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const __attribute__((address_space(1))) float* rp = resp + (size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col0 + jh * 64;
-                        rv[0][r] = rp[0];
-                        rv[1][r] = rp[32];
+                    for (int jj = 0; jj < JP; ++jj) {
+                        gptr rb = (gptr)(p.res + (size_t)rowt * p.ldr + colw + (jh * JP + jj) * 32);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[jj][r] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(rb + vr[r]);
                     }
                 }
-                float vv[2][16];
+                float vv[JP][16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowb + (r & 3) + 8 * (r >> 2);
+                for (int jj = 0; jj < JP; ++jj) {
+                    const int j = jh * JP + jj;
+                    char* ob = reinterpret_cast<char*>(p.out + (size_t)rowt * p.ldo + colw + j * 32);   // fp32 output only
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int j = jh * 2 + jj;
-                        float v = acc[i][j][r] + bv[j];
-                        if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
-                        if (resp) v += rv[jj][r];
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r] + bv[j] + tv[j];
+                        if (p.res) v += rv[jj][r];
                         v *= p.scale;
-                        if constexpr (!OUT16) outp[(size_t)row * p.ldo + col0 + jh * 64 + jj * 32] = v;
+                        if constexpr (!OUT16) *reinterpret_cast<float*>(ob + vo[r]) = v;
                         vv[jj][r] = v;
                         cs[ii][j] += v;
                         cq[ii][j] += v * v;
@@ -76,18 +101,20 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
                 }
                 if constexpr (OUT16) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {   // rows r = 2k (kept by the even lane) and 2k + 1 = the next row (odd lane)
-                        const int row = rowb + ((2 * k) & 3) + 8 * ((2 * k) >> 2) + (odd ? 1 : 0);
+                    for (int jj = 0; jj < JP; ++jj) {
+                        char* oh = reinterpret_cast<char*>(reinterpret_cast<_Float16*>(p.out) + (size_t)rowt * p.ldo + colw + (jh * JP + jj) * 32);
 #pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
+                        for (int k = 0; k < 8; ++k) {
                             const float mine = odd ? vv[jj][2 * k + 1] : vv[jj][2 * k];
                             const float other = sw_swap1(odd ? vv[jj][2 * k] : vv[jj][2 * k + 1]);
-                            // even lane: columns (lr, lr + 1) of row r = 2k; odd lane: columns (lr - 1, lr) of row r = 2k + 1
                             const dp_half2 h = {(_Float16)(odd ? other : mine), (_Float16)(odd ? mine : other)};
-                            *reinterpret_cast<dp_half2*>(outh + (size_t)row * p.ldo + (col0 - (odd ? 1 : 0)) + jh * 64 + jj * 32) = h;
+                            *reinterpret_cast<dp_half2*>(oh + vo[k]) = h;
                         }
                     }
                 }
+                // 256-register kernel: the next pass's residual loads stay behind this pass's stores (hoisted, all 4 x 16 of
+                // them are live at once and the accumulators go to scratch)
+                if constexpr (JP == 1) asm volatile("" ::: "memory");
             }
             if (p.colstats) {
 #pragma unroll
@@ -100,7 +127,7 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
         if (p.colstats && lk == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float* d = p.colstats + (size_t)(tile_m * 4 + wr * 2 + q) * 2 * p.N + col0 + j * 32;
+                float* d = p.colstats + (size_t)(rec0 + q) * 2 * p.N + col0 + j * 32;
                 d[0] = cs[0][j] + cs[1][j];
                 d[p.N] = cq[0][j] + cq[1][j];
             }
@@ -108,10 +135,11 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[4
     }
 }
 
-__device__ __forceinline__ void sw_epilogue_any(const ConvH2Args& p, f32x16 (&acc)[4][4], int m0, int n0, int tile_m, int wr, int wc,
-                                                int lr, int lk, int HW) {
-    if (p.ofmt) sw_epilogue<true>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
-    else sw_epilogue<false>(p, acc, m0, n0, tile_m, wr, wc, lr, lk, HW);
+template <int NQ, int JP>
+__device__ __forceinline__ void sw_epilogue_any(const ConvH2Args& p, f32x16 (&acc)[2 * NQ][4], int row0, int colw, int rec0, int lr, int lk,
+                                                int HW) {
+    if (p.ofmt) sw_epilogue<true, NQ, JP>(p, acc, row0, colw, rec0, lr, lk, HW);
+    else sw_epilogue<false, NQ, JP>(p, acc, row0, colw, rec0, lr, lk, HW);
 }
 
 // Measured on this epilogue and NOT kept (tests/probes/pp_ablate.py, B=64, bit-identical results):

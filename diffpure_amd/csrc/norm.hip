@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "dp_common.h"
+#include "dp_tune.h"
 
 namespace {
 
@@ -607,7 +608,7 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
 #define GN_APPLY_LAUNCH(H2_, ACT_) \
     hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_>), dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots)
     // h2 output: the lane-contiguous quad kernel unless DP_GN_APPLY_QUAD=0 (A/B switch; both give identical bytes)
-    static const bool quad = [] { const char* e = getenv("DP_GN_APPLY_QUAD"); return !e || atoi(e) != 0; }();
+    const bool quad = dp_tune(DP_T_GN_APPLY_QUAD) != 0;
     if (out_fmt == 2) {
         const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;
         if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 2>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);

@@ -763,6 +763,36 @@ def prof_enable(on=True):
     _lib.call("dp_prof_enable", 1 if on else 0)
 
 
+def set_tuning(name, value):
+    """Flip a kernel-variant switch of the library in-process (csrc/dp_tune.h; all variants give identical bits).  The library
+    reads its DP_* environment variables once, at first use - this is the only way to change one afterwards."""
+    _lib.call("dp_set_tuning", name.encode(), int(value))
+
+
+def get_tuning(name):
+    v = ctypes.c_int(0)
+    _lib.call("dp_get_tuning", name.encode(), ctypes.addressof(v))
+    return v.value
+
+
+class tuning:
+    """with ops.tuning(DP_H2_DW=2, DP_H2_SW=0): ...   (restores the previous values on exit)"""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_tuning(k)
+            set_tuning(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_tuning(k, v)
+        return False
+
+
 def prof_enabled():
     return _PROF_ON
 

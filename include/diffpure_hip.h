@@ -30,6 +30,13 @@ extern "C" {
 int dp_abi_version(void);
 const char* dp_last_error(void);
 
+/* Tuning switches (csrc/dp_tune.h lists them: kernel-variant selectors, all bit-identical in their results).  Each is read
+ * from the environment variable of the same name ONCE, on first use, and never again; dp_set_tuning() is the only way to
+ * change one afterwards (probes, A/B tests).  Unknown name -> non-zero.  No reference counterpart (the reference tunes
+ * through cudnn.benchmark, eval_sde_adv.py:303). */
+int dp_set_tuning(const char* name, int value);
+int dp_get_tuning(const char* name, int* value);
+
 /* Per-launch timing of the convolution kernels with hipEvents recorded on the launch stream (bench.py's roofline leg).
  * dp_prof_enable(1) opens a recording window (previous records are discarded), dp_prof_enable(0) closes it (records are
  * kept); dp_prof_collect() synchronises the recorded events and returns, per launch kind, total milliseconds, launches

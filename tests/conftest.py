@@ -42,3 +42,34 @@ def _build_lib():
         build.build()
     except Exception as e:  # no hipcc on this machine: tests that need the .so will fail loudly
         print("WARNING: could not build libdiffpure_hip.so:", e)
+
+
+class _Tune:
+    """Kernel-variant switches of the HIP library for one test (ops.set_tuning; the library reads its DP_* environment once,
+    so monkeypatch.setenv would change nothing).  Same surface as the monkeypatch calls the tests used to make."""
+
+    def __init__(self):
+        self.old = {}
+
+    def setenv(self, name, value):
+        from diffpure_amd import ops
+        self.old.setdefault(name, ops.get_tuning(name))
+        ops.set_tuning(name, int(value))
+
+    def delenv(self, name, raising=True):
+        from diffpure_amd import ops
+        if name in self.old:
+            ops.set_tuning(name, self.old.pop(name))
+
+    def restore(self):
+        from diffpure_amd import ops
+        for name, v in self.old.items():
+            ops.set_tuning(name, v)
+        self.old = {}
+
+
+@pytest.fixture
+def tune():
+    t = _Tune()
+    yield t
+    t.restore()

@@ -24,6 +24,14 @@ Files
                            continuous adjoint for a seeded cotangent (BASELINE.json configs[4] at reduced batch)
   guided_full.pt           (rewritten) one forward of the full guided UNet, B=1: the WHOLE [1,6,256,256] output
   guided_full_vjp.pt       dL/dx of that forward for a seeded cotangent on the eps channels (torch.autograd)
+Round 3 (each ~10 min on 8 cores):
+  guided_ddpm_loop100.pt   256x256 guided UNet, B=2, t=100: the reference's OWN sampling loop of
+                           runners/diffpure_guided.py:58-75 - `create_model_and_diffusion` (imagenet.yml) ->
+                           SpacedDiffusion.p_sample through _WrappedModel (respace.py:124-136), learned-range variance
+                           and x0 clamp of gaussian_diffusion.py:240-334, 403-447 - with `th.randn_like` returning the
+                           engine's Philox draw of that step.  Nothing of this loop is restated: it is in-tree upstream.
+  guided_loop150.pt        the SDE loop at t*=0.15, dt=1e-3 = 150 EM steps (what run_scripts/imagenet/*.sh run), B=1
+  guided_loop100_seeds.pt  the 100-step SDE loop, B=1, for two more noise seeds (x0 = sample 0 of guided_loop100.pt)
 """
 import os
 import sys
@@ -149,6 +157,72 @@ def ode_adjoint():
     print("ncsnpp_ode_adjoint100", len(tau) - 1, float(x_final.abs().mean()), float(grad.abs().mean()))
 
 
+def guided_ddpm_loop():
+    """runners/diffpure_guided.py:58-75 with the reference's own diffusion object; only the two noise sources
+    (torch.randn_like at :59, th.randn_like in p_sample, gaussian_diffusion.py:438) are replaced by the Philox draws."""
+    import guided_diffusion.gaussian_diffusion as gd
+    from guided_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    mc = model_and_diffusion_defaults()
+    mc.update(yaml.safe_load(open(os.path.join(mg.REF, "configs/imagenet.yml")))["model"])
+    mc["use_fp16"] = False
+    model, diffusion = create_model_and_diffusion(**mc)
+    model = mg.load_synth(model, SEED)
+    betas = torch.from_numpy(diffusion.betas).float()                     # :39
+    b, t_int = 2, 100
+    x0 = torch.rand(b, 3, 256, 256, generator=torch.Generator().manual_seed(95)) * 2 - 1
+    e = philox_nchw(x0.shape, SEED, 0, -1)
+    a = (1 - betas).cumprod(dim=0)                                        # :61-62
+    x = x0 * a[t_int - 1].sqrt() + e * (1.0 - a[t_int - 1]).sqrt()
+    keep, step = {}, [0]
+    orig = gd.th.randn_like
+    gd.th.randn_like = lambda t_: philox_nchw(tuple(t_.shape), SEED, 0, step[0])
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            for k, i in enumerate(reversed(range(t_int))):                # :66-71
+                step[0] = k
+                t = torch.tensor([i] * b)
+                x = diffusion.p_sample(model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None)["sample"]
+                if k + 1 in (1, 10, 50):
+                    keep[k + 1] = x.clone()
+                if k % 10 == 0:
+                    print(f"  ddpm step {k} (i={i}): {time.time() - t0:.0f} s", flush=True)
+    finally:
+        gd.th.randn_like = orig
+    kw = {k: mc[k] for k in ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma", "class_cond",
+                             "attention_resolutions", "num_heads", "num_head_channels", "num_heads_upsample",
+                             "use_scale_shift_norm", "resblock_updown", "use_fp16", "use_new_attention_order")}
+    torch.save(dict(cfg=kw, seed=SEED, noise_seed=SEED, t=t_int, steps=t_int, x0=x0, out=x, snaps=keep),
+               os.path.join(HERE, "guided_ddpm_loop100.pt"))
+    print("guided_ddpm_loop100", float(x.abs().mean()))
+
+
+def guided_loop150():
+    RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
+    mod, kw = build_guided()
+    rv = RevVPSDE(model=mod, score_type="guided_diffusion", img_shape=(3, 256, 256), model_kwargs=None)
+    x0 = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(94)) * 2 - 1
+    with torch.no_grad():
+        x, keep, n = em_loop(rv, x0, 150, 1e-3, SEED, snaps=(100,))
+    torch.save(dict(cfg=kw, seed=SEED, noise_seed=SEED, t=150, dt=1e-3, steps=n, x0=x0, out=x, snaps=keep),
+               os.path.join(HERE, "guided_loop150.pt"))
+    print("guided_loop150", n, float(x.abs().mean()))
+
+
+def guided_loop_seeds():
+    RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
+    mod, kw = build_guided()
+    rv = RevVPSDE(model=mod, score_type="guided_diffusion", img_shape=(3, 256, 256), model_kwargs=None)
+    x0 = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(99)) * 2 - 1)[:1]    # sample 0 of guided_loop100.pt
+    outs = {}
+    for seed in (7, 20240926):
+        with torch.no_grad():
+            x, _, n = em_loop(rv, x0, 100, 1e-3, seed)
+        outs[seed] = x
+        print("guided_loop100 seed", seed, n, float(x.abs().mean()), flush=True)
+    torch.save(dict(cfg=kw, seed=SEED, t=100, dt=1e-3, steps=n, x0=x0, outs=outs), os.path.join(HERE, "guided_loop100_seeds.pt"))
+
+
 def guided_full(with_vjp):
     mod, kw = build_guided()
     xb = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(4321)) * 2 - 1
@@ -186,6 +260,12 @@ def main():
             guided_full(False)
         elif w == "guided_vjp":
             guided_full(True)
+        elif w == "guided_ddpm_loop":
+            guided_ddpm_loop()
+        elif w == "guided_loop150":
+            guided_loop150()
+        elif w == "guided_loop_seeds":
+            guided_loop_seeds()
         else:
             raise SystemExit(f"unknown target {w}")
         print(f"{w}: {time.time() - t0:.0f} s", flush=True)

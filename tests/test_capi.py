@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/diffpure_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.dp_abi_version() == 3
+    assert lib.dp_abi_version() == 4
 
 
 def test_ctypes_table_matches_the_header_prototypes():
@@ -96,6 +96,7 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
     for src, must in (("igemm_h2_pp.hip", ("conv_igemm_h2_ppILi256ELi256ELi0E", "conv_igemm_h2_ppILi512ELi128ELi0E")),
                       ("igemm_h2.hip", ("conv_igemm_h2ILi128ELi128ELi32ELi0E", "conv_igemm_h2ILi64ELi64ELi32ELi0E")),
                       ("igemm_h2_sw.hip", ("conv_igemm_swILi0E",)),
+                      ("igemm_h2_dw.hip", ("conv_igemm_dwILi3ELi0E", "conv_igemm_dwILi4ELi0E")),
                       ("attention.hip", ("attn_flash_kernelILi4E", "attn_flash_kernelILi2E"))):
         out = tmp_path / (src + ".s")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",

@@ -298,7 +298,7 @@ PP_CASES = [
 
 
 @pytest.mark.parametrize("case", PP_CASES, ids=[str(c) for c in PP_CASES])
-def test_conv2d_h2_pingpong_variant_is_bit_identical(dev, case, monkeypatch):
+def test_conv2d_h2_pingpong_variant_is_bit_identical(dev, case, tune):
     """The 8-wave 256x256 variant (igemm_h2_pp.hip) against the fp64 convolution AND bit-for-bit against the
     128x128 / 64x64 variants, column-sum records included; repeated launches screen for LDS-DMA races."""
     from diffpure_amd import ops
@@ -321,9 +321,9 @@ def test_conv2d_h2_pingpong_variant_is_bit_identical(dev, case, monkeypatch):
                           colstats=True)
         return y.t, y.cols.buf.clone()
 
-    monkeypatch.setenv("DP_H2_PP", "0")
+    tune.setenv("DP_H2_PP", "0")
     base, base_cs = run()
-    monkeypatch.setenv("DP_H2_PP", "1")
+    tune.setenv("DP_H2_PP", "1")
     for _ in range(6):
         got, got_cs = run()
         assert torch.equal(got, base)
@@ -349,7 +349,7 @@ H1_CASES = H2_CASES + PP_CASES + [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (8, 64
 
 @pytest.mark.parametrize("passes", [2, 1])
 @pytest.mark.parametrize("case", H1_CASES, ids=[str(c) for c in H1_CASES])
-def test_conv2d_h1_fp16_activations(dev, case, passes, monkeypatch):
+def test_conv2d_h1_fp16_activations(dev, case, passes, tune):
     """Plain-fp16 activation operand ("h1") x split-fp16 weights: passes=2 ("f16x2") must equal the exact convolution of
     the fp16-ROUNDED activations with the full weights to fp32-class accuracy, passes=1 ("f16") the one with the
     fp16-rounded weights as well; every tile variant gives the same bits (column-sum records included)."""
@@ -374,22 +374,22 @@ def test_conv2d_h1_fp16_activations(dev, case, passes, monkeypatch):
                           colstats=True, passes=passes)
         return y.t, y.cols.buf.clone()
 
-    monkeypatch.setenv("DP_H2_PP", "0")
+    tune.setenv("DP_H2_PP", "0")
     base, base_cs = run()
     close(base, ref, rtol=2e-5, atol=2e-5)
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
-        monkeypatch.setenv("DP_H2_PP", "1")
+        tune.setenv("DP_H2_PP", "1")
         for _ in range(4):
             got, got_cs = run()
             assert torch.equal(got, base)
             assert torch.equal(got_cs, base_cs)
-    monkeypatch.delenv("DP_H2_PP")
+    tune.delenv("DP_H2_PP")
     got, got_cs = run()                      # the dispatcher's own choice
     assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
 
 
 @pytest.mark.parametrize("case", H1_CASES, ids=[str(c) for c in H1_CASES])
-def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
+def test_conv2d_fp16_weights_single_pass(dev, case, tune):
     """Plain fp16 activations x plain fp16 weights (w_fmt 1, one MFMA pass - "f16" / "f16sr"): equals the exact
     convolution of the two fp16-rounded operands to fp32-class accuracy; every tile variant gives the same bits."""
     from diffpure_amd import ops
@@ -414,36 +414,48 @@ def test_conv2d_fp16_weights_single_pass(dev, case, monkeypatch):
                           colstats=True, w_fmt=1)
         return y.t, y.cols.buf.clone()
 
-    monkeypatch.setenv("DP_H2_PP", "0")
+    tune.setenv("DP_H2_PP", "0")
     base, base_cs = run()
     close(base, ref, rtol=2e-5, atol=2e-5)
     # every 256x256 variant: per-tap ping-pong, halo-tile ping-pong, one-wave-per-SIMD software-pipelined
     if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64):
-        monkeypatch.setenv("DP_H2_PP", "1")
-        # (last entry: the spread-DMA schedule of the one-wave-per-SIMD kernel with the residual prefetch on)
-        # (var: the one-wave-per-SIMD kernel with its DMA issues back to back / spread between the fragment reads)
-        for sw, halo, var in (("0", "0", "0"), ("0", "1", "0"), ("1", "0", "0"), ("1", "0", "1")):
-            monkeypatch.setenv("DP_H2_SW", sw)
-            monkeypatch.setenv("DP_H2_HALO", halo)
-            monkeypatch.setenv("DP_H2_SW_VAR", var)
+        tune.setenv("DP_H2_PP", "1")
+        tune.setenv("DP_H2_DW", "0")
+        for sw, halo in (("0", "0"), ("0", "1"), ("1", "0")):
+            tune.setenv("DP_H2_SW", sw)
+            tune.setenv("DP_H2_HALO", halo)
             for _ in range(3):
                 got, got_cs = run()
-                assert torch.equal(got, base), (sw, halo, var)
-                assert torch.equal(got_cs, base_cs), (sw, halo, var)
-        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_SW_VAR"):
-            monkeypatch.delenv(name)
-        monkeypatch.setenv("DP_H2_PP", "0")
+                assert torch.equal(got, base), (sw, halo)
+                assert torch.equal(got_cs, base_cs), (sw, halo)
+        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_DW"):
+            tune.delenv(name)
+        tune.setenv("DP_H2_PP", "0")
+    # the two-workgroups-per-CU kernel (igemm_h2_dw.hip: 128x256 tiles; both activation-ring depths, with and without the
+    # start-up stagger of a CU's second workgroup - the stagger changes timing only)
+    if B * H * W % 128 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
+        tune.setenv("DP_H2_DW", "2")
+        tune.setenv("DP_H2_DW_MINROUNDS", "0")
+        for adepth, stagger in ((3, 0), (4, 0), (3, 300), (4, 300)):
+            tune.setenv("DP_H2_DW_ADEPTH", adepth)
+            tune.setenv("DP_H2_DW_STAGGER", stagger)
+            for _ in range(3):
+                got, got_cs = run()
+                assert torch.equal(got, base), ("dw", adepth, stagger)
+                assert torch.equal(got_cs, base_cs), ("dw", adepth, stagger)
+        for name in ("DP_H2_DW", "DP_H2_DW_MINROUNDS", "DP_H2_DW_ADEPTH", "DP_H2_DW_STAGGER"):
+            tune.delenv(name)
     # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
     y1 = ops.conv2d_h2(xh, ops.pack_conv_weight_h2(w, dev), N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N],
                        res=res, scale=scale, passes=1)
     assert torch.equal(y1, base)
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
-        monkeypatch.setenv("DP_H2_PP", "1")
+        tune.setenv("DP_H2_PP", "1")
         for _ in range(4):
             got, got_cs = run()
             assert torch.equal(got, base)
             assert torch.equal(got_cs, base_cs)
-    monkeypatch.delenv("DP_H2_PP")
+    tune.delenv("DP_H2_PP")
     got, got_cs = run()
     assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
 
@@ -664,7 +676,7 @@ FP16_OUT_CASES = [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (1, 128, 128, 64, 256,
 
 
 @pytest.mark.parametrize("case", FP16_OUT_CASES, ids=[str(c) for c in FP16_OUT_CASES])
-def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
+def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, tune):
     """dp_conv2d_nhwc_h2 out_fmt 1: the tensor is stored as plain fp16 = the fp32 result rounded to nearest, bit for bit, in
     every tile variant (generic 128 / 64 tiles, split-K level, ping-pong, halo, one-wave-per-SIMD with the paired-lane
     packed stores); the column records stay those of the unrounded values."""
@@ -686,14 +698,20 @@ def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, monkeypatch):
     base32 = basecs = None
     combos = [("0", None, None, None)]
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
-        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"), ("1", "1", "0", "1")]
-    for pp, sw, halo, var in combos:
-        monkeypatch.setenv("DP_H2_PP", pp)
-        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo), ("DP_H2_SW_VAR", var)):
+        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0")]
+    if B * H * W % 128 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
+        combos += [("0", None, None, "3"), ("0", None, None, "4")]           # the two-workgroups-per-CU kernel
+    for pp, sw, halo, dw in combos:
+        tune.setenv("DP_H2_PP", pp)
+        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo)):
             if val is None:
-                monkeypatch.delenv(name, raising=False)
+                tune.delenv(name, raising=False)
             else:
-                monkeypatch.setenv(name, val)
+                tune.setenv(name, val)
+        tune.setenv("DP_H2_DW", "2" if dw else "0")
+        if dw:
+            tune.setenv("DP_H2_DW_ADEPTH", dw)
+        var = dw
         y32, cs32 = run(False)
         y16, cs16 = run(True)
         assert y16.dtype == torch.float16 and y16.shape == y32.shape
@@ -747,7 +765,7 @@ NN_CASES = [(2, 32, 32, 64, 6), (1, 256, 256, 32, 6), (3, 64, 64, 96, 3), (1, 12
 
 
 @pytest.mark.parametrize("case", NN_CASES, ids=[str(c) for c in NN_CASES])
-def test_conv2d_few_output_channels_kernel(dev, case, monkeypatch):
+def test_conv2d_few_output_channels_kernel(dev, case, tune):
     """igemm_h2_nn.hip (3x3, fp16 x fp16, N <= 32: the 6-channel head): identical bits to the generic tile kernel it replaces, and the
     exact convolution of the fp16-rounded operands to fp32-class accuracy; one to three channel slices, one / several image rows
     per 256-pixel tile, a wide image, the last tile of the tensor."""
@@ -760,10 +778,10 @@ def test_conv2d_few_output_channels_kernel(dev, case, monkeypatch):
     ref = (ref * 0.5).float()
     xh = _h1_bordered(x, dev)
     w16 = ops.order_conv_weight_w16(w).half().to(dev)
-    monkeypatch.setenv("DP_H2_NN", "0")
+    tune.setenv("DP_H2_NN", "0")
     base = ops.conv2d_h2(xh, w16, N, 3, bias=bias, scale=0.5, w_fmt=1)
     close(base, ref, rtol=2e-5, atol=2e-5)
-    monkeypatch.setenv("DP_H2_NN", "1")
+    tune.setenv("DP_H2_NN", "1")
     for _ in range(3):
         got = ops.conv2d_h2(xh, w16, N, 3, bias=bias, scale=0.5, w_fmt=1)
         assert torch.equal(got, base)
