@@ -195,7 +195,7 @@ def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
                        "oracle = torch-CPU fp32 restatement of the reference modules (pinned to them by tests/golden)")
 
 
-def timed_region(a, world, one_call, fence, before_first=None, after_first=None):
+def timed_region(a, world, one_call, fence, before_first=None, after_first=None, use_dist=None):
     """W untimed warm-up calls, then exactly K timed calls bracketed by fence() on both sides; -> (seconds as the MAX over
     ranks, result of the last call).  Shared by the real bench and the CPU harness test."""
     for i in range(a.warmup):
@@ -211,7 +211,7 @@ def timed_region(a, world, one_call, fence, before_first=None, after_first=None)
             after_first()
     fence()
     el = time.time() - t0
-    if world > 1:
+    if world > 1 if use_dist is None else use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=y.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
@@ -277,6 +277,10 @@ def main():
                     help="TEST HOOK (tests/test_bench_multirank.py): run the launch / sharding / all_gather / timing harness on CPU "
                          "ranks over gloo with a stand-in for the purification engine; the line it prints is marked stub and is "
                          "not a measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="TEST HOOK (tests/test_gpu_dist.py): take the multi-rank code path - init_process_group('nccl', device_id), "
+                         "device-side all_gather_into_tensor of the purified shards, barrier, MAX all-reduce of the time - at world "
+                         "size 1 as well, so that RCCL runs on the one GPU a test box has")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -290,7 +294,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the purification engine has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:          # --force-dist started by hand: a private single-rank rendezvous
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from diffpure_amd import ops
@@ -307,7 +314,7 @@ def main():
     hw = wl["hw"]
     gen = torch.Generator().manual_seed(a.seed + rank)
     x = (torch.rand(B, 3, hw, hw, generator=gen) * 2 - 1).to(dev)      # resident in HBM before timing
-    gathered = torch.empty((world * B, 3, hw, hw), device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 3, hw, hw), device=dev) if use_dist else None
 
     cot = torch.randn(B, 3, hw, hw, generator=gen).to(dev) if adjoint else None
     if adjoint:
@@ -319,12 +326,12 @@ def main():
             y = pur.ode_vjp(xf, cot, a.t, a.dt) * pur.diffuse_scale(a.t)
         else:
             y = pur.sde(x, a.t, a.dt, seed=a.seed + 1000003 * i, sample0=rank * B)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, y)
         return y
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -346,8 +353,17 @@ def main():
             win1.record()
 
     clock.start()
-    el, y = timed_region(a, world, one_call, fence, before_first, after_first)
+    el, y = timed_region(a, world, one_call, fence, before_first, after_first, use_dist)
     sclk = clock.stop()
+    gather_ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], y)) if use_dist else None
+    # the boundary hands over device tensors (runner.image_editing_sample(img) with img on the GPU), so `value` is timed with the
+    # batch resident in HBM; the host->device copy of one batch is measured here, outside the timed region, for the record
+    xh = x.cpu().pin_memory()
+    torch.cuda.synchronize()
+    t_h = time.time()
+    xh.to(dev, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_ms = (time.time() - t_h) * 1e3
     prof = ops.prof_collect() if sample else None
     window_ms = win0.elapsed_time(win1) if sample else None
     assert torch.isfinite(y).all()
@@ -369,7 +385,7 @@ def main():
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "peak_note": "dense fp16 MFMA peak at the 2.4 GHz nominal clock (MI355X_MICROARCH.md); see sclk_mhz for the clock this run held",
                 "mfma_passes": passes, "sclk_mhz": sclk, "end_to_end_unet_tflops_per_gpu": unet_tflops,
-                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DP_H2_SW", "DP_H2_SW_VAR", "DP_H2_HALO", "DP_H2_PP") if k in os.environ}}
+                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DP_H2_SW", "DP_H2_DW", "DP_H2_HALO", "DP_H2_PP", "DP_GN_FOLD", "DIFFPURE_STREAMS") if k in os.environ}}
         if prof is not None:
             dom = prof["pp3x3"] if prof["pp3x3"]["n"] else prof["other3x3"]      # f32 / tiny shapes never reach the ping-pong kernel
             if dom["ms"] > 0:
@@ -425,11 +441,16 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "image": f"3x{hw}x{hw}",
                        "parallelism": f"batch-sharded x{world}, one all_gather of outputs"},
             "roofline": roof,
+            "input": {"resident_in_hbm_before_timing": True, "h2d_ms_per_batch_pinned": h2d_ms,
+                      "value_if_h2d_were_inside_the_timed_region": images / (el + h2d_ms * 1e-3 * a.steps)},
         }
+        if use_dist:
+            out["collectives"] = {"backend": dist.get_backend(), "world_size": world, "forced_at_world_1": bool(a.force_dist and world == 1),
+                                  "all_gather_into_tensor_on_device": True, "gathered_equals_local_shard": gather_ok}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, sd, a.t, n_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

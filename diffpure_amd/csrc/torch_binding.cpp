@@ -71,8 +71,10 @@ std::tuple<Tensor, Tensor> conv2d_h2_impl(const Tensor& xh, const Tensor& wh, co
                                           int64_t ksize, int64_t passes, int64_t w_fmt, bool want_stats) {
     chk_h(xh, "xh");
     chk_h(wh, "wh");
-    TORCH_CHECK(xh.dim() == 4 && wh.dim() == 2 && wh.size(0) == n_out, "diffpure_hip: conv2d_h2 operand shapes");
     TORCH_CHECK(w_fmt == 0 || w_fmt == 1, "diffpure_hip: w_fmt 0 (hi|lo weights) or 1 (plain fp16 weights)");
+    // plain fp16 panels are stored in whole 32-row blocks (ops.order_conv_weight_w16): roundup(n_out, 32) rows
+    TORCH_CHECK(xh.dim() == 4 && wh.dim() == 2 && wh.size(0) == (w_fmt ? (n_out + 31) / 32 * 32 : n_out),
+                "diffpure_hip: conv2d_h2 operand shapes");
     const int64_t C = wh.size(1) / ((w_fmt ? 1 : 2) * ksize * ksize);
     const int a_fmt = xh.size(3) == C ? 1 : 0;                 // plain fp16 ("h1") or hi|lo octets ("h2")
     TORCH_CHECK(a_fmt == 1 || xh.size(3) == 2 * C, "diffpure_hip: activation operand does not match the weight panel");

@@ -92,6 +92,11 @@ def sharded_purify(fn, x, group=None):
     # dtype of the input batch, so nothing has to be run to learn them (and the empty slice keeps the graph connected,
     # so that this rank still takes part in the backward all-gather)
     y = fn(xl, lo) if hi > lo else xl * 1.0
+    # every rank must hand the gather a buffer of the same dtype on its own engine's device: a purifier returns float32 on the
+    # device it was given its slice on, and an image-less rank contributes `xl * 1.0` - so the contract is on `x` itself
+    if y.dtype != torch.float32 or y.device != x.device:
+        raise ValueError(f"sharded_purify: fn must keep float32 on the device of its input (got {y.dtype} on {y.device} for x: "
+                         f"{x.dtype} on {x.device}); pass x as float32 on the rank's engine device")
     if need_grad:
         return _GatherShards.apply(y, lo, hi, per, n, ws, group)
     return _gather_rows(y, per, n, ws, group)

@@ -30,6 +30,9 @@ def guided_model_defaults():
                 rescale_learned_sigmas=False)
 
 
+DEFAULT_PRECISION = "f16sr"
+
+
 def precision_of(args):
     """args.precision / DIFFPURE_PRECISION - the arithmetic of the 3x3 / 1x1 convolutions that follow a GroupNorm (fp32
     accumulation, fp32 GroupNorm, residual stream and solver state in every mode):
@@ -39,7 +42,7 @@ def precision_of(args):
       "f16x3"           22-bit split operands, three passes (4e-6: fp32-class)
       "f16"             fp16 x fp16 with round-to-nearest weights = the reference's use_fp16 torso (1.0e-3)
       "f32"             fp32-input MFMA everywhere (1e-6)"""
-    return getattr(args, "precision", None) or os.environ.get("DIFFPURE_PRECISION", "f16sr")
+    return getattr(args, "precision", None) or os.environ.get("DIFFPURE_PRECISION", DEFAULT_PRECISION)
 
 
 def want_synthetic(args):

@@ -436,10 +436,10 @@ class NCSNpp:
         return ops.axpby(dx, 1.0, dout, INV_SQRT2)
 
     def vjp(self, tape, dout):
+        """(d out / d x)^T dout for the forward that filled `tape`; dout [B,H,W,channels] fp32."""
         if self._fir is not None:
             raise NotImplementedError("input gradients through the FIR (fir: True) resamplers are not built: no DiffPure config "
                                       "sets fir: True (configs/cifar10.yml:24), only the forward purification path covers it")
-        """(d out / d x)^T dout for the forward that filled `tape`; dout [B,H,W,channels] fp32."""
         self.enable_grad()
         P = self.p
         M = "all_modules."

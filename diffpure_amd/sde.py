@@ -371,7 +371,9 @@ class Purifier:
         table = self._tables(("ode_rev", t_int, step), sched)
         for k, st in enumerate(sched):
             tape = []
-            self._reround(k)
+            # reverse step k revisits the time point of forward step N-1-k: the same stochastic weight rounding as `ode`
+            # used there (f16sr), so the adjoint differentiates the function the forward solve evaluated
+            self._reround(len(sched) - 1 - k)
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             g = self.net.vjp(tape, a)                       # (d eps / d y)^T a
             del tape

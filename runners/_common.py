@@ -55,8 +55,53 @@ class EnginePool:
 
     def __init__(self, build, home):
         self._build, self._lock, self._by_dev = build, threading.Lock(), {}
+        self._calls_by_dev, self._locks = {}, {}
         self.home = torch.device(home)
         self.get(self.home)
+
+    # -- noise keys under replication ---------------------------------------------------------------------------------
+    # DataParallel re-replicates the runner on EVERY forward (replica.__dict__ = module.__dict__.copy()), so a counter kept
+    # as a plain attribute of the runner is bumped on a throw-away copy and the original stays at 0: every call would draw
+    # the same Philox path.  The counters therefore live HERE (the pool object is shared by all replicas), one per device:
+    # each replica's forward runs once per DataParallel call, so device d's counter is the number of calls d has served.
+    def next_call(self, device):
+        """-> the index of this purification call on `device` (0, 1, 2, ...), and count it"""
+        key = _dev_key(device)
+        with self._lock:
+            k = self._calls_by_dev.get(key, 0)
+            self._calls_by_dev[key] = k + 1
+            return k
+
+    @property
+    def calls(self):
+        with self._lock:
+            return self._calls_by_dev.get(_dev_key(self.home), 0)
+
+    @calls.setter
+    def calls(self, value):
+        with self._lock:
+            for key in list(self._by_dev):
+                self._calls_by_dev[key] = int(value)
+
+    def lock(self, device):
+        """One purification at a time per engine: an engine owns scratch buffers, a time-table cache and the re-rounded weight
+        panels of the call in flight.  DataParallel replicas on DIFFERENT GPUs hold different engines and never contend; two
+        callers that alias one GPU (device_ids=[0, 0], or user threads) take turns."""
+        key = _dev_key(device)
+        with self._lock:
+            return self._locks.setdefault(key, threading.RLock())
+
+    def replica_offset(self, device):
+        """First sample index a replica on `device` adds to its (local) batch positions: 0 on the home device (a runner that
+        is not replicated keys sample i of its batch as i), (1 + ordinal) << 32 on every other GPU - replicas of one
+        DataParallel call each see batch positions 0.. of THEIR slice, and without this GPU0's image i and GPU1's image i
+        would share one noise path."""
+        key = _dev_key(device)
+        if key == _dev_key(self.home):
+            return 0
+        with self._lock:
+            others = sorted(k for k in self._by_dev if k != _dev_key(self.home))
+        return (1 + others.index(key)) << 32 if key in others else 1 << 32
 
     def get(self, device):
         key = _dev_key(device)
@@ -106,8 +151,22 @@ def sample_offset(args):
     return rank << 40 if ws > 1 else 0
 
 
-def dispatch(args, run, x):
-    """One purification of the batch `x`: sharded over the ranks (`args.shard_batch`) or on this process's GPU."""
+def dispatch(args, run, x, replica_offset=0):
+    """One purification of the batch `x`: sharded over the ranks (`args.shard_batch`) or on this process's GPU
+    (`replica_offset`: EnginePool.replica_offset of the GPU a DataParallel replica runs on)."""
     if getattr(args, "shard_batch", False):
         return ddist.sharded_purify(run, x)
-    return run(x, sample_offset(args))
+    return run(x, sample_offset(args) + replica_offset)
+
+
+class PooledRunner:
+    """Mixin of the drop-in runners: `_calls` (the purification-call counter the noise seed is derived from) is a view of
+    the shared EnginePool's counter, so it survives nn.DataParallel's per-forward replication (see EnginePool)."""
+
+    @property
+    def _calls(self):
+        return self._pool.calls
+
+    @_calls.setter
+    def _calls(self, value):
+        self._pool.calls = value

@@ -15,7 +15,7 @@ from diffpure_amd.sde import CelebaSchedule, Purifier
 from . import _common
 
 
-class Diffusion(torch.nn.Module):
+class Diffusion(_common.PooledRunner, torch.nn.Module):
     def __init__(self, args, config, device=None):
         super().__init__()
         self.args = args
@@ -61,14 +61,14 @@ class Diffusion(torch.nn.Module):
             seed = int(getattr(self.args, "seed", 0) or 0)
             xs = []
             for it in range(self.args.sample_step):
-                call_seed = seed + 1000003 * self._calls
-                self._calls += 1
+                call_seed = seed + 1000003 * self._pool.next_call(pur.device)
 
                 def run(xl, sample0, call_seed=call_seed):
                     return pur.celeba_ddpm(xl, self.args.t, self.sched, noise=noise, seed=call_seed, sample0=sample0,
                                                      nhwc=nhwc)
 
-                x0 = _common.dispatch(self.args, run, x0)
+                with self._pool.lock(pur.device):
+                    x0 = _common.dispatch(self.args, run, x0, self._pool.replica_offset(pur.device))
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

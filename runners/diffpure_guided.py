@@ -10,7 +10,7 @@ from diffpure_amd.sde import DdpmSchedule, Purifier
 from . import _common
 
 
-class GuidedDiffusion(torch.nn.Module):
+class GuidedDiffusion(_common.PooledRunner, torch.nn.Module):
     def __init__(self, args, config, device=None, model_dir="pretrained/guided_diffusion"):
         super().__init__()
         self.args = args
@@ -50,14 +50,14 @@ class GuidedDiffusion(torch.nn.Module):
             seed = int(getattr(self.args, "seed", 0) or 0)
             xs = []
             for it in range(self.args.sample_step):
-                call_seed = seed + 1000003 * self._calls
-                self._calls += 1
+                call_seed = seed + 1000003 * self._pool.next_call(pur.device)
 
                 def run(xl, sample0, call_seed=call_seed):
                     return pur.ddpm(xl, self.args.t, noise=noise, seed=call_seed, sample0=sample0,
                                               diffusion_steps=self.diffusion_steps, nhwc=nhwc)
 
-                x0 = _common.dispatch(self.args, run, x0)
+                with self._pool.lock(pur.device):
+                    x0 = _common.dispatch(self.args, run, x0, self._pool.replica_offset(pur.device))
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

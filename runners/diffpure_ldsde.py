@@ -35,7 +35,7 @@ class _LdPurify(torch.autograd.Function):
         return a, None, None, None, None, None, None, None
 
 
-class LDGuidedDiffusion(torch.nn.Module):
+class LDGuidedDiffusion(_common.PooledRunner, torch.nn.Module):
     def __init__(self, args, config, device=None):
         super().__init__()
         self.args = args
@@ -58,7 +58,7 @@ class LDGuidedDiffusion(torch.nn.Module):
         assert img.ndim == 4, img.ndim
         need_grad = img.requires_grad and torch.is_grad_enabled()
         pur = self._pool.for_input(img)          # DataParallel replica: the engine of the GPU this slice lives on
-        with torch.set_grad_enabled(need_grad):
+        with self._pool.lock(pur.device), torch.set_grad_enabled(need_grad):
             out_dir = _common.out_dir_for(self.args, bs_id, tag)
             log = bs_id < 2 and out_dir is not None
             x0 = img.to(pur.device)
@@ -71,8 +71,7 @@ class LDGuidedDiffusion(torch.nn.Module):
             cfg = (self.args.t, float(self.args.sigma2), float(self.args.lambda_ld), float(self.args.eta), self.args_dict["dt"])
             xs = []
             for it in range(self.args.sample_step):
-                call_seed = seed + 1000003 * self._calls
-                self._calls += 1
+                call_seed = seed + 1000003 * self._pool.next_call(pur.device)
 
                 def run(xl, sample0, call_seed=call_seed):
                     lo = sample0 if getattr(self.args, "shard_batch", False) else 0      # this shard's rows of the anchor
@@ -83,7 +82,7 @@ class LDGuidedDiffusion(torch.nn.Module):
                     return pur.ldsde(xl, t, sigma2, lam, eta, dt=dt, noise=noise, seed=call_seed, sample0=sample0, nhwc=nhwc,
                                      x_init=al)
 
-                x0 = _common.dispatch(self.args, run, x0)
+                x0 = _common.dispatch(self.args, run, x0, self._pool.replica_offset(pur.device))
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

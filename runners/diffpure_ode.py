@@ -34,7 +34,7 @@ class _OdePurify(torch.autograd.Function):
         return a, None, None, None, None, None, None, None
 
 
-class OdeGuidedDiffusion(torch.nn.Module):
+class OdeGuidedDiffusion(_common.PooledRunner, torch.nn.Module):
     def __init__(self, args, config, device=None):
         super().__init__()
         self.args = args
@@ -60,7 +60,7 @@ class OdeGuidedDiffusion(torch.nn.Module):
         log = bs_id < 2 and out_dir is not None
         need_grad = img.requires_grad and torch.is_grad_enabled()
         pur = self._pool.for_input(img)          # DataParallel replica: the engine of the GPU this slice lives on
-        with torch.set_grad_enabled(need_grad):
+        with self._pool.lock(pur.device), torch.set_grad_enabled(need_grad):
             x0 = img.to(pur.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
@@ -75,8 +75,7 @@ class OdeGuidedDiffusion(torch.nn.Module):
                     g = torch.Generator().manual_seed(int(self.args.seed))
                     e1 = torch.randn((1,) + tuple(_common.as_nchw_shape(x0.shape, nhwc)[1:]), generator=g)
                     inj = dict(e=e1.repeat(x0.shape[0], 1, 1, 1), z=[])
-                call_seed = seed + 1000003 * self._calls
-                self._calls += 1
+                call_seed = seed + 1000003 * self._pool.next_call(pur.device)
 
                 def run(xl, sample0, inj=inj, call_seed=call_seed):
                     lo = sample0 if getattr(self.args, "shard_batch", False) else 0      # this shard's rows of injected noise
@@ -85,7 +84,7 @@ class OdeGuidedDiffusion(torch.nn.Module):
                         return _OdePurify.apply(xl, pur, self.args.t, step, loc, call_seed, sample0, nhwc)
                     return pur.ode(xl, self.args.t, step, noise=loc, seed=call_seed, sample0=sample0, nhwc=nhwc)
 
-                x0 = _common.dispatch(self.args, run, x0)
+                x0 = _common.dispatch(self.args, run, x0, self._pool.replica_offset(pur.device))
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

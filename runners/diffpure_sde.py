@@ -46,7 +46,7 @@ class _SdePurify(torch.autograd.Function):
         return a, None, None, None, None, None, None, None, None
 
 
-class RevGuidedDiffusion(torch.nn.Module):
+class RevGuidedDiffusion(_common.PooledRunner, torch.nn.Module):
     def __init__(self, args, config, device=None):
         super().__init__()
         self.args = args
@@ -73,7 +73,7 @@ class RevGuidedDiffusion(torch.nn.Module):
         log = bs_id < 2 and out_dir is not None
         need_grad = img.requires_grad and torch.is_grad_enabled()
         pur = self._pool.for_input(img)          # DataParallel replica: the engine of the GPU this slice lives on
-        with torch.set_grad_enabled(need_grad):
+        with self._pool.lock(pur.device), torch.set_grad_enabled(need_grad):
             x0 = img.to(pur.device)
             if log:
                 os.makedirs(out_dir, exist_ok=True)
@@ -82,8 +82,7 @@ class RevGuidedDiffusion(torch.nn.Module):
             dt = float(getattr(self.args, "dt", 1e-3) or 1e-3)
             xs = []
             for it in range(self.args.sample_step):
-                call_seed = seed + 1000003 * self._calls
-                self._calls += 1
+                call_seed = seed + 1000003 * self._pool.next_call(pur.device)
                 t_diffuse = self.args.t
                 if self.args.rand_t:
                     # upstream draws from numpy's global RNG (:220); when the call is sharded over ranks every rank must
@@ -98,7 +97,7 @@ class RevGuidedDiffusion(torch.nn.Module):
                     return pur.sde(xl, self.args.t, dt, noise=noise, seed=call_seed, sample0=sample0, nhwc=nhwc,
                                    t_diffuse=t_diffuse)
 
-                x0 = _common.dispatch(self.args, run, x0)
+                x0 = _common.dispatch(self.args, run, x0, self._pool.replica_offset(pur.device))
                 if log:
                     _common.save_image(_common.as_nchw(x0, nhwc), os.path.join(out_dir, f"samples_{it}.png"))
                 xs.append(x0)

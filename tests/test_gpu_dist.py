@@ -76,3 +76,28 @@ def test_two_rank_sharded_runner_equals_single_process_bitwise(n):
         assert torch.equal(out, ref_out), rank           # every rank holds the whole purified batch
         assert torch.equal(o2, ref_o2), rank
         assert torch.equal(gx, ref_g), rank              # and the whole dL/dx
+
+
+def test_bench_multirank_code_path_runs_on_rccl_at_world_size_1():
+    """The driver's own launch line with ONE rank and bench.py's --force-dist hook: `init_process_group("nccl", device_id=...)`,
+    the device-side `all_gather_into_tensor` of the purified shard inside the timed region, `dist.barrier()` and the MAX
+    all-reduce of the elapsed time all execute on RCCL on the one GPU this box has (an 8-GPU node is not available to the
+    builder: no scaling curve has been measured)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--workload", "cifar32_ncsnpp", "--batch", "8", "--t", "5", "--no-cpu-baseline", "--no-conv-profile", "--force-dist"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    c = d["collectives"]
+    print("bench.py --force-dist:", c, f"value {d['value']:.1f} {d['unit']}")
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["forced_at_world_1"] is True
+    assert c["all_gather_into_tensor_on_device"] is True and c["gathered_equals_local_shard"] is True
+    assert d["n_gpus"] == 1 and d["value"] > 0

@@ -12,6 +12,17 @@ from diffpure_amd.synth import synth_state_dict
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+# Tolerances by arithmetic.  "f16x3" carries 22-bit operands: north_star's bar (1e-3 on purified pixels) and 5e-3 relative on
+# gradients hold on any grid.  "f16sr" - the arithmetic every runner SHIPS with - rounds activations and weights to fp16 afresh at
+# every UNet call: a zero-mean perturbation of eps that enters the state scaled by beta h / sigma per step.  The loops in this
+# file are 8-10 steps at dt = 1e-2 on small networks (ten times the product's step): per step the perturbation is ten times
+# larger than at dt = 1e-3 and has nothing to average over, so the bars for f16sr here are the measured error x ~3; at the
+# product's grid (100-150 steps, dt = 1e-3) f16sr holds 1e-3 on every loop: tests/test_gpu_loops.py.
+PIX_TOL = {"f32": 1e-3, "f16x3": 1e-3, "f16sr": 5e-3}
+GRAD_TOL = {"f32": 5e-3, "f16x3": 5e-3, "f16sr": 3e-2}
+SHIPPED = ["f16x3", "f16sr"]
+
+
 
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
@@ -168,7 +179,8 @@ def test_config5_adjoint_ode_vs_oracle():
         assert relerr(got, ref) < 5e-3, (precision, relerr(got, ref))
 
 
-def test_ode_runner_autograd_on_gpu(tmp_path):
+@pytest.mark.parametrize("precision", SHIPPED)
+def test_ode_runner_autograd_on_gpu(tmp_path, precision):
     from runners.diffpure_ode import OdeGuidedDiffusion
     g = load_golden("ncsnpp_small.pt")
 
@@ -181,7 +193,7 @@ def test_ode_runner_autograd_on_gpu(tmp_path):
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path),
-                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=1e-2, precision="f16x3")
+                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=1e-2, precision=precision)
     runner = OdeGuidedDiffusion(args, config, device=config.device)
     x = (torch.rand(3, 3, 16, 16) * 2 - 1).to(DEV).requires_grad_(True)
     out = runner.image_editing_sample(x, bs_id=9)
@@ -190,7 +202,8 @@ def test_ode_runner_autograd_on_gpu(tmp_path):
     assert gx.shape == x.shape and torch.isfinite(gx).all() and gx.abs().max() > 0
 
 
-def test_sde_stochastic_adjoint_vs_oracle():
+@pytest.mark.parametrize("precision", SHIPPED)
+def test_sde_stochastic_adjoint_vs_oracle(precision):
     """dL/dx through the reverse-SDE solve with injected noise, full NCSN++, 10 steps."""
     from diffpure_amd import ncsnpp as pn
     from diffpure_amd.sde import Purifier
@@ -205,16 +218,18 @@ def test_sde_stochastic_adjoint_vs_oracle():
     e = torch.randn(x0.shape, generator=gen)
     zs = [torch.randn(x0.shape, generator=gen) for _ in range(10)]
     cot = torch.randn(x0.shape, generator=gen)
-    net = pn.NCSNpp(cfg, DEV, "f16x3").load_state_dict(sd)
+    net = pn.NCSNpp(cfg, DEV, precision).load_state_dict(sd)
     pur = Purifier(net, "ncsnpp", DEV)
     noise = dict(e=e, z=zs)
     xf = pur.sde(x0, 100, dt, noise=noise)
     with torch.no_grad():
         xf_ref = osol.sde_purify(score, x0, e, zs, 100, dt)
-    assert (xf.cpu() - xf_ref).abs().max() < 1e-3
+    err_x = (xf.cpu() - xf_ref).abs().max().item()
     ref = osol.ode_diffuse_grad(osol.sde_adjoint_grad(score, xf_ref, cot, zs, 100, dt), 100)
     got = (pur.sde_vjp(xf, cot, 100, dt, noise=noise) * pur.diffuse_scale(100)).cpu()
-    assert relerr(got, ref) < 5e-3, relerr(got, ref)
+    print(f"stochastic adjoint, full NCSN++, 10 steps [{precision}]: x max-abs {err_x:.3e}, dL/dx rel. error {relerr(got, ref):.3e}")
+    assert err_x < PIX_TOL[precision], err_x
+    assert relerr(got, ref) < GRAD_TOL[precision], relerr(got, ref)
     # with Philox noise the backward pass regenerates the forward path: deterministic
     xf2 = pur.sde(x0, 100, dt, seed=3, sample0=0)
     g1 = pur.sde_vjp(xf2, cot, 100, dt, seed=3, sample0=0)
@@ -263,8 +278,9 @@ class _TinyClassifier(torch.nn.Module):
         return x.mean(dim=(2, 3)) @ self.w.t()
 
 
+@pytest.mark.parametrize("precision", SHIPPED)
 @pytest.mark.parametrize("diffusion_type", ["sde", "ode"])
-def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, diffusion_type):
+def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, diffusion_type, precision):
     """diffpure_amd.adv_model.SDE_Adv_Model (fused resize/affine/repack kernels, NHWC in and out of the runner)
     against the upstream composition of eval_sde_adv.py:73-89 spelled with torch ops around the same runner:
     logits, and dL/dx of the whole defence (adjoint resize o adjoint purifier o adjoint resize)."""
@@ -280,7 +296,7 @@ def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, 
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path),
-                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=2e-2, dt=2e-2, precision="f16x3",
+                              score_type="score_sde", seed=1234, synthetic_weights=True, step_size=2e-2, dt=2e-2, precision=precision,
                               diffusion_type=diffusion_type, domain="cifar10", classifier_name="none", diffusion_size=(16, 16))
     model = SDE_Adv_Model(args, config, classifier=_TinyClassifier())
     runner = model.runner
@@ -315,7 +331,8 @@ def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, 
     assert (eot[0] - eot[1]).abs().max() > 0 if diffusion_type == "sde" else True
 
 
-def test_ldsde_runner_autograd_on_gpu_vs_oracle_adjoint(tmp_path):
+@pytest.mark.parametrize("precision", SHIPPED)
+def test_ldsde_runner_autograd_on_gpu_vs_oracle_adjoint(tmp_path, precision):
     """LDGuidedDiffusion.image_editing_sample is differentiable w.r.t. the input on the HIP engine; dL/dx equals the oracle's
     restated stochastic adjoint (through the initial state) on the same injected noise."""
     from oracle import ncsnpp as on
@@ -333,7 +350,7 @@ def test_ldsde_runner_autograd_on_gpu_vs_oracle_adjoint(tmp_path):
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path), score_type="score_sde",
-                              seed=1234, synthetic_weights=True, sigma2=0.001, lambda_ld=0.01, eta=5, precision="f16x3")
+                              seed=1234, synthetic_weights=True, sigma2=0.001, lambda_ld=0.01, eta=5, precision=precision)
     runner = LDGuidedDiffusion(args, config, device=config.device)
     sd = synth_state_dict(pn.param_shapes(pn.parse_config(g["cfg"])), 1234)
     score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
@@ -347,5 +364,7 @@ def test_ldsde_runner_autograd_on_gpu_vs_oracle_adjoint(tmp_path):
     with torch.no_grad():
         xf = osol.ldsde_purify(score, x0, zs, 100, 0.001, 0.01, 5)
     ref = osol.ldsde_adjoint_grad(score, xf, cot, x0, zs, 100, 0.001, 0.01, 5)
-    assert (out.detach().cpu() - xf).abs().max() < 1e-3
-    assert relerr(gx.cpu(), ref) < 5e-3
+    err_x = (out.detach().cpu() - xf).abs().max().item()
+    print(f"ldsde runner + adjoint, small NCSN++ [{precision}]: x max-abs {err_x:.3e}, dL/dx rel. error {relerr(gx.cpu(), ref):.3e}")
+    assert err_x < PIX_TOL[precision], err_x
+    assert relerr(gx.cpu(), ref) < GRAD_TOL[precision], relerr(gx.cpu(), ref)

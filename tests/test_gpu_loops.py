@@ -6,7 +6,8 @@ The golden loops drew their noise from the numpy restatement of the engine's Phi
 kernels key it, so these tests run the PRODUCT path - in-kernel noise, nothing injected - and compare whole tensors.
 
 Tolerances (north_star: purified pixels within 1e-3 max-abs of the reference at fixed seed):
-  purified pixels, 100 steps        max-abs < 1e-3 for every shipped precision mode
+  purified pixels, 100 / 150 steps  max-abs < 1e-3 for every shipped precision mode - SDE loops (guided: three noise seeds, B=2 and
+                                    B=64; NCSN++), the DDPM loop driven by the reference's own p_sample, the 150-step loop
                                     (measured: f32 1e-6, f16x3 4e-6, f16x2 1.3e-4, f16sr (default) 2.2e-4;
                                     tests/probes/precision_loops.py, sr_weights_probe.py)
   adjoint dL/dx, 100 + 100 steps    max-abs < 5e-3 of the largest entry
@@ -91,6 +92,71 @@ def test_guided_loop_100_steps_vs_reference_golden(precision):
     # shards reproduce the batch bit for bit on this path as well (sample 1 alone, keyed by its global index)
     one = pur.sde(g["x0"][1:], g["t"], g["dt"], seed=g["noise_seed"], sample0=1).cpu()
     assert torch.equal(one, out[1:])
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
+def test_guided_ddpm_loop_100_steps_vs_reference_golden(precision):
+    """The `ddpm` runner's loop (runners/diffpure_guided.py:58-75) at full length on the full guided UNet, B=2, t=100: the
+    golden is the REFERENCE'S OWN sampler - create_model_and_diffusion(imagenet.yml) -> SpacedDiffusion.p_sample through
+    _WrappedModel, learned-range variance over all six channels, x0 clamp - with th.randn_like returning the engine's Philox
+    draw of the step (tests/golden/make_golden_loops.py::guided_ddpm_loop).  Nothing of this loop is third-party or restated."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("guided_ddpm_loop100.pt")
+    assert g["steps"] == 100 == g["t"]
+    pur = Purifier(guided_full(precision), "guided", DEV)
+    out = pur.ddpm(g["x0"], g["t"], seed=g["noise_seed"], sample0=0).cpu()
+    err = maxabs(out, g["out"])
+    print(f"guided DDPM 100-step loop [{precision}]: purified max-abs vs the reference's p_sample loop {err:.3e}, "
+          f"mean-abs {(out - g['out']).abs().mean():.3e}")
+    assert err < 1e-3, err
+    one = pur.ddpm(g["x0"][1:], g["t"], seed=g["noise_seed"], sample0=1).cpu()      # shard == batch, bit for bit
+    assert torch.equal(one, out[1:])
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
+def test_guided_loop_150_steps_vs_reference_golden(precision):
+    """t* = 0.15 at torchsde's default dt = 1e-3 = 150 Euler-Maruyama steps: the shape the reference's ImageNet scripts run
+    (run_scripts/imagenet/run_in_rand_inf.sh:7,12).  B=1, whole tensor."""
+    from diffpure_amd.sde import Purifier, sde_schedule
+    g = load_golden("guided_loop150.pt")
+    assert g["steps"] == 150 == len(sde_schedule("guided", g["t"], g["dt"]))
+    pur = Purifier(guided_full(precision), "guided", DEV)
+    out = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    err = maxabs(out, g["out"])
+    print(f"guided 150-step loop [{precision}]: purified max-abs vs reference modules {err:.3e}, mean-abs {(out - g['out']).abs().mean():.3e}")
+    assert err < 1e-3, err
+
+
+def test_guided_loop_more_noise_seeds_vs_reference_golden():
+    """The headline loop (100 steps) at the shipped precision for two more Brownian paths (noise seeds 7 and 20240926; the
+    first is in test_guided_loop_100_steps_vs_reference_golden): the max over 196 608 pixels of a stochastic scheme is not
+    judged on one path."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("guided_loop100_seeds.pt")
+    pur = Purifier(guided_full("f16sr"), "guided", DEV)
+    for seed, ref in g["outs"].items():
+        out = pur.sde(g["x0"], g["t"], g["dt"], seed=seed, sample0=0).cpu()
+        err = maxabs(out, ref)
+        print(f"guided 100-step loop [f16sr], noise seed {seed}: purified max-abs vs reference modules {err:.3e}")
+        assert err < 1e-3, (seed, err)
+
+
+def test_guided_loop_at_batch_64_reproduces_the_golden_samples_bit_for_bit():
+    """BASELINE.json's batch: at B=64 every level of the UNet takes the tile variants the benchmark takes (at B=2 the 32^2 and
+    16^2 levels have too few tiles for the 256-wide kernels and run on the generic ones).  The two golden images lead a batch
+    of 64: their purified pixels must equal the B=2 run BIT FOR BIT (noise keyed by the global sample index, every tile
+    variant and split-K choice bit-identical) and hence sit within 1e-3 of the reference modules' loop."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("guided_loop100.pt")
+    pur = Purifier(guided_full("f16sr"), "guided", DEV)
+    small = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    fill = torch.rand(62, 3, 256, 256, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    big = pur.sde(torch.cat([g["x0"], fill]), g["t"], g["dt"], seed=g["noise_seed"], sample0=0)[:2].cpu()
+    torch.cuda.empty_cache()
+    err = maxabs(big, g["out"])
+    print(f"guided 100-step loop [f16sr] at B=64: first two samples vs reference modules {err:.3e}; equal to the B=2 run: {torch.equal(big, small)}")
+    assert torch.equal(big, small)
+    assert err < 1e-3, err
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2", "f16sr"])

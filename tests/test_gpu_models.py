@@ -14,6 +14,17 @@ from diffpure_amd.synth import synth_state_dict
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+# Tolerances by arithmetic.  "f16x3" carries 22-bit operands: north_star's bar (1e-3 on purified pixels) and 5e-3 relative on
+# gradients hold on any grid.  "f16sr" - the arithmetic every runner SHIPS with - rounds activations and weights to fp16 afresh at
+# every UNet call: a zero-mean perturbation of eps that enters the state scaled by beta h / sigma per step.  The loops in this
+# file are 8-10 steps at dt = 1e-2 on small networks (ten times the product's step): per step the perturbation is ten times
+# larger than at dt = 1e-3 and has nothing to average over, so the bars for f16sr here are the measured error x ~3; at the
+# product's grid (100-150 steps, dt = 1e-3) f16sr holds 1e-3 on every loop: tests/test_gpu_loops.py.
+PIX_TOL = {"f32": 1e-3, "f16x3": 1e-3, "f16sr": 5e-3}
+GRAD_TOL = {"f32": 5e-3, "f16x3": 5e-3, "f16sr": 3e-2}
+SHIPPED = ["f16x3", "f16sr"]
+
+
 
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
@@ -159,7 +170,8 @@ def test_shard_invariance_bitwise():
     assert torch.isfinite(full).all()
 
 
-def test_drop_in_runner_boundary(tmp_path):
+@pytest.mark.parametrize("precision", SHIPPED)
+def test_drop_in_runner_boundary(tmp_path, precision):
     """The reference's constructor/method surface: Runner(args, config, device).image_editing_sample."""
     import argparse
     from runners.diffpure_sde import RevGuidedDiffusion
@@ -174,7 +186,7 @@ def test_drop_in_runner_boundary(tmp_path):
     config = ns(g["cfg"])
     config.device = torch.device(DEV)
     args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=2, log_dir=str(tmp_path),
-                              score_type="score_sde", seed=1234, synthetic_weights=True, dt=1e-2, precision="f16x3")
+                              score_type="score_sde", seed=1234, synthetic_weights=True, dt=1e-2, precision=precision)
     runner = RevGuidedDiffusion(args, config, device=config.device)
     assert isinstance(runner, torch.nn.Module)
     x = torch.rand(3, 3, 16, 16) * 2 - 1
@@ -314,7 +326,8 @@ def test_ddpm_unet_full_vs_reference_golden():
     assert abs(out.abs().mean().item() - g["y_abs_mean"].item()) < 1e-4
 
 
-def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path):
+@pytest.mark.parametrize("precision", SHIPPED)
+def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path, precision):
     import argparse
     from oracle import ddpm_unet as od
     from runners.diffpure_ddpm import Diffusion
@@ -326,7 +339,7 @@ def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path):
             setattr(n, k, ns(v) if isinstance(v, dict) else v)
         return n
 
-    args = argparse.Namespace(t=8, sample_step=1, log_dir=str(tmp_path), seed=g["seed"], synthetic_weights=True, precision="f16x3")
+    args = argparse.Namespace(t=8, sample_step=1, log_dir=str(tmp_path), seed=g["seed"], synthetic_weights=True, precision=precision)
     runner = Diffusion(args, ns(g["cfg"]), device=DEV)
     sd = synth_state_dict(dict(zip(g["keys"], g["shapes"])), g["seed"])
     ocfg = od.parse_ddpm_config(g["cfg"])
@@ -339,7 +352,9 @@ def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path):
     with torch.no_grad():
         ref = od.celeba_ddpm_purify(lambda x, t: od.unet_forward(sd, ocfg, x, t), sched, x0, e, zs, 8)
     out = runner.image_editing_sample(x0, bs_id=5, noise=dict(e=e, z=zs)).cpu()
-    assert (out - ref).abs().max() < 1e-3            # north_star's bar on purified pixels
+    err = (out - ref).abs().max().item()
+    print(f"CelebA-HQ DDPM runner, small UNet, 8 steps [{precision}]: purified max-abs vs oracle {err:.3e}")
+    assert err < PIX_TOL[precision], err
     xb = torch.rand(5, 3, 16, 16, generator=torch.Generator().manual_seed(9)) * 2 - 1
     full = runner.purifier.celeba_ddpm(xb, 8, runner.sched, seed=3, sample0=0)
     parts = torch.cat([runner.purifier.celeba_ddpm(xb[:2], 8, runner.sched, seed=3, sample0=0),
@@ -347,8 +362,9 @@ def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path):
     assert torch.equal(full, parts)
 
 
+@pytest.mark.parametrize("precision", SHIPPED)
 @pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
-def test_ldsde_runner_loop_vs_oracle(kind):
+def test_ldsde_runner_loop_vs_oracle(kind, precision):
     """Langevin-dynamics runner (runners/diffpure_ldsde.py) on the HIP engine against the oracle loop, injected noise."""
     from diffpure_amd import guided_unet as pg
     from diffpure_amd import ncsnpp as pn
@@ -360,13 +376,13 @@ def test_ldsde_runner_loop_vs_oracle(kind):
         g = load_golden("ncsnpp_small.pt")
         cfg = pn.parse_config(g["cfg"])
         sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
-        net = pn.NCSNpp(cfg, DEV, precision="f16x3").load_state_dict(sd)
+        net = pn.NCSNpp(cfg, DEV, precision=precision).load_state_dict(sd)
         score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
     else:
         g = load_golden("guided_small.pt")
         cfg = pg.parse_config(g["cfg"])
         sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
-        net = pg.GuidedUNet(cfg, DEV, precision="f16x3").load_state_dict(sd)
+        net = pg.GuidedUNet(cfg, DEV, precision=precision).load_state_dict(sd)
         score = osol.make_score_fn("guided", sd, og.parse_guided_config(g["cfg"]))
     x0 = g["x"]
     gen = torch.Generator().manual_seed(7)
@@ -375,7 +391,9 @@ def test_ldsde_runner_loop_vs_oracle(kind):
         ref = osol.ldsde_purify(score, x0, zs, 100, 0.001, 0.01, 5)
     pur = Purifier(net, kind, DEV)
     out = pur.ldsde(x0, 100, 0.001, 0.01, 5, noise=dict(z=zs)).cpu()
-    assert (out - ref).abs().max() < 1e-3
+    err = (out - ref).abs().max().item()
+    print(f"ldsde loop, small {kind} [{precision}]: max-abs vs oracle {err:.3e}")
+    assert err < PIX_TOL[precision], err
     xb = torch.rand(4, *x0.shape[1:], generator=torch.Generator().manual_seed(2)) * 2 - 1
     full = pur.ldsde(xb, 100, 0.001, 0.01, 5, seed=9)
     assert torch.equal(full, torch.cat([pur.ldsde(xb[:1], 100, 0.001, 0.01, 5, seed=9), pur.ldsde(xb[1:], 100, 0.001, 0.01, 5, seed=9, sample0=1)]))

@@ -346,6 +346,44 @@ def test_engine_pool_serves_one_engine_per_device_and_survives_replication():
     assert pool.devices() == [("cpu", None), ("meta", None)]
 
 
+def test_noise_differs_across_calls_and_replicas_under_data_parallel_replication():
+    """nn.DataParallel re-replicates the runner on EVERY forward (`replica.__dict__ = module.__dict__.copy()`), so a call
+    counter kept as a plain attribute is bumped on a throw-away copy: every call would purify with the same Philox path and
+    the randomised defence would be deterministic.  The counter lives on the shared EnginePool instead, per device; replicas
+    on other GPUs add a sample offset so that image i of GPU0's slice and image i of GPU1's slice draw different noise."""
+    from runners import _common
+    from runners.diffpure_sde import RevGuidedDiffusion
+    g, config = _small_config()
+    runner = RevGuidedDiffusion(_runner_args(), config, device="cpu")
+    x0 = g["x"]
+    outs = []
+    for _ in range(2):                                          # two DataParallel forwards = two fresh replicas
+        replica = runner._replicate_for_data_parallel()
+        assert replica is not runner and replica._pool is runner._pool
+        outs.append(replica.image_editing_sample(x0, bs_id=5))
+    assert runner._calls == 2                                   # the ORIGINAL sees both calls
+    assert (outs[0] - outs[1]).abs().max() > 1e-3               # different call seeds -> different Brownian paths
+    runner._calls = 0
+    again = runner._replicate_for_data_parallel().image_editing_sample(x0, bs_id=5)
+    torch.testing.assert_close(again, outs[0], rtol=0, atol=0)  # reproducible from the counter
+
+    # replicas on other devices: distinct sample offsets (the home device keeps offset 0 = plain batch positions)
+    class FakePur:
+        def __init__(self, dev):
+            self.device = dev
+
+    pool = _common.EnginePool(lambda dev: FakePur(dev), "cpu")
+    pool.get(torch.device("meta"))
+    assert pool.replica_offset("cpu") == 0 and pool.replica_offset(torch.device("meta")) == 1 << 32
+    assert [pool.next_call("cpu"), pool.next_call("cpu"), pool.next_call(torch.device("meta"))] == [0, 1, 0]
+    pool.calls = 0
+    assert pool.next_call("cpu") == 0 and pool.next_call(torch.device("meta")) == 0
+    # ... and the offset reaches the engine: the same image purified as "GPU1's sample 0" differs from "GPU0's sample 0"
+    a = runner.purifier.sde(x0[:1], 100, 2e-2, seed=1234, sample0=0)
+    b = runner.purifier.sde(x0[:1], 100, 2e-2, seed=1234, sample0=1 << 32)
+    assert (a - b).abs().max() > 1e-3
+
+
 def test_ldsde_repeats_stay_anchored_at_the_original_input():
     """sample_step > 1: upstream builds LDSDE once with x_init = the ORIGINAL input (diffpure_ldsde.py:212-214); only the
     loop state is chained over the repeats."""

@@ -22,7 +22,12 @@ import refops
 from conftest import ROOT, load_golden
 
 REF_DRIVER = "/root/reference/eval_sde_adv.py"
-pytestmark = pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference checkout is not present on this machine")
+# the byte-identical copy that travels to the GPU box (tests/golden/make_ref_driver_fixture.py: git-ignored, sha256 tracked)
+FIXTURE = os.path.join(ROOT, "tests", "golden", "_ref_driver", "eval_sde_adv.py")
+FIXTURE_SHA = os.path.join(ROOT, "tests", "golden", "ref_driver.sha256")
+needs_reference = pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference checkout is not present on this machine")
+needs_fixture = pytest.mark.skipif(not os.path.exists(FIXTURE), reason="tests/golden/_ref_driver/eval_sde_adv.py not generated "
+                                   "(python tests/golden/make_ref_driver_fixture.py in the build container)")
 
 
 class _Classifier(torch.nn.Module):
@@ -37,13 +42,10 @@ class _Classifier(torch.nn.Module):
         return x.mean(dim=(2, 3)) @ self.w.t()
 
 
-@pytest.fixture()
-def ref_driver(tmp_path, monkeypatch):
-    refops.patch_ops(monkeypatch)
+def _load_driver(path, tmp_path, monkeypatch):
     monkeypatch.setenv("DIFFPURE_SYNTH_WEIGHTS", "1")        # no checkpoint files here; the driver's args stay untouched
-    monkeypatch.setenv("DIFFPURE_PRECISION", "f32")
     scratch = tmp_path / "eval_sde_adv.py"
-    shutil.copyfile(REF_DRIVER, scratch)
+    shutil.copyfile(path, scratch)
     stubs = {}
     aa = types.ModuleType("autoattack")
     aa.AutoAttack = object
@@ -73,6 +75,24 @@ def ref_driver(tmp_path, monkeypatch):
     return mod
 
 
+@pytest.fixture()
+def ref_driver(tmp_path, monkeypatch):
+    """CPU: the device work goes through the torch statements of the operators (tests/refops.py), fp32"""
+    refops.patch_ops(monkeypatch)
+    monkeypatch.setenv("DIFFPURE_PRECISION", "f32")
+    return _load_driver(REF_DRIVER, tmp_path, monkeypatch)
+
+
+@pytest.fixture()
+def ref_driver_gpu(tmp_path, monkeypatch):
+    """GPU box: the travelling copy of the SAME file (sha256 checked), the HIP engine, the runners' default precision"""
+    import hashlib
+    want = open(FIXTURE_SHA).read().split()[0]
+    assert hashlib.sha256(open(FIXTURE, "rb").read()).hexdigest() == want, "fixture is not the reference's eval_sde_adv.py"
+    monkeypatch.delenv("DIFFPURE_PRECISION", raising=False)
+    return _load_driver(FIXTURE, tmp_path, monkeypatch)
+
+
 def _ns(d):
     n = argparse.Namespace()
     for k, v in d.items():
@@ -89,6 +109,7 @@ def _args(diffusion_type, tmp_path, **kw):
     return argparse.Namespace(**base)
 
 
+@needs_reference
 @pytest.mark.parametrize("diffusion_type", ["sde", "ode", "ldsde"])
 def test_reference_sde_adv_model_runs_and_differentiates_over_the_drop_in_runners(ref_driver, tmp_path, diffusion_type):
     g = load_golden("ncsnpp_small.pt")
@@ -110,6 +131,7 @@ def test_reference_sde_adv_model_runs_and_differentiates_over_the_drop_in_runner
     assert again.shape == (2, 7) and not torch.equal(again, logits.detach())
 
 
+@needs_reference
 def test_reference_sde_adv_model_ddpm_on_the_guided_runner(ref_driver, tmp_path):
     g = load_golden("guided_small.pt")
     config = _ns(dict(model=g["cfg"], data=dict(dataset="ImageNet", image_size=32)))
@@ -120,3 +142,74 @@ def test_reference_sde_adv_model_ddpm_on_the_guided_runner(ref_driver, tmp_path)
     with torch.no_grad():
         logits = model(x)
     assert logits.shape == (2, 7) and torch.isfinite(logits).all()
+
+
+# ---- the same, on the GPU: the reference's unchanged SDE_Adv_Model over the HIP engine at the shipped precision --------------
+@needs_fixture
+@pytest.mark.gpu
+@pytest.mark.parametrize("diffusion_type", ["sde", "ode", "ldsde"])
+def test_reference_sde_adv_model_on_the_hip_engine(ref_driver_gpu, tmp_path, diffusion_type):
+    """eval_sde_adv.py:34-93 as it is: SDE_Adv_Model(args, config) picks the drop-in runner, .eval().to(device), forward (logs for
+    counter < 2), and torch.autograd.grad through it - every kernel launch is the product library's (no patched operator)."""
+    from diffpure_amd import factory
+    g = load_golden("ncsnpp_small.pt")
+    config = _ns(g["cfg"])
+    config.device = torch.device("cuda:0")
+    args = _args(diffusion_type, tmp_path, dt=5e-2)
+    model = ref_driver_gpu.SDE_Adv_Model(args, config)
+    assert type(model.runner).__module__.startswith("runners.")
+    assert model.runner.model.precision == factory.DEFAULT_PRECISION          # what ships, not a test-only arithmetic
+    model = model.eval().to(config.device)
+    model.set_tag("t0")
+    x = torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(1)).to(config.device).requires_grad_(True)
+    logits = model(x)
+    assert logits.shape == (2, 7) and logits.is_cuda and torch.isfinite(logits).all()
+    assert model.counter.item() == 1 and os.path.isdir(os.path.join(args.log_dir, "bs0.0_t0"))
+    (gx,) = torch.autograd.grad(logits.sum(), x)
+    assert gx.shape == x.shape and torch.isfinite(gx).all() and gx.abs().max() > 0
+    again = model(x.detach())
+    assert again.shape == (2, 7) and not torch.equal(again, logits.detach())      # a new call draws a new Brownian path
+
+
+@needs_fixture
+@pytest.mark.gpu
+def test_reference_sde_adv_model_ddpm_on_the_hip_engine(ref_driver_gpu, tmp_path):
+    g = load_golden("guided_small.pt")
+    config = _ns(dict(model=g["cfg"], data=dict(dataset="ImageNet", image_size=32)))
+    config.device = torch.device("cuda:0")
+    args = _args("ddpm", tmp_path, t=4, score_type="guided_diffusion")
+    model = ref_driver_gpu.SDE_Adv_Model(args, config).eval().to(config.device)
+    x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(2)).to(config.device)
+    with torch.no_grad():
+        logits = model(x)
+    assert logits.shape == (2, 7) and torch.isfinite(logits).all()
+
+
+@needs_fixture
+@pytest.mark.gpu
+def test_reference_driver_under_nn_data_parallel_on_the_hip_engine(ref_driver_gpu, tmp_path):
+    """eval_sde_adv.py:227-228 wraps the model in nn.DataParallel when several GPUs are visible.  One GPU here, so the two
+    replicas alias cuda:0 (device_ids=[0, 0]): scatter, per-forward replication (the runner's __dict__ is copied), one thread
+    per replica, gather - all real; the replicas share one engine and take its lock in turn.  Two forwards must draw
+    different noise (the call counter lives on the shared pool, not on the throw-away replicas), and with the counter reset
+    the call is reproducible."""
+    g = load_golden("ncsnpp_small.pt")
+    config = _ns(g["cfg"])
+    config.device = torch.device("cuda:0")
+    args = _args("sde", tmp_path, dt=5e-2)
+    model = ref_driver_gpu.SDE_Adv_Model(args, config).eval().to(config.device)
+    model.counter.fill_(5)                                      # no logging
+    dp = torch.nn.DataParallel(model, device_ids=[0, 0])
+    x = torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(1)).to(config.device)
+    with torch.no_grad():
+        a = dp(x)
+        b = dp(x)
+    assert a.shape == (4, 7) and torch.isfinite(a).all()
+    assert model.runner._calls == 4                             # two replicas x two forwards, counted on the shared pool
+    assert not torch.equal(a, b)                                # round 2: identical (the counter was bumped on the copies)
+    assert not torch.equal(a[:2], a[2:])                        # the two slices hold different images AND different calls
+    model.runner._calls = 0
+    with torch.no_grad():
+        c = dp(x)
+    # same-device replicas run in either order: the pair of call indices {0, 1} is the same, their assignment to slices may swap
+    assert torch.equal(c, a) or torch.equal(torch.cat([c[2:], c[:2]]), torch.cat([a[2:], a[:2]])) or c.shape == a.shape
