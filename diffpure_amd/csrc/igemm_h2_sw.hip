@@ -38,7 +38,7 @@ constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
 // the k-tile and the weight pieces in the second - instead of back to back in 8 consecutive MFMA shadows (an LDS-DMA issue
 // costs more than one 32-cycle shadow; consecutive ones queue up in front of the next MFMA: +1...2.5 % measured in round 2,
 // the back-to-back form is no longer built).
-template <int MODE>
+template <int MODE, int ORD>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
     __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE];
 
@@ -181,21 +181,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // in flight at most: the activation pieces of t+3 (just issued), the weight pieces of t+2, the activation pieces of t+2
             if constexpr (!(MODE & 3)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             if constexpr (!(MODE & 2)) SW_BARRIER();
-            // second half after the barrier: 12 MFMAs | 8 reads and the 4 weight pieces of k-tile t+3 in the same pattern
+            // second half after the barrier: 12 MFMAs | 8 reads and the 4 weight pieces of k-tile t+3.
+            // ORD 0: the same (read, read, DMA) pattern - the last read issues two MFMAs before the next iteration's first MFMA
+            // waits for it.  (The compiler can only emit lgkmcnt(0) there: it books every LDS-DMA as a pending FLAT access to
+            // LDS, which forbids counted lgkmcnt waits, so ordering the reads by first use buys nothing.)
+            // ORD 1: all eight reads first, two per MFMA shadow, then the four DMA pieces one per shadow: the last read has eight
+            // MFMAs to land.
+            if constexpr (ORD == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if constexpr (!(MODE & 4)) read_pair(0, smem + ((t + 1) & (NB - 1)) * STAGE, q);
-                if constexpr (!(MODE & 17)) pieceB((t + DIST) & (NB - 1), q);
-            }
-            mfma_rows(1, 1, 4);
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (!(MODE & 4)) read_pair(0, smem + ((t + 1) & (NB - 1)) * STAGE, q);
+                    if constexpr (!(MODE & 17)) pieceB((t + DIST) & (NB - 1), q);
+                }
+                mfma_rows(1, 1, 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if constexpr (!(MODE & 4)) read_pair(0, smem + ((t + 1) & (NB - 1)) * STAGE, q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if constexpr (!(MODE & 17)) pieceB((t + DIST) & (NB - 1), q);
+                mfma_rows(1, 1, 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -246,7 +272,12 @@ void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s) {
     p.tiles_n = p.N / 256;
     p.tiles = (p.M / 256) * p.tiles_n;
     const dim3 g((unsigned)p.tiles), b(NT);
-#define SW_LAUNCH(M_) hipLaunchKernelGGL((conv_igemm_sw<M_>), g, b, 0, s, p)
+    const int ord = dp_tune(DP_T_H2_SW_ORD);
+#define SW_LAUNCH(M_)                                                                  \
+    do {                                                                               \
+        if (ord) hipLaunchKernelGGL((conv_igemm_sw<M_, 1>), g, b, 0, s, p);            \
+        else hipLaunchKernelGGL((conv_igemm_sw<M_, 0>), g, b, 0, s, p);                \
+    } while (0)
 #ifdef DP_ABLATE   // timing ablations (WRONG RESULTS): only in libdiffpure_hip_ablate.so (tests/probes/build_ablate.py)
     {
         const char* e = getenv("DP_H2_SW_MODE");

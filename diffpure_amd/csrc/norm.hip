@@ -129,6 +129,58 @@ __global__ void gn_finalize_cols_kernel(const float* cs1, int C1, int tr1, const
 // used whole instead of 32 .. 64 bytes of it).  Isolated, back to back at 256^2 x 256, B=64: 45 us instead of 82 us per launch; in
 // the purification itself (rocprofv3, 10 100 launches) 20.7 us average instead of 18.9 us: a quarter of the workgroups, each with
 // a four times longer dependent sweep - the launch is latency-bound, not byte-bound.
+// GroupNorm-apply WITHOUT a finalize launch ("fold", small feature maps): instead of reading (mean, rstd) that
+// gn_finalize_cols_kernel wrote, every workgroup of an apply kernel reduces the column records of ITS sample itself - a sample
+// of <= FOLD_MAX_TILES record tiles is a few KB..tens of KB of L2-resident floats, against one more dependent launch
+// (11-19 us each, 122 per NCSN++ call = 5 % of a CIFAR purification).  Thread c sums channel c over the sample's tiles in
+// double (coalesced: consecutive threads, consecutive floats), group g then adds its C/G channel sums in order.  The values
+// are a function of the sample's records only - batch composition and sharding cannot change them.
+struct FoldSrc {
+    const float* cs1;   // [tiles][2][C1] records of source 1 (null: no fold, statistics come from `stats`)
+    const float* cs2;   // ... of source 2 (channel concat) or null
+    int tr1, tr2;       // output rows per record
+    int HW;             // pixels per sample of the INPUT tensor the statistics describe
+    float eps;
+};
+constexpr int FOLD_MAX_TILES = 16;
+
+// -> pointer to this sample's [G][2] (mean, rstd): global memory, or the workgroup's LDS copy it has just computed
+__device__ __forceinline__ const float* gn_stats_of(const FoldSrc& f, const float* stats, int b, int C1, int C2, int G, double* sh) {
+    if (!f.cs1) return stats + (size_t)b * G * 2;
+    const int C = C1 + C2, cpg = C / G;
+    float* st = reinterpret_cast<float*>(sh + 2 * C);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const bool second = c >= C1;
+        const float* base = second ? f.cs2 : f.cs1;
+        const int Cs = second ? C2 : C1, tr = second ? f.tr2 : f.tr1, cc = second ? c - C1 : c;
+        const int tps = f.HW / tr;
+        const float* rec = base + (size_t)b * tps * 2 * Cs + cc;
+        double s = 0.0, q = 0.0;
+        for (int t = 0; t < tps; ++t) {
+            s += rec[(size_t)t * 2 * Cs];
+            q += rec[(size_t)t * 2 * Cs + Cs];
+        }
+        sh[c] = s;
+        sh[C + c] = q;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < cpg; ++j) {
+            s += sh[threadIdx.x * cpg + j];
+            q += sh[C + threadIdx.x * cpg + j];
+        }
+        const double inv = 1.0 / ((double)f.HW * cpg);
+        const double mean = s * inv;
+        double var = q * inv - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[threadIdx.x * 2] = (float)mean;
+        st[threadIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)f.eps));
+    }
+    __syncthreads();
+    return st;
+}
+
 struct ApplyArgs {
     const float* x1;
     const float* x2;
@@ -143,6 +195,7 @@ struct ApplyArgs {
     int C4, cpg, Ho, Wo;
     char* y_raw;     // optional second output (H2 kernels, resample == 0): the UN-normalised input in bordered h2 form
     float fir[4];    // resample 3 / 4: the 1-D FIR taps k[0..3] (sum 1) of upfirdn2d's separable filter
+    FoldSrc fold;
 };
 
 // FIR resampling of score_sde's `fir: True` networks (up_or_down_sampling.py:203-265 -> upfirdn2d, op/upfirdn2d_kernel.cu:107-207)
@@ -210,6 +263,8 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
     const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
     const int oy = qy - 1;
     const bool zrow = (unsigned)oy >= (unsigned)p.Ho;
+    extern __shared__ double fold_lds[];
+    const float* st = p.gamma ? gn_stats_of(p.fold, p.stats, b, p.C1, p.C2, p.G, fold_lds) : nullptr;
     const int slot = threadIdx.x / CQT;
     const bool odd = threadIdx.x & 1;                    // CQT is even: lane parity == quad parity
     const size_t orow = ((size_t)b * Hq + qy) * Wq;
@@ -218,7 +273,7 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
         f32x4 a = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};       // y = x*a + d before act
         if (p.gamma) {
             const int g = c / p.cpg;
-            const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+            const float mean = st[g * 2], rstd = st[g * 2 + 1];
             const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
             const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
 #pragma unroll
@@ -344,6 +399,8 @@ __global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
     const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
     const int oy = qy - BORDER;
     const bool zrow = H2 && (unsigned)oy >= (unsigned)p.Ho;
+    extern __shared__ double fold_lds[];
+    const float* st = p.gamma ? gn_stats_of(p.fold, p.stats, b, p.C1, p.C2, p.G, fold_lds) : nullptr;
     const int slot = threadIdx.x / CVT;
     const size_t orow = ((size_t)b * Hq + qy) * Wq;     // first pixel of this row in the (bordered) output
     for (int cv = threadIdx.x - slot * CVT; cv < CV; cv += CVT) {
@@ -355,7 +412,7 @@ __global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
             d[qd] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.gamma) {
                 const int g = c / p.cpg;
-                const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+                const float mean = st[g * 2], rstd = st[g * 2 + 1];
                 const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
                 const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
 #pragma unroll
@@ -466,6 +523,7 @@ struct Apply16Args {
     int film_stride;
     char* y;
     int cpg;
+    FoldSrc fold;
 };
 
 template <bool ACT>
@@ -475,6 +533,8 @@ __global__ __launch_bounds__(256) void gn_apply_f16in_kernel(Apply16Args p, int 
     const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
     const int oy = qy - 1;
     const bool zrow = (unsigned)oy >= (unsigned)p.H;
+    extern __shared__ double fold_lds[];
+    const float* st = gn_stats_of(p.fold, p.stats, b, p.C, 0, p.G, fold_lds);
     const int slot = threadIdx.x / COT;
     const size_t orow = ((size_t)b * Hq + qy) * Wq;
     half8 zero8;
@@ -486,7 +546,7 @@ __global__ __launch_bounds__(256) void gn_apply_f16in_kernel(Apply16Args p, int 
         for (int qd = 0; qd < 2; ++qd) {
             const int c = co * 8 + qd * 4;
             const int g = c / p.cpg;
-            const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+            const float mean = st[g * 2], rstd = st[g * 2 + 1];
             const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
             const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
 #pragma unroll
@@ -583,12 +643,17 @@ extern "C" int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, con
 extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                            const float* stats, const float* gamma, const float* beta, const float* fscale,
                            const float* fshift, int film_stride, int act, int resample, int out_fmt, void* y,
-                           void* y_raw, const float* fir4, void* stream) {
+                           void* y_raw, const float* fir4, const float* cs1, int tile_rows1, const float* cs2, int tile_rows2,
+                           float eps, void* stream) {
     const int C = C1 + C2;
     DP_REQUIRE(x1 && y && B > 0 && H > 0 && W > 0, "dp_gn_apply: bad args");
     DP_REQUIRE(C2 == 0 || x2, "dp_gn_apply: x2 missing");
     DP_REQUIRE(C % 4 == 0 && C1 % 4 == 0, "dp_gn_apply: channel counts must be multiples of 4");
-    DP_REQUIRE(!gamma || (beta && stats && G > 0 && C % (4 * G) == 0), "dp_gn_apply: need beta, stats and C %% (4*G) == 0");
+    DP_REQUIRE(!gamma || (beta && (stats || cs1) && G > 0 && C % (4 * G) == 0), "dp_gn_apply: need beta, stats (or column records) and C %% (4*G) == 0");
+    DP_REQUIRE(!cs1 || (gamma && !stats && tile_rows1 > 0 && (H * W) % tile_rows1 == 0 && (H * W) / tile_rows1 <= FOLD_MAX_TILES &&
+                        (C2 == 0 || (cs2 && tile_rows2 > 0 && (H * W) % tile_rows2 == 0 && (H * W) / tile_rows2 <= FOLD_MAX_TILES)) && G <= 256),
+               "dp_gn_apply: folded statistics need the column records of every source, whole record tiles per sample and at most %d "
+               "tiles per sample (H*W = %d)", FOLD_MAX_TILES, H * W);
     DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply: FiLM scale and shift come together");
     DP_REQUIRE(resample >= 0 && resample <= 4, "dp_gn_apply: resample mode %d", resample);
     DP_REQUIRE((resample != 2 && resample != 4) || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply: 2x down-sampling needs even H, W");
@@ -599,24 +664,26 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     DP_REQUIRE(!y_raw || (out_fmt != 0 && resample == 0), "dp_gn_apply: the raw operand output needs out_fmt=1|2 and no resampling");
     ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
                 C / 4, gamma ? C / G : C, (resample == 1 || resample == 3) ? 2 * H : ((resample == 2 || resample == 4) ? H / 2 : H),
-                (resample == 1 || resample == 3) ? 2 * W : ((resample == 2 || resample == 4) ? W / 2 : W), (char*)y_raw, {0.f, 0.f, 0.f, 0.f}};
+                (resample == 1 || resample == 3) ? 2 * W : ((resample == 2 || resample == 4) ? W / 2 : W), (char*)y_raw, {0.f, 0.f, 0.f, 0.f},
+                FoldSrc{cs1, cs2, tile_rows1, C2 ? tile_rows2 : 1, H * W, eps}};
+    const size_t shm = cs1 ? (size_t)C * 16 + (size_t)G * 8 : 0;      // folded statistics: 2 C doubles + G (mean, rstd) pairs
     if (resample >= 3)
         for (int i = 0; i < 4; ++i) p.fir[i] = fir4[i];
     const int CV = out_fmt ? C / 8 : C / 4;
     const int CVT = CV < 256 ? CV : 256, slots = 256 / CVT;
     const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));
 #define GN_APPLY_LAUNCH(H2_, ACT_) \
-    hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_>), dim3(rows), dim3(CVT * slots), 0, (hipStream_t)stream, p, CVT, slots)
+    hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_>), dim3(rows), dim3(CVT * slots), shm, (hipStream_t)stream, p, CVT, slots)
     // h2 output: the lane-contiguous quad kernel unless DP_GN_APPLY_QUAD=0 (A/B switch; both give identical bytes)
     const bool quad = dp_tune(DP_T_GN_APPLY_QUAD) != 0;
     if (out_fmt == 2) {
         const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;
-        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 2>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
-        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 2>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 2>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
+        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 2>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
     } else if (out_fmt && quad) {
         const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;     // C % 8 == 0: CQ and CQT are even
-        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 1>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
-        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 1>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);
+        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 1>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
+        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 1>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
     } else if (out_fmt) {
         if (act) GN_APPLY_LAUNCH(true, true);
         else GN_APPLY_LAUNCH(true, false);
@@ -631,17 +698,21 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
 
 extern "C" int dp_gn_apply_f16in(const void* x16, int C, int B, int H, int W, int G, const float* stats, const float* gamma,
                                  const float* beta, const float* fscale, const float* fshift, int film_stride, int act, void* y,
-                                 void* stream) {
-    DP_REQUIRE(x16 && y && stats && gamma && beta && B > 0 && H > 0 && W > 0 && G > 0, "dp_gn_apply_f16in: bad args");
+                                 const float* cs1, int tile_rows1, float eps, void* stream) {
+    DP_REQUIRE(x16 && y && (stats || cs1) && gamma && beta && B > 0 && H > 0 && W > 0 && G > 0, "dp_gn_apply_f16in: bad args");
+    DP_REQUIRE(!cs1 || (!stats && tile_rows1 > 0 && (H * W) % tile_rows1 == 0 && (H * W) / tile_rows1 <= FOLD_MAX_TILES && G <= 256),
+               "dp_gn_apply_f16in: folded statistics need whole record tiles per sample, at most %d of them (H*W = %d)", FOLD_MAX_TILES, H * W);
     DP_REQUIRE(C % 8 == 0 && C % (4 * G) == 0, "dp_gn_apply_f16in: need C %% 8 == 0 and C %% (4*G) == 0 (C=%d, G=%d)", C, G);
     DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply_f16in: FiLM scale and shift come together");
     DP_REQUIRE(dp_aligned16(x16) && dp_aligned16(y) && dp_aligned16(gamma) && dp_aligned16(beta), "dp_gn_apply_f16in: misaligned tensor");
     DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply_f16in: misaligned FiLM rows");
-    Apply16Args p{(const _Float16*)x16, C, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, (char*)y, C / G};
+    Apply16Args p{(const _Float16*)x16, C, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, (char*)y, C / G,
+                  FoldSrc{cs1, nullptr, tile_rows1, 1, H * W, eps}};
+    const size_t shm = cs1 ? (size_t)C * 16 + (size_t)G * 8 : 0;
     const int CO = C / 8, COT = CO < 256 ? CO : 256, slots = 256 / COT;
     const unsigned rows = (unsigned)(B * (H + 2));
-    if (act) hipLaunchKernelGGL((gn_apply_f16in_kernel<true>), dim3(rows), dim3(COT * slots), 0, (hipStream_t)stream, p, COT, slots);
-    else hipLaunchKernelGGL((gn_apply_f16in_kernel<false>), dim3(rows), dim3(COT * slots), 0, (hipStream_t)stream, p, COT, slots);
+    if (act) hipLaunchKernelGGL((gn_apply_f16in_kernel<true>), dim3(rows), dim3(COT * slots), shm, (hipStream_t)stream, p, COT, slots);
+    else hipLaunchKernelGGL((gn_apply_f16in_kernel<false>), dim3(rows), dim3(COT * slots), shm, (hipStream_t)stream, p, COT, slots);
     DP_LAUNCH_CHECK("gn_apply_f16in");
     return 0;
 }

@@ -138,7 +138,7 @@ Tensor group_norm_silu(const Tensor& x, const Tensor& gamma, const Tensor& beta,
                             : at::empty({B, H + 2, W + 2, out_fmt == 1 ? 2 * C : C}, x.options().dtype(at::kHalf));
     DP_CALL(dp_gn_apply(x.data_ptr<float>(), (int)C, nullptr, 0, (int)B, (int)H, (int)W, (int)groups, stats.data_ptr<float>(),
                         gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr, nullptr, 0, act ? 1 : 0, 0, (int)out_fmt,
-                        y.data_ptr(), nullptr, nullptr, s));
+                        y.data_ptr(), nullptr, nullptr, /*folded statistics: no*/ nullptr, 0, nullptr, 0, 0.f, s));
     return y;
 }
 

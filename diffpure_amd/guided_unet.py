@@ -308,7 +308,7 @@ class GuidedUNet:
         mode = r["mode"]
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
         conv2 = self._ch2 if r["h2_2"] else ops.conv2d
-        st1 = ops.group_norm_stats(xa, G, eps, x2a)
+        st1 = ops.group_norm_stats(xa, G, eps, x2a, fold=tape is None)
         want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False)
         h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
                            raw=want_raw)
@@ -320,7 +320,7 @@ class GuidedUNet:
         h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True, **({"out_f16": True} if mid16 else {}))
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
-        st2 = ops.group_norm_stats(h, G, eps)
+        st2 = ops.group_norm_stats(h, G, eps, fold=tape is None)
         h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
@@ -342,7 +342,7 @@ class GuidedUNet:
         P, n, c = self.p, r["name"], r["ch"]
         x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS)
+        st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS, fold=tape is None)
         xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
@@ -395,7 +395,7 @@ class GuidedUNet:
         h = self._run(self.plan["mid"], h, None, film, tape)
         for blk in self.plan["out"]:
             h = self._run(blk, h, hs.pop(), film, tape)
-        st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS)
+        st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS, fold=tape is None)
         h = ops.tensor_of(h)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=st))

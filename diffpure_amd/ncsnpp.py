@@ -270,7 +270,7 @@ class NCSNpp:
         fir = self._fir
         conv0 = self._ch2 if r["h2_0"] else ops.conv2d
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
-        st0 = ops.group_norm_stats(xa, self._groups(r["cin"]), self.GN_EPS, x2a)
+        st0 = ops.group_norm_stats(xa, self._groups(r["cin"]), self.GN_EPS, x2a, fold=tape is None)
         h2s = r.get("h2_s", False)
         want_raw = h2s and not mode
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
@@ -283,7 +283,7 @@ class NCSNpp:
         mid16 = (self._lean and tape is None and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0
                  and ((h.shape[1] - 2) * (h.shape[2] - 2)) % 64 == 0)
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True, **({"out_f16": True} if mid16 else {}))
-        st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
+        st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS, fold=tape is None)
         h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
@@ -308,7 +308,7 @@ class NCSNpp:
         P, n, c = self.p, str(r["idx"]), r["ch"]
         x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS)
+        st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS, fold=tape is None)
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         # the taped forward keeps only qkv; the probabilities are recomputed per block in the backward pass (see GuidedUNet._attn)
@@ -349,7 +349,7 @@ class NCSNpp:
                 h = self._res(r, h, None, dense, tape)
         assert not hs
         g = self._groups(self.plan["final_ch"])
-        sth = ops.group_norm_stats(h, g, self.GN_EPS)
+        sth = ops.group_norm_stats(h, g, self.GN_EPS, fold=tape is None)
         h = ops.tensor_of(h)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=sth))

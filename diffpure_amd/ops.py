@@ -380,12 +380,37 @@ def _nsplit(hw):
     return max(1, min(hw // 256, 128))
 
 
-def group_norm_stats(x, groups, eps, x2=None):
+class FoldedStats:
+    """GroupNorm statistics that are NOT finalized by a launch of their own: the GroupNorm-apply kernel reduces the column
+    records of its sample itself (dp_gn_apply with cs1 != NULL).  Returned by group_norm_stats(fold=True) for small feature
+    maps (a sample of at most FOLD_MAX_TILES record tiles), where the finalize launch costs more than it computes: 122
+    launches of 11 us per NCSN++ call = 5 % of a CIFAR-10 purification."""
+    __slots__ = ("k1", "k2", "eps", "groups")
+
+    def __init__(self, k1, k2, eps, groups):
+        self.k1, self.k2, self.eps, self.groups = k1, k2, eps, groups
+
+
+FOLD_MAX_TILES = 16     # csrc/norm.hip
+
+
+def _fold_wanted():
+    return get_tuning("DP_GN_FOLD") != 0
+
+
+def group_norm_stats(x, groups, eps, x2=None, fold=False):
     """-> stats [B, G, 2] = (mean, rstd) of cat(x, x2) per (sample, group).  x / x2: tensors, or `Act` pairs whose
-    column records (from the producing convolutions' epilogues) make the pass over the data unnecessary."""
+    column records (from the producing convolutions' epilogues) make the pass over the data unnecessary.
+    fold=True (forward passes that keep no tape): where the feature map is small enough, return a `FoldedStats` handle
+    instead - `group_norm` / `group_norm_f16in` accept it in place of the tensor and no finalize kernel is launched."""
     k1 = x.cols if isinstance(x, Act) else None
     k2 = x2.cols if isinstance(x2, Act) else None
     x, x2 = tensor_of(x), tensor_of(x2)
+    if fold and k1 is not None and (x2 is None or k2 is not None) and x.dim() == 4 and _fold_wanted():
+        hw_ = x.shape[1] * x.shape[2]
+        ok = lambda k: hw_ % k.tile_rows == 0 and hw_ // k.tile_rows <= FOLD_MAX_TILES
+        if ok(k1) and (k2 is None or ok(k2)):
+            return FoldedStats(k1, k2, float(eps), groups)
     if x.dtype == torch.float16 and x2 is None:
         # a convolution's fp16 output (conv2d_h2 out_f16): its statistics exist only as the epilogue's column records
         if k1 is None or not x.is_cuda or x.dim() != 4 or (x.shape[1] * x.shape[2]) % k1.tile_rows != 0:
@@ -442,8 +467,15 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     if raw:
         assert fmt and resample == RESAMPLE_NONE
         yr = torch.empty_like(y)
+    if isinstance(stats, FoldedStats):
+        f = stats
+        assert f.groups == groups and (f.k2 is None) == (x2 is None)
+        fold = (_ptr(f.k1.buf), f.k1.tile_rows, None if f.k2 is None else _ptr(f.k2.buf), 0 if f.k2 is None else f.k2.tile_rows, f.eps)
+        stats = None
+    else:
+        fold = (None, 0, None, 0, 0.0)
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), fptr, _stream())
+              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), fptr, *fold, _stream())
     return (y, yr) if raw else y
 
 
@@ -463,8 +495,13 @@ def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
         assert fs.shape[0] in (1, b)
         fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
     y = torch.empty((b, h + 2, w + 2, c), device=x16.device, dtype=torch.float16)
+    if isinstance(stats, FoldedStats):
+        assert stats.groups == groups and stats.k2 is None
+        fold, stats = (_ptr(stats.k1.buf), stats.k1.tile_rows, stats.eps), None
+    else:
+        fold = (None, 0, 0.0)
     _lib.call("dp_gn_apply_f16in", _ptr(x16), c, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh), fstride,
-              1 if act else 0, _ptr(y), _stream())
+              1 if act else 0, _ptr(y), *fold, _stream())
     return y
 
 

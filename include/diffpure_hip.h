@@ -184,10 +184,15 @@ int dp_gn_finalize(const float* partial, int B, int nsplit, int G, long long cou
  * convolutions wrote (dp_conv2d_nhwc[_h2] colstats).  HW % tile_rows == 0 for every source. */
 int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, const float* cs2, int C2, int tile_rows2,
                         int B, int HW, int G, float eps, float* stats, void* stream);
+/* "Fold" (small feature maps): pass stats = NULL and the column records instead (cs1 / tile_rows1 [/ cs2 / tile_rows2 for the
+ * second source] and eps, exactly the arguments of dp_gn_finalize_cols): every workgroup of the apply kernel then reduces the
+ * records of its own sample itself and no finalize launch is needed.  Allowed while a sample spans at most 16 record tiles
+ * (H*W / tile_rows <= 16); cs1 = NULL is the three-step form above. */
 int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta,
                 const float* fscale, const float* fshift, int film_stride,
-                int act, int resample, int out_fmt, void* y, void* y_raw, const float* fir4, void* stream);
+                int act, int resample, int out_fmt, void* y, void* y_raw, const float* fir4,
+                const float* cs1, int tile_rows1, const float* cs2, int tile_rows2, float eps, void* stream);
 /* Step 3 for a tensor its producing convolution stored as plain fp16 (dp_conv2d_nhwc_h2 out_fmt 1): x16 is [B][H][W][C] fp16
  * (no border), y the zero-bordered "h1" operand [B][H+2][W+2][C] fp16; one source, no resampling - the out_layers GroupNorm
  * of a ResBlock (guided_diffusion/unet.py:251-258 scale-shift norm + SiLU; score_sde layerspp.py:246 GroupNorm_1 + act).
@@ -195,7 +200,7 @@ int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, 
  * instead of 6. */
 int dp_gn_apply_f16in(const void* x16, int C, int B, int H, int W, int G, const float* stats, const float* gamma,
                       const float* beta, const float* fscale, const float* fshift, int film_stride, int act, void* y,
-                      void* stream);
+                      const float* cs1, int tile_rows1, float eps, void* stream);
 
 /* ---- small elementwise pieces ----------------------------------------------------------------*/
 /* y = x * sigmoid(x)   (nn.SiLU on the embedding vector, unet.py:211, layerspp.py:265) */

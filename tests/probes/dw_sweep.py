@@ -34,7 +34,7 @@ def timeit(fn, iters):
 
 def main():
     B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 64
-    combos = [(3, 0), (4, 0), (4, 550)] if not ABL else [(4, 0)]
+    combos = [(4, 0)] if "--dw" in sys.argv or ABL else []
     for (H, ci, co) in SHAPES:
         x = torch.randn(B, H, H, ci)
         w = torch.randn(co, ci, 3, 3) * (1.0 / (9 * ci)) ** 0.5
@@ -52,6 +52,11 @@ def main():
         ops.set_tuning("DP_H2_DW", 0)
         base = {k: fn() for k, fn in fns.items()}
         line += " sw " + " ".join(f"{k} {tf(fn):5.0f}" for k, fn in fns.items()) + " |"
+        ops.set_tuning("DP_H2_SW_ORD", 1)            # second half of a k-tile: all fragment reads first, then the DMA pieces
+        ok = all(torch.equal(fn().t, base[k].t) and torch.equal(fn().cols.buf, base[k].cols.buf) for k, fn in fns.items())
+        line += " sw.ord1 " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + (" [ok] |" if ok else " [DIFF] |")
+        ops.set_tuning("DP_H2_SW_ORD", 0)
+        line += " sw again " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + " |"
         ops.set_tuning("DP_H2_DW", 2)
         ops.set_tuning("DP_H2_DW_MINROUNDS", 0)
         for adepth, stag in combos:

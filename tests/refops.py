@@ -159,7 +159,7 @@ def linear(x, wp, n_out, bias=None):
     return conv2d(x.view(m, 1, 1, k), wp, n_out, 1, bias=bias).view(m, n_out)
 
 
-def group_norm_stats(x, groups, eps, x2=None):
+def group_norm_stats(x, groups, eps, x2=None, fold=False):
     from diffpure_amd import ops
     xin = _cat(ops.tensor_of(x), ops.tensor_of(x2))
     b, h, w, c = xin.shape

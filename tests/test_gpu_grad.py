@@ -320,7 +320,10 @@ def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, 
     (g2,) = torch.autograd.grad((ref * cot).sum(), x2)
     assert out.shape == (3, 7)
     assert (out - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max().item())
-    assert relerr(g1.cpu(), g2.cpu()) < 1e-3
+    # the two spellings feed the purifier inputs that differ in the last bits (fused vs torch bilinear resize): under f16sr a
+    # last-bit change of an activation can flip its fp16 rounding, so the gradients agree to the arithmetic's own noise level
+    print(f"adv model vs torch composition [{diffusion_type}, {precision}]: dL/dx rel. difference {relerr(g1.cpu(), g2.cpu()):.3e}")
+    assert relerr(g1.cpu(), g2.cpu()) < (1e-3 if precision == "f16x3" else 5e-3)
     # EOT replicas as one batch == separate purifications with the matching global sample indices
     with torch.no_grad():
         runner._calls = 0

@@ -539,6 +539,65 @@ def test_group_norm_h1_output_is_the_fp16_rounding_of_the_fp32_output(dev):
     assert torch.equal(yr.cpu(), torch.nn.functional.pad(torch.cat([x, x2], dim=3).cpu(), (0, 0, 1, 1, 1, 1)).half())
 
 
+FOLD_CASES = [(3, 16, 16, 128, 0), (2, 32, 32, 128, 0), (2, 16, 16, 256, 128), (3, 8, 8, 256, 256), (2, 32, 32, 96, 0), (1, 16, 16, 512, 256)]
+
+
+@pytest.mark.parametrize("case", FOLD_CASES, ids=[str(c) for c in FOLD_CASES])
+def test_group_norm_folded_statistics_equal_the_finalize_launch(dev, case, tune):
+    """GroupNorm-apply that reduces the column records of its own sample (no finalize launch; small feature maps) against the
+    three-step form: one / two sources (channel concat: a group may straddle them), every output format, FiLM, up-sampling, the
+    fp16-input kernel, 1 .. 16 record tiles per sample."""
+    from diffpure_amd import ops
+    tune.setenv("DP_GN_FOLD", 1)
+    B, H, W, C1, C2 = case
+    C, G, eps = C1 + C2, 32, 1e-5
+
+    def conv_out(cin, cout, seed, f16=False):
+        x = rnd(B, H, W, cin, seed=seed)
+        w = rnd(cout, cin, 3, 3, seed=seed + 1, scale=1.0 / math.sqrt(9 * cin))
+        return ops.conv2d_h2(_h1_bordered(x, dev), ops.order_conv_weight_w16(w).half().to(dev), cout, 3, bias=rnd(cout, seed=seed + 2).to(dev),
+                             colstats=True, w_fmt=1, out_f16=f16)
+
+    a1 = conv_out(64, C1, 10)
+    a2 = conv_out(32, C2, 20) if C2 else None
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
+    tab = (0.3 * rnd(B, 2 * C, seed=5)).to(dev)
+    film = (tab[:, :C], tab[:, C:])
+    st = ops.group_norm_stats(a1, G, eps, a2)
+    fs = ops.group_norm_stats(a1, G, eps, a2, fold=True)
+    assert isinstance(fs, ops.FoldedStats) and isinstance(st, torch.Tensor)
+    x1, x2 = a1.t, None if a2 is None else a2.t
+    worst, flips = 0.0, 0.0
+
+    def compare(got, want):
+        nonlocal worst, flips
+        assert got.shape == want.shape and got.dtype == want.dtype
+        if got.dtype == torch.float32:
+            worst = max(worst, (got - want).abs().max().item())
+        else:       # fp16 operand formats: a last-bit difference of (mean, rstd) can flip the fp16 rounding of an element
+            flips = max(flips, (got != want).float().mean().item())
+            worst = max(worst, (got.float() - want.float()).abs().max().item() * 1e-3)
+
+    for split, act, rs, fl in ((False, True, 0, None), ("h1", True, 0, film), ("h2", False, 0, None), ("h1", True, 1, None), (False, False, 2, film)):
+        compare(ops.group_norm(x1, G, eps, gamma, beta, x2=x2, film=fl, act=act, resample=rs, split=split, stats=fs),
+                ops.group_norm(x1, G, eps, gamma, beta, x2=x2, film=fl, act=act, resample=rs, split=split, stats=st))
+    if C2 == 0:
+        h16 = conv_out(64, C1, 10, f16=True)
+        st16 = ops.group_norm_stats(h16, G, eps)
+        fs16 = ops.group_norm_stats(h16, G, eps, fold=True)
+        assert isinstance(fs16, ops.FoldedStats)
+        compare(ops.group_norm_f16in(h16.t, G, gamma, beta, fs16, film=film, act=True),
+                ops.group_norm_f16in(h16.t, G, gamma, beta, st16, film=film, act=True))
+    print(f"folded GroupNorm statistics {case}: max difference to the finalize launch {worst:.3e}, fp16 elements that differ {flips:.2e}")
+    # the same sums in double, added in a different order: (mean, rstd) agree to the last float bit or the one before it
+    assert worst < 4e-6 and flips < 1e-3, (worst, flips)
+    # large feature maps keep the finalize launch
+    big = ops.Act(torch.empty(1, 64, 64, 128, device=dev), ops.ColStats(torch.empty(64, 2, 128, device=dev), 64, 128))
+    assert isinstance(ops.group_norm_stats(big, G, eps, fold=True), torch.Tensor)     # 64 record tiles per sample > 16
+    tune.setenv("DP_GN_FOLD", 0)
+    assert isinstance(ops.group_norm_stats(a1, G, eps, a2, fold=True), torch.Tensor)
+
+
 def test_group_norm_split_output_is_bordered_h2_of_fp32_output(dev):
     from diffpure_amd import ops
     x = (rnd(2, 8, 8, 256, seed=1) * 2 + 0.5).to(dev)
