@@ -23,8 +23,10 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int D = 64;                 // head dimension (guided diffusion: num_head_channels = 64)
-constexpr int SL = D / 32;            // 128-byte slices per K row
+// D = head dimension: 64 (guided diffusion: num_head_channels = 64) or 256 (NCSN++ AttnBlockpp at 16x16: one head of C = 256
+// channels, layerspp.py:75-91 - in round 2 still two fp32 GEMMs and a softmax pass over a materialised [B, 256, 256] score
+// tensor).  SL = D / 32 = 128-byte slices per K row.  With D = 256 a wave keeps Q (128 registers) and O^T (128 accumulators)
+// resident: one wave per SIMD, 64 KB of K / V^T per stage.
 constexpr int KB = 32;                // keys per block
 
 __device__ __forceinline__ int swz128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
@@ -49,6 +51,7 @@ __device__ __forceinline__ void split8(const float* v, float scale, half8& hi, h
 }
 
 // grid.x = z * (T/32) + block; 256 threads.  Q/K: thread -> (token, d-octet); V^T: thread -> (d, position octet)
+template <int D>
 __global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
     const int nblk = p.T / KB;
     const int z = blockIdx.x / nblk, blk = blockIdx.x - z * nblk;
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
     const int tid = threadIdx.x;
     const size_t row0 = (size_t)b * p.T + (size_t)blk * KB;      // first token of this block in qkv
     const int c3 = 3 * p.C;
-    {   // Q and K: 32 tokens x 8 octets = 256 items
-        const int tok = tid >> 3, oc = tid & 7;
+    for (int item = tid; item < KB * (D / 8); item += 256) {   // Q and K: 32 tokens x D/8 octets
+        const int tok = item / (D / 8), oc = item - tok * (D / 8);
         const float* src = p.qkv + (row0 + tok) * c3 + h * p.sh + oc * 8;
         float v[8];
         half8 hi, lo;
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
         dk[0] = hi;
         dk[1] = lo;
     }
-    {   // V^T: 64 d x 4 position octets = 256 items; lanes run along d (coalesced reads of V rows)
-        const int dd = tid & 63, po = tid >> 6;
+    for (int item = tid; item < D * 4; item += 256) {   // V^T: D d x 4 position octets; lanes run along d (coalesced reads of V rows)
+        const int dd = item % D, po = item / D;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -107,10 +110,11 @@ struct FlashArgs {
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 // QW waves per workgroup, 32 queries each.  LDS per stage: K tile SL slices x 32 rows x 128 B, V^T tile D rows x 128 B.
-template <int QW>
-__global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
+template <int QW, int D>
+__global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 64 ? 1 : 8))) void attn_flash_kernel(FlashArgs p) {
     constexpr int NT = QW * 64;
-    constexpr int KT = SL * KB * 128, VT = D * 128, STAGE = KT + VT;        // 8 KB + 8 KB
+    constexpr int SL = D / 32;
+    constexpr int KT = SL * KB * 128, VT = D * 128, STAGE = KT + VT;        // D = 64: 8 KB + 8 KB; D = 256: 32 KB + 32 KB
     constexpr int PIECES = STAGE / (NT * 16);                               // DMA instructions per thread per block
     constexpr int ROWS_PER_PIECE = NT / 8;                                  // 128-byte rows per workgroup-wide piece
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
@@ -125,8 +129,9 @@ __global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
 
     // ---- staging: the stage image is STAGE/128 rows of 128 B: rows [0, SL*32) = K (slice-major), then D rows of V^T
     const int r_in_piece = tid >> 3, ps = tid & 7;
+    static_assert((SL * KB) % ROWS_PER_PIECE == 0, "a DMA piece is all K rows or all V^T rows");
     const char* src[PIECES];
-    int sstep[PIECES];          // bytes to advance the source per key block
+    // bytes to advance the source per key block: piece i is K rows for i < SL*KB / ROWS_PER_PIECE, V^T rows after (compile time)
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const int row = i * ROWS_PER_PIECE + r_in_piece;
@@ -134,11 +139,9 @@ __global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
         if (row < SL * KB) {
             const int sl = row / KB, key = row - sl * KB;
             src[i] = p.kh + (((size_t)z * p.T + key) * D) * 4 + sl * 128 + ls * 16;
-            sstep[i] = KB * D * 4;
         } else {
             const int dd = row - SL * KB;
             src[i] = p.vt + (((size_t)z * nkb) * D + dd) * 128 + ls * 16;
-            sstep[i] = D * 128;
         }
     }
     const int wdst = wave * 8 * 128;        // this wave's first row inside a piece (wave-uniform)
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             AT_GLDS(src[i], base + i * ROWS_PER_PIECE * 128);
-            src[i] += sstep[i];
+            src[i] += (i * ROWS_PER_PIECE < SL * KB) ? KB * D * 4 : D * 128;
         }
     };
 
@@ -268,9 +271,9 @@ __global__ __launch_bounds__(QW * 64) void attn_flash_kernel(FlashArgs p) {
 extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, void* out, int out_fmt, int W,
                                   void* work, void* stream) {
     DP_REQUIRE(qkv && out && work && B > 0 && T > 0 && C > 0 && n_heads > 0, "dp_attention_fused: bad args");
-    DP_REQUIRE(C % n_heads == 0 && C / n_heads == D, "dp_attention_fused: head dimension must be %d (got %d)", D,
-               n_heads ? C / n_heads : 0);
-    DP_REQUIRE(T % 64 == 0, "dp_attention_fused: token count must be a multiple of 64 (got %d)", T);
+    const int D = C / n_heads;
+    DP_REQUIRE(C % n_heads == 0 && (D == 64 || D == 256), "dp_attention_fused: head dimension must be 64 or 256 (got %d)", D);
+    DP_REQUIRE(T % 64 == 0 && (D == 64 || T % 128 == 0), "dp_attention_fused: token count must be a multiple of 64 (128 at head dimension 256), got %d", T);
     DP_REQUIRE(layout == 0 || layout == 1, "dp_attention_fused: layout %d", layout);
     DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && W > 0 && T % W == 0), "dp_attention_fused: out_fmt 1 (bordered fp16 operand) needs the image width W | T (got %d, W=%d)", out_fmt, W);
     DP_REQUIRE(dp_aligned16(qkv) && dp_aligned16(out) && dp_aligned16(work), "dp_attention_fused: misaligned tensor");
@@ -283,11 +286,13 @@ extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_h
     pa.qscale = 1.0f / sqrtf((float)D);
     pa.qh = (char*)work; pa.kh = pa.qh + part; pa.vt = pa.kh + part;
     const int Z = B * n_heads;
-    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
+    if (D == 64) hipLaunchKernelGGL(attn_pack_kernel<64>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
+    else hipLaunchKernelGGL(attn_pack_kernel<256>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
     DP_LAUNCH_CHECK("attn_pack");
     FlashArgs fa{pa.qh, pa.kh, pa.vt, static_cast<float*>(out), T, C, n_heads, out_fmt, out_fmt ? W : 1};
-    if (T % 128 == 0) hipLaunchKernelGGL(attn_flash_kernel<4>, dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
-    else hipLaunchKernelGGL(attn_flash_kernel<2>, dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
+    if (D == 256) hipLaunchKernelGGL((attn_flash_kernel<4, 256>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
+    else if (T % 128 == 0) hipLaunchKernelGGL((attn_flash_kernel<4, 64>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
+    else hipLaunchKernelGGL((attn_flash_kernel<2, 64>), dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
     DP_LAUNCH_CHECK("attn_flash");
     return 0;
 }

@@ -224,6 +224,11 @@ class NCSNpp:
                 P[n + ".wqkv"] = self._pack_h2w(wq.t().contiguous()) if r["h2"] else ops.pack_nin_weight(wq).to(dev)
                 P[n + ".cqkv"] = torch.cat([sd[p + f".NIN_{j}.b"].detach().float() for j in range(3)]).contiguous().to(dev)
                 P[n + ".w3"], P[n + ".c3"] = ops.pack_nin_weight(sd[p + ".NIN_3.W"].detach()).to(dev), vec(p + ".NIN_3.b")
+                # lean fp16 x fp16 modes: the fused attention kernel (head dimension C = 256 at 16x16) writes the zero-bordered
+                # fp16 operand of NIN_3 itself, which then runs on the fp16 matrix path (as proj_out does in GuidedUNet)
+                r["proj16"] = self._lean and r["h2"] and r["ch"] == 256
+                if r["proj16"]:
+                    P[n + ".w3h"] = self._pack_h2w(sd[p + ".NIN_3.W"].detach().float().t().contiguous())
         P["dense.w"] = ops.pack_linear_weight(torch.cat(dw, dim=0)).to(dev)
         P["dense.b"] = torch.cat(db, dim=0).contiguous().to(dev)
         self.dense_cols = off
@@ -312,9 +317,12 @@ class NCSNpp:
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         # the taped forward keeps only qkv; the probabilities are recomputed per block in the backward pass (see GuidedUNet._attn)
-        a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
         if tape is not None:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv))
+        if r.get("proj16") and tape is None and ops.attention_fused_ok(hh * ww, c):
+            ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), 1, "split", operand_hw=(hh, ww))
+            return self._ch2(ah, P[n + ".w3h"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True)
+        a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
         return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True)
 
     def time_table(self, labels):

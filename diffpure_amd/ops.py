@@ -633,8 +633,9 @@ def _attn_offsets(c, d, layout):
 
 
 def attention_fused_ok(t, d):
-    """shapes the flash-style kernel covers (head dimension 64, whole 64-token blocks); DIFFPURE_ATTN_FUSED=0 disables it"""
-    return d == 64 and t % 64 == 0 and os.environ.get("DIFFPURE_ATTN_FUSED", "1") != "0"
+    """shapes the flash-style kernel covers (head dimension 64 with whole 64-token blocks, or 256 with whole 128-token blocks);
+    DIFFPURE_ATTN_FUSED=0 disables it"""
+    return ((d == 64 and t % 64 == 0) or (d == 256 and t % 128 == 0)) and os.environ.get("DIFFPURE_ATTN_FUSED", "1") != "0"
 
 
 def attention_fused(qkv, n_heads, layout, operand_hw=None):

@@ -144,7 +144,9 @@ def test_attention(dev, case):
 
 
 FUSED_ATT_CASES = [(2, 64, 128, 2, "legacy", 1.0), (3, 256, 256, 4, "legacy", 1.0), (1, 1024, 512, 8, "legacy", 1.0),
-                   (2, 256, 128, 2, "split", 1.0), (2, 1024, 128, 2, "legacy", 8.0), (5, 64, 1024, 16, "legacy", 3.0)]
+                   (2, 256, 128, 2, "split", 1.0), (2, 1024, 128, 2, "legacy", 8.0), (5, 64, 1024, 16, "legacy", 3.0),
+                   # head dimension 256: NCSN++'s AttnBlockpp at 16x16 (one head of C = 256; layerspp.py:75-91), and 2 x 256 / long rows
+                   (3, 256, 256, 1, "split", 1.0), (2, 256, 256, 1, "split", 6.0), (1, 512, 512, 2, "legacy", 1.0), (2, 128, 512, 2, "split", 2.0)]
 
 
 @pytest.mark.parametrize("case", FUSED_ATT_CASES, ids=[str(c) for c in FUSED_ATT_CASES])
@@ -803,8 +805,9 @@ def test_attention_fused_operand_output(dev):
     """dp_attention_fused out_fmt 1: the attention output lands as the zero-bordered fp16 operand of proj_out - the fp32
     result rounded to nearest in the interior pixels, zeros on the border."""
     from diffpure_amd import ops
-    for (B, hh, ww, heads, layout) in ((2, 8, 8, 4, "legacy"), (1, 16, 16, 8, "legacy"), (2, 8, 16, 2, "split")):
-        c = heads * 64
+    for (B, hh, ww, heads, layout, d) in ((2, 8, 8, 4, "legacy", 64), (1, 16, 16, 8, "legacy", 64), (2, 8, 16, 2, "split", 64),
+                                          (3, 16, 16, 1, "split", 256)):
+        c = heads * d
         qkv = rnd(B, hh * ww, 3 * c, seed=11).to(dev)
         ref = ops.attention_fused(qkv, heads, layout)
         got = ops.attention_fused(qkv, heads, layout, operand_hw=(hh, ww))
