@@ -144,9 +144,8 @@ struct FoldSrc {
 };
 constexpr int FOLD_MAX_TILES = 16;
 
-// -> pointer to this sample's [G][2] (mean, rstd): global memory, or the workgroup's LDS copy it has just computed
-__device__ __forceinline__ const float* gn_stats_of(const FoldSrc& f, const float* stats, int b, int C1, int C2, int G, double* sh) {
-    if (!f.cs1) return stats + (size_t)b * G * 2;
+// (mean, rstd) of every group of sample b from its column records -> LDS (behind the 2 C doubles of scratch)
+__device__ __forceinline__ float* gn_fold_reduce(const FoldSrc& f, int b, int C1, int C2, int G, double* sh) {
     const int C = C1 + C2, cpg = C / G;
     float* st = reinterpret_cast<float*>(sh + 2 * C);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -179,6 +178,22 @@ __device__ __forceinline__ const float* gn_stats_of(const FoldSrc& f, const floa
     }
     __syncthreads();
     return st;
+}
+
+// -> pointer to this sample's [G][2] (mean, rstd): global memory, or the workgroup's LDS copy it has just computed
+__device__ __forceinline__ const float* gn_stats_of(const FoldSrc& f, const float* stats, int b, int C1, int C2, int G, double* sh) {
+    if (!f.cs1) return stats + (size_t)b * G * 2;
+    return gn_fold_reduce(f, b, C1, C2, G, sh);
+}
+
+// gn_finalize_cols for small feature maps (a sample of <= FOLD_MAX_TILES record tiles): ONE workgroup per sample reduces all G
+// groups with the arithmetic of gn_stats_of - B workgroups instead of B * G (8192 workgroups of a 256-wide tree for a few hundred
+// floats each at CIFAR sizes: the launch was pure overhead, 11 us x 122 per NCSN++ call).
+__global__ __launch_bounds__(256) void gn_finalize_cols_sample_kernel(FoldSrc f, int C1, int C2, int G, float* stats) {
+    extern __shared__ double fold_lds[];
+    const int b = blockIdx.x;
+    const float* st = gn_fold_reduce(f, b, C1, C2, G, fold_lds);
+    if ((int)threadIdx.x < 2 * G) stats[(size_t)b * G * 2 + threadIdx.x] = st[threadIdx.x];
 }
 
 struct ApplyArgs {
@@ -634,6 +649,15 @@ extern "C" int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, con
     DP_REQUIRE((C1 + C2) % G == 0, "dp_gn_finalize_cols: C must be a multiple of G");
     DP_REQUIRE(tile_rows1 > 0 && HW % tile_rows1 == 0 && (C2 == 0 || (tile_rows2 > 0 && HW % tile_rows2 == 0)),
                "dp_gn_finalize_cols: a convolution tile must not straddle two samples (HW %% tile_rows != 0)");
+    const bool small = HW / tile_rows1 <= FOLD_MAX_TILES && (C2 == 0 || HW / tile_rows2 <= FOLD_MAX_TILES) && G <= 128 &&
+                       dp_tune(DP_T_GN_FINALIZE_SAMPLE) != 0;
+    if (small) {     // one workgroup per sample (same values: tests/test_gpu_ops.py compares the two bit for bit)
+        const FoldSrc f{cs1, cs2, tile_rows1, C2 ? tile_rows2 : 1, HW, eps};
+        hipLaunchKernelGGL(gn_finalize_cols_sample_kernel, dim3((unsigned)B), dim3(256), (size_t)(C1 + C2) * 16 + (size_t)G * 8,
+                           (hipStream_t)stream, f, C1, C2, G, stats);
+        DP_LAUNCH_CHECK("gn_finalize_cols_sample");
+        return 0;
+    }
     hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3((unsigned)(B * G)), dim3(256), 0, (hipStream_t)stream, cs1, C1, tile_rows1,
                        cs2, C2, C2 ? tile_rows2 : 1, HW, G, eps, stats);
     DP_LAUNCH_CHECK("gn_finalize_cols");

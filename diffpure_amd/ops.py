@@ -595,7 +595,7 @@ def to_h2(x, mode=RESAMPLE_NONE, fmt="h2", fir=None):
     ho, wo = _out_hw(h, w, mode)
     fkeep, fptr = _fir_arg(mode, fir)
     y = torch.empty((b, ho + 2, wo + 2, (2 * c) if f == FMT_H2 else c), device=x.device, dtype=torch.float16)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, f, _ptr(y), None, fptr, _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, f, _ptr(y), None, fptr, None, 0, None, 0, 0.0, _stream())
     return y
 
 
@@ -617,7 +617,7 @@ def resample(x, mode, fir=None):
     ho, wo = _out_hw(h, w, mode)
     fkeep, fptr = _fir_arg(mode, fir)
     y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), None, fptr, _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), None, fptr, None, 0, None, 0, 0.0, _stream())
     return y
 
 

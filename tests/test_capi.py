@@ -61,6 +61,49 @@ def test_ctypes_table_matches_the_header_prototypes():
         assert got == want, f"{name}: header {want} vs ctypes {got}"
 
 
+def test_every_ctypes_call_site_passes_the_declared_number_of_arguments():
+    """The GPU operators are stood in for on the CPU (tests/refops.py), so a call site of the C ABI that was not updated with a
+    changed prototype would only fail on the GPU box (round 3: two dp_gn_apply call sites, found there).  Count the arguments of
+    every `_lib.call("dp_...", ...)` in the package against the ctypes table (call sites that splat a tuple are counted with the
+    tuple's length where it is a literal in the same function)."""
+    import ast
+    from diffpure_amd import _lib
+    checked = 0
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "diffpure_amd")):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+                tuples = {}       # name -> set of literal tuple lengths assigned in this function
+                for n in ast.walk(fn):
+                    if isinstance(n, ast.Assign):
+                        tgts, val = n.targets, n.value
+                        if len(tgts) == 1 and isinstance(tgts[0], ast.Tuple) and isinstance(val, ast.Tuple) and len(tgts[0].elts) == len(val.elts):
+                            pairs = zip(tgts[0].elts, val.elts)
+                        else:
+                            pairs = [(t, val) for t in tgts]
+                        for t, v in pairs:
+                            if isinstance(t, ast.Name) and isinstance(v, ast.Tuple):
+                                tuples.setdefault(t.id, set()).add(len(v.elts))
+                for n in ast.walk(fn):
+                    if not (isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute) and n.func.attr == "call"
+                            and isinstance(n.func.value, ast.Name) and n.func.value.id == "_lib" and n.args
+                            and isinstance(n.args[0], ast.Constant) and isinstance(n.args[0].value, str)):
+                        continue
+                    name, want = n.args[0].value, len(_lib.SIGNATURES[n.args[0].value])
+                    fixed = sum(1 for a in n.args[1:] if not isinstance(a, ast.Starred))
+                    star = [a for a in n.args[1:] if isinstance(a, ast.Starred)]
+                    if not star:
+                        assert fixed == want, f"{f}:{n.lineno}: {name} gets {fixed} arguments, the prototype has {want}"
+                        checked += 1
+                    elif all(isinstance(a.value, ast.Name) and len(tuples.get(a.value.id, ())) == 1 for a in star):
+                        got = fixed + sum(next(iter(tuples[a.value.id])) for a in star)
+                        assert got == want, f"{f}:{n.lineno}: {name} gets {got} arguments, the prototype has {want}"
+                        checked += 1
+    assert checked >= 30, checked
+
+
 def test_argument_validation_reports_errors_without_a_gpu():
     from diffpure_amd import _lib
     lib = _lib.load()

@@ -541,7 +541,7 @@ def test_group_norm_h1_output_is_the_fp16_rounding_of_the_fp32_output(dev):
     assert torch.equal(yr.cpu(), torch.nn.functional.pad(torch.cat([x, x2], dim=3).cpu(), (0, 0, 1, 1, 1, 1)).half())
 
 
-FOLD_CASES = [(3, 16, 16, 128, 0), (2, 32, 32, 128, 0), (2, 16, 16, 256, 128), (3, 8, 8, 256, 256), (2, 32, 32, 96, 0), (1, 16, 16, 512, 256)]
+FOLD_CASES = [(3, 16, 16, 128, 0), (2, 32, 32, 128, 0), (2, 16, 16, 256, 128), (3, 8, 8, 256, 256), (2, 32, 32, 384, 0), (1, 16, 16, 512, 256)]
 
 
 @pytest.mark.parametrize("case", FOLD_CASES, ids=[str(c) for c in FOLD_CASES])
@@ -565,7 +565,10 @@ def test_group_norm_folded_statistics_equal_the_finalize_launch(dev, case, tune)
     gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
     tab = (0.3 * rnd(B, 2 * C, seed=5)).to(dev)
     film = (tab[:, :C], tab[:, C:])
+    tune.setenv("DP_GN_FINALIZE_SAMPLE", 0)          # one workgroup per (sample, group)
     st = ops.group_norm_stats(a1, G, eps, a2)
+    tune.setenv("DP_GN_FINALIZE_SAMPLE", 1)          # small feature maps: one workgroup per sample
+    assert torch.equal(ops.group_norm_stats(a1, G, eps, a2), st)
     fs = ops.group_norm_stats(a1, G, eps, a2, fold=True)
     assert isinstance(fs, ops.FoldedStats) and isinstance(st, torch.Tensor)
     x1, x2 = a1.t, None if a2 is None else a2.t
