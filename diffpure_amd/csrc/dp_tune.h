@@ -9,8 +9,7 @@
 enum DpTune {
     DP_T_H2_PP = 0,        // DP_H2_PP: 8-wave ping-pong kernels - 0 never, 1 whenever the shape allows, 2 when it also fills the chip
     DP_T_H2_HALO,          // DP_H2_HALO: halo-tile variant of the ping-pong kernel - 0 never, 1 W >= 16, 2 W >= 32
-    DP_T_H2_SW,            // DP_H2_SW: one-wave-per-SIMD 256x256 kernel (igemm_h2_sw.hip) - 0 off
-    DP_T_H2_SW_ORD,        // DP_H2_SW_ORD: second half of its k-tile - 0 reads and DMA interleaved, 1 all fragment reads first
+    DP_T_H2_SW,            // DP_H2_SW: one-wave-per-SIMD kernel (igemm_h2_sw.hip) - 0 off, 1 its 256x256 tiles only, 2 also 512x128 tiles (N % 256 != 0)
     DP_T_H2_NN,            // DP_H2_NN: few-output-channels kernel - 0 off
     DP_T_H2_PP_SCHED,      // DP_H2_PP_SCHED: phases per k-tile of the fp16-operand ping-pong kernels - 0 four, 1 two
     DP_T_H2_PP_STAGGER,    // DP_H2_PP_STAGGER: start-up stagger of the ping-pong kernel, cycles per k-tile and phase (0 off)

@@ -50,8 +50,9 @@ bool dp_conv_halo_applies(const ConvH2Args& p, int min_w);
 void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);
 
 // One-wave-per-SIMD software-pipelined variant (igemm_h2_sw.hip): fp16 x fp16, 256x256 tile, 4 waves of 128x128.
-bool dp_conv_sw_applies(const ConvH2Args& p);
-void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s);
+// bn = 256: 256x256 tiles (M % 256 == 0, N % 256 == 0); bn = 128: 512x128 tiles (M % 512 == 0, N % 128 == 0).
+bool dp_conv_sw_applies(const ConvH2Args& p, int bn);
+void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn);
 
 // Two workgroups per CU, 128x256 tiles, 4 waves of 64x128 (igemm_h2_dw.hip): fp16 x fp16; the launcher fills p.tiles / p.stagger.
 bool dp_conv_dw_applies(const ConvH2Args& p);

@@ -29,45 +29,67 @@ namespace {
 constexpr int NT = 256;
 constexpr int NXCD = 8;
 constexpr int NB = 4, DIST = 3;                 // LDS ring stages, prefetch distance in k-tiles
-constexpr int TILE = 256 * 64;                  // one operand tile of a k-tile: 256 rows x 64 bytes (32 fp16)
-constexpr int STAGE = 2 * TILE;                 // A tile, then B tile
+
+template <int N>
+__device__ __forceinline__ void sw_wait_vm() {
+    if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else {
+        static_assert(N == 0, "add the immediate");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
 
 // MODE (timing ablations, DP_H2_SW_MODE, DP_ABLATE builds only; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait, 4 = no ds_reads,
 // 8 = no activation DMA, 16 = no weight DMA
-// The 8 DMA issues of a k-tile are SPREAD - one behind every second fragment read, the activation pieces in the first half of
-// the k-tile and the weight pieces in the second - instead of back to back in 8 consecutive MFMA shadows (an LDS-DMA issue
-// costs more than one 32-cycle shadow; consecutive ones queue up in front of the next MFMA: +1...2.5 % measured in round 2,
-// the back-to-back form is no longer built).
-template <int MODE, int ORD>
+// BN = 256: 256 x 256 tile, waves 2 (M) x 2 (N).  BN = 128 (round 3; layers with 128 output channels - the 32 x 32 level of the
+// CIFAR-10 NCSN++, until then on the 8-wave ping-pong kernel at 566 TFLOP/s): 512 x 128 tile, waves 4 (M) x 1 (N), 40 KB per
+// LDS stage = all 160 KB.  The wave tile is 128 x 128 in both; a wave stages BM / 64 activation pieces and BN / 64 weight pieces
+// per k-tile.
+// The DMA issues of a k-tile are SPREAD - behind every second fragment read, the activation pieces in the first half of the
+// k-tile and the weight pieces in the second - instead of back to back in consecutive MFMA shadows (an LDS-DMA issue costs
+// more than one 32-cycle shadow; consecutive ones queue up in front of the next MFMA: +1...2.5 % measured in round 2).
+template <int MODE, int BN>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
+    constexpr int BM = BN == 256 ? 256 : 512;
+    constexpr int TILE_A = BM * 64, TILE_B = BN * 64;       // one operand tile of a k-tile: rows x 64 bytes (32 fp16)
+    constexpr int STAGE = TILE_A + TILE_B;                  // A tile, then B tile
+    constexpr int NPA = BM / 64, NPB = BN / 64;             // DMA pieces (16 rows) per wave and k-tile
     __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = BN == 256 ? wave >> 1 : wave, wc = BN == 256 ? wave & 1 : 0;
     int tile;
     {   // XCD-aware bijective remap (speed only)
         const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
     }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
 
-    // ---- staging: wave w fills rows [64 w, 64 w + 64) of the A tile and of the B tile, 16 rows per DMA instruction;
-    // lane -> row (lane >> 2) of the group, physical slot lane & 3, logical slot XOR-ed with the row key (row >> 2) & 3
+    // ---- staging: wave w fills rows [w BM/4, (w+1) BM/4) of the A tile and [w BN/4, (w+1) BN/4) of the B tile, 16 rows per DMA
+    // instruction; lane -> row (lane >> 2) of the piece, physical slot lane & 3, logical slot XOR-ed with the row key (row >> 2) & 3
     const int lrow = lane >> 2;
     const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
-    const char* actr[4];                        // centre pixel of the lane's A row, + slot
-    const char* bptr[4];
+    const char* actr[NPA];                      // centre pixel of the lane's A row, + slot
+    const char* bptr[NPB];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int m = m0 + wave * 64 + it * 16 + lrow;
+    for (int it = 0; it < NPA; ++it) {
+        const int m = m0 + wave * (BM / 4) + it * 16 + lrow;
         const int b = m / HW, rem = m - b * HW;
         const int oy = rem / p.W, ox = rem - oy * p.W;
         actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
-        const int n = n0 + wave * 64 + it * 16 + lrow;              // block layout of the fp16 panels (ops.order_conv_weight_w16)
+    }
+#pragma unroll
+    for (int it = 0; it < NPB; ++it) {
+        const int n = n0 + wave * (BN / 4) + it * 16 + lrow;        // block layout of the fp16 panels (ops.order_conv_weight_w16)
         bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
     int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next k-tile to stage
@@ -80,29 +102,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             a_off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + a_off),
-                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + wave * 64 * 64 + it * 16 * 64), 16, 0, 0);
-        if (it == 3 && ++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (wave * (BM / 4) + it * 16) * 64), 16, 0, 0);
+        if (it == NPA - 1 && ++cur_tap == taps) { cur_tap = 0; ++cur_c; }
     };
     auto pieceB = [&](int stage, int it) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
-                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + wave * 64 * 64 + TILE + it * 16 * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + TILE_A + (wave * (BN / 4) + it * 16) * 64), 16, 0, 0);
         bptr[it] += 2048;
     };
     auto issue = [&](int stage) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) pieceA(stage, it);
+        for (int it = 0; it < NPA; ++it) pieceA(stage, it);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) pieceB(stage, it);
+        for (int it = 0; it < NPB; ++it) pieceB(stage, it);
     };
-    // (tried in round 3: scalar 64-bit bases advanced once per k-tile + fixed 32-bit lane offsets, to take the eight 64-bit
-    //  vector adds per k-tile out of the loop - the instruction selector only forms the SADDR addressing mode when the
-    //  zero-extension of the lane offset sits in the loop's own basic block, the optimiser hoists it, and the variants that pin
-    //  it there pushed the loop-carried state into scratch.  Not pursued: the adds sit in MFMA shadows.)
+    // (tried in round 3: scalar 64-bit bases advanced once per k-tile + fixed 32-bit lane offsets, to take the 64-bit vector
+    //  adds out of the loop - the instruction selector only forms the SADDR addressing mode when the zero-extension of the lane
+    //  offset sits in the loop's own basic block, the optimiser hoists it, and the variants that pin it there pushed the
+    //  loop-carried state into scratch.  Not pursued: the adds sit in MFMA shadows.)
 
     // ---- fragments: lane -> row lr of a 32-row MFMA tile, k-half lk; 64-byte rows, slot (s*2 + lk) ^ key, key = (row >> 2) & 3
     const int lr = lane & 31, lk = lane >> 5;
     const int arow = (wr * 128 + lr) * 64;                  // + i * 32 * 64
-    const int brow = TILE + (wc * 128 + lr) * 64;           // + j * 32 * 64
+    const int brow = TILE_A + (wc * 128 + lr) * 64;         // + j * 32 * 64
     int soff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) soff[s] = ((s * 2 + lk) ^ ((lr >> 2) & 3)) << 4;
@@ -142,9 +164,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int d = 0; d < DIST; ++d)
         if (d < nt) issue(d);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nt > 2) sw_wait_vm<2 * (NPA + NPB)>();
+    else if (nt > 1) sw_wait_vm<NPA + NPB>();
+    else sw_wait_vm<0>();
     SW_BARRIER();
     read_frags(0, smem);
 
@@ -154,77 +176,65 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const char* st = smem + (t & (NB - 1)) * STAGE;
         // Instruction order, pinned with sched_group_barrier (left alone the compiler sinks the fragment reads towards their
         // use, and the wave then waits for LDS with an idle matrix pipe).  Each half of a k-tile runs 16 MFMAs on one fragment
-        // set and, BEHIND its first MFMA, issues the 8 reads of the other set one per MFMA shadow, then the 8 DMA issues of
-        // k-tile t+3 one per MFMA shadow: the lgkmcnt wait before a half's first MFMA finds reads issued >= 8 MFMAs earlier.
-        {
-            // first half: 16 MFMAs | 8 reads and the 4 activation pieces of k-tile t+3 as (read, read, DMA) x 4, one per MFMA shadow
+        // set and, BEHIND its first MFMA, issues the 8 reads of the other set and the DMA pieces of k-tile t+3 in MFMA shadows:
+        // the lgkmcnt wait before a half's first MFMA finds reads issued >= 4 MFMAs earlier.
+        // first half: 16 MFMAs | 8 reads and the NPA activation pieces of k-tile t+3: (read, read, DMA [, DMA]) x 4
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if constexpr (!(MODE & 4)) read_pair(1, st, q);
-                if constexpr (!(MODE & 9)) pieceA((t + DIST) & (NB - 1), q);
-            }
-            mfma_rows(0, 0, 4);
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (!(MODE & 4)) read_pair(1, st, q);
+#pragma unroll
+            for (int e = 0; e < NPA / 4; ++e)
+                if constexpr (!(MODE & 9)) pieceA((t + DIST) & (NB - 1), q * (NPA / 4) + e);
+        }
+        mfma_rows(0, 0, 4);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (NPA == 4) {       // read | MFMA | read | MFMA | DMA | MFMA
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            } else {                        // read | MFMA | read, DMA | MFMA | DMA | MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_rows(1, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // in flight at most: the activation pieces of t+3 (just issued), the weight pieces of t+2, the activation pieces of t+2
-            if constexpr (!(MODE & 3)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            if constexpr (!(MODE & 2)) SW_BARRIER();
-            // second half after the barrier: 12 MFMAs | 8 reads and the 4 weight pieces of k-tile t+3.
-            // ORD 0: the same (read, read, DMA) pattern - the last read issues two MFMAs before the next iteration's first MFMA
-            // waits for it.  (The compiler can only emit lgkmcnt(0) there: it books every LDS-DMA as a pending FLAT access to
-            // LDS, which forbids counted lgkmcnt waits, so ordering the reads by first use buys nothing.)
-            // ORD 1: all eight reads first, two per MFMA shadow, then the four DMA pieces one per shadow: the last read has eight
-            // MFMAs to land.
-            if constexpr (ORD == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (!(MODE & 4)) read_pair(0, smem + ((t + 1) & (NB - 1)) * STAGE, q);
-                    if constexpr (!(MODE & 17)) pieceB((t + DIST) & (NB - 1), q);
-                }
-                mfma_rows(1, 1, 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if constexpr (!(MODE & 4)) read_pair(0, smem + ((t + 1) & (NB - 1)) * STAGE, q);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if constexpr (!(MODE & 17)) pieceB((t + DIST) & (NB - 1), q);
-                mfma_rows(1, 1, 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // in flight at most: the activation pieces of t+3 (just issued), the weight pieces of t+2, the activation pieces of t+2
+        if constexpr (!(MODE & 3)) sw_wait_vm<2 * NPA + NPB>();
+        if constexpr (!(MODE & 2)) SW_BARRIER();
+        // second half after the barrier: 12 MFMAs | 8 reads and the NPB weight pieces of k-tile t+3 in the same pattern.
+        // (Tried in round 3: all eight reads first, two per shadow, then the pieces - no difference.  The compiler can only
+        //  emit lgkmcnt(0) in front of a half: it books every LDS-DMA as a pending FLAT access to LDS, which forbids counted
+        //  lgkmcnt waits, so ordering the reads by first use buys nothing either.)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (!(MODE & 4)) read_pair(0, smem + ((t + 1) & (NB - 1)) * STAGE, q);
+            if constexpr (!(MODE & 17)) {
+                if (q < NPB) pieceB((t + DIST) & (NB - 1), q);
+            }
+        }
+        mfma_rows(1, 1, 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            if (k < NPB) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     // tail: the last DIST k-tiles, nothing left to stage
     for (; t < nt; ++t) {
@@ -237,8 +247,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 2 < nt) sw_wait_vm<NPA + NPB>();
+        else sw_wait_vm<0>();
         SW_BARRIER();
         if (t + 1 < nt) read_frags(0, smem + ((t + 1) & (NB - 1)) * STAGE);
         __builtin_amdgcn_sched_barrier(0);
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    sw_epilogue_any<2, 1>(p, acc, m0 + wr * 128, n0 + wc * 128, tile_m * 4 + wr * 2, lr, lk, HW);
+    sw_epilogue_any<2, 1>(p, acc, m0 + wr * 128, n0 + wc * 128, tile_m * (BM / 64) + wr * 2, lr, lk, HW);
 }
 
 
@@ -264,27 +274,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 //     gains 9 %, this kernel's 3 %).
 }  // namespace
 
-bool dp_conv_sw_applies(const ConvH2Args& p) {
-    return p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % 256 == 0 && p.N % 256 == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0);
+bool dp_conv_sw_applies(const ConvH2Args& p, int bn) {
+    return (bn == 256 || bn == 128) && p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % (bn == 256 ? 256 : 512) == 0 &&
+           p.N % bn == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0);
 }
 
-void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s) {
-    p.tiles_n = p.N / 256;
-    p.tiles = (p.M / 256) * p.tiles_n;
+void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn) {
+    p.tiles_n = p.N / bn;
+    p.tiles = (p.M / (bn == 256 ? 256 : 512)) * p.tiles_n;
     const dim3 g((unsigned)p.tiles), b(NT);
-    const int ord = dp_tune(DP_T_H2_SW_ORD);
 #define SW_LAUNCH(M_)                                                                  \
     do {                                                                               \
-        if (ord) hipLaunchKernelGGL((conv_igemm_sw<M_, 1>), g, b, 0, s, p);            \
-        else hipLaunchKernelGGL((conv_igemm_sw<M_, 0>), g, b, 0, s, p);                \
+        if (bn == 256) hipLaunchKernelGGL((conv_igemm_sw<M_, 256>), g, b, 0, s, p);    \
+        else hipLaunchKernelGGL((conv_igemm_sw<M_, 128>), g, b, 0, s, p);              \
     } while (0)
 #ifdef DP_ABLATE   // timing ablations (WRONG RESULTS): only in libdiffpure_hip_ablate.so (tests/probes/build_ablate.py)
     {
         const char* e = getenv("DP_H2_SW_MODE");
         switch (e ? atoi(e) : 0) {
             case 1: SW_LAUNCH(1); return;
-            case 2: SW_LAUNCH(2); return;
-            case 3: SW_LAUNCH(3); return;
             case 4: SW_LAUNCH(4); return;
             case 7: SW_LAUNCH(7); return;
             case 8: SW_LAUNCH(8); return;

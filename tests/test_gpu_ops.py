@@ -433,6 +433,18 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
         for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_DW"):
             tune.delenv(name)
         tune.setenv("DP_H2_PP", "0")
+    # the 512x128 form of the one-wave-per-SIMD kernel (layers with 128 output channels; DP_H2_SW=2)
+    if B * H * W % 512 == 0 and N % 128 == 0 and not (H * W <= 64):
+        tune.setenv("DP_H2_PP", "1")
+        tune.setenv("DP_H2_DW", "0")
+        tune.setenv("DP_H2_SW", "2")
+        for _ in range(3):
+            got, got_cs = run()
+            assert torch.equal(got, base), "sw 512x128"
+            assert torch.equal(got_cs, base_cs), "sw 512x128"
+        for name in ("DP_H2_SW", "DP_H2_DW"):
+            tune.delenv(name)
+        tune.setenv("DP_H2_PP", "0")
     # the two-workgroups-per-CU kernel (igemm_h2_dw.hip: 128x256 tiles; both activation-ring depths, with and without the
     # start-up stagger of a CU's second workgroup - the stagger changes timing only)
     if B * H * W % 128 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
@@ -762,7 +774,7 @@ def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, tune):
     base32 = basecs = None
     combos = [("0", None, None, None)]
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
-        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0")]
+        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"), ("1", "2", "0", "0")]
     if B * H * W % 128 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
         combos += [("0", None, None, "3"), ("0", None, None, "4")]           # the two-workgroups-per-CU kernel
     for pp, sw, halo, dw in combos:
