@@ -538,7 +538,9 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             const int hv = dp_tune(DP_T_H2_HALO);
             // fp16 x fp16, N % 256 == 0: the one-wave-per-SIMD software-pipelined kernel (igemm_h2_sw.hip) - measured
             // fastest on every shape of both networks (tests/probes/pp_ablate.py --w16); DP_H2_SW=0 falls back
-            if (dp_tune(DP_T_H2_SW) != 0 && (bn == 256 || dp_tune(DP_T_H2_SW) >= 2) && dp_conv_sw_applies(p, bn)) dp_launch_conv_sw(p, s, bn);
+            // (its 512x128 form only for 3x3 layers: on 1x1 layers with 128 output channels it measured 5 % slower than the
+            //  ping-pong kernel; tests/probes/n128_probe.py)
+            if (dp_tune(DP_T_H2_SW) != 0 && (bn == 256 || (dp_tune(DP_T_H2_SW) >= 2 && KS == 3)) && dp_conv_sw_applies(p, bn)) dp_launch_conv_sw(p, s, bn);
             else if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
             else
             dp_launch_conv_h2_pp(p, s, bn);
