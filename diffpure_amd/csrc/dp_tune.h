@@ -10,6 +10,7 @@ enum DpTune {
     DP_T_H2_PP = 0,        // DP_H2_PP: 8-wave ping-pong kernels - 0 never, 1 whenever the shape allows, 2 when it also fills the chip
     DP_T_H2_HALO,          // DP_H2_HALO: halo-tile variant of the ping-pong kernel - 0 never, 1 W >= 16, 2 W >= 32
     DP_T_H2_SW,            // DP_H2_SW: one-wave-per-SIMD kernel (igemm_h2_sw.hip) - 0 off, 1 its 256x256 tiles only, 2 also 512x128 tiles (N % 256 != 0)
+    DP_T_H2_SW_PERSIST,    // DP_H2_SW_PERSIST: that kernel as one persistent workgroup per CU (next tile's operands in flight under the epilogue) - 0 off
     DP_T_H2_NN,            // DP_H2_NN: few-output-channels kernel - 0 off
     DP_T_H2_PP_SCHED,      // DP_H2_PP_SCHED: phases per k-tile of the fp16-operand ping-pong kernels - 0 four, 1 two
     DP_T_H2_PP_STAGGER,    // DP_H2_PP_STAGGER: start-up stagger of the ping-pong kernel, cycles per k-tile and phase (0 off)

@@ -53,7 +53,11 @@ __device__ __forceinline__ void sw_wait_vm() {
 // The DMA issues of a k-tile are SPREAD - behind every second fragment read, the activation pieces in the first half of the
 // k-tile and the weight pieces in the second - instead of back to back in consecutive MFMA shadows (an LDS-DMA issue costs
 // more than one 32-cycle shadow; consecutive ones queue up in front of the next MFMA: +1...2.5 % measured in round 2).
-template <int MODE, int BN>
+// PERSIST: the grid is one workgroup per CU and every workgroup walks its tiles itself; the operands of the NEXT tile's first
+// three k-tiles are put in flight BEFORE the epilogue of the current tile (the LDS ring is idle there: the last fragment read
+// of a tile precedes the last barrier of its k-loop), so that the ~2 us a tile used to wait for its first operands - and the
+// dispatch of a new workgroup - sit under the epilogue's stores.
+template <int MODE, int BN, bool PERSIST>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
     constexpr int BM = BN == 256 ? 256 : 512;
     constexpr int TILE_A = BM * 64, TILE_B = BN * 64;       // one operand tile of a k-tile: rows x 64 bytes (32 fp16)
@@ -64,15 +68,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = BN == 256 ? wave >> 1 : wave, wc = BN == 256 ? wave & 1 : 0;
-    int tile;
-    {   // XCD-aware bijective remap (speed only)
-        const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
-    }
-    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
+    // XCD-aware bijective remap of a (virtual) workgroup id to a tile (speed only); a persistent workgroup b takes the ids
+    // b, b + gridDim.x, ... - all on its own XCD, because gridDim.x is a multiple of 8
+    auto tile_of = [&](int v) {
+        const int x = v % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
+        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / NXCD;
+    };
+    int tile_m = 0, tile_n = 0, m0 = 0, n0 = 0;
 
     // ---- staging: wave w fills rows [w BM/4, (w+1) BM/4) of the A tile and [w BN/4, (w+1) BN/4) of the B tile, 16 rows per DMA
     // instruction; lane -> row (lane >> 2) of the piece, physical slot lane & 3, logical slot XOR-ed with the row key (row >> 2) & 3
@@ -80,19 +84,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
     const char* actr[NPA];                      // centre pixel of the lane's A row, + slot
     const char* bptr[NPB];
-#pragma unroll
-    for (int it = 0; it < NPA; ++it) {
-        const int m = m0 + wave * (BM / 4) + it * 16 + lrow;
-        const int b = m / HW, rem = m - b * HW;
-        const int oy = rem / p.W, ox = rem - oy * p.W;
-        actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
-    }
-#pragma unroll
-    for (int it = 0; it < NPB; ++it) {
-        const int n = n0 + wave * (BN / 4) + it * 16 + lrow;        // block layout of the fp16 panels (ops.order_conv_weight_w16)
-        bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
-    }
     int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next k-tile to stage
+    int nm0 = 0, nn0 = 0, ntile_m = 0, ntile_n = 0;     // the tile the staging pointers belong to
+    auto stage_setup = [&](int tile) {
+        ntile_n = tile % p.tiles_n;
+        ntile_m = tile / p.tiles_n;
+        nm0 = ntile_m * BM;
+        nn0 = ntile_n * BN;
+#pragma unroll
+        for (int it = 0; it < NPA; ++it) {
+            const int m = nm0 + wave * (BM / 4) + it * 16 + lrow;
+            const int b = m / HW, rem = m - b * HW;
+            const int oy = rem / p.W, ox = rem - oy * p.W;
+            actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
+        }
+#pragma unroll
+        for (int it = 0; it < NPB; ++it) {
+            const int n = nn0 + wave * (BN / 4) + it * 16 + lrow;   // block layout of the fp16 panels (ops.order_conv_weight_w16)
+            bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
+        }
+        cur_tap = 0;
+        cur_c = 0;
+    };
+    auto adopt = [&]() { tile_m = ntile_m; tile_n = ntile_n; m0 = nm0; n0 = nn0; };
     // one piece at a time, in PROGRAM order between the fragment reads (an LDS-DMA write and a ds_read may alias as far
     // as the scheduler knows: it never moves one across the other, so the interleave has to be written)
     long long a_off = 0;
@@ -147,12 +161,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     };
 
     f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto mfma_rows = [&](int set, int i0, int i1) {           // MFMA tile rows [i0, i1) of k16 step `set`
 #pragma unroll
         for (int i = i0; i < i1; ++i)
@@ -160,10 +168,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: k-tiles 0 .. DIST-1 in flight, k-tile 0 landed, fragments (0, s=0) read
+    // ---- prologue of a tile: k-tiles 0 .. DIST-1 in flight
+    auto prologue_issue = [&]() {
 #pragma unroll
-    for (int d = 0; d < DIST; ++d)
-        if (d < nt) issue(d);
+        for (int d = 0; d < DIST; ++d)
+            if (d < nt) issue(d);
+    };
+    stage_setup(tile_of(blockIdx.x));
+    prologue_issue();
+  for (int vid = blockIdx.x;;) {                // one iteration per tile (exactly one without PERSIST)
+    adopt();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // k-tile 0 landed, fragments (0, s=0) read
     if (nt > 2) sw_wait_vm<2 * (NPA + NPB)>();
     else if (nt > 1) sw_wait_vm<NPA + NPB>();
     else sw_wait_vm<0>();
@@ -256,7 +277,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    // every fragment read of this tile precedes the last barrier of its k-loop: the ring is free for the next tile's operands
+    bool more = false;
+    if constexpr (PERSIST) {
+        vid += gridDim.x;
+        more = vid < p.tiles;
+        if (more) {
+            stage_setup(tile_of(vid));
+            prologue_issue();
+        }
+    }
     sw_epilogue_any<2, 1>(p, acc, m0 + wr * 128, n0 + wc * 128, tile_m * (BM / 64) + wr * 2, lr, lk, HW);
+    if (!more) break;
+    if constexpr (PERSIST) {
+        // The staging pointers of the next tile are REBUILT here instead of being kept live across the epilogue (16 registers
+        // more there make the register allocator spill an accumulator tile): same arithmetic on an id the optimiser cannot
+        // see through, then moved past the DIST k-tiles that are already in flight.
+        int v2 = vid;
+        asm volatile("" : "+s"(v2));
+        stage_setup(tile_of(v2));
+        const int adv = nt < DIST ? nt : DIST;
+#pragma unroll
+        for (int it = 0; it < NPB; ++it) bptr[it] += 2048 * adv;
+        cur_tap = adv;
+        while (cur_tap >= taps) {
+            cur_tap -= taps;
+            ++cur_c;
+        }
+    }
+  }
 }
 
 
@@ -282,11 +331,15 @@ bool dp_conv_sw_applies(const ConvH2Args& p, int bn) {
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn) {
     p.tiles_n = p.N / bn;
     p.tiles = (p.M / (bn == 256 ? 256 : 512)) * p.tiles_n;
-    const dim3 g((unsigned)p.tiles), b(NT);
-#define SW_LAUNCH(M_)                                                                  \
-    do {                                                                               \
-        if (bn == 256) hipLaunchKernelGGL((conv_igemm_sw<M_, 256>), g, b, 0, s, p);    \
-        else hipLaunchKernelGGL((conv_igemm_sw<M_, 128>), g, b, 0, s, p);              \
+    // persistent form: one workgroup per CU, each walking tiles b, b + 256, ... (only when there is more than one round)
+    const bool persist = dp_tune(DP_T_H2_SW_PERSIST) != 0 && p.tiles > 256;
+    const dim3 g((unsigned)(persist ? 256 : p.tiles)), b(NT);
+#define SW_LAUNCH(M_)                                                                               \
+    do {                                                                                            \
+        if (bn == 256 && persist) hipLaunchKernelGGL((conv_igemm_sw<M_, 256, true>), g, b, 0, s, p);  \
+        else if (bn == 256) hipLaunchKernelGGL((conv_igemm_sw<M_, 256, false>), g, b, 0, s, p);       \
+        else if (persist) hipLaunchKernelGGL((conv_igemm_sw<M_, 128, true>), g, b, 0, s, p);          \
+        else hipLaunchKernelGGL((conv_igemm_sw<M_, 128, false>), g, b, 0, s, p);                      \
     } while (0)
 #ifdef DP_ABLATE   // timing ablations (WRONG RESULTS): only in libdiffpure_hip_ablate.so (tests/probes/build_ablate.py)
     {

@@ -23,7 +23,7 @@ __device__ __forceinline__ float sw_swap1(float v) {
 // row0: first output row of the wave tile; colw: its first column; rec0: index of its first 64-row column record
 // JP: column tiles handled per pass (16 JP residual loads in flight per lane)
 // Addressing: every global access is (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): the lane offsets of
-// the 16 rows a lane owns in a 32-row MFMA tile are computed ONCE (16 registers) and serve every tile of the wave; the
+// a lane's first row is ONE register per tensor, the row of each accumulator register is a wave-uniform addend of the base; the
 // per-element 64-bit multiply-adds of the first version of this epilogue (two VALU instructions and a register pair per
 // element) are gone - which is also what lets the 256-register kernel keep its accumulators out of scratch.
 template <bool OUT16, int NQ, int JP>
@@ -42,22 +42,14 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
     float bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[col0 + j * 32] : 0.f;
-    // lane offsets (bytes) inside a 32-row tile: row 4 lk + (r & 3) + 8 (r >> 2), column lr
-    unsigned vo[OUT16 ? 8 : 16], vr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rr = 4 * lk + (r & 3) + 8 * (r >> 2);
-        vr[r] = ((unsigned)rr * (unsigned)p.ldr + (unsigned)lr) * 4u;
-        if constexpr (!OUT16) vo[r] = ((unsigned)rr * (unsigned)p.ldo + (unsigned)lr) * 4u;
-    }
-    if constexpr (OUT16) {
-        // pair store: the even lane keeps row r = 2k and stores columns (lr, lr + 1); the odd lane keeps row 2k + 1, columns (lr - 1, lr)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int rr = 4 * lk + ((2 * k) & 3) + 8 * ((2 * k) >> 2) + odd;
-            vo[k] = ((unsigned)rr * (unsigned)p.ldo + (unsigned)(lr - odd)) * 2u;
-        }
-    }
+    // lane offsets (bytes) inside a 32-row tile: the lane's FIRST row (4 lk) and column lr - one register per tensor; the row
+    // the r-th accumulator register belongs to, 4 lk + (r & 3) + 8 (r >> 2), adds a wave-uniform (r & 3) + 8 (r >> 2) rows,
+    // which goes into the scalar base of the access
+    const unsigned vr0 = ((unsigned)(4 * lk) * (unsigned)p.ldr + (unsigned)lr) * 4u;
+    const unsigned vo0 = OUT16 ? ((unsigned)(4 * lk + odd) * (unsigned)p.ldo + (unsigned)(lr - odd)) * 2u     // pair store, below
+                               : ((unsigned)(4 * lk) * (unsigned)p.ldo + (unsigned)lr) * 4u;
+    const size_t ldr_b = (size_t)p.ldr * 4, ldo_b = (size_t)p.ldo * (OUT16 ? 2 : 4);
+    auto rows_of = [](int r) { return (r & 3) + 8 * (r >> 2); };
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {                  // one 64-row column record = two 32-row MFMA tiles
         float cs[2][4], cq[2][4];
@@ -80,7 +72,8 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                     for (int jj = 0; jj < JP; ++jj) {
                         gptr rb = (gptr)(p.res + (size_t)rowt * p.ldr + colw + (jh * JP + jj) * 32);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) rv[jj][r] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(rb + vr[r]);
+                        for (int r = 0; r < 16; ++r)
+                            rv[jj][r] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(rb + rows_of(r) * ldr_b + vr0);
                     }
                 }
                 float vv[JP][16];
@@ -93,7 +86,7 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                         float v = acc[i][j][r] + bv[j] + tv[j];
                         if (p.res) v += rv[jj][r];
                         v *= p.scale;
-                        if constexpr (!OUT16) *reinterpret_cast<float*>(ob + vo[r]) = v;
+                        if constexpr (!OUT16) *reinterpret_cast<float*>(ob + rows_of(r) * ldo_b + vo0) = v;
                         vv[jj][r] = v;
                         cs[ii][j] += v;
                         cq[ii][j] += v * v;
@@ -108,7 +101,8 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                             const float mine = odd ? vv[jj][2 * k + 1] : vv[jj][2 * k];
                             const float other = sw_swap1(odd ? vv[jj][2 * k] : vv[jj][2 * k + 1]);
                             const dp_half2 h = {(_Float16)(odd ? other : mine), (_Float16)(odd ? mine : other)};
-                            *reinterpret_cast<dp_half2*>(oh + vo[k]) = h;
+                            // the even lane keeps row r = 2k and stores columns (lr, lr + 1); the odd lane keeps row 2k + 1, columns (lr - 1, lr)
+                            *reinterpret_cast<dp_half2*>(oh + rows_of(2 * k) * ldo_b + vo0) = h;
                         }
                     }
                 }

@@ -52,10 +52,10 @@ def main():
         ops.set_tuning("DP_H2_DW", 0)
         base = {k: fn() for k, fn in fns.items()}
         line += " sw " + " ".join(f"{k} {tf(fn):5.0f}" for k, fn in fns.items()) + " |"
-        ops.set_tuning("DP_H2_SW", 2)
+        ops.set_tuning("DP_H2_SW_PERSIST", 1)
         ok = all(torch.equal(fn().t, base[k].t) and torch.equal(fn().cols.buf, base[k].cols.buf) for k, fn in fns.items())
-        line += " sw=2 " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + (" [ok] |" if ok else " [DIFF] |")
-        ops.set_tuning("DP_H2_SW", 1)
+        line += " sw.persist " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + (" [ok] |" if ok else " [DIFF] |")
+        ops.set_tuning("DP_H2_SW_PERSIST", 0)
         line += " sw again " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + " |"
         ops.set_tuning("DP_H2_DW", 2)
         ops.set_tuning("DP_H2_DW_MINROUNDS", 0)

@@ -346,7 +346,10 @@ H1_CASES = H2_CASES + PP_CASES + [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (8, 64
                                   (2, 256, 256, 64, 256, 3, 2, True, 1.0), (3, 64, 64, 96, 512, 3, 0, True, 1.0),
                                   (5, 16, 16, 160, 256, 3, 2, False, 1.0),
                                   # one / several image rows per 256-pixel tile, 1 .. 3 channel slices, two column tiles, a wide image
-                                  (1, 256, 256, 96, 512, 3, 1, True, 1.0), (4, 32, 32, 32, 256, 3, 2, True, 0.5), (1, 8, 512, 64, 256, 3, 0, False, 1.0)]
+                                  (1, 256, 256, 96, 512, 3, 1, True, 1.0), (4, 32, 32, 32, 256, 3, 2, True, 0.5), (1, 8, 512, 64, 256, 3, 0, False, 1.0),
+                                  # > 256 tiles: the persistent form of the one-wave-per-SIMD kernel walks 2-3 tiles per workgroup, the last
+                                  # round is ragged (600 tiles of 256x256; 300 of 512x128)
+                                  (3, 160, 320, 64, 256, 3, 2, True, 0.5), (3, 160, 320, 32, 128, 3, 1, False, 1.0)]
 
 
 @pytest.mark.parametrize("passes", [2, 1])
@@ -423,14 +426,15 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
     if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64):
         tune.setenv("DP_H2_PP", "1")
         tune.setenv("DP_H2_DW", "0")
-        for sw, halo in (("0", "0"), ("0", "1"), ("1", "0")):
+        for sw, halo, persist in (("0", "0", 0), ("0", "1", 0), ("1", "0", 0), ("1", "0", 1)):
             tune.setenv("DP_H2_SW", sw)
             tune.setenv("DP_H2_HALO", halo)
+            tune.setenv("DP_H2_SW_PERSIST", persist)      # one persistent workgroup per CU walking the tiles (> 256 tiles only)
             for _ in range(3):
                 got, got_cs = run()
                 assert torch.equal(got, base), (sw, halo)
                 assert torch.equal(got_cs, base_cs), (sw, halo)
-        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_DW"):
+        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_DW", "DP_H2_SW_PERSIST"):
             tune.delenv(name)
         tune.setenv("DP_H2_PP", "0")
     # the 512x128 form of the one-wave-per-SIMD kernel (layers with 128 output channels; DP_H2_SW=2)
@@ -438,11 +442,13 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
         tune.setenv("DP_H2_PP", "1")
         tune.setenv("DP_H2_DW", "0")
         tune.setenv("DP_H2_SW", "2")
-        for _ in range(3):
-            got, got_cs = run()
-            assert torch.equal(got, base), "sw 512x128"
-            assert torch.equal(got_cs, base_cs), "sw 512x128"
-        for name in ("DP_H2_SW", "DP_H2_DW"):
+        for persist in (0, 1):
+            tune.setenv("DP_H2_SW_PERSIST", persist)
+            for _ in range(3):
+                got, got_cs = run()
+                assert torch.equal(got, base), ("sw 512x128", persist)
+                assert torch.equal(got_cs, base_cs), ("sw 512x128", persist)
+        for name in ("DP_H2_SW", "DP_H2_DW", "DP_H2_SW_PERSIST"):
             tune.delenv(name)
         tune.setenv("DP_H2_PP", "0")
     # the two-workgroups-per-CU kernel (igemm_h2_dw.hip: 128x256 tiles; both activation-ring depths, with and without the
