@@ -15,7 +15,7 @@ enum DpTune {
     DP_T_H2_PP_SCHED,      // DP_H2_PP_SCHED: phases per k-tile of the fp16-operand ping-pong kernels - 0 four, 1 two
     DP_T_H2_PP_STAGGER,    // DP_H2_PP_STAGGER: start-up stagger of the ping-pong kernel, cycles per k-tile and phase (0 off)
     DP_T_GN_APPLY_QUAD,    // DP_GN_APPLY_QUAD: lane-contiguous quad form of GroupNorm-apply - 0 off
-    DP_T_H2_DW,            // DP_H2_DW: two-workgroups-per-CU 128x256 kernel (igemm_h2_dw.hip) - 0 off, 1 where it measured faster, 2 wherever it applies
+    DP_T_H2_DW,            // DP_H2_DW: two-workgroups-per-CU 128x256 kernel (igemm_h2_dw.hip) - 0 off, 1 where the launch fills every CU twice, 2 wherever it applies, 8 its 8-wave 256x256 form
     DP_T_H2_DW_STAGGER,    // DP_H2_DW_STAGGER: half-tile start-up delay of a CU's second workgroup, cycles per k-tile (0 off)
     DP_T_H2_DW_MINROUNDS,  // DP_H2_DW_MINROUNDS: launches with fewer rounds of 512 tiles are not staggered
     DP_T_H2_DW_ADEPTH,     // DP_H2_DW_ADEPTH: stages of its activation ring - 3 (72 KB of LDS per workgroup) or 4 (80 KB)

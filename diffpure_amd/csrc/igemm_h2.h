@@ -55,8 +55,10 @@ bool dp_conv_sw_applies(const ConvH2Args& p, int bn);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn);
 
 // Two workgroups per CU, 128x256 tiles, 4 waves of 64x128 (igemm_h2_dw.hip): fp16 x fp16; the launcher fills p.tiles / p.stagger.
-bool dp_conv_dw_applies(const ConvH2Args& p);
-void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s);
+// waves = 4: two workgroups per CU on 128x256 tiles; waves = 8: one 8-wave workgroup per CU on 256x256 tiles (two free-running
+// waves per SIMD sharing the tile).
+bool dp_conv_dw_applies(const ConvH2Args& p, int waves);
+void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int waves);
 
 // Few output channels (N <= 32: the 6-channel head), 3x3, fp16 x fp16: 256 x 32 tiles over x-halo activation runs (igemm_h2_nn.hip).
 bool dp_conv_nn_applies(const ConvH2Args& p);

@@ -507,9 +507,10 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     } while (0)
     {   // fp16 x fp16: two workgroups per CU on 128x256 tiles (igemm_h2_dw.hip); DP_H2_DW = 0 never, 1 when the launch fills
         // every CU twice, 2 wherever the shape allows.  Bit-identical to the other variants.
-        const int dw = dp_tune(DP_T_H2_DW);
-        if (dw != 0 && dp_conv_dw_applies(p) && (dw == 2 || tiles(128, 256) >= 512)) {
-            dp_launch_conv_dw(p, s);
+        const int dw = dp_tune(DP_T_H2_DW);          // 0 off; 1 / 2: 4 waves (where the launch fills every CU twice / always); 8: the 8-wave form
+        const int dww = dw == 8 ? 8 : 4;
+        if (dw != 0 && dp_conv_dw_applies(p, dww) && (dw == 2 || (dw == 8 && tiles(256, 256) >= 256) || (dw == 1 && tiles(128, 256) >= 512))) {
+            dp_launch_conv_dw(p, s, dww);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);

@@ -35,10 +35,8 @@
 
 namespace {
 
-constexpr int NT = 256;
 constexpr int NXCD = 8;
-constexpr int ATILE = 128 * 64;                 // activation tile of one k-tile: 128 rows x 64 bytes (32 fp16)
-constexpr int BTILE = 256 * 64;                 // weight tile
+constexpr int BTILE = 256 * 64;                 // weight tile of one k-tile: 256 rows x 64 bytes (32 fp16)
 constexpr int BDEPTH = 3;
 
 // one arrival counter per CU (index: XCC id, then bits 15:8 of HW_ID = CU / SH / SE ids); parity decides who starts late
@@ -46,6 +44,7 @@ __device__ unsigned dw_cu_ticket[8 * 256];
 
 template <int N>
 __device__ __forceinline__ void dw_wait_vm() {
+    static_assert(N == 8 || N == 6 || N == 4 || N == 0, "add the immediate");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -54,9 +53,18 @@ __device__ __forceinline__ void dw_wait_vm() {
 
 // MODE (timing ablations, DP_ABLATE builds only; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait,
 // 4 = no ds_reads, 8 = no epilogue stores, 16 = no activation DMA, 32 = no weight DMA
-template <int ADEPTH, int MODE>
-__global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
+// NW = 4: the kernel described above (128 x 256 tile, two workgroups per CU).
+// NW = 8 (round 3, "one workgroup, two free-running waves per SIMD"): ONE workgroup of eight waves per CU on a 256 x 256 tile - the
+// operand traffic of the one-wave-per-SIMD kernel (32 KB per k-tile: the two waves of a SIMD share the tile in LDS) with two
+// waves per SIMD to fill each other's issue stalls, at 1.5x that kernel's ds_reads per MFMA (wave tile 64 x 128).  Unlike the
+// ping-pong kernel (same geometry) the waves are not assigned roles: every wave runs the interleaved MFMA / read / DMA stream
+// and meets the others at ONE barrier per k-tile.  The epilogues of its waves still coincide (one tile per CU at a time).
+template <int ADEPTH, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2Args p) {
     constexpr int DA = ADEPTH - 1;              // prefetch distance of the activation ring (weights: 2)
+    constexpr int BMT = NW * 32;                // tile rows: every wave stages 32 of them (2 pieces) and 256 / NW weight rows
+    constexpr int ATILE = BMT * 64;             // activation tile of one k-tile
+    constexpr int NPB = 256 / NW / 16;          // weight pieces per wave and k-tile (4 | 2)
     constexpr int BBASE = ADEPTH * ATILE;
     __shared__ __attribute__((aligned(1024))) char smem[ADEPTH * ATILE + BDEPTH * BTILE];
 
@@ -69,13 +77,13 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
     }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 256;
+    const int m0 = tile_m * BMT, n0 = tile_n * 256;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
 
     // ---- de-phase the two workgroups of a CU: of the launch's first residents, the second arrival on a CU sleeps for about
     // half a tile (p.stagger cycles per k-tile); every later workgroup inherits the phase of the one it replaces
-    if (p.stagger > 0 && blockIdx.x < 512) {
+    if (NW == 4 && p.stagger > 0 && blockIdx.x < 512) {
         unsigned* flag = reinterpret_cast<unsigned*>(smem + BBASE + 2 * BTILE);    // a stage nothing writes before iteration 0
         if (tid == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
     const int lrow = lane >> 2;
     const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
     const char* actr[2];                        // centre pixel of the lane's A row, + slot
-    const char* bptr[4];
+    const char* bptr[NPB];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int m = m0 + wave * 32 + it * 16 + lrow;
@@ -105,8 +113,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
         actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int n = n0 + wave * 64 + it * 16 + lrow;              // block layout of the fp16 panels (ops.order_conv_weight_w16)
+    for (int it = 0; it < NPB; ++it) {
+        const int n = n0 + wave * (256 / NW) + it * 16 + lrow;      // block layout of the fp16 panels (ops.order_conv_weight_w16)
         bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
     int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next activation k-tile to stage
@@ -122,13 +130,13 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
     };
     auto pieceB = [&](int boff, int it) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
-                                         (__attribute__((address_space(3))) void*)(smem + boff + (wave * 64 + it * 16) * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + boff + (wave * (256 / NW) + it * 16) * 64), 16, 0, 0);
         bptr[it] += 2048;
     };
     auto issueA = [&](int aoff) { pieceA(aoff, 0); pieceA(aoff, 1); };
     auto issueB = [&](int boff) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) pieceB(boff, it);
+        for (int it = 0; it < NPB; ++it) pieceB(boff, it);
     };
 
     // ---- fragments: lane -> row lr of a 32-row MFMA tile, k-half lk; 64-byte rows, slot (s*2 + lk) ^ key, key = (row >> 2) & 3
@@ -186,32 +194,32 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
     issueA(ar[1]);
     issueB(br[1]);
     if constexpr (DA == 3) issueA(ar[2]);
-    dw_wait_vm<DA == 3 ? 8 : 6>();              // k-tile 0 landed; A(1), B(1), [A(2)] may fly
+    dw_wait_vm<NPB + 2 + (DA == 3 ? 2 : 0)>();  // k-tile 0 landed; A(1), B(1), [A(2)] may fly
     SW_BARRIER();
     read_frags(0, ar[0], br[0]);
 
     // steady state: k-tiles t+2 (weights) and t+DA (activations) exist
     int t = 0;
     for (; t + DA < nt; ++t) {
-        // first half: 8 MFMAs on fragment set 0 | the 6 reads of set 1 and the 6 DMA pieces, one (read, piece) pair per MFMA shadow
-        if constexpr (!(MODE & 4)) readA(1, ar[0], 0);
-        if constexpr (!(MODE & 33)) pieceB(br[2], 0);
-        if constexpr (!(MODE & 4)) readA(1, ar[0], 1);
-        if constexpr (!(MODE & 33)) pieceB(br[2], 1);
-        if constexpr (!(MODE & 4)) readB(1, br[0], 0);
-        if constexpr (!(MODE & 33)) pieceB(br[2], 2);
-        if constexpr (!(MODE & 4)) readB(1, br[0], 1);
-        if constexpr (!(MODE & 33)) pieceB(br[2], 3);
-        if constexpr (!(MODE & 4)) readB(1, br[0], 2);
-        if constexpr (!(MODE & 17)) pieceA(ar[DA], 0);
-        if constexpr (!(MODE & 4)) readB(1, br[0], 3);
-        if constexpr (!(MODE & 17)) pieceA(ar[DA], 1);
+        // first half: 8 MFMAs on fragment set 0 | the 6 reads of set 1 and the NPB + 2 DMA pieces, one (read, piece) pair per MFMA shadow
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if constexpr (!(MODE & 4)) {
+                if (k < 2) readA(1, ar[0], k);
+                else readB(1, br[0], k - 2);
+            }
+            if (k < NPB) {
+                if constexpr (!(MODE & 33)) pieceB(br[2], k);
+            } else if (k < NPB + 2) {
+                if constexpr (!(MODE & 17)) pieceA(ar[DA], k - NPB);
+            }
+        }
         mfma_rows(0, 0, 2);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (k < NPB + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
         mfma_rows(1, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         // outstanding in issue order: [.., B(t+1), A(t+DA-1)] from iteration t-1, [B(t+2), A(t+DA)] from this one
-        if constexpr (!(MODE & 3)) dw_wait_vm<DA == 3 ? 8 : 6>();
+        if constexpr (!(MODE & 3)) dw_wait_vm<NPB + 2 + (DA == 3 ? 2 : 0)>();
         if constexpr (!(MODE & 2)) SW_BARRIER();
         // second half: 4 MFMAs | the 6 reads of set 0 of k-tile t+1, two per MFMA shadow
         if constexpr (!(MODE & 4)) read_frags(0, ar[1], br[1]);
@@ -244,8 +252,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        // DA == 3, t == nt-3: outstanding [B(nt-2), A(nt-1)], [B(nt-1)] -> the 2 + 4 pieces behind B(nt-2) may fly
-        if (DA == 3 && t + 2 < nt) dw_wait_vm<6>();
+        // DA == 3, t == nt-3: outstanding [B(nt-2), A(nt-1)], [B(nt-1)] -> the 2 + NPB pieces behind B(nt-2) may fly
+        if (DA == 3 && t + 2 < nt) dw_wait_vm<NPB + 2>();
         else dw_wait_vm<0>();
         SW_BARRIER();
         if (t + 1 < nt) read_frags(0, ar[1], br[1]);
@@ -255,37 +263,38 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dw(ConvH2Args p) {
         rotate();
     }
 
-    if constexpr (!(MODE & 8)) sw_epilogue_any<1, 1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * 2 + wr, lr, lk, HW);
+    if constexpr (!(MODE & 8)) sw_epilogue_any<1, 1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
 }
 
 }  // namespace
 
-bool dp_conv_dw_applies(const ConvH2Args& p) {
-    return p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % 128 == 0 && p.N % 256 == 0 && p.C % 32 == 0 && p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0);
+bool dp_conv_dw_applies(const ConvH2Args& p, int waves) {
+    return (waves == 4 || waves == 8) && p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % (waves * 32) == 0 &&
+           p.N % 256 == 0 && p.C % 32 == 0 && p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0);
 }
 
-void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s) {
+void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int waves) {
     p.tiles_n = p.N / 256;
-    p.tiles = (p.M / 128) * p.tiles_n;
-    // start-up stagger: only where the launch runs long enough to earn it back (rounds of 512 resident workgroups)
-    p.stagger = p.tiles >= 512 * dp_tune(DP_T_H2_DW_MINROUNDS) ? dp_tune(DP_T_H2_DW_STAGGER) : 0;
+    p.tiles = (p.M / (waves * 32)) * p.tiles_n;
+    // start-up stagger (two workgroups per CU only): only where the launch runs long enough to earn it back (rounds of 512)
+    p.stagger = waves == 4 && p.tiles >= 512 * dp_tune(DP_T_H2_DW_MINROUNDS) ? dp_tune(DP_T_H2_DW_STAGGER) : 0;
     const int adepth = dp_tune(DP_T_H2_DW_ADEPTH);
-    const dim3 g((unsigned)p.tiles), b(NT);
-#define DW_LAUNCH(M_)                                                                      \
-    do {                                                                                   \
-        if (adepth == 4) hipLaunchKernelGGL((conv_igemm_dw<4, M_>), g, b, 0, s, p);        \
-        else hipLaunchKernelGGL((conv_igemm_dw<3, M_>), g, b, 0, s, p);                    \
+    const dim3 g((unsigned)p.tiles), b((unsigned)(waves * 64));
+#define DW_LAUNCH(M_)                                                                              \
+    do {                                                                                           \
+        if (waves == 8 && adepth == 4) hipLaunchKernelGGL((conv_igemm_dw<4, M_, 8>), g, b, 0, s, p);  \
+        else if (waves == 8) hipLaunchKernelGGL((conv_igemm_dw<3, M_, 8>), g, b, 0, s, p);            \
+        else if (adepth == 4) hipLaunchKernelGGL((conv_igemm_dw<4, M_, 4>), g, b, 0, s, p);           \
+        else hipLaunchKernelGGL((conv_igemm_dw<3, M_, 4>), g, b, 0, s, p);                            \
     } while (0)
 #ifdef DP_ABLATE   // timing ablations (WRONG RESULTS): only in libdiffpure_hip_ablate.so (tests/probes/build_ablate.py)
     {
         const char* e = getenv("DP_H2_DW_MODE");
         switch (e ? atoi(e) : 0) {
             case 1: DW_LAUNCH(1); return;
-            case 2: DW_LAUNCH(2); return;
             case 4: DW_LAUNCH(4); return;
             case 7: DW_LAUNCH(7); return;
             case 8: DW_LAUNCH(8); return;
-            case 15: DW_LAUNCH(15); return;
             case 16: DW_LAUNCH(16); return;
             case 32: DW_LAUNCH(32); return;
             default: break;

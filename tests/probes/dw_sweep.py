@@ -52,11 +52,12 @@ def main():
         ops.set_tuning("DP_H2_DW", 0)
         base = {k: fn() for k, fn in fns.items()}
         line += " sw " + " ".join(f"{k} {tf(fn):5.0f}" for k, fn in fns.items()) + " |"
-        ops.set_tuning("DP_H2_SW_PERSIST", 1)
-        ok = all(torch.equal(fn().t, base[k].t) and torch.equal(fn().cols.buf, base[k].cols.buf) for k, fn in fns.items())
-        line += " sw.persist " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + (" [ok] |" if ok else " [DIFF] |")
-        ops.set_tuning("DP_H2_SW_PERSIST", 0)
         line += " sw again " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + " |"
+        for adepth in (3, 4):                   # 8-wave form: one workgroup per CU, 256x256 tile, two free-running waves per SIMD
+            ops.set_tuning("DP_H2_DW", 8)
+            ops.set_tuning("DP_H2_DW_ADEPTH", adepth)
+            ok = all(torch.equal(fn().t, base[k].t) and torch.equal(fn().cols.buf, base[k].cols.buf) for k, fn in fns.items())
+            line += f" dw8 a{adepth} " + " ".join(f"{tf(fn):5.0f}" for fn in fns.values()) + (" [ok] |" if ok else " [DIFF] |")
         ops.set_tuning("DP_H2_DW", 2)
         ops.set_tuning("DP_H2_DW_MINROUNDS", 0)
         for adepth, stag in combos:

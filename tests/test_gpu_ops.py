@@ -463,6 +463,16 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
                 got, got_cs = run()
                 assert torch.equal(got, base), ("dw", adepth, stagger)
                 assert torch.equal(got_cs, base_cs), ("dw", adepth, stagger)
+        if B * H * W % 256 == 0:        # its 8-wave form: one workgroup per CU on 256x256 tiles, two free-running waves per SIMD
+            tune.setenv("DP_H2_DW", "8")
+            tune.setenv("DP_H2_PP", "1")    # (DP_H2_DW=8 is taken only where the launch has >= 256 tiles; elsewhere the other variants run)
+            for adepth in (3, 4):
+                tune.setenv("DP_H2_DW_ADEPTH", adepth)
+                for _ in range(3):
+                    got, got_cs = run()
+                    assert torch.equal(got, base), ("dw8", adepth)
+                    assert torch.equal(got_cs, base_cs), ("dw8", adepth)
+            tune.delenv("DP_H2_PP")
         for name in ("DP_H2_DW", "DP_H2_DW_MINROUNDS", "DP_H2_DW_ADEPTH", "DP_H2_DW_STAGGER"):
             tune.delenv(name)
     # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
