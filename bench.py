@@ -378,8 +378,10 @@ def main():
         unet_tflops = value / world * wl["gflop"] * n_steps / 1e3
         roof = {"bound": "mfma",
                 "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
-                          (f"conv_igemm_sw (3x3 implicit GEMM, 256x256 tile, one wave per SIMD with 128x128 wave tiles, software-pipelined "
-                           f"4-stage LDS ring; {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
+                          (f"conv_igemm_dw<8 waves> (3x3 implicit GEMM, 256x256 tile, one 8-wave workgroup per CU: two free-running waves per "
+                           f"SIMD with 64x128 wave tiles sharing the tile in LDS, separate LDS rings for activations and weights, counted "
+                           f"vmcnt, one barrier per k-tile; launches with fewer than 256 tiles run conv_igemm_sw, the one-wave-per-SIMD "
+                           f"form; {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
                            f"conv_igemm_h2_pp (3x3 implicit GEMM on the 8-wave ping-pong kernel; {passes} x v_mfma_f32_32x32x16_f16 per "
                            f"product; executed MFMA flops = {passes} x achieved)"),
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,

@@ -19,7 +19,7 @@ import sys
 
 
 def short(name):
-    if "conv_igemm_sw" in name or "conv_igemm_halo" in name or "conv_igemm_h2_pp" in name:
+    if "conv_igemm_dw" in name or "conv_igemm_sw" in name or "conv_igemm_halo" in name or "conv_igemm_h2_pp" in name:
         return "conv_igemm_h2_pp"            # the dominant kernel: the 256-wide-tile convolution in its one-wave-per-SIMD / ping-pong variants
     m = re.search(r"(conv_igemm_h2|conv_igemm_f32|splitk_epilogue|gn_apply_f16in|gn_apply_h2q|gn_apply|round_weights|gn_finalize_cols|gn_stats|"
                   r"gn_finalize|attn_flash|attn_pack|em_step|ddpm_step|temb|softmax_rows|gemm_strided|philox|axpby|silu|pack_h2)", name)
@@ -62,7 +62,7 @@ def main():
     dom = out.get("conv_igemm_h2_pp")
     B = a.batch or (64 if a.workload == "imagenet256_guided" else (128 if a.workload.endswith("_adjoint") else 256))
     if dom:
-        row = dict(workload=a.workload, per_gpu_batch=B, precision=a.precision, kernel="conv_igemm_sw + conv_igemm_h2_pp (the 256-wide-tile fp16 convolution: one-wave-per-SIMD kernel, and the ping-pong kernel where N % 256 != 0; 3x3 and 1x1 launches)",
+        row = dict(workload=a.workload, per_gpu_batch=B, precision=a.precision, kernel="conv_igemm_dw + conv_igemm_sw + conv_igemm_h2_pp (the 256-wide-tile fp16 convolution: the 8-wave free-running kernel, the one-wave-per-SIMD kernel where a launch has < 256 tiles or N % 256 != 0, the ping-pong kernel on what is left; 3x3 and 1x1 launches)",
                    launches_profiled=dom["launches"], fetch_bytes_per_launch=dom["fetch_bytes_per_launch"],
                    write_bytes_per_launch=dom["write_bytes_per_launch"], hbm_bytes_per_launch=dom["hbm_bytes_per_launch"],
                    corrections="FETCH_SIZE x2 (gfx950 reports one half for 16 B/lane streaming reads), KB -> bytes; WRITE_SIZE as reported",
