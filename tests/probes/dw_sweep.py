@@ -75,9 +75,16 @@ def main():
                 os.environ["DP_H2_SW_MODE"] = str(m)
                 line += f" m{m} {tf(fns['plain']):5.0f}"
             os.environ["DP_H2_SW_MODE"] = "0"
+            ops.set_tuning("DP_H2_DW", 8)
+            ops.set_tuning("DP_H2_DW_ADEPTH", 4)
+            line += " dw8 abl:"
+            for m in (1, 16, 32, 4, 7, 8):
+                os.environ["DP_H2_DW_MODE"] = str(m)
+                line += f" m{m} {tf(fns['plain']):5.0f}"
+            os.environ["DP_H2_DW_MODE"] = "0"
             ops.set_tuning("DP_H2_DW", 2)
             ops.set_tuning("DP_H2_DW_ADEPTH", 4)
-            for stag in (0, 550):
+            for stag in (0,):
                 ops.set_tuning("DP_H2_DW_STAGGER", stag)
                 line += f" abl s{stag}:"
                 for m in (1, 16, 32, 4, 7, 8):
