@@ -104,6 +104,22 @@ def test_every_ctypes_call_site_passes_the_declared_number_of_arguments():
     assert checked >= 30, checked
 
 
+def test_product_library_carries_no_timing_ablation_modes():
+    """The DP_H2_*_MODE timing ablations (kernels with their loads, waits or stores removed: wrong results, they exist to attribute
+    time) are compiled only with -DDP_ABLATE into libdiffpure_hip_ablate.so (tests/probes/build_ablate.py); round 2 shipped them
+    in the product library behind environment variables.  Neither the variable names nor getenv-per-call survive in the product."""
+    from diffpure_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"_MODE" not in blob
+    for f in os.listdir(os.path.join(ROOT, "diffpure_amd", "csrc")):
+        if f.endswith((".hip", ".h", ".cpp")):
+            src = open(os.path.join(ROOT, "diffpure_amd", "csrc", f)).read()
+            for m in re.finditer(r"getenv\(", src):
+                head = src[:m.start()]
+                in_ablate = head.rfind("#ifdef DP_ABLATE") > head.rfind("#endif")
+                assert in_ablate or f == "elementwise.hip", f"{f}: getenv outside the once-only tuning table / a DP_ABLATE block"
+
+
 def test_argument_validation_reports_errors_without_a_gpu():
     from diffpure_amd import _lib
     lib = _lib.load()
