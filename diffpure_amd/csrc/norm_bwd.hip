@@ -9,7 +9,8 @@
 // Same three-launch, atomics-free structure as the forward: slab partial sums of (dxh, dxh*xh) per
 // (sample, group) in a fixed order, a double-precision combine, then one elementwise pass.
 // The adjoint of the resampler is folded into the load of dy: forward nearest-x2 -> sum of the 2x2
-// block; forward mean-2x2 -> 0.25 * dy[y/2][x/2].
+// block; forward mean-2x2 -> 0.25 * dy[y/2][x/2]; the FIR resamplers of `fir: True` networks (modes 3 / 4,
+// csrc/norm.hip fir_up2 / fir_down2) -> the transposed 4-tap stencils of fir_adjoint below.
 #include "dp_common.h"
 
 namespace {
@@ -36,9 +37,54 @@ struct BwdArgs {
     float* dx1;
     float* dx2;
     int out_fmt;
+    float fir[4];                // resample 3 / 4: the forward's 1-D taps k[0..3]
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Transposes of the FIR x2 resamplers (forward per axis, zero outside the image - csrc/norm.hip):
+//   up   : out[2i] = 2 (k3 x[i-1] + k1 x[i]),  out[2i+1] = 2 (k2 x[i] + k0 x[i+1])
+//          => dx[i] = 2 (k0 dy[2i-1] + k1 dy[2i] + k2 dy[2i+1] + k3 dy[2i+2])                   (4 x 4 taps in 2-D)
+//   down : out[i] = sum_j k[3-j] x[2i+j-1]
+//          => dx[2n] = k2 dy[n] + k0 dy[n-1],  dx[2n+1] = k1 dy[n] + k3 dy[n+1]                 (2 x 2 taps in 2-D)
+// for channel quad c of INPUT pixel (y, x) of sample b; dy is [B][Ho][Wo][C], out-of-range dy counts as zero.
+__device__ __forceinline__ f32x4 fir_adjoint(const float* dy, int b, int Ho, int Wo, int C, int c, int y, int x, int mode,
+                                             const float* k) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (mode == 3) {
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            const int oy = 2 * y - 1 + ty;
+            if ((unsigned)oy >= (unsigned)Ho) continue;
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx) {
+                const int ox = 2 * x - 1 + tx;
+                if ((unsigned)ox >= (unsigned)Wo) continue;
+                const f32x4 s = ld4(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
+                const float w = (2.f * k[ty]) * (2.f * k[tx]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaf(w, s[j], o[j]);
+            }
+        }
+        return o;
+    }
+    const int ny = y >> 1, nx = x >> 1;
+    const int oy2[2] = {ny, (y & 1) ? ny + 1 : ny - 1}, ox2[2] = {nx, (x & 1) ? nx + 1 : nx - 1};
+    const float wy[2] = {(y & 1) ? k[1] : k[2], (y & 1) ? k[3] : k[0]}, wx[2] = {(x & 1) ? k[1] : k[2], (x & 1) ? k[3] : k[0]};
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+        if ((unsigned)oy2[ty] >= (unsigned)Ho) continue;
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+            if ((unsigned)ox2[tx] >= (unsigned)Wo) continue;
+            const f32x4 s = ld4(dy + (((size_t)b * Ho + oy2[ty]) * Wo + ox2[tx]) * C + c);
+            const float w = wy[ty] * wx[tx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(w, s[j], o[j]);
+        }
+    }
+    return o;
+}
 
 // da (gradient w.r.t. the pre-resample activation) for channel quad c of input pixel (b, y, x)
 __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, int c) {
@@ -52,6 +98,7 @@ __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, 
         for (int j = 0; j < 4; ++j) o[j] = (a[j] + b2[j]) + (c2[j] + d[j]);
         return o;
     }
+    if (p.resample >= 3) return fir_adjoint(p.dy, b, p.Ho, p.Wo, C, c, y, x, p.resample, p.fir);
     f32x4 v = ld4(p.dy + (((size_t)b * p.Ho + (y >> 1)) * p.Wo + (x >> 1)) * C + c);  // forward was mean 2x2
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] *= 0.25f;
@@ -188,9 +235,12 @@ __global__ void gn_bwd_apply_kernel(BwdArgs p) {
     }
 }
 
+struct Fir4 { float k[4]; };
+
 // adjoint of the plain 2x resamplers (x-branch of a resampling ResBlock)
-__global__ void resample_bwd_kernel(const float* dy, int B, int Ho, int Wo, int C4, int mode, float* dx) {
-    const int H = mode == 1 ? Ho / 2 : Ho * 2, W = mode == 1 ? Wo / 2 : Wo * 2;
+__global__ void resample_bwd_kernel(const float* dy, int B, int Ho, int Wo, int C4, int mode, Fir4 fir, float* dx) {
+    const bool up = mode == 1 || mode == 3;
+    const int H = up ? Ho / 2 : Ho * 2, W = up ? Wo / 2 : Wo * 2;
     const long long total = (long long)B * H * W * C4;
     const int C = C4 * 4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -205,6 +255,8 @@ __global__ void resample_bwd_kernel(const float* dy, int B, int Ho, int Wo, int 
             const f32x4 a = ld4(r0), b2 = ld4(r0 + C), c2 = ld4(r0 + (size_t)Wo * C), d = ld4(r0 + (size_t)Wo * C + C);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (a[j] + b2[j]) + (c2[j] + d[j]);
+        } else if (mode >= 3) {
+            o = fir_adjoint(dy, b, Ho, Wo, C, cq * 4, y, x, mode, fir.k);
         } else {
             o = ld4(dy + (((size_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + cq * 4);
 #pragma unroll
@@ -246,22 +298,26 @@ inline unsigned grid_cap(long long items, int block, int cap) {
 
 int fill_common(BwdArgs& p, const char* fn, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta, const float* fscale, const float* fshift,
-                int film_stride, int act, int resample, const float* dy) {
+                int film_stride, int act, int resample, const float* fir4, const float* dy) {
     const int C = C1 + C2;
     DP_REQUIRE(x1 && stats && gamma && beta && dy && B > 0 && H > 0 && W > 0 && G > 0, "%s: bad args", fn);
     DP_REQUIRE(C2 == 0 || x2, "%s: x2 missing", fn);
     DP_REQUIRE(C % (4 * G) == 0 && C1 % 8 == 0 && C % 8 == 0, "%s: need C %% (4*G) == 0 and C1, C %% 8 == 0 (C=%d+%d, G=%d)", fn, C1, C2, G);
     DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "%s: FiLM scale and shift come together", fn);
-    DP_REQUIRE(resample >= 0 && resample <= 2, "%s: resample mode %d", fn, resample);
-    DP_REQUIRE(resample != 2 || (H % 2 == 0 && W % 2 == 0), "%s: mean 2x2 needs even H, W", fn);
+    DP_REQUIRE(resample >= 0 && resample <= 4, "%s: resample mode %d", fn, resample);
+    DP_REQUIRE((resample != 2 && resample != 4) || (H % 2 == 0 && W % 2 == 0), "%s: 2x down-sampling needs even H, W", fn);
+    DP_REQUIRE(resample < 3 || fir4, "%s: the FIR resampling modes (3, 4) need the 4 filter taps", fn);
     DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(dy), "%s: misaligned tensor", fn);
     p = BwdArgs{};
     p.x1 = x1; p.x2 = x2; p.C1 = C1; p.C2 = C2; p.B = B; p.H = H; p.W = W; p.G = G;
     p.stats = stats; p.gamma = gamma; p.beta = beta; p.fscale = fscale; p.fshift = fshift;
     p.film_stride = film_stride; p.act = act; p.resample = resample; p.dy = dy;
     p.C4 = C / 4; p.cpg = C / G;
-    p.Ho = resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H);
-    p.Wo = resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W);
+    const bool up = resample == 1 || resample == 3, down = resample == 2 || resample == 4;
+    p.Ho = up ? 2 * H : (down ? H / 2 : H);
+    p.Wo = up ? 2 * W : (down ? W / 2 : W);
+    if (resample >= 3)
+        for (int i = 0; i < 4; ++i) p.fir[i] = fir4[i];
     return 0;
 }
 
@@ -269,11 +325,11 @@ int fill_common(BwdArgs& p, const char* fn, const float* x1, int C1, const float
 
 extern "C" int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                                const float* stats, const float* gamma, const float* beta, const float* fscale,
-                               const float* fshift, int film_stride, int act, int resample, const float* dy,
+                               const float* fshift, int film_stride, int act, int resample, const float* fir4, const float* dy,
                                int nsplit, float* partial, float* sums, void* stream) {
     BwdArgs p;
     if (int rc = fill_common(p, "dp_gn_bwd_stats", x1, C1, x2, C2, B, H, W, G, stats, gamma, beta, fscale, fshift,
-                             film_stride, act, resample, dy)) return rc;
+                             film_stride, act, resample, fir4, dy)) return rc;
     DP_REQUIRE(partial && sums && nsplit > 0, "dp_gn_bwd_stats: scratch missing");
     DP_REQUIRE(p.C4 <= 1024 && G <= p.C4, "dp_gn_bwd_stats: C too wide");
     p.nsplit = nsplit; p.partial = partial; p.cpg4 = p.C4 / G;
@@ -289,11 +345,11 @@ extern "C" int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2,
 
 extern "C" int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                                const float* stats, const float* gamma, const float* beta, const float* fscale,
-                               const float* fshift, int film_stride, int act, int resample, const float* dy,
+                               const float* fshift, int film_stride, int act, int resample, const float* fir4, const float* dy,
                                const float* sums, int out_fmt, void* dx1, float* dx2, void* stream) {
     BwdArgs p;
     if (int rc = fill_common(p, "dp_gn_bwd_apply", x1, C1, x2, C2, B, H, W, G, stats, gamma, beta, fscale, fshift,
-                             film_stride, act, resample, dy)) return rc;
+                             film_stride, act, resample, fir4, dy)) return rc;
     DP_REQUIRE(sums && dx1 && (C2 == 0 || dx2), "dp_gn_bwd_apply: output missing");
     DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && C2 == 0), "dp_gn_bwd_apply: h2 output needs a single source");
     p.sums = sums; p.dx1 = (float*)dx1; p.dx2 = dx2; p.out_fmt = out_fmt;
@@ -303,12 +359,17 @@ extern "C" int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2,
     return 0;
 }
 
-extern "C" int dp_resample_bwd(const float* dy, int B, int Ho, int Wo, int C, int mode, float* dx, void* stream) {
-    DP_REQUIRE(dy && dx && B > 0 && Ho > 0 && Wo > 0 && C % 4 == 0 && (mode == 1 || mode == 2), "dp_resample_bwd: bad args");
-    DP_REQUIRE(mode != 1 || (Ho % 2 == 0 && Wo % 2 == 0), "dp_resample_bwd: odd output size");
-    const long long total = (long long)B * (mode == 1 ? Ho / 2 : Ho * 2) * (mode == 1 ? Wo / 2 : Wo * 2) * (C / 4);
+extern "C" int dp_resample_bwd(const float* dy, int B, int Ho, int Wo, int C, int mode, const float* fir4, float* dx, void* stream) {
+    DP_REQUIRE(dy && dx && B > 0 && Ho > 0 && Wo > 0 && C % 4 == 0 && mode >= 1 && mode <= 4, "dp_resample_bwd: bad args");
+    const bool up = mode == 1 || mode == 3;
+    DP_REQUIRE(!up || (Ho % 2 == 0 && Wo % 2 == 0), "dp_resample_bwd: odd output size");
+    DP_REQUIRE(mode < 3 || fir4, "dp_resample_bwd: the FIR resampling modes (3, 4) need the 4 filter taps");
+    Fir4 fir{};
+    if (mode >= 3)
+        for (int i = 0; i < 4; ++i) fir.k[i] = fir4[i];
+    const long long total = (long long)B * (up ? Ho / 2 : Ho * 2) * (up ? Wo / 2 : Wo * 2) * (C / 4);
     hipLaunchKernelGGL(resample_bwd_kernel, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, dy, B, Ho, Wo,
-                       C / 4, mode, dx);
+                       C / 4, mode, fir, dx);
     DP_LAUNCH_CHECK("resample_bwd");
     return 0;
 }

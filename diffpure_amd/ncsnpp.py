@@ -410,17 +410,18 @@ class NCSNpp:
 
     def _res_bwd(self, t, dout):
         r, P = t["r"], self.p
-        n, co, ci, mode = str(r["idx"]), r["cout"], r["cin"], r["mode"]
+        n, co, ci, mode = str(r["idx"]), r["cout"], r["cin"], self._rmode(r["mode"])
+        fir = self._fir
         # out = (skip + conv1(h3)) * s
         dh3 = self._dconv(dout, n + ".dw1", r["dh2_1"], co, 3, scale=INV_SQRT2)
         dh2, _ = ops.group_norm_bwd(t["hmid"], self._groups(co), P[n + ".g1"], P[n + ".b1"], t["st1"], dh3, act=True,
                                     split=r["dh2_0"])
         dh1 = self._dconv(dh2, n + ".dw0", r["dh2_0"], ci, 3)
         dx, dx2 = ops.group_norm_bwd(t["x"], self._groups(ci), P[n + ".g0"], P[n + ".b0"], t["st0"], dh1, x2=t["x2"], act=True,
-                                     resample=mode)
+                                     resample=mode, fir=fir)
         if mode:
             ds = ops.conv2d(dout, P[n + ".dw2a"], ci, 1, scale=INV_SQRT2)
-            dx = ops.add(dx, ops.resample_bwd(ds, mode))
+            dx = ops.add(dx, ops.resample_bwd(ds, mode, fir=fir))
         elif ci != co:
             c1 = t["x"].shape[3]
             dx = ops.add(dx, ops.conv2d(dout, P[n + ".dw2a"], c1, 1, scale=INV_SQRT2))
@@ -445,9 +446,6 @@ class NCSNpp:
 
     def vjp(self, tape, dout):
         """(d out / d x)^T dout for the forward that filled `tape`; dout [B,H,W,channels] fp32."""
-        if self._fir is not None:
-            raise NotImplementedError("input gradients through the FIR (fir: True) resamplers are not built: no DiffPure config "
-                                      "sets fir: True (configs/cifar10.yml:24), only the forward purification path covers it")
         self.enable_grad()
         P = self.p
         M = "all_modules."

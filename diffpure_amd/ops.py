@@ -505,9 +505,10 @@ def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
     return y
 
 
-def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False):
-    """Input gradient of `group_norm` (same arguments, `stats` from the forward, dy at the forward's
-    output resolution). -> (dx, dx2); with split=True (single source) dx is the zero-bordered h2
+def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False,
+                   fir=None):
+    """Input gradient of `group_norm` (same arguments - incl. the FIR taps for resample modes 3 / 4 -, `stats` from the forward,
+    dy at the forward's output resolution). -> (dx, dx2); with split=True (single source) dx is the zero-bordered h2
     operand for the next dgrad convolution."""
     _chk(x, "gn_bwd.x", 4)
     _chk(dy, "gn_bwd.dy", 4)
@@ -520,14 +521,15 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
         fs, fh = film
         assert fs.shape[0] in (1, b) and fs.shape[-1] == c and fs.stride(-1) == 1 and fh.stride() == fs.stride()
         fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
-    ho, wo = (h * 2, w * 2) if resample == RESAMPLE_UP else ((h // 2, w // 2) if resample == RESAMPLE_DOWN else (h, w))
+    ho, wo = _out_hw(h, w, resample)
     assert dy.shape == (b, ho, wo, c), (dy.shape, (b, ho, wo, c))
+    fkeep, fptr = _fir_arg(resample, fir)
     ns = _nsplit(h * w)
     partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
     sums = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
     s = _stream()
     common = (_ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
-              fstride, 1 if act else 0, resample, _ptr(dy))
+              fstride, 1 if act else 0, resample, fptr, _ptr(dy))
     _lib.call("dp_gn_bwd_stats", *common, ns, _ptr(partial), _ptr(sums), s)
     if split:
         assert x2 is None
@@ -540,13 +542,14 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
     return dx, dx2
 
 
-def resample_bwd(dy, mode):
-    """Adjoint of `resample(x, mode)`; dy at the forward's output resolution."""
+def resample_bwd(dy, mode, fir=None):
+    """Adjoint of `resample(x, mode, fir)`; dy at the forward's output resolution."""
     _chk(dy, "resample_bwd.dy", 4)
     b, ho, wo, c = dy.shape
-    h, w = (ho // 2, wo // 2) if mode == RESAMPLE_UP else (ho * 2, wo * 2)
+    h, w = (ho // 2, wo // 2) if mode in (RESAMPLE_UP, RESAMPLE_FIR_UP) else (ho * 2, wo * 2)
     dx = torch.empty((b, h, w, c), device=dy.device, dtype=torch.float32)
-    _lib.call("dp_resample_bwd", _ptr(dy), b, ho, wo, c, mode, _ptr(dx), _stream())
+    fkeep, fptr = _fir_arg(mode, fir)
+    _lib.call("dp_resample_bwd", _ptr(dy), b, ho, wo, c, mode, fptr, _ptr(dx), _stream())
     return dx
 
 

@@ -252,14 +252,19 @@ int dp_ddpm_step(const float* x, const float* out6, int B, int HW, int C,
 int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                     const float* stats, const float* gamma, const float* beta,
                     const float* fscale, const float* fshift, int film_stride, int act, int resample,
-                    const float* dy, int nsplit, float* partial, float* sums, void* stream);
+                    const float* fir4, const float* dy, int nsplit, float* partial, float* sums, void* stream);
 int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                     const float* stats, const float* gamma, const float* beta,
                     const float* fscale, const float* fshift, int film_stride, int act, int resample,
-                    const float* dy, const float* sums, int out_fmt, void* dx1, float* dx2, void* stream);
+                    const float* fir4, const float* dy, const float* sums, int out_fmt, void* dx1, float* dx2, void* stream);
 /* Adjoint of the plain 2x resamplers: mode 1 (forward was nearest x2): dx[Ho/2][Wo/2] = sum of the
- * 2x2 dy block; mode 2 (forward was mean 2x2): dx[2Ho][2Wo] = 0.25 * dy[y/2][x/2]. */
-int dp_resample_bwd(const float* dy, int B, int Ho, int Wo, int C, int mode, float* dx, void* stream);
+ * 2x2 dy block; mode 2 (forward was mean 2x2): dx[2Ho][2Wo] = 0.25 * dy[y/2][x/2]; modes 3 / 4 (forward was the
+ * FIR x2 up / down of dp_gn_apply with taps fir4[4]): the transposed stencils
+ *   up:   dx[i]  = 2 (k0 dy[2i-1] + k1 dy[2i] + k2 dy[2i+1] + k3 dy[2i+2])      per axis, dx [Ho/2][Wo/2]
+ *   down: dx[2n] = k2 dy[n] + k0 dy[n-1],  dx[2n+1] = k1 dy[n] + k3 dy[n+1]      per axis, dx [2Ho][2Wo]
+ * (the adjoint of up_or_down_sampling.py:203-265 that torch autograd derives for the reference's upfirdn2d).
+ * fir4 may be NULL for modes 1 / 2; dp_gn_bwd_stats / _apply take the same `resample` + `fir4` pair. */
+int dp_resample_bwd(const float* dy, int B, int Ho, int Wo, int C, int mode, const float* fir4, float* dx, void* stream);
 /* Softmax backward in place on dP given P: dS = P * (dP - sum_j dP_j P_j) per row. */
 int dp_softmax_bwd_rows(const float* p, float* dp, long long rows, int cols, void* stream);
 /* out = a + b (gradient accumulation at fan-out points). n % 4 == 0. */

@@ -255,7 +255,8 @@ def attention_bwd(qkv, probs, dout, n_heads, layout):
     return g
 
 
-def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False):
+def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False,
+                   fir=None):
     """autograd through the torch statement of the forward (eps folded back out of `stats`)."""
     with torch.enable_grad():
         a = x.detach().clone().requires_grad_(True)
@@ -275,7 +276,7 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
             y = y * (1 + fs.reshape(-1, 1, 1, c)) + fh.reshape(-1, 1, 1, c)
         if act:
             y = F.silu(y)
-        y = _resample(y, resample)
+        y = _resample(y, resample, fir)
         grads = torch.autograd.grad(y, [a] + ([] if b2 is None else [b2]), dy)
     dx = grads[0]
     dx2 = grads[1] if b2 is not None else None
@@ -284,13 +285,35 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
     return dx.contiguous(), None if dx2 is None else dx2.contiguous()
 
 
-def resample_bwd(dy, mode):
+def resample_bwd(dy, mode, fir=None):
     b, ho, wo, c = dy.shape
-    h, w = (ho // 2, wo // 2) if mode == RESAMPLE_UP else (ho * 2, wo * 2)
+    h, w = (ho // 2, wo // 2) if mode in (RESAMPLE_UP, 3) else (ho * 2, wo * 2)
     with torch.enable_grad():
         x = torch.zeros(b, h, w, c, dtype=dy.dtype, requires_grad=True)
-        (g,) = torch.autograd.grad(_resample(x, mode), x, dy)
+        (g,) = torch.autograd.grad(_resample(x, mode, fir), x, dy)
     return g.contiguous()
+
+
+def fir_adjoint_stencil(dy, mode, fir):
+    """The transposed FIR stencils as csrc/norm_bwd.hip fir_adjoint evaluates them (pure indexing, no autograd):
+    up   (3): dx[i]  = 2 (k0 dy[2i-1] + k1 dy[2i] + k2 dy[2i+1] + k3 dy[2i+2])   per axis
+    down (4): dx[2n] = k2 dy[n] + k0 dy[n-1],  dx[2n+1] = k1 dy[n] + k3 dy[n+1]  per axis;  dy zero outside."""
+    k = [float(v) for v in fir]
+
+    def axis(t, dim):
+        t = t.movedim(dim, 0)
+        n = t.shape[0]
+        z = torch.zeros_like(t[:1])
+        if mode == 3:
+            pad = torch.cat([z, t, z, z], 0)                   # pad[j] = dy[j - 1]
+            out = sum(2 * k[a] * pad[a:a + n:2][: n // 2] for a in range(4))   # dy[2i - 1 + a]
+        else:
+            prev = torch.cat([z, t[:-1]], 0)                   # dy[n-1]
+            nxt = torch.cat([t[1:], z], 0)                     # dy[n+1]
+            out = torch.stack([k[2] * t + k[0] * prev, k[1] * t + k[3] * nxt], 1).reshape(2 * n, *t.shape[1:])
+        return out.movedim(0, dim)
+
+    return axis(axis(dy, 1), 2).contiguous()
 
 
 def add(a, b):

@@ -470,5 +470,28 @@ def test_ncsnpp_fir_engine_wiring():
     torch.testing.assert_close(out, g["out"], rtol=2e-4, atol=2e-5)
     plain = load_golden("ncsnpp_small.pt")
     assert (g["out"] - plain["out"]).abs().max() > 1e-2 or not torch.equal(g["x"], plain["x"])    # fir changes the function
-    with pytest.raises(NotImplementedError):
-        net.vjp([], torch.zeros(1))
+    # input gradient through the FIR blocks: the engine's backward wiring (taped forward + vjp, the resampler adjoints taken in
+    # the GroupNorm backward of the h-branch and in resample_bwd of the skip branch) against torch.autograd THROUGH THE REFERENCE
+    # MODULE for a seeded cotangent
+    tape = []
+    net.forward(nhwc(g["x"]), g["labels"], tape=tape)
+    got = nchw(net.vjp(tape, nhwc(g["cot"])))
+    torch.testing.assert_close(got, g["vjp"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("taps", [(1, 3, 3, 1), (1, 2, 3, 4)], ids=str)
+def test_fir_adjoint_stencils_match_autograd(taps):
+    """The transposed FIR stencils csrc/norm_bwd.hip evaluates (restated index by index in refops.fir_adjoint_stencil) against
+    torch.autograd through the upfirdn2d statement, for the symmetric filter of score_sde and an asymmetric one (which would expose
+    a flipped tap order), odd and minimal sizes; and against autograd through the reference's own upsample_2d / downsample_2d
+    (golden fir_ops.pt)."""
+    from diffpure_amd import ops
+    k = ops.fir_taps(taps)
+    for mode, shape in ((3, (2, 12, 16, 8)), (4, (2, 6, 8, 8)), (3, (1, 2, 2, 4)), (4, (1, 1, 1, 4)), (3, (1, 6, 10, 4)), (4, (1, 3, 5, 4))):
+        dy = torch.randn(shape, dtype=torch.float64, generator=torch.Generator().manual_seed(7))
+        torch.testing.assert_close(refops.fir_adjoint_stencil(dy, mode, k), refops.resample_bwd(dy, mode, k), rtol=1e-12, atol=1e-12)
+    if taps == (1, 3, 3, 1):
+        g = load_golden("fir_ops.pt")
+        for mode, name in ((ops.RESAMPLE_FIR_UP, "up"), (ops.RESAMPLE_FIR_DOWN, "down")):
+            got = nchw(refops.fir_adjoint_stencil(nhwc(g["dy_" + name]), mode, k))
+            torch.testing.assert_close(got, g["dx_" + name], rtol=1e-5, atol=1e-6)
