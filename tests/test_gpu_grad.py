@@ -147,7 +147,7 @@ def test_ncsnpp_fir_vjp_vs_reference_autograd(precision):
     got = nchw(net.vjp(tape, nhwc(g["cot"]).to(DEV))).cpu()
     err = relerr(got, g["vjp"])
     print(f"fir NCSN++ vjp [{precision}] vs reference autograd: rel {err:.3e} (forward max-abs {(out - g['out']).abs().max():.3e})")
-    assert err < (2e-3 if precision != "f16sr" else 3e-2), err
+    assert err < (2e-3 if precision != "f16sr" else 5e-3), err
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
