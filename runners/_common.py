@@ -156,6 +156,11 @@ def dispatch(args, run, x, replica_offset=0):
     (`replica_offset`: EnginePool.replica_offset of the GPU a DataParallel replica runs on)."""
     if getattr(args, "shard_batch", False):
         return ddist.sharded_purify(run, x)
+    if x.shape[0] == 0:
+        # an empty batch (the tail slice nn.DataParallel hands a replica when there are fewer images than GPUs never gets here -
+        # scatter drops it - but a caller's empty evaluation batch does): the reference's solvers return an empty tensor of the
+        # input's shape; nothing is launched (the kernels refuse B = 0 loudly)
+        return x * 1.0
     return run(x, sample_offset(args) + replica_offset)
 
 

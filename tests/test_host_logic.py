@@ -246,6 +246,9 @@ def test_celeba_ddpm_runner_matches_oracle_loop(tmp_path):
     b = torch.cat([runner.purifier.celeba_ddpm(x0[:1], 6, runner.sched, seed=g["seed"], sample0=0),
                    runner.purifier.celeba_ddpm(x0[1:], 6, runner.sched, seed=g["seed"], sample0=1)])
     torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6)
+    # an empty batch comes back empty, in the input's shape, without a launch (the kernels refuse B = 0)
+    empty = runner.image_editing_sample(x0[:0], bs_id=5)
+    assert empty.shape == x0[:0].shape and empty.dtype == x0.dtype
 
 
 @pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
