@@ -23,6 +23,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC: RCCL's intra-node transport fails with `hipIpcGetMemHandle: invalid
+# argument` without it.  Exported on the GPU boxes already; set here too so that a bare torchrun line works.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
