@@ -19,8 +19,9 @@ enum DpTune {
     DP_T_H2_DW_STAGGER,    // DP_H2_DW_STAGGER: half-tile start-up delay of a CU's second workgroup, cycles per k-tile (0 off)
     DP_T_H2_DW_MINROUNDS,  // DP_H2_DW_MINROUNDS: launches with fewer rounds of 512 tiles are not staggered
     DP_T_H2_DW_ADEPTH,     // DP_H2_DW_ADEPTH: stages of its activation ring - 3 (72 KB of LDS per workgroup) or 4 (80 KB)
-    DP_T_GN_FOLD,
-    DP_T_GN_FINALIZE_SAMPLE, // DP_GN_FINALIZE_SAMPLE: small feature maps - one finalize workgroup per sample instead of per (sample, group) - 0 off          // DP_GN_FOLD: GroupNorm-apply reduces its own (sample, group) records instead of a finalize launch - 0 off
+    DP_T_GN_FOLD,          // DP_GN_FOLD: GroupNorm-apply reduces its own (sample, group) records instead of a finalize launch - 0 off
+    DP_T_GN_FINALIZE_SAMPLE, // DP_GN_FINALIZE_SAMPLE: small feature maps - one finalize workgroup per sample instead of per (sample, group) - 0 off
+    DP_T_H2_DW_UNROLL,     // DP_H2_DW_UNROLL: 3x3 launches of the 8-wave kernel run the slice-unrolled loop (nine taps per body) - 0 the rolled loop
     DP_T_COUNT
 };
 

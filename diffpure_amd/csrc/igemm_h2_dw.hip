@@ -266,6 +266,187 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
     if constexpr (!(MODE & 8)) sw_epilogue_any<1, 1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
 }
 
+
+// ---- the 8-wave kernel for 3x3 convolutions with the NINE TAPS OF A CHANNEL SLICE UNROLLED ("dw8u", round 3) -------------------
+// Same tile, staging, rings, waits, instruction order and arithmetic as conv_igemm_dw<3, 0, 8> - bit-identical - but the loop
+// body is one channel slice = nine k-tiles, so that everything the rolled loop recomputed per k-tile in scalar code is a
+// compile-time constant: the ring stages (9 = 0 mod 3: stage = q mod 3, so the LDS addresses of the fragment reads are
+// immediates and the M0 values of the DMA pieces are one s_add from a wave constant), the tap of the activation piece (nine
+// 64-bit offsets from the centre pixel, computed once) and the loop control.  The rolled loop spends ~50 scalar and ~10 vector
+// instructions per k-tile beside its 16 MFMAs, 12 ds_reads and 4 DMA pieces (tap -> (ky, kx) -> 64-bit byte offset by
+// multiplies, three-register ring rotations, M0 arithmetic); an in-order wave pays ~5 cycles of issue for each, in the gaps
+// where its partner on the SIMD would want the matrix pipe back.
+template <int Q>
+struct dw_const { static constexpr int value = Q; };
+
+__global__ __launch_bounds__(512, 1) void conv_igemm_dw8u(ConvH2Args p) {
+    constexpr int NW = 8, ADEPTH = 3, BMT = 256, ATILE = BMT * 64, NPB = 2, BBASE = ADEPTH * ATILE;
+    __shared__ __attribute__((aligned(1024))) char smem[ADEPTH * ATILE + BDEPTH * BTILE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    int tile;
+    {   // XCD-aware bijective remap (speed only)
+        const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
+    }
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BMT, n0 = tile_n * 256;
+    const int HW = p.H * p.W, Wp = p.W + 2;
+    const int nsl = p.C / 32;                   // channel slices; k-tile t = 9 * slice + tap
+
+    // ---- staging (as conv_igemm_dw): wave w fills rows [32 w, 32 w + 32) of both tiles, 16 rows per DMA instruction
+    const int lrow = lane >> 2;
+    const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
+    const char* actr[2];                        // centre pixel of the lane's A row, + slot, + 64 bytes per finished slice
+    const char* bptr[NPB];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int m = m0 + wave * 32 + it * 16 + lrow;
+        const int b = m / HW, rem = m - b * HW;
+        const int oy = rem / p.W, ox = rem - oy * p.W;
+        actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
+    }
+#pragma unroll
+    for (int it = 0; it < NPB; ++it) {
+        const int n = n0 + wave * 32 + it * 16 + lrow;
+        bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
+    }
+    // byte offset of the activation k-tile staged in position q of a slice (= k-tile q + 2: tap (q + 2) mod 9, of the NEXT slice
+    // for q >= 7) from the centre pixel of the current slice
+    long long toffx[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int tap = (q + 2) % 9, ky = tap / 3, kx = tap - ky * 3;
+        toffx[q] = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (q + 2 >= 9 ? 64 : 0);
+    }
+    const int wdst = wave * 32 * 64;            // this wave's rows inside an A or B stage
+    auto pieceA = [&](long long off, int stage, int it) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + off),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * ATILE + wdst + it * 1024), 16, 0, 0);
+    };
+    auto pieceB = [&](int stage, int it) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
+                                         (__attribute__((address_space(3))) void*)(smem + BBASE + stage * BTILE + wdst + it * 1024), 16, 0, 0);
+        bptr[it] += 2048;
+    };
+
+    // ---- fragments (as conv_igemm_dw)
+    const int lr = lane & 31, lk = lane >> 5;
+    const char* afr[2];                         // [k16 step]: the lane's row of the wave's first MFMA tile in stage 0, + slot
+    const char* bfr[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int so = ((s * 2 + lk) ^ ((lr >> 2) & 3)) << 4;
+        afr[s] = smem + (wr * 64 + lr) * 64 + so;
+        bfr[s] = smem + BBASE + (wc * 128 + lr) * 64 + so;
+    }
+    half8 fa[2][2], fb[2][4];
+    auto readA = [&](int set, int stage, int i) { fa[set][i] = *reinterpret_cast<const half8*>(afr[set] + stage * ATILE + i * 2048); };
+    auto readB = [&](int set, int stage, int j) { fb[set][j] = *reinterpret_cast<const half8*>(bfr[set] + stage * BTILE + j * 2048); };
+    auto read_frags = [&](int set, int stage) {
+        readA(set, stage, 0);
+        readA(set, stage, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) readB(set, stage, j);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfma_rows = [&](int set, int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: B(0), A(0), A(1), B(1) in flight, in that order (see conv_igemm_dw)
+    {
+        const long long t0 = ((long long)(0 - p.pad) * Wp + (0 - p.pad)) * p.C * 2, t1 = t0 + (long long)p.C * 2;
+        pieceB(0, 0); pieceB(0, 1);
+        pieceA(t0, 0, 0); pieceA(t0, 0, 1);
+        pieceA(t1, 1, 0); pieceA(t1, 1, 1);
+        pieceB(1, 0); pieceB(1, 1);
+    }
+    dw_wait_vm<NPB + 2>();
+    SW_BARRIER();
+    read_frags(0, 0);
+
+    // steady-state k-tile in position q of a slice: k-tiles t + 2 (both operands) are staged
+    auto iter = [&](auto Q) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value, s0 = q % 3, s1 = (q + 1) % 3, s2 = (q + 2) % 3;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k < 2) readA(1, s0, k);
+            else readB(1, s0, k - 2);
+            if (k < NPB) pieceB(s2, k);
+            else if (k < NPB + 2) pieceA(toffx[q], s2, k - NPB);
+        }
+        mfma_rows(0, 0, 2);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k < NPB + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        dw_wait_vm<NPB + 2>();                  // [B(t+1), A(t+1)] of the previous k-tile landed; [B(t+2), A(t+2)] may fly
+        SW_BARRIER();
+        read_frags(0, s1);
+        mfma_rows(1, 1, 2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the last two k-tiles of the convolution (positions 7 and 8 of the last slice): nothing left to stage
+    auto tail = [&](auto Q) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value, s0 = q % 3, s1 = (q + 1) % 3;
+        mfma_rows(0, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1, s0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(0, 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        dw_wait_vm<0>();
+        SW_BARRIER();
+        if (q < 8) read_frags(0, s1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int s = 0; s + 1 < nsl; ++s) {
+        iter(dw_const<0>{}); iter(dw_const<1>{}); iter(dw_const<2>{});
+        iter(dw_const<3>{}); iter(dw_const<4>{}); iter(dw_const<5>{});
+        iter(dw_const<6>{}); iter(dw_const<7>{}); iter(dw_const<8>{});
+        actr[0] += 64;
+        actr[1] += 64;
+    }
+    iter(dw_const<0>{}); iter(dw_const<1>{}); iter(dw_const<2>{});
+    iter(dw_const<3>{}); iter(dw_const<4>{}); iter(dw_const<5>{});
+    iter(dw_const<6>{});
+    tail(dw_const<7>{});
+    tail(dw_const<8>{});
+
+    sw_epilogue_any<1, 1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
+}
+
 }  // namespace
 
 bool dp_conv_dw_applies(const ConvH2Args& p, int waves) {
@@ -280,6 +461,8 @@ void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int waves) {
     p.stagger = waves == 4 && p.tiles >= 512 * dp_tune(DP_T_H2_DW_MINROUNDS) ? dp_tune(DP_T_H2_DW_STAGGER) : 0;
     const int adepth = dp_tune(DP_T_H2_DW_ADEPTH);
     const dim3 g((unsigned)p.tiles), b((unsigned)(waves * 64));
+    // 3x3, 8 waves, ring depth 3: the slice-unrolled form (DP_H2_DW_UNROLL=0: the rolled loop)
+    const bool unrolled = waves == 8 && adepth != 4 && p.KS == 3 && dp_tune(DP_T_H2_DW_UNROLL) != 0;
 #define DW_LAUNCH(M_)                                                                              \
     do {                                                                                           \
         if (waves == 8 && adepth == 4) hipLaunchKernelGGL((conv_igemm_dw<4, M_, 8>), g, b, 0, s, p);  \
@@ -301,6 +484,7 @@ void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int waves) {
         }
     }
 #endif
-    DW_LAUNCH(0);
+    if (unrolled) hipLaunchKernelGGL(conv_igemm_dw8u, g, b, 0, s, p);
+    else DW_LAUNCH(0);
 #undef DW_LAUNCH
 }
