@@ -381,7 +381,7 @@ def main():
         unet_tflops = value / world * wl["gflop"] * n_steps / 1e3
         roof = {"bound": "mfma",
                 "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
-                          (f"conv_igemm_dw<8 waves> (3x3 implicit GEMM, 256x256 tile, one 8-wave workgroup per CU: two free-running waves per "
+                          (f"conv_igemm_dw8u = conv_igemm_dw<8 waves> with the nine taps of a channel slice unrolled (3x3 implicit GEMM, 256x256 tile, one 8-wave workgroup per CU: two free-running waves per "
                            f"SIMD with 64x128 wave tiles sharing the tile in LDS, separate LDS rings for activations and weights, counted "
                            f"vmcnt, one barrier per k-tile; launches with fewer than 256 tiles run conv_igemm_sw, the one-wave-per-SIMD "
                            f"form; {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
