@@ -475,6 +475,9 @@ void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int waves) {
         const char* e = getenv("DP_H2_DW_MODE");
         switch (e ? atoi(e) : 0) {
             case 1: DW_LAUNCH(1); return;
+            case 2: DW_LAUNCH(2); return;
+            case 3: DW_LAUNCH(3); return;
+            case 6: DW_LAUNCH(6); return;
             case 4: DW_LAUNCH(4); return;
             case 7: DW_LAUNCH(7); return;
             case 8: DW_LAUNCH(8); return;
