@@ -140,6 +140,20 @@ def pmc_traffic(workload, batch, precision):
     return None
 
 
+def pmc_mfma_busy():
+    """MFMA utilisation of the dominant kernel by rocprofv3's own counter, from the committed PMC pass over its most common
+    shape (3x3 256->256 at 256^2, B=64; tools/pmc_conv.sh): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
+    Collected offline (counters cannot be read from inside the timed process), at the profiler's clock.  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r03", "pmc_conv_igemm_dw8u_256x256_256to256_b64.json")
+    try:
+        row = json.load(open(path))["conv_igemm_dw8u"]
+        return dict(value=row["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * row["GRBM_GUI_ACTIVE"] / 8.0),
+                    source="profiles/r03/pmc_conv_igemm_dw8u_256x256_256to256_b64.json (SQ_VALU_MFMA_BUSY_CYCLES over the SIMD "
+                           "cycles of the launch, 3x3 256->256 at 256^2, B=64, under rocprofv3 --pmc)")
+    except Exception:
+        return None
+
+
 def build_engine(workload, device, seed, precision):
     from diffpure_amd import guided_unet, ncsnpp, synth
     if workload == "imagenet256_guided":
@@ -409,6 +423,10 @@ def main():
                     "other_kernels_share_of_step": {"3x3 on other tile variants (stem, head, split-K levels)": prof["other3x3"]["ms"] / window_ms,
                                                     "1x1 convolutions / linear": (prof["conv1x1"]["ms"] + prof["pp1x1"]["ms"]) / window_ms},
                 })
+                if a.workload == "imagenet256_guided" and a.precision in ("f16", "f16sr"):
+                    busy = pmc_mfma_busy()
+                    if busy is not None:
+                        roof["mfma_busy_by_pmc"] = busy
                 row = pmc_traffic(a.workload, B, a.precision)
                 if row is not None:
                     # rocprofv3 aggregates per kernel NAME: the ping-pong kernel's 3x3 and 1x1 launches together
