@@ -197,6 +197,10 @@ __global__ void gn_bwd_apply_kernel(BwdArgs p) {
             half8 z;
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+            if (p.out_fmt == 2) {
+                *reinterpret_cast<half8*>(reinterpret_cast<char*>(p.dx1) + ((size_t)qpix * C8 + c8) * 16) = z;
+                continue;
+            }
             half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.dx1) + ((size_t)qpix * C8 + c8) * 32);
             dst[0] = z;
             dst[1] = z;
@@ -215,7 +219,12 @@ __global__ void gn_bwd_apply_kernel(BwdArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[h][j] = rstd * (dxh[j] - m1 - xh[j] * m2);
         }
-        if (p.out_fmt) {
+        if (p.out_fmt == 2) {       // plain fp16 operand ("h1") of a one-pass fp16 x fp16 dgrad convolution
+            half8 hv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)o[j >> 2][j & 3];
+            *reinterpret_cast<half8*>(reinterpret_cast<char*>(p.dx1) + ((size_t)qpix * C8 + c8) * 16) = hv;
+        } else if (p.out_fmt) {
             half8 hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -351,9 +360,10 @@ extern "C" int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2,
     if (int rc = fill_common(p, "dp_gn_bwd_apply", x1, C1, x2, C2, B, H, W, G, stats, gamma, beta, fscale, fshift,
                              film_stride, act, resample, fir4, dy)) return rc;
     DP_REQUIRE(sums && dx1 && (C2 == 0 || dx2), "dp_gn_bwd_apply: output missing");
-    DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && C2 == 0), "dp_gn_bwd_apply: h2 output needs a single source");
+    DP_REQUIRE(out_fmt == 0 || ((out_fmt == 1 || out_fmt == 2) && C2 == 0), "dp_gn_bwd_apply: operand output (1 = h2, 2 = h1) needs a single source");
     p.sums = sums; p.dx1 = (float*)dx1; p.dx2 = dx2; p.out_fmt = out_fmt;
-    const long long total = (long long)B * (H + 2 * out_fmt) * (W + 2 * out_fmt) * (p.C4 / 2);
+    const int border = out_fmt ? 1 : 0;
+    const long long total = (long long)B * (H + 2 * border) * (W + 2 * border) * (p.C4 / 2);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     DP_LAUNCH_CHECK("gn_bwd_apply");
     return 0;

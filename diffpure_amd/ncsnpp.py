@@ -266,6 +266,8 @@ class NCSNpp:
         purification loops pass the step index.  No-op in every other mode."""
         if self._pool is not None:
             self._pool.round(key)
+        if getattr(self, "_gpool", None) is not None:
+            self._gpool.round(key)
 
     def _res(self, r, xa, x2a, dense, tape=None):
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
@@ -373,35 +375,59 @@ class NCSNpp:
         sd, dev, P = self._sd, self.device, self.p
         M = "all_modules."
 
-        def dg(w, n_in_dgrad, lo=None, hi=None):
+        # fp16 x fp16 modes ("f16", "f16sr"): the input-gradient convolutions run in the arithmetic of the forward they
+        # differentiate - ONE fp16 MFMA pass on plain-fp16 gradient operands and fp16 dgrad panels that live in a second
+        # weight pool, re-rounded with the forward's panels (stochastically, per network call, in "f16sr") - instead of the
+        # three-pass split-fp16 path (which the 22-bit modes keep): a third of the MFMA work, on the fast tile kernels.
+        # DIFFPURE_GRAD16=0 keeps the three-pass gradients.
+        gpool = None
+        if self._pool is not None and os.environ.get("DIFFPURE_GRAD16", "1") != "0":
+            gpool = ops.WeightPool(dev, stochastic=self.precision == "f16sr", seed=0x6AAD5EED)
+        pooled = []
+
+        def dg(w, n_in_dgrad, lo=None, hi=None, key=None):
             wd = ops.dgrad_weight(w.detach().float())
             if lo is not None:
                 wd = wd[lo:hi]
+            if gpool is not None and n_in_dgrad % 32 == 0 and key is not None:
+                gpool.add(key, wd)
+                pooled.append(key)
+                return None, "h1"
             if self.h2mode and n_in_dgrad % 32 == 0:
                 return ops.pack_conv_weight_h2(wd, dev), True
             return ops.pack_conv_weight(wd).to(dev), False
 
-        P["stem.dw"], _ = dg(sd[M + f"{self.plan['stem']['idx']}.weight"], -1)
+        P["stem.dw"], self._stem_dh2 = dg(sd[M + f"{self.plan['stem']['idx']}.weight"], self.cfg["nf"] if gpool is not None else -1, key="stem.dw")
         recs = [r for b in self.plan["down"] for r in b] + self.plan["mid"] + self.plan["up"]
         for r in recs:
             p, n = M + str(r["idx"]), str(r["idx"])
             if r["kind"] == "res":
-                P[n + ".dw1"], r["dh2_1"] = dg(sd[p + ".Conv_1.weight"], r["cout"])
-                P[n + ".dw0"], r["dh2_0"] = dg(sd[p + ".Conv_0.weight"], r["cout"])
+                P[n + ".dw1"], r["dh2_1"] = dg(sd[p + ".Conv_1.weight"], r["cout"], key=n + ".dw1")
+                P[n + ".dw0"], r["dh2_0"] = dg(sd[p + ".Conv_0.weight"], r["cout"], key=n + ".dw0")
                 if r["cin"] != r["cout"] or r["mode"]:
                     c1 = r.get("c1", r["cin"])
-                    P[n + ".dw2a"], _ = dg(sd[p + ".Conv_2.weight"], -1, 0, c1)
+                    g1x1 = r["cout"] if gpool is not None else -1       # the 1x1 dgrads join the fp16 path only in the fp16 x fp16 modes
+                    P[n + ".dw2a"], r["dh2_2"] = dg(sd[p + ".Conv_2.weight"], g1x1, 0, c1, key=n + ".dw2a")
                     if c1 != r["cin"]:
-                        P[n + ".dw2b"], _ = dg(sd[p + ".Conv_2.weight"], -1, c1, r["cin"])
+                        P[n + ".dw2b"], _ = dg(sd[p + ".Conv_2.weight"], g1x1, c1, r["cin"], key=n + ".dw2b")
             else:
                 c = r["ch"]
                 wq = torch.cat([sd[p + f".NIN_{j}.W"].detach().float() for j in range(3)], dim=1)   # [C, 3C] (in, out)
-                P[n + ".dwqkv"], r["dh2"] = dg(wq.t().contiguous(), 3 * c)                            # as OI conv weight
-                P[n + ".dw3"], _ = dg(sd[p + ".NIN_3.W"].detach().float().t().contiguous(), -1)
+                P[n + ".dwqkv"], r["dh2"] = dg(wq.t().contiguous(), 3 * c, key=n + ".dwqkv")          # as OI conv weight
+                P[n + ".dw3"], r["dh2_3"] = dg(sd[p + ".NIN_3.W"].detach().float().t().contiguous(), c if gpool is not None else -1, key=n + ".dw3")
+        self._gpool = gpool
+        if gpool is not None:
+            gpool.finalize()
+            for key in pooled:
+                P[key] = gpool.view(key)
         self._grad_ready = True
         return self
 
     def _dconv(self, dy, key, is_h2, n_out, ksize, scale=1.0):
+        if is_h2 == "h1":             # one fp16 pass: plain-fp16 gradient operand x pooled fp16 dgrad panel
+            if dy.dtype != torch.float16:
+                dy = ops.to_h2(dy, fmt="h1")
+            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale, w_fmt=1)
         if is_h2:
             if dy.dtype != torch.float16:
                 dy = ops.to_h2(dy)
@@ -413,20 +439,25 @@ class NCSNpp:
         n, co, ci, mode = str(r["idx"]), r["cout"], r["cin"], self._rmode(r["mode"])
         fir = self._fir
         # out = (skip + conv1(h3)) * s
-        dh3 = self._dconv(dout, n + ".dw1", r["dh2_1"], co, 3, scale=INV_SQRT2)
+        if r["dh2_1"] == "h1":        # one plain-fp16 copy of dout serves the 3x3 and the 1x1 dgrad convolutions
+            dout16 = ops.to_h2(dout, fmt="h1")
+        else:
+            dout16 = dout
+        g2 = r.get("dh2_2", False) if r["dh2_1"] == "h1" else False
+        dh3 = self._dconv(dout16, n + ".dw1", r["dh2_1"], co, 3, scale=INV_SQRT2)
         dh2, _ = ops.group_norm_bwd(t["hmid"], self._groups(co), P[n + ".g1"], P[n + ".b1"], t["st1"], dh3, act=True,
                                     split=r["dh2_0"])
         dh1 = self._dconv(dh2, n + ".dw0", r["dh2_0"], ci, 3)
         dx, dx2 = ops.group_norm_bwd(t["x"], self._groups(ci), P[n + ".g0"], P[n + ".b0"], t["st0"], dh1, x2=t["x2"], act=True,
                                      resample=mode, fir=fir)
         if mode:
-            ds = ops.conv2d(dout, P[n + ".dw2a"], ci, 1, scale=INV_SQRT2)
+            ds = self._dconv(dout16 if g2 else dout, n + ".dw2a", g2, ci, 1, scale=INV_SQRT2)
             dx = ops.add(dx, ops.resample_bwd(ds, mode, fir=fir))
         elif ci != co:
             c1 = t["x"].shape[3]
-            dx = ops.add(dx, ops.conv2d(dout, P[n + ".dw2a"], c1, 1, scale=INV_SQRT2))
+            dx = ops.add(dx, self._dconv(dout16 if g2 else dout, n + ".dw2a", g2, c1, 1, scale=INV_SQRT2))
             if dx2 is not None:
-                dx2 = ops.add(dx2, ops.conv2d(dout, P[n + ".dw2b"], ci - c1, 1, scale=INV_SQRT2))
+                dx2 = ops.add(dx2, self._dconv(dout16 if g2 else dout, n + ".dw2b", g2, ci - c1, 1, scale=INV_SQRT2))
         else:
             dx = ops.axpby(dx, 1.0, dout, INV_SQRT2)
         return dx, dx2
@@ -435,7 +466,7 @@ class NCSNpp:
         r, P = t["r"], self.p
         n, c = str(r["idx"]), r["ch"]
         b, hh, ww, _ = dout.shape
-        da = ops.conv2d(dout, P[n + ".dw3"], c, 1, scale=INV_SQRT2)
+        da = self._dconv(dout, n + ".dw3", r.get("dh2_3", False) == "h1" and "h1", c, 1, scale=INV_SQRT2)
         qkv = t["qkv"].view(b, hh * ww, 3 * c)
         _, probs = ops.attention(qkv, 1, "split", return_probs=True)                   # recomputed, freed after this block
         dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), 1, "split")
@@ -476,4 +507,4 @@ class NCSNpp:
                 dh = self._res_bwd(t, dh)[0] if r["kind"] == "res" else self._attn_bwd(t, dh)
         dh = ops.add(dh, skips.pop())
         assert not skips and not tape
-        return ops.conv2d(dh, P["stem.dw"], self.cfg["channels"], 3)
+        return self._dconv(dh, "stem.dw", self._stem_dh2 == "h1" and "h1", self.cfg["channels"], 3)

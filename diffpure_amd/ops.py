@@ -531,14 +531,15 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
     common = (_ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
               fstride, 1 if act else 0, resample, fptr, _ptr(dy))
     _lib.call("dp_gn_bwd_stats", *common, ns, _ptr(partial), _ptr(sums), s)
-    if split:
+    ofmt = 0 if not split else (2 if split == "h1" else 1)     # split: True / "h2" -> h2 operand, "h1" -> plain fp16 operand
+    if ofmt:
         assert x2 is None
-        dx = torch.empty((b, h + 2, w + 2, 2 * c), device=x.device, dtype=torch.float16)
+        dx = torch.empty((b, h + 2, w + 2, c if ofmt == 2 else 2 * c), device=x.device, dtype=torch.float16)
         dx2 = None
     else:
         dx = torch.empty_like(x)
         dx2 = None if x2 is None else torch.empty_like(x2)
-    _lib.call("dp_gn_bwd_apply", *common, _ptr(sums), 1 if split else 0, _ptr(dx), _ptr(dx2), s)
+    _lib.call("dp_gn_bwd_apply", *common, _ptr(sums), ofmt, _ptr(dx), _ptr(dx2), s)
     return dx, dx2
 
 

@@ -248,7 +248,8 @@ int dp_ddpm_step(const float* x, const float* out6, int B, int HW, int C,
  * H, W = INPUT resolution of the forward; dy: [B][Ho][Wo][C] fp32 (Ho, Wo per `resample`).
  * dp_gn_bwd_stats: slab partials [B][nsplit][G][2] -> sums [B][G][2] = the two group means.
  * dp_gn_bwd_apply: dx1 [B][H][W][C1] (+ dx2 [B][H][W][C2]) fp32, or with out_fmt=1 (C2 == 0) dx1 in
- * the zero-bordered h2 operand format, ready for the next dgrad convolution. */
+ * the zero-bordered h2 operand format, out_fmt=2 in the zero-bordered plain-fp16 ("h1") operand format, ready for the
+ * next dgrad convolution (three-pass / one-pass fp16 matrix path). */
 int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                     const float* stats, const float* gamma, const float* beta,
                     const float* fscale, const float* fshift, int film_stride, int act, int resample,

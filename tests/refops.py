@@ -280,6 +280,8 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
         grads = torch.autograd.grad(y, [a] + ([] if b2 is None else [b2]), dy)
     dx = grads[0]
     dx2 = grads[1] if b2 is not None else None
+    if split == "h1":
+        return F.pad(dx, (0, 0, 1, 1, 1, 1)).half(), None
     if split:
         return h2_encode(F.pad(dx, (0, 0, 1, 1, 1, 1))), None
     return dx.contiguous(), None if dx2 is None else dx2.contiguous()

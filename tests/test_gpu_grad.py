@@ -91,6 +91,8 @@ def test_group_norm_bwd(case):
     else:
         gh, _ = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), film=film_d, act=act, resample=rs, split=True, fir=fir)
         assert torch.equal(gh.cpu(), refops.to_h2(g1.cpu()))     # h2 form of the same gradient
+        g16, _ = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), film=film_d, act=act, resample=rs, split="h1", fir=fir)
+        assert torch.equal(g16.cpu(), torch.nn.functional.pad(g1.cpu(), (0, 0, 1, 1, 1, 1)).half())     # and its plain-fp16 form
 
 
 @pytest.mark.parametrize("case", [(2, 16, 256, 1, "split"), (2, 64, 128, 2, "legacy"), (1, 256, 256, 4, "legacy"), (2, 64, 128, 2, "split")],
