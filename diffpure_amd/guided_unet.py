@@ -299,6 +299,8 @@ class GuidedUNet:
         purification loops pass the step index.  No-op in every other mode."""
         if self._pool is not None:
             self._pool.round(key)
+        if getattr(self, "_gpool", None) is not None:
+            self._gpool.round(key)
 
     def _res(self, r, xa, x2a, film_table, tape=None):
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
@@ -413,7 +415,14 @@ class GuidedUNet:
             return self
         sd, dev, P = self._sd, self.device, self.p
 
-        def dg(key, n_in_dgrad, lo=None, hi=None, out_lo=None, out_hi=None):
+        # fp16 x fp16 modes: one-pass fp16 dgrad convolutions on pooled fp16 dgrad panels (see NCSNpp.enable_grad);
+        # DIFFPURE_GRAD16=0 keeps the three-pass gradients
+        gpool = None
+        if self._pool is not None and os.environ.get("DIFFPURE_GRAD16", "1") != "0":
+            gpool = ops.WeightPool(dev, stochastic=self.precision == "f16sr", seed=0x6AAD5EED)
+        pooled = []
+
+        def dg(key, n_in_dgrad, lo=None, hi=None, out_lo=None, out_hi=None, name=None):
             """dgrad panel of conv `key`; [lo:hi) selects input channels of the forward conv (= output
             columns of the dgrad), [out_lo:out_hi) output channels of the forward (= dgrad input)."""
             w = sd[key].detach().float()
@@ -422,6 +431,10 @@ class GuidedUNet:
             wd = ops.dgrad_weight(w)                       # [I, O, kh, kw]
             if lo is not None:
                 wd = wd[lo:hi]
+            if gpool is not None and n_in_dgrad % 32 == 0 and name is not None:
+                gpool.add(name, wd)
+                pooled.append(name)
+                return None, "h1"
             if self.h2mode and n_in_dgrad % 32 == 0:
                 return ops.pack_conv_weight_h2(wd, dev), True
             return ops.pack_conv_weight(wd).to(dev), False
@@ -430,23 +443,33 @@ class GuidedUNet:
         for r in blocks:
             n = r["name"]
             if r["kind"] == "stem":
-                P[n + ".dw"], _ = dg(n + ".weight", -1)
+                P[n + ".dw"], r["dh2"] = dg(n + ".weight", r["cout"] if gpool is not None else -1, name=n + ".dw")
             elif r["kind"] == "res":
                 c1 = r.get("split", r["cin"])
-                P[n + ".dw2"], r["dh2_2"] = dg(n + ".out_layers.3.weight", r["cout"])
+                P[n + ".dw2"], r["dh2_2"] = dg(n + ".out_layers.3.weight", r["cout"], name=n + ".dw2")
                 # conv1's dgrad writes the gradient of the (concatenated) normalised input: one panel
-                P[n + ".dw1"], r["dh2_1"] = dg(n + ".in_layers.2.weight", r["cout"])
+                P[n + ".dw1"], r["dh2_1"] = dg(n + ".in_layers.2.weight", r["cout"], name=n + ".dw1")
                 if r["cin"] != r["cout"]:
-                    P[n + ".dws1"], _ = dg(n + ".skip_connection.weight", -1, 0, c1)
+                    g1x1 = r["cout"] if gpool is not None else -1       # the 1x1 dgrads join the fp16 path in the fp16 x fp16 modes only
+                    P[n + ".dws1"], r["dh2_s"] = dg(n + ".skip_connection.weight", g1x1, 0, c1, name=n + ".dws1")
                     if c1 != r["cin"]:
-                        P[n + ".dws2"], _ = dg(n + ".skip_connection.weight", -1, c1, r["cin"])
+                        P[n + ".dws2"], _ = dg(n + ".skip_connection.weight", g1x1, c1, r["cin"], name=n + ".dws2")
             else:
-                P[n + ".dwqkv"], r["dh2"] = dg(n + ".qkv.weight", 3 * r["ch"])
-                P[n + ".dwproj"], _ = dg(n + ".proj_out.weight", -1)
+                P[n + ".dwqkv"], r["dh2"] = dg(n + ".qkv.weight", 3 * r["ch"], name=n + ".dwqkv")
+                P[n + ".dwproj"], r["dh2_p"] = dg(n + ".proj_out.weight", r["ch"] if gpool is not None else -1, name=n + ".dwproj")
+        self._gpool = gpool
+        if gpool is not None:
+            gpool.finalize()
+            for name in pooled:
+                P[name] = gpool.view(name)
         self._grad_ready = True
         return self
 
     def _dconv(self, dy, key, is_h2, n_out, ksize, scale=1.0):
+        if is_h2 == "h1":             # one fp16 pass: plain-fp16 gradient operand x pooled fp16 dgrad panel
+            if dy.dtype != torch.float16:
+                dy = ops.to_h2(dy, fmt="h1")
+            return ops.conv2d_h2(dy, self.p[key], n_out, ksize, scale=scale, w_fmt=1)
         if is_h2:
             if dy.dtype != torch.float16:
                 dy = ops.to_h2(dy)
@@ -457,7 +480,10 @@ class GuidedUNet:
         r, P = t["r"], self.p
         n, co, ci, mode = r["name"], r["cout"], r["cin"], r["mode"]
         G = self.GN_GROUPS
-        dh3 = self._dconv(dout, n + ".dw2", r["dh2_2"], co, 3)
+        lean = r["dh2_2"] == "h1"
+        dout16 = ops.to_h2(dout, fmt="h1") if lean else dout      # one plain-fp16 copy serves the 3x3 and the 1x1 dgrads
+        gs = r.get("dh2_s", False) if lean else False
+        dh3 = self._dconv(dout16, n + ".dw2", r["dh2_2"], co, 3)
         dh2, _ = ops.group_norm_bwd(t["hmid"], G, P[n + ".g2"], P[n + ".b2"], t["st2"], dh3, film=t["film"], act=True,
                                     split=r["dh2_1"])
         dh1 = self._dconv(dh2, n + ".dw1", r["dh2_1"], ci, 3)
@@ -466,9 +492,9 @@ class GuidedUNet:
             dx = ops.add(dx, ops.resample_bwd(dout, mode))
         elif ci != co:
             c1 = t["x"].shape[3]
-            dx = ops.add(dx, ops.conv2d(dout, P[n + ".dws1"], c1, 1))
+            dx = ops.add(dx, self._dconv(dout16 if gs else dout, n + ".dws1", gs, c1, 1))
             if dx2 is not None:
-                dx2 = ops.add(dx2, ops.conv2d(dout, P[n + ".dws2"], ci - c1, 1))
+                dx2 = ops.add(dx2, self._dconv(dout16 if gs else dout, n + ".dws2", gs, ci - c1, 1))
         else:
             dx = ops.add(dx, dout)
         return dx, dx2
@@ -477,7 +503,7 @@ class GuidedUNet:
         r, P = t["r"], self.p
         n, c = r["name"], r["ch"]
         b, hh, ww, _ = dout.shape
-        da = ops.conv2d(dout, P[n + ".dwproj"], c, 1)
+        da = self._dconv(dout, n + ".dwproj", r.get("dh2_p", False) == "h1" and "h1", c, 1)
         qkv = t["qkv"].view(b, hh * ww, 3 * c)
         _, probs = ops.attention(qkv, r["heads"], t["layout"], return_probs=True)      # recomputed, freed after this block
         dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), r["heads"], t["layout"])
@@ -522,4 +548,4 @@ class GuidedUNet:
         dh = ops.add(dh, skips.pop())
         assert not skips and not tape
         stem = self.plan["inp"][0][0]
-        return ops.conv2d(dh, P[stem["name"] + ".dw"], stem["cin"], 3)
+        return self._dconv(dh, stem["name"] + ".dw", stem.get("dh2", False) == "h1" and "h1", stem["cin"], 3)
