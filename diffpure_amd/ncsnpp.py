@@ -321,7 +321,7 @@ class NCSNpp:
         # the taped forward keeps only qkv; the probabilities are recomputed per block in the backward pass (see GuidedUNet._attn)
         if tape is not None:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv))
-        if r.get("proj16") and tape is None and ops.attention_fused_ok(hh * ww, c):
+        if r.get("proj16") and ops.attention_fused_ok(hh * ww, c):      # with or without a tape, as GuidedUNet._attn
             ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), 1, "split", operand_hw=(hh, ww))
             return self._ch2(ah, P[n + ".w3h"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True)
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
