@@ -460,6 +460,10 @@ class GuidedUNet:
         self._gpool = gpool
         if gpool is not None:
             gpool.finalize()
+            # built lazily by the first vjp of a loop, i.e. AFTER that call's reround: take the key the forward's panels carry, so
+            # that the first backward step is rounded like every later one (and a repeated call reproduces the first bit for bit)
+            if self._pool._last_key is not None:
+                gpool.round(self._pool._last_key)
             for name in pooled:
                 P[name] = gpool.view(name)
         self._grad_ready = True

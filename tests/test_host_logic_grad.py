@@ -65,6 +65,65 @@ def test_guided_vjp_matches_autograd(precision):
     torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
 
 
+@pytest.mark.parametrize("grad16", ["1", "0"])
+@pytest.mark.parametrize("precision", ["f16", "f16sr"])
+@pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
+def test_fp16_modes_gradient_wiring(kind, precision, grad16, monkeypatch):
+    """fp16 x fp16 modes: the dgrad convolutions take plain-fp16 gradient operands and fp16 dgrad panels that are views into a
+    SECOND weight pool, re-rounded together with the forward's panels ("Gradients"); DIFFPURE_GRAD16=0 keeps
+    the three-pass split-fp16 panels.  Either way the VJP agrees with torch.autograd through the oracle to fp16 accuracy."""
+    monkeypatch.setenv("DIFFPURE_GRAD16", grad16)
+    if kind == "ncsnpp":
+        g = load_golden("ncsnpp_small.pt")
+        cfg = pn.parse_config(g["cfg"])
+        sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+        net = pn.NCSNpp(cfg, "cpu", precision).load_state_dict(sd)
+        x, lab = g["x"], g["labels"]
+        xr = x.clone().requires_grad_(True)
+        out = on.ncsnpp_forward(sd, on.parse_ncsnpp_config(g["cfg"]), xr, lab)
+        args = (nhwc(x), lab)
+    else:
+        g = load_golden("guided_small.pt")
+        cfg = pg.parse_config(g["cfg"])
+        sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
+        net = pg.GuidedUNet(cfg, "cpu", precision).load_state_dict(sd)
+        x, t = g["x"], g["t"]
+        xr = x.clone().requires_grad_(True)
+        out = og.guided_unet_forward(sd, og.parse_guided_config(g["cfg"]), xr, t)[:, :3]
+        args = (nhwc(x), t.float())
+    u = torch.randn(x.shape, generator=torch.Generator().manual_seed(3))
+    (ref,) = torch.autograd.grad(out, xr, u)
+    tape = []
+    net.reround(7)
+    net.forward(*args, tape=tape)
+    got = nchw(net.vjp(tape, nhwc(u)))
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-2, err
+    # the gradient panels are built lazily by the first vjp, after that call's reround: they must carry the call's key all the same
+    tape = []
+    net.reround(7)
+    net.forward(*args, tape=tape)
+    assert torch.equal(nchw(net.vjp(tape, nhwc(u))), got)
+    panels = {k: v for k, v in net.p.items() if ".dw" in k}
+    assert panels
+    if grad16 == "1":
+        pool = net._gpool
+        assert pool is not None and pool.stochastic == (precision == "f16sr")
+        base = pool.work.untyped_storage().data_ptr()
+        pooled = [k for k, v in panels.items() if v.dtype == torch.float16 and v.untyped_storage().data_ptr() == base]
+        assert len(pooled) >= len(panels) - 1, (len(pooled), len(panels))         # everything but the 3-channel head's dgrad
+        net.reround(7)                 # (the pool was created inside vjp, after the call's reround: finalize() rounds with key 0)
+        before = pool.work.clone()
+        net.reround(8)
+        if precision == "f16sr":       # re-rounded together with the forward's panels, keyed by the call
+            assert 0.2 < (pool.work != before).float().mean().item() < 0.8
+            net.reround(7)
+        assert torch.equal(pool.work, before)
+    else:
+        assert net._gpool is None
+        assert all(v.dtype == torch.float16 and v.shape[1] % 2 == 0 or v.dtype == torch.float32 for v in panels.values())
+
+
 def test_ode_adjoint_matches_oracle():
     g = load_golden("ncsnpp_small.pt")
     cfg = pn.parse_config(g["cfg"])
