@@ -271,7 +271,9 @@ __device__ __forceinline__ f32x4 gn_load(const ApplyArgs& p, size_t pix, int c) 
 // FMT = 2 ("h1": plain fp16, 2 bytes per element, the operand of the two-pass / one-pass convolutions): a lane simply
 // stores its own quad as 4 fp16 (8 bytes at byte offset 8 * quad) - same values as the hi halves of the h2 form.
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-template <bool ACT, int FMT>
+// FIR: instantiated with and without the upfirdn2d stencils of `fir: True` networks - compiled into the common instantiation they
+// cost every network 45 registers per lane (141 instead of 96: three resident waves per SIMD instead of five in an HBM-bound kernel)
+template <bool ACT, int FMT, bool FIR>
 __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT, int slots) {
     const int CQ = p.C4;                                 // quads per pixel
     const int Hq = p.Ho + 2, Wq = p.Wo + 2;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
             } else if (p.resample == 1) {
                 raw = gn_load(p, ((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1), c);
                 o = xf(raw);
-            } else if (p.resample >= 3) {
+            } else if (FIR && p.resample >= 3) {
                 auto src = [&](int y, int x) { return xf(gn_load(p, ((size_t)b * p.H + y) * p.W + x, c)); };
                 o = p.resample == 3 ? fir_up2(p, oy, ox, src) : fir_down2(p, oy, ox, src);
                 raw = o;
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
 // normalisation / FiLM coefficients are formed once, not per pixel) and walks the row's pixels in
 // steps of `slots`, so the inner loop has no integer division: load, fma, SiLU, convert, store.
 // Lanes run along the channels: a wave touches 64 * VEC * 4 contiguous bytes per step.
-template <bool H2, bool ACT>
-__global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
+template <bool H2, bool ACT, bool FIR>
+__global__ __launch_bounds__(256) void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {      // CVT * slots <= 256 threads
     constexpr int VEC = H2 ? 8 : 4, NQ = VEC / 4;
     constexpr int BORDER = H2 ? 1 : 0;
     const int CV = p.C4 * 4 / VEC;
@@ -483,7 +485,7 @@ __global__ void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {
                     o[qd] = xf(((size_t)b * p.H + oy) * p.W + ox);
                 } else if (p.resample == 1) {
                     o[qd] = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
-                } else if (p.resample >= 3) {
+                } else if (FIR && p.resample >= 3) {
                     auto src = [&](int y, int x) { return xf(((size_t)b * p.H + y) * p.W + x); };
                     o[qd] = p.resample == 3 ? fir_up2(p, oy, ox, src) : fir_down2(p, oy, ox, src);
                 } else {
@@ -697,17 +699,25 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     const int CVT = CV < 256 ? CV : 256, slots = 256 / CVT;
     const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));
 #define GN_APPLY_LAUNCH(H2_, ACT_) \
-    hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_>), dim3(rows), dim3(CVT * slots), shm, (hipStream_t)stream, p, CVT, slots)
+    do {                                                                                                                              \
+        if (resample >= 3) hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_, true>), dim3(rows), dim3(CVT * slots), shm, (hipStream_t)stream, p, CVT, slots);   \
+        else hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_, false>), dim3(rows), dim3(CVT * slots), shm, (hipStream_t)stream, p, CVT, slots);              \
+    } while (0)
+#define GN_H2Q_LAUNCH(ACT_, FMT_)                                                                                                      \
+    do {                                                                                                                              \
+        if (resample >= 3) hipLaunchKernelGGL((gn_apply_h2q_kernel<ACT_, FMT_, true>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);  \
+        else hipLaunchKernelGGL((gn_apply_h2q_kernel<ACT_, FMT_, false>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);             \
+    } while (0)
     // h2 output: the lane-contiguous quad kernel unless DP_GN_APPLY_QUAD=0 (A/B switch; both give identical bytes)
     const bool quad = dp_tune(DP_T_GN_APPLY_QUAD) != 0;
     if (out_fmt == 2) {
         const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;
-        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 2>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
-        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 2>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
+        if (act) GN_H2Q_LAUNCH(true, 2);
+        else GN_H2Q_LAUNCH(false, 2);
     } else if (out_fmt && quad) {
         const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;     // C % 8 == 0: CQ and CQT are even
-        if (act) hipLaunchKernelGGL((gn_apply_h2q_kernel<true, 1>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
-        else hipLaunchKernelGGL((gn_apply_h2q_kernel<false, 1>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);
+        if (act) GN_H2Q_LAUNCH(true, 1);
+        else GN_H2Q_LAUNCH(false, 1);
     } else if (out_fmt) {
         if (act) GN_APPLY_LAUNCH(true, true);
         else GN_APPLY_LAUNCH(true, false);
@@ -716,6 +726,7 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
         else GN_APPLY_LAUNCH(false, false);
     }
 #undef GN_APPLY_LAUNCH
+#undef GN_H2Q_LAUNCH
     DP_LAUNCH_CHECK("gn_apply");
     return 0;
 }

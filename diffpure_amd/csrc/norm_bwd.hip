@@ -86,7 +86,10 @@ __device__ __forceinline__ f32x4 fir_adjoint(const float* dy, int b, int Ho, int
     return o;
 }
 
-// da (gradient w.r.t. the pre-resample activation) for channel quad c of input pixel (b, y, x)
+// da (gradient w.r.t. the pre-resample activation) for channel quad c of input pixel (b, y, x).
+// FIR: the kernels are instantiated with and without the FIR stencils - compiled into the common instantiation, the sixteen-tap
+// stencil (inlined twice into gn_bwd_apply_kernel) cost EVERY network 196 bytes of scratch per lane and doubled that kernel's time
+template <bool FIR>
 __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, int c) {
     const int C = p.C4 * 4;
     if (p.resample == 0) return ld4(p.dy + (((size_t)b * p.Ho + y) * p.Wo + x) * C + c);
@@ -98,7 +101,7 @@ __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, 
         for (int j = 0; j < 4; ++j) o[j] = (a[j] + b2[j]) + (c2[j] + d[j]);
         return o;
     }
-    if (p.resample >= 3) return fir_adjoint(p.dy, b, p.Ho, p.Wo, C, c, y, x, p.resample, p.fir);
+    if constexpr (FIR) return fir_adjoint(p.dy, b, p.Ho, p.Wo, C, c, y, x, p.resample, p.fir);
     f32x4 v = ld4(p.dy + (((size_t)b * p.Ho + (y >> 1)) * p.Wo + (x >> 1)) * C + c);  // forward was mean 2x2
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] *= 0.25f;
@@ -106,6 +109,7 @@ __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, 
 }
 
 // returns dxh and xh for one channel quad of one input pixel
+template <bool FIR>
 __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, int y, int x, int c, f32x4& dxh, f32x4& xh) {
     const f32x4 xv = (c < p.C1) ? ld4(p.x1 + pix * p.C1 + c) : ld4(p.x2 + pix * p.C2 + (c - p.C1));
     const int g = c / p.cpg;
@@ -118,7 +122,7 @@ __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = 1.f + fs[j];
     }
-    const f32x4 da = load_da(p, b, y, x, c);
+    const f32x4 da = load_da<FIR>(p, b, y, x, c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         xh[j] = (xv[j] - mean) * rstd;
@@ -132,6 +136,7 @@ __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, i
     }
 }
 
+template <bool FIR>
 __global__ void gn_bwd_stats_kernel(BwdArgs p) {
     __shared__ float red_s[1024];
     __shared__ float red_q[1024];
@@ -145,7 +150,7 @@ __global__ void gn_bwd_stats_kernel(BwdArgs p) {
     for (int px = p0 + pl; px < p1; px += p.ppb) {
         const int y = px / p.W, x = px - y * p.W;
         f32x4 dxh, xh;
-        quad_grad(p, b, (size_t)b * HW + px, y, x, cq * 4, dxh, xh);
+        quad_grad<FIR>(p, b, (size_t)b * HW + px, y, x, cq * 4, dxh, xh);
         s += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
         q += (dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3]);
     }
@@ -181,7 +186,8 @@ __global__ void reduce_partials_kernel(const float* partial, int B, int nsplit, 
 }
 
 // one work item = 8 channels of one input pixel (so that the h2 output form is one 32-byte block)
-__global__ void gn_bwd_apply_kernel(BwdArgs p) {
+template <bool FIR>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
     const int C = p.C4 * 4, C8 = C / 8;
     const int BORDER = p.out_fmt ? 1 : 0;
     const int Hq = p.H + 2 * BORDER, Wq = p.W + 2 * BORDER;
@@ -212,7 +218,7 @@ __global__ void gn_bwd_apply_kernel(BwdArgs p) {
         for (int h = 0; h < 2; ++h) {
             const int c = c8 * 8 + h * 4;
             f32x4 dxh, xh;
-            quad_grad(p, b, pix, y, x, c, dxh, xh);
+            quad_grad<FIR>(p, b, pix, y, x, c, dxh, xh);
             const int g = c / p.cpg;
             const float m1 = p.sums[(b * p.G + g) * 2], m2 = p.sums[(b * p.G + g) * 2 + 1];
             const float rstd = p.stats[(b * p.G + g) * 2 + 1];
@@ -345,7 +351,8 @@ extern "C" int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2,
     p.ppb = p.C4 >= 256 ? 1 : 256 / p.C4;
     const int block = p.C4 * p.ppb;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
+    if (resample >= 3) hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
+    else hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
     const double inv = 1.0 / ((double)H * W * p.cpg);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, partial, B, nsplit, G, inv, sums);
     DP_LAUNCH_CHECK("gn_bwd_stats");
@@ -364,7 +371,8 @@ extern "C" int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2,
     p.sums = sums; p.dx1 = (float*)dx1; p.dx2 = dx2; p.out_fmt = out_fmt;
     const int border = out_fmt ? 1 : 0;
     const long long total = (long long)B * (H + 2 * border) * (W + 2 * border) * (p.C4 / 2);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    if (resample >= 3) hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     DP_LAUNCH_CHECK("gn_bwd_apply");
     return 0;
 }

@@ -168,6 +168,28 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
                 assert int(spills) == 0, f"{full} spills {spills} VGPRs"
 
 
+def test_elementwise_and_norm_kernels_use_no_scratch(tmp_path):
+    """The GroupNorm forward / backward kernels carry the rarely used upfirdn2d stencils of `fir: True` networks.  Compiled into
+    the common instantiations they once cost every network 196 bytes of scratch per lane in gn_bwd_apply (2x its time) and 45
+    registers in the apply kernels; they are template-instantiated apart now, and NO kernel of these files may touch scratch."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "diffpure_amd", "csrc")
+    for src in ("norm.hip", "norm_bwd.hip", "elementwise.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                        "-o", str(out), os.path.join(csrc, src)], check=True, capture_output=True)
+        found = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", out.read_text())
+        assert found, src
+        for name, scratch, vgprs in found:
+            assert int(scratch) == 0, f"{name} uses {scratch} bytes of scratch per lane"
+            if "gn_apply_h2q_kernelILb1ELi2ELb0E" in name:      # the headline's GroupNorm-apply: five resident waves per SIMD
+                assert int(vgprs) <= 102, (name, vgprs)
+
+
 def test_torch_dispatcher_registration():
     """diffpure_amd.torch_ops loads csrc/libdiffpure_torch.so, whose TORCH_LIBRARY block registers the hot operators as
     torch.ops.diffpure_hip.* for the CUDA (= HIP) key only: they resolve, carry schemas, and refuse CPU tensors (no CPU
