@@ -22,6 +22,7 @@ enum DpTune {
     DP_T_GN_FOLD,          // DP_GN_FOLD: GroupNorm-apply reduces its own (sample, group) records instead of a finalize launch - 0 off
     DP_T_GN_FINALIZE_SAMPLE, // DP_GN_FINALIZE_SAMPLE: small feature maps - one finalize workgroup per sample instead of per (sample, group) - 0 off
     DP_T_H2_DW_UNROLL,     // DP_H2_DW_UNROLL: 3x3 launches of the 8-wave kernel run the slice-unrolled loop (nine taps per body) - 0 the rolled loop
+    DP_T_H2_DW_PRIO,       // DP_H2_DW_PRIO: that loop with s_setprio 1 on waves 4-7 (the younger wave of every SIMD; timing only) - 0 off
     DP_T_COUNT
 };
 

@@ -27,7 +27,7 @@ struct TuneEntry { const char* name; int def; };
 const TuneEntry kTune[DP_T_COUNT] = {
     {"DP_H2_PP", 2}, {"DP_H2_HALO", 2}, {"DP_H2_SW", 2}, {"DP_H2_SW_PERSIST", 0}, {"DP_H2_NN", 1}, {"DP_H2_PP_SCHED", 1},
     {"DP_H2_PP_STAGGER", 0}, {"DP_GN_APPLY_QUAD", 1}, {"DP_H2_DW", 8}, {"DP_H2_DW_STAGGER", 550}, {"DP_H2_DW_MINROUNDS", 12},
-    {"DP_H2_DW_ADEPTH", 3}, {"DP_GN_FOLD", 0}, {"DP_GN_FINALIZE_SAMPLE", 1}, {"DP_H2_DW_UNROLL", 1},
+    {"DP_H2_DW_ADEPTH", 3}, {"DP_GN_FOLD", 0}, {"DP_GN_FINALIZE_SAMPLE", 1}, {"DP_H2_DW_UNROLL", 1}, {"DP_H2_DW_PRIO", 1},
 };
 int g_tune[DP_T_COUNT];
 std::once_flag g_tune_once;

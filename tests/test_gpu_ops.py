@@ -467,15 +467,16 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
             tune.setenv("DP_H2_DW", "8")
             tune.setenv("DP_H2_PP", "1")    # (DP_H2_DW=8 is taken only where the launch has >= 256 tiles; elsewhere the other variants run)
             # (depth 3: the 3x3 launches run the slice-unrolled loop by default, DP_H2_DW_UNROLL=0 the rolled one)
-            for adepth, unroll in ((3, 1), (3, 0), (4, 1)):
+            for adepth, unroll, prio in ((3, 1, 0), (3, 1, 1), (3, 0, 0), (4, 1, 0)):
                 tune.setenv("DP_H2_DW_ADEPTH", adepth)
                 tune.setenv("DP_H2_DW_UNROLL", unroll)
+                tune.setenv("DP_H2_DW_PRIO", prio)       # static priority of waves 4-7: timing only
                 for _ in range(3):
                     got, got_cs = run()
                     assert torch.equal(got, base), ("dw8", adepth, unroll)
                     assert torch.equal(got_cs, base_cs), ("dw8", adepth, unroll)
             tune.delenv("DP_H2_PP")
-        for name in ("DP_H2_DW", "DP_H2_DW_MINROUNDS", "DP_H2_DW_ADEPTH", "DP_H2_DW_STAGGER", "DP_H2_DW_UNROLL"):
+        for name in ("DP_H2_DW", "DP_H2_DW_MINROUNDS", "DP_H2_DW_ADEPTH", "DP_H2_DW_STAGGER", "DP_H2_DW_UNROLL", "DP_H2_DW_PRIO"):
             tune.delenv(name)
     # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
     y1 = ops.conv2d_h2(xh, ops.pack_conv_weight_h2(w, dev), N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N],
