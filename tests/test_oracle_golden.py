@@ -47,6 +47,26 @@ def test_ncsnpp_full_matches_reference():
     torch.testing.assert_close(out, g["out"], rtol=1e-3, atol=1e-4)
 
 
+def test_fir_resamplers_and_fir_ncsnpp_match_reference_forward_and_gradient():
+    """`fir: True`: the oracle's upfirdn2d / upsample_2d / downsample_2d restatement against the reference's own
+    functions (golden fir_ops.pt: outputs AND torch.autograd input gradients), and the fir NCSN++ against the reference module's
+    forward and input gradient for a seeded cotangent (ncsnpp_fir_small.pt) - tests/golden/make_golden_fir.py."""
+    g = load_golden("fir_ops.pt")
+    for name, fn in (("up", on.upsample_2d), ("down", on.downsample_2d)):
+        x = g["x"].clone().requires_grad_(True)
+        y = fn(x, g["k"])
+        torch.testing.assert_close(y, g[name], **TOL)
+        (dx,) = torch.autograd.grad(y, x, g["dy_" + name])
+        torch.testing.assert_close(dx, g["dx_" + name], **TOL)
+    g, cfg, sd = _ncsnpp("ncsnpp_fir_small.pt")
+    assert cfg["fir"] and cfg["fir_kernel"] == (1, 3, 3, 1)
+    x = g["x"].clone().requires_grad_(True)
+    out = on.ncsnpp_forward(sd, cfg, x, g["labels"])
+    torch.testing.assert_close(out, g["out"], **TOL)
+    (vjp,) = torch.autograd.grad(out, x, g["cot"])
+    torch.testing.assert_close(vjp, g["vjp"], **TOL)
+
+
 @pytest.mark.slow
 def test_guided_full_matches_reference():
     g, cfg, sd = _guided("guided_full.pt")
