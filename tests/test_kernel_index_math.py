@@ -69,3 +69,105 @@ def test_swizzle_is_conflict_free_for_shifted_rows():
             for g in groups:
                 banks = {(((lr + shift) * 64 + ((slot ^ (((lr + shift) >> 2) & 3)) << 4)) // 16) % 16 for lr in g}
                 assert len(banks) == 16, (shift, slot)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# csrc/igemm_h2_dw.hip::conv_igemm_dw8u - the slice-unrolled k-loop of the 8-wave 256x256 convolution kernel.
+# Restated: which 16-byte unit of the bordered fp16 operand / of the fp16 weight panel every LDS-DMA piece of every k-tile
+# fetches, into which ring stage, in which iteration it is issued and waited for - and that every MFMA fragment read of k-tile t
+# finds k-tile t's data (tap t % 9 of channel slice t // 9) in the stage it addresses, for every output row / column of the tile.
+def _dw8u_schedule(nsl):
+    """-> list of (iteration t, [('A'|'B', k-tile staged, ring stage)]) in issue order, incl. the prologue (t = -1)"""
+    nt = 9 * nsl
+    sched = [(-1, [("B", 0, 0), ("A", 0, 0), ("A", 1, 1), ("B", 1, 1)])]
+    for t in range(nt):
+        q = t % 9
+        last = t // 9 == nsl - 1
+        if last and q >= 7:
+            sched.append((t, []))                        # tail iterations: nothing left to stage
+        else:
+            sched.append((t, [("B", t + 2, (q + 2) % 3), ("A", t + 2, (q + 2) % 3)]))
+    return sched
+
+
+@pytest.mark.parametrize("nsl", [1, 2, 3, 8])
+def test_dw8u_ring_schedule_has_no_raw_or_war_hazard(nsl):
+    """Ring of three stages, prefetch distance two, ONE barrier per k-tile (after the wave's own pieces of k-tile t+1 landed):
+    every k-tile is staged exactly once, into stage (k-tile mod 3) - the compile-time stage of position q = t mod 9 because
+    9 = 0 (mod 3) -; it is staged at least one barrier before its first read (RAW) and never while the k-tile it overwrites can
+    still be read (WAR: reads of k-tile t happen in iterations t-1 (after the barrier) and t (before the barrier))."""
+    nt = 9 * nsl
+    staged_at, stage_of = {}, {}
+    for t, pieces in _dw8u_schedule(nsl):
+        for op, kt, st in pieces:
+            assert (op, kt) not in staged_at, "staged twice"
+            assert kt < nt and st == kt % 3
+            staged_at[(op, kt)], stage_of[(op, kt)] = t, st
+    for op in "AB":
+        assert sorted(k for (o, k) in staged_at if o == op) == list(range(nt))
+        for kt in range(nt):
+            issue = staged_at[(op, kt)]
+            # RAW: the first read of k-tile kt comes after the barrier of iteration kt - 1; the wait before that barrier
+            # covers every piece issued up to iteration kt - 2 (pieces of iteration kt - 1 may still fly)
+            assert issue <= kt - 2 or issue == -1, (op, kt, issue)
+            # WAR: the stage held k-tile kt - 3, last read before the barrier of iteration kt - 3; the write is issued in
+            # iteration kt - 2 (or the prologue)
+            if kt >= 3:
+                assert issue >= kt - 2
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 32, 32), (2, 16, 16, 64), (1, 64, 64, 96), (1, 8, 512, 64)], ids=str)
+def test_dw8u_pieces_and_fragment_reads_agree(shape):
+    B, H, W, C = shape
+    Wp, HW, pad = W + 2, H * W, 1
+    nsl = C // 32
+    ATILE = 256 * 64
+    total = B * (H + 2) * Wp * C
+    toffx = []                                            # as the kernel builds it: byte offset of the k-tile staged at position q
+    for q in range(9):
+        tap = (q + 2) % 9
+        ky, kx = divmod(tap, 3)
+        toffx.append(((ky - pad) * Wp + (kx - pad)) * C * 2 + (64 if q + 2 >= 9 else 0))
+    t0 = ((0 - pad) * Wp + (0 - pad)) * C * 2
+    for tile_m in range(B * HW // 256):
+        m0 = tile_m * 256
+        lds = {}                                          # (stage, byte offset in stage) -> (k-tile, element offset fetched)
+        actr_slice = 0                                    # + 64 bytes per finished slice
+
+        def piece_a(off, stage, kt):
+            for wave in range(8):
+                for it in range(2):
+                    for lane in range(64):
+                        lrow = lane >> 2
+                        ls = (lane & 3) ^ ((lrow >> 2) & 3)
+                        m = m0 + wave * 32 + it * 16 + lrow
+                        b, rem = divmod(m, HW)
+                        oy, ox = divmod(rem, W)
+                        src = ((b * (H + 2) + oy + 1) * Wp + ox + 1) * C * 2 + ls * 16 + actr_slice + off
+                        assert src % 16 == 0 and 0 <= src // 2 and src // 2 + 8 <= total, "fetch outside the tensor"
+                        lds[(stage, wave * 2048 + it * 1024 + lane * 16)] = (kt, src // 2)
+
+        piece_a(t0, 0, 0)
+        piece_a(t0 + C * 2, 1, 1)
+        for t in range(9 * nsl):
+            s, q = divmod(t, 9)
+            # reads of k-tile t (set 1 in this iteration's first half; set 0 was read after the previous barrier): stage q % 3
+            tap = t % 9
+            ky, kx = divmod(tap, 3)
+            for wr in range(4):
+                for i in range(2):
+                    for lr in range(32):
+                        row = wr * 64 + i * 32 + lr
+                        m = m0 + row
+                        b, rem = divmod(m, HW)
+                        oy, ox = divmod(rem, W)
+                        for slot in range(4):             # k-slot s * 2 + lk: 8 channels each
+                            so = (slot ^ ((lr >> 2) & 3)) << 4
+                            kt, got = lds[(q % 3, row * 64 + so)]
+                            want = ((b * (H + 2) + oy + ky) * Wp + ox + kx) * C + s * 32 + slot * 8
+                            assert kt == t and got == want, (tile_m, t, row, slot)
+            if not (s == nsl - 1 and q >= 7):
+                piece_a(toffx[q], (q + 2) % 3, t + 2)
+            if q == 8:
+                actr_slice += 64
+        assert ATILE == 8 * 2048
