@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "dp_common.h"
@@ -19,34 +20,32 @@ void dp_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dp_last_error(void) { return g_dp_err; }
-extern "C" int dp_abi_version(void) { return 5; }
+extern "C" int dp_abi_version(void) { return 6; }
 
 // ---- tuning switches (dp_tune.h): environment read once, then only dp_set_tuning() changes a value -----------------
 namespace {
 struct TuneEntry { const char* name; int def; };
 const TuneEntry kTune[DP_T_COUNT] = {
-    {"DP_H2_PP", 2}, {"DP_H2_HALO", 2}, {"DP_H2_SW", 2}, {"DP_H2_SW_PERSIST", 0}, {"DP_H2_NN", 1}, {"DP_H2_PP_SCHED", 1},
-    {"DP_H2_PP_STAGGER", 0}, {"DP_GN_APPLY_QUAD", 1}, {"DP_H2_DW", 8}, {"DP_H2_DW_STAGGER", 550}, {"DP_H2_DW_MINROUNDS", 12},
-    {"DP_H2_DW_ADEPTH", 3}, {"DP_GN_FOLD", 0}, {"DP_GN_FINALIZE_SAMPLE", 1}, {"DP_H2_DW_UNROLL", 1}, {"DP_H2_DW_PRIO", 1},
+    {"DP_H2_PP", 2}, {"DP_H2_SW", 2}, {"DP_H2_NN", 1}, {"DP_H2_DW", 1}, {"DP_GN_FINALIZE_SAMPLE", 1}, {"DP_H2_DW_UNROLL", 1}, {"DP_H2_DW_PRIO", 1},
 };
-int g_tune[DP_T_COUNT];
+std::atomic<int> g_tune[DP_T_COUNT];       // relaxed: read on every launch, possibly from several host threads (DataParallel replicas)
 std::once_flag g_tune_once;
 void tune_load() {
     for (int k = 0; k < DP_T_COUNT; ++k) {
         const char* e = getenv(kTune[k].name);
-        g_tune[k] = e ? atoi(e) : kTune[k].def;
+        g_tune[k].store(e ? atoi(e) : kTune[k].def, std::memory_order_relaxed);
     }
 }
 }  // namespace
 int dp_tune(DpTune k) {
     std::call_once(g_tune_once, tune_load);
-    return g_tune[k];
+    return g_tune[k].load(std::memory_order_relaxed);
 }
 extern "C" int dp_set_tuning(const char* name, int value) {
     std::call_once(g_tune_once, tune_load);
     for (int k = 0; k < DP_T_COUNT; ++k)
         if (name && strcmp(name, kTune[k].name) == 0) {
-            g_tune[k] = value;
+            g_tune[k].store(value, std::memory_order_relaxed);
             return 0;
         }
     dp_set_error("dp_set_tuning: unknown switch '%s'", name ? name : "(null)");
@@ -56,7 +55,7 @@ extern "C" int dp_get_tuning(const char* name, int* value) {
     std::call_once(g_tune_once, tune_load);
     for (int k = 0; k < DP_T_COUNT; ++k)
         if (name && value && strcmp(name, kTune[k].name) == 0) {
-            *value = g_tune[k];
+            *value = g_tune[k].load(std::memory_order_relaxed);
             return 0;
         }
     dp_set_error("dp_get_tuning: unknown switch '%s'", name ? name : "(null)");

@@ -24,12 +24,27 @@ struct ConvH2Args {
     int passes;         // MFMA passes per product: 3 = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi ("f16x3"); 2 = a_hi*w_lo + a_hi*w_hi
                         // (activations rounded to fp16, weights to 22 bits); 12 = a_lo*w_hi + a_hi*w_hi (weights rounded);
                         // 1 = a_hi*w_hi (plain fp16 operands, fp32 accumulation)
-    int stagger;        // igemm_h2_pp.hip / igemm_h2_dw.hip: cycles per k-tile of the start-up stagger (0 = none)
+    int stagger;        // igemm_h2_dw.hip: the DP_H2_DW_PRIO switch of the slice-unrolled kernel (timing only)
     int wfmt;           // weight panel: 0 = h2 (hi|lo), 1 = plain fp16 (afmt 1, passes 1 only)
     int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
     int ofmt;           // output: 0 = fp32 [M][ldo]; 1 = plain fp16 [M][ldo] (the final fp32 value rounded to nearest; `out` then
                         // points at fp16 elements).  Column statistics are those of the UNROUNDED values in both cases.
+    int rfmt;           // residual: 0 = fp32 [M][ldr]; 1 = plain fp16 [M][ldr] (`res` then points at fp16 elements) - the fp16
+                        // residual stream of the fp16 x fp16 modes (the reference's own `use_fp16` torso keeps h in fp16,
+                        // guided_diffusion/unet.py:626-632, fp16_util.py:23-40)
+    // 1x1 "skip" K-segments (igemm_h2_dw.hip only; dp_conv_seg_applies): after the KS*KS*C reduction over `x` the k-loop runs on
+    // over the channels of up to two PLAIN fp16 NHWC tensors [B][H][W][Cs] (no border: a 1x1 tap never leaves the image) whose
+    // weight columns follow in the same panel: out += [seg1 | seg2] . W[:, KS*KS*C :].  K counts all of it.  This is the 1x1
+    // skip_connection of a ResBlock (unet.py:223-230, 262-264; layerspp.py:268-272) folded into its second 3x3 convolution.
+    const char* seg1;
+    const char* seg2;
+    int segC1, segC2;
 };
+
+// residual value of output element (row, col) in the format p.rfmt names (generic per-element path)
+__device__ __forceinline__ float dp_conv_res(const ConvH2Args& p, size_t row, int col) {
+    return p.rfmt ? (float)reinterpret_cast<const _Float16*>(p.res)[row * p.ldr + col] : p.res[row * p.ldr + col];
+}
 
 typedef _Float16 dp_half2 __attribute__((ext_vector_type(2)));
 typedef _Float16 dp_half4 __attribute__((ext_vector_type(4)));
@@ -44,21 +59,15 @@ __device__ __forceinline__ void dp_conv_store(const ConvH2Args& p, size_t row, i
 // bn = 128 -> 512x128 tiles (M % 512 == 0, N % 128 == 0); C % 32 == 0.  Fills p.tiles / p.tiles_n itself.
 void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn);
 
-// 2-D halo-tile variant of the 256x256 ping-pong kernel for 3x3 convolutions with fp16 activations and fp16 weights
-// (igemm_h2_halo.hip).  dp_conv_halo_applies: shape / format test; the launcher fills p.tiles / p.tiles_n itself.
-bool dp_conv_halo_applies(const ConvH2Args& p, int min_w);
-void dp_launch_conv_halo(ConvH2Args& p, hipStream_t s);
-
 // One-wave-per-SIMD software-pipelined variant (igemm_h2_sw.hip): fp16 x fp16, 256x256 tile, 4 waves of 128x128.
 // bn = 256: 256x256 tiles (M % 256 == 0, N % 256 == 0); bn = 128: 512x128 tiles (M % 512 == 0, N % 128 == 0).
 bool dp_conv_sw_applies(const ConvH2Args& p, int bn);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn);
 
-// Two workgroups per CU, 128x256 tiles, 4 waves of 64x128 (igemm_h2_dw.hip): fp16 x fp16; the launcher fills p.tiles / p.stagger.
-// waves = 4: two workgroups per CU on 128x256 tiles; waves = 8: one 8-wave workgroup per CU on 256x256 tiles (two free-running
-// waves per SIMD sharing the tile).
-bool dp_conv_dw_applies(const ConvH2Args& p, int waves);
-void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int waves);
+// One 8-wave workgroup per CU on 256x256 tiles, two free-running waves per SIMD sharing the tile (igemm_h2_dw.hip): fp16 x fp16;
+// the launcher fills p.tiles / p.stagger.  The only kernel that takes 1x1 K-segments (p.seg1).
+bool dp_conv_dw_applies(const ConvH2Args& p);
+void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s);
 
 // Few output channels (N <= 32: the 6-channel head), 3x3, fp16 x fp16: 256 x 32 tiles over x-halo activation runs (igemm_h2_nn.hip).
 bool dp_conv_nn_applies(const ConvH2Args& p);

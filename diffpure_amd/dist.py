@@ -84,6 +84,11 @@ def sharded_purify(fn, x, group=None):
     rank, ws = world()
     if ws == 1:
         return fn(x, 0)
+    # checked on `x` BEFORE anything rank-specific runs: x is identical on every rank, so every rank raises together (a check on
+    # each rank's own result would let the image-less ranks - which return `xl * 1.0` in x's dtype - raise alone while the
+    # others enter the all-gather and hang)
+    if x.dtype != torch.float32:
+        raise ValueError(f"sharded_purify: x must be float32 (got {x.dtype}); pass the batch as float32 on the rank's engine device")
     n = x.shape[0]
     lo, hi, per = shard_bounds(n, rank, ws)
     need_grad = x.requires_grad and torch.is_grad_enabled()

@@ -18,6 +18,7 @@ import math
 
 import numpy as np
 import os
+import threading
 
 import torch
 
@@ -191,15 +192,20 @@ def _state_out(x, nhwc):
 def _on_own_device(method):
     """Run an engine entry point with ITS device current: kernels launch on torch's current stream of the current
     device and the library's per-device scratch is keyed by hipGetDevice(), so a Purifier built for cuda:1 must not
-    run with cuda:0 current (what a caller that never calls torch.cuda.set_device would otherwise get)."""
+    run with cuda:0 current (what a caller that never calls torch.cuda.set_device would otherwise get).
+    One entry point at a time per engine: an engine owns the re-rounded weight panels of the call in flight (forward pool
+    AND the gradient pool the adjoints re-round), the time-table cache and the lazily packed dgrad panels.  The lock is taken
+    HERE, not only in the runners' forward, because the adjoint solves (`*_vjp`) run later, on autograd's thread, outside any
+    lock a runner's image_editing_sample held (two DataParallel replicas aliasing one GPU, or user threads)."""
     import functools
 
     @functools.wraps(method)
     def wrapped(self, *a, **kw):
-        if self.device.type != "cuda":
-            return method(self, *a, **kw)
-        with torch.cuda.device(self.device):
-            return method(self, *a, **kw)
+        with self._entry_lock:
+            if self.device.type != "cuda":
+                return method(self, *a, **kw)
+            with torch.cuda.device(self.device):
+                return method(self, *a, **kw)
     return wrapped
 
 
@@ -218,6 +224,7 @@ class Purifier:
         self._abar = discrete_alphas_cumprod()
         self._sched_cache = {}
         self._graphs = {}
+        self._entry_lock = threading.RLock()
 
     # -- shared pieces ----------------------------------------------------------------------------
     def _diffuse(self, x0, t_int, noise, seed, sample0, abar=None):
@@ -371,8 +378,9 @@ class Purifier:
         table = self._tables(("ode_rev", t_int, step), sched)
         for k, st in enumerate(sched):
             tape = []
-            # reverse step k revisits the time point of forward step N-1-k: the same stochastic weight rounding as `ode`
-            # used there (f16sr), so the adjoint differentiates the function the forward solve evaluated
+            # reverse step k re-crosses the INTERVAL of forward step N-1-k (from its far end: it evaluates eps at
+            # s = 1e-5 + k*step, the forward step evaluated it at the interval's other end) and takes that step's stochastic
+            # weight rounding (f16sr): per interval, forward and adjoint see the same rounded network
             self._reround(len(sched) - 1 - k)
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             g = self.net.vjp(tape, a)                       # (d eps / d y)^T a

@@ -135,7 +135,7 @@ def sde_purify(score_fn, x0, e, noises, t_int, dt=1e-3):
     return x
 
 
-def sde_adjoint_grad(score_fn, x_final, grad_out, noises, t_int, dt=1e-3):
+def sde_adjoint_grad(score_fn, x_final, grad_out, noises, t_int, dt=1e-3, k_stop=0, return_state=False):
     """Stochastic adjoint of the reverse VP-SDE solve (what torchsde.sdeint_adjoint provides for
     runners/diffpure_sde.py:236-238; torchsde itself is absent, so this restates the published scheme,
     Li et al. 2020, for this SDE): the diffusion g(t) does not depend on the state, so the adjoint process
@@ -147,10 +147,13 @@ def sde_adjoint_grad(score_fn, x_final, grad_out, noises, t_int, dt=1e-3):
         a_k = a_{k+1} + h_k (df/dy (t_{k+1}, y_{k+1}))^T a_{k+1}
     ("parity unpinned" against torchsde, which walks its own grid from the far end and queries its
     BrownianInterval there; pinned instead to torch.autograd through the unrolled forward loop, to which it
-    converges as dt -> 0: tests/test_host_logic_grad.py).  -> dL/dx at t'_0 (before the diffusion scaling)."""
+    converges as dt -> 0: tests/test_host_logic_grad.py; since round 4 also to a golden the reference's own RevVPSDE.f / .g and
+    torch.autograd through the reference NCSNpp produced over the product grid: tests/test_oracle_golden.py).
+    -> dL/dx at t'_0 (before the diffusion scaling); k_stop > 0 stops after walking steps n-1 .. k_stop (tests re-walk a
+    stretch of a stored path), return_state=True also returns the re-integrated state y."""
     grid = sde_time_grid(t_int, dt)
     y, a = x_final.clone(), grad_out.clone()
-    for k in reversed(range(len(grid) - 1)):
+    for k in reversed(range(k_stop, len(grid) - 1)):
         tk, tn = grid[k], grid[k + 1]
         h = tn - tk
         with torch.enable_grad():
@@ -160,7 +163,7 @@ def sde_adjoint_grad(score_fn, x_final, grad_out, noises, t_int, dt=1e-3):
         g = rev_sde_g(tn, y.shape[0])[:, None, None, None]
         y = y - f.detach() * h - g * (noises[k] * torch.sqrt(h))
         a = a + h * vjp
-    return a
+    return (a, y) if return_state else a
 
 
 # ----------------------------------------------------------------------------------------------
@@ -324,4 +327,4 @@ def ldsde_adjoint_grad(score_fn, x_final, grad_out, x_init, noises, t_int, sigma
         g = ldsde_g(y.shape[0], lambda_ld, eta)[:, None, None, None]
         y = y - f.detach() * h - g * (noises[k] * torch.sqrt(h))
         a = a + h * vjp
-    return a
+    return (a, y) if return_state else a

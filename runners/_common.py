@@ -93,15 +93,15 @@ class EnginePool:
 
     def replica_offset(self, device):
         """First sample index a replica on `device` adds to its (local) batch positions: 0 on the home device (a runner that
-        is not replicated keys sample i of its batch as i), (1 + ordinal) << 32 on every other GPU - replicas of one
+        is not replicated keys sample i of its batch as i), (1 + GPU index) << 32 on every other GPU - replicas of one
         DataParallel call each see batch positions 0.. of THEIR slice, and without this GPU0's image i and GPU1's image i
-        would share one noise path."""
+        would share one noise path.  A pure function of the device (NOT of which engines the pool has built so far: the
+        engines are built lazily from the replica threads, in whatever order those threads get there), so the offsets
+        of a GPU are the same on the first call and on every later one."""
         key = _dev_key(device)
         if key == _dev_key(self.home):
             return 0
-        with self._lock:
-            others = sorted(k for k in self._by_dev if k != _dev_key(self.home))
-        return (1 + others.index(key)) << 32 if key in others else 1 << 32
+        return (1 + (key[1] or 0)) << 32
 
     def get(self, device):
         key = _dev_key(device)

@@ -32,6 +32,12 @@ Round 3 (each ~10 min on 8 cores):
                            engine's Philox draw of that step.  Nothing of this loop is restated: it is in-tree upstream.
   guided_loop150.pt        the SDE loop at t*=0.15, dt=1e-3 = 150 EM steps (what run_scripts/imagenet/*.sh run), B=1
   guided_loop100_seeds.pt  the 100-step SDE loop, B=1, for two more noise seeds (x0 = sample 0 of guided_loop100.pt)
+Round 4:
+  ncsnpp_sde_adjoint100.pt CIFAR NCSN++, B=2, t*=0.1, dt=1e-3: 100 EM steps through the reference's RevVPSDE.f / .g, then the
+                           stochastic adjoint over the reversed SAME Brownian path (what torchsde.sdeint_adjoint gives the
+                           `--diffusion_type sde` attacks, runners/diffpure_sde.py:236-238), every vector-Jacobian product by
+                           torch.autograd THROUGH THE REFERENCE'S RevVPSDE.f (score network included), seeded cotangent
+  guided_sde_adjoint10.pt  the same on the full 256x256 guided UNet, B=1, t=10 (10 EM steps of dt=1e-3 + 10 adjoint steps)
 """
 import os
 import sys
@@ -157,6 +163,63 @@ def ode_adjoint():
     print("ncsnpp_ode_adjoint100", len(tau) - 1, float(x_final.abs().mean()), float(grad.abs().mean()))
 
 
+def sde_adjoint_loop(rv, x0, cot, t_int, dt, seed, snap_after=10):
+    """forward: em_loop (reference f / g); backward: Euler on the forward clock walked in reverse along the regenerated
+    Brownian path - y_k = y_{k+1} - f(t_{k+1}, y_{k+1}) h_k - g(t_{k+1}) dW_k, a_k = a_{k+1} + h_k (df/dy)^T a_{k+1} (g is
+    state-independent: no noise term and no Ito correction in the adjoint) - with f, g and df/dy^T a all taken from the
+    reference's RevVPSDE by torch.autograd.  -> x_final, dL/dx0 (incl. the forward-diffusion scaling)."""
+    b = x0.shape[0]
+    with torch.no_grad():
+        x_final, _, n = em_loop(rv, x0, t_int, dt, seed)
+    grid = osol.sde_time_grid(t_int, dt)
+    y, a = x_final.clone(), cot.clone()
+    t0 = time.time()
+    snap = {}
+    for k in reversed(range(len(grid) - 1)):
+        if k == len(grid) - 2 - snap_after:              # state after `snap_after` adjoint steps (the CPU suite re-walks only those)
+            snap = dict(k_stop=k + 1, y=y.clone(), a=a.clone())
+        tk, tn = grid[k], grid[k + 1]
+        h = tn - tk
+        with torch.enable_grad():
+            yy = y.detach().requires_grad_(True)
+            f = rv.f(tn, yy.reshape(b, -1)).reshape(y.shape)
+            (vjp,) = torch.autograd.grad(f, yy, a)
+        with torch.no_grad():
+            g = rv.g(tn, y.reshape(b, -1)).reshape(y.shape)
+            z = philox_nchw(x0.shape, seed, 0, k)
+            y = y - f.detach() * h - g * (z * torch.sqrt(h))
+            a = a + h * vjp
+        if k % 10 == 0:
+            print(f"  adjoint step {k}: {time.time() - t0:.0f} s", flush=True)
+    return x_final, osol.ode_diffuse_grad(a, t_int), y, n, snap
+
+
+def ncsnpp_sde_adjoint():
+    RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
+    mod, cfg = build_ncsnpp()
+    rv = RevVPSDE(model=mod, score_type="score_sde", img_shape=(3, 32, 32), model_kwargs=None)
+    b, t_int, dt = 2, 100, 1e-3
+    x0 = torch.rand(b, 3, 32, 32, generator=torch.Generator().manual_seed(93)) * 2 - 1
+    cot = torch.randn(b, 3, 32, 32, generator=torch.Generator().manual_seed(92))
+    x_final, grad, y_back, n, snap = sde_adjoint_loop(rv, x0, cot, t_int, dt, SEED)
+    torch.save(dict(cfg=cfg, snap=snap, seed=SEED, noise_seed=SEED, t=t_int, dt=dt, steps=n, x0=x0, cot=cot, x_final=x_final, grad=grad,
+                    y_back=y_back), os.path.join(HERE, "ncsnpp_sde_adjoint100.pt"))
+    print("ncsnpp_sde_adjoint100", n, float(x_final.abs().mean()), float(grad.abs().mean()), float(grad.abs().max()))
+
+
+def guided_sde_adjoint():
+    RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
+    mod, kw = build_guided()
+    rv = RevVPSDE(model=mod, score_type="guided_diffusion", img_shape=(3, 256, 256), model_kwargs=None)
+    b, t_int, dt = 1, 10, 1e-3
+    x0 = torch.rand(b, 3, 256, 256, generator=torch.Generator().manual_seed(91)) * 2 - 1
+    cot = torch.randn(b, 3, 256, 256, generator=torch.Generator().manual_seed(90))
+    x_final, grad, y_back, n, _ = sde_adjoint_loop(rv, x0, cot, t_int, dt, SEED)
+    torch.save(dict(cfg=kw, seed=SEED, noise_seed=SEED, t=t_int, dt=dt, steps=n, x0=x0, cot=cot, x_final=x_final,
+                    grad=grad), os.path.join(HERE, "guided_sde_adjoint10.pt"))
+    print("guided_sde_adjoint10", n, float(x_final.abs().mean()), float(grad.abs().mean()), float(grad.abs().max()))
+
+
 def guided_ddpm_loop():
     """runners/diffpure_guided.py:58-75 with the reference's own diffusion object; only the two noise sources
     (torch.randn_like at :59, th.randn_like in p_sample, gaussian_diffusion.py:438) are replaced by the Philox draws."""
@@ -266,6 +329,10 @@ def main():
             guided_loop150()
         elif w == "guided_loop_seeds":
             guided_loop_seeds()
+        elif w == "ncsnpp_sde_adjoint":
+            ncsnpp_sde_adjoint()
+        elif w == "guided_sde_adjoint":
+            guided_sde_adjoint()
         else:
             raise SystemExit(f"unknown target {w}")
         print(f"{w}: {time.time() - t0:.0f} s", flush=True)

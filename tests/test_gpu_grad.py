@@ -370,6 +370,53 @@ def test_adv_model_equals_the_torch_composition_and_is_differentiable(tmp_path, 
     assert (eot[0] - eot[1]).abs().max() > 0 if diffusion_type == "sde" else True
 
 
+def test_bpda_purify_mode_with_150_replicas_per_image_on_gpu(tmp_path):
+    """The BPDA+EOT driver's model (eval_sde_adv_bpda.py:83-106) on the HIP engine at the shipped arithmetic: `mode='purify'`
+    arrives with `eot_defense_reps` = 150 replicas of every image in ONE batch (bpda_eot_attack.py:98-110) - a large-effective-batch
+    forward.  Checked: shapes and ranges of the three modes, the call counter, that the 150 replicas of an image are 150 DIFFERENT
+    purifications (noise keyed by the global sample index r * B + b), that any replica equals a separate purification of that image
+    under the same sample index, and 'purify_and_classify' == classify(purify)."""
+    from diffpure_amd.adv_model import SDE_Adv_Model
+    g = load_golden("ncsnpp_small.pt")
+
+    def ns(d):
+        n = argparse.Namespace()
+        for k, v in d.items():
+            setattr(n, k, ns(v) if isinstance(v, dict) else v)
+        return n
+
+    config = ns(g["cfg"])
+    config.device = torch.device(DEV)
+    args = argparse.Namespace(t=100, rand_t=False, t_delta=15, use_bm=False, sample_step=1, log_dir=str(tmp_path),
+                              score_type="score_sde", seed=1234, synthetic_weights=True, dt=2e-2, precision="f16sr",
+                              diffusion_type="sde", domain="cifar10", classifier_name="none")
+    model = SDE_Adv_Model(args, config, classifier=_TinyClassifier())
+    runner = model.runner
+    reps, b = 150, 2
+    x = torch.rand(b, 3, 16, 16, generator=torch.Generator().manual_seed(8)).to(DEV)
+    with torch.no_grad():
+        runner._calls = 0
+        model.counter.fill_(7)
+        pur = model(x.repeat(reps, 1, 1, 1), mode="purify")            # [300, 3, 16, 16] in [0, 1]-ish
+        assert pur.shape == (reps * b, 3, 16, 16) and torch.isfinite(pur).all() and int(model.counter.item()) == 8
+        per_img = pur.reshape(reps, b, 3, 16, 16)
+        spread = (per_img - per_img[:1]).abs().amax(dim=(1, 2, 3, 4))
+        assert (spread[1:] > 1e-3).all()                               # every replica walked its own Brownian path
+        # replica r of image i is sample r * b + i of the call: a separate purification with that sample index reproduces it
+        r, i = 77, 1
+        runner._calls = 0
+        one = runner.purifier.sde((x[i:i + 1] - 0.5) * 2, args.t, args.dt, seed=args.seed, sample0=r * b + i)
+        # (tolerance, not equality: the fused resize/affine kernel and the torch spelling may differ in the last bit of the input,
+        #  which under f16sr can flip an fp16 rounding; a WRONG sample index would differ by ~1e-1)
+        assert ((one + 1) * 0.5 - per_img[r, i:i + 1]).abs().max() < 1e-4
+        logits = model(pur, mode="classify")
+        assert logits.shape == (reps * b, 7) and torch.equal(logits, model.resnet(pur))
+        runner._calls = 0
+        assert torch.equal(model(x.repeat(reps, 1, 1, 1), mode="purify_and_classify"), logits)
+    with pytest.raises(NotImplementedError):
+        model(x, mode="nonsense")
+
+
 @pytest.mark.parametrize("precision", SHIPPED)
 def test_ldsde_runner_autograd_on_gpu_vs_oracle_adjoint(tmp_path, precision):
     """LDGuidedDiffusion.image_editing_sample is differentiable w.r.t. the input on the HIP engine; dL/dx equals the oracle's

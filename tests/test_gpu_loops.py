@@ -229,3 +229,80 @@ def test_guided_full_stochastic_adjoint_runs_at_batch_8():
     # deterministic: the Brownian path is regenerated from the Philox key, nothing stored
     g2 = (pur.sde_vjp(xf, cot, 100, 1e-2, seed=3, sample0=0) * pur.diffuse_scale(100)).cpu()
     assert torch.equal(g, g2)
+
+
+# ---- round 4: the configurations BASELINE.json benchmarks, at THEIR batch; the stochastic adjoint at the product grid ----------
+def test_ncsnpp_loop_at_batch_256_reproduces_the_golden_samples_bit_for_bit():
+    """BASELINE.json configs[1] runs B=256: the 32^2 / 16^2 levels then take the 256-wide tile kernels (`conv_igemm_dw8u`, the
+    512x128 one-wave-per-SIMD tiles) that a B=4 batch never reaches.  The four golden images lead a batch of 256: bit-identical
+    to the B=4 run, hence within 1e-3 of the reference modules' 100-step loop."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("ncsnpp_loop100.pt")
+    pur = Purifier(ncsnpp_full("f16sr"), "ncsnpp", DEV)
+    small = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    fill = torch.rand(252, 3, 32, 32, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    big = pur.sde(torch.cat([g["x0"], fill]), g["t"], g["dt"], seed=g["noise_seed"], sample0=0)[:4].cpu()
+    err = maxabs(big, g["out"])
+    print(f"NCSN++ 100-step loop [f16sr] at B=256: first four samples vs reference modules {err:.3e}; equal to the B=4 run: {torch.equal(big, small)}")
+    assert torch.equal(big, small)
+    assert err < 1e-3, err
+
+
+def test_config5_adjoint_at_batch_128_reproduces_the_golden_samples_bit_for_bit():
+    """BASELINE.json configs[4] runs B=128: forward ODE + continuous adjoint with the two golden samples leading a batch of 128 -
+    x(1e-5) and dL/dx of those samples bit-identical to the B=2 run (every gradient tile variant and split-K choice included),
+    hence within the bars of the reference-generated golden."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("ncsnpp_ode_adjoint100.pt")
+    pur = Purifier(ncsnpp_full("f16sr"), "ncsnpp", DEV)
+    xs = pur.ode(g["x0"], g["t"], g["step"], seed=g["noise_seed"], sample0=0)
+    gs = (pur.ode_vjp(xs, g["cot"], g["t"], g["step"]) * pur.diffuse_scale(g["t"])).cpu()
+    gen = torch.Generator().manual_seed(4)
+    x0 = torch.cat([g["x0"], torch.rand(126, 3, 32, 32, generator=gen) * 2 - 1])
+    cot = torch.cat([g["cot"], torch.randn(126, 3, 32, 32, generator=gen)])
+    xb = pur.ode(x0, g["t"], g["step"], seed=g["noise_seed"], sample0=0)
+    gb = (pur.ode_vjp(xb, cot, g["t"], g["step"]) * pur.diffuse_scale(g["t"]))[:2].cpu()
+    scale = g["grad"].abs().max().item()
+    err_x, err_g = maxabs(xb[:2].cpu(), g["x_final"]), maxabs(gb, g["grad"])
+    print(f"adjoint-ODE 100+100 [f16sr] at B=128: x {err_x:.3e}, dL/dx {err_g:.3e} of {scale:.3f}; equal to the B=2 run: "
+          f"{torch.equal(xb[:2].cpu(), xs.cpu())} / {torch.equal(gb, gs)}")
+    assert torch.equal(xb[:2].cpu(), xs.cpu()) and torch.equal(gb, gs)
+    assert err_x < 1e-3 and err_g < 5e-3 * scale, (err_x, err_g, scale)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
+def test_sde_stochastic_adjoint_100_plus_100_steps_vs_reference_golden(precision):
+    """SURVEY 8f-1 at the PRODUCT grid (t*=0.1, dt=1e-3): 100 EM steps, then the stochastic adjoint over the regenerated Brownian
+    path - against the reference's own RevVPSDE.f / .g driven over the same path with torch.autograd through the reference NCSNpp for
+    every vector-Jacobian product (tests/golden/make_golden_loops.py ncsnpp_sde_adjoint).  This is the gradient every
+    `--diffusion_type sde` adaptive attack takes (runners/diffpure_sde.py:236-238)."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("ncsnpp_sde_adjoint100.pt")
+    assert g["steps"] == 100
+    pur = Purifier(ncsnpp_full(precision), "ncsnpp", DEV)
+    xf = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0)
+    err_x = maxabs(xf.cpu(), g["x_final"])
+    grad = (pur.sde_vjp(xf, g["cot"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0) * pur.diffuse_scale(g["t"])).cpu()
+    scale = g["grad"].abs().max().item()
+    err_g = maxabs(grad, g["grad"])
+    print(f"stochastic adjoint 100+100 [{precision}]: x max-abs {err_x:.3e}; dL/dx max-abs {err_g:.3e} (largest entry {scale:.3f})")
+    assert err_x < 1e-3, err_x
+    assert err_g < 5e-3 * scale, (err_g, scale)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
+def test_guided_sde_stochastic_adjoint_10_steps_vs_reference_golden(precision):
+    """The same on the FULL 256x256 guided UNet, B=1: the last 10 steps of the product grid (t=10, dt=1e-3) forward, then 10 adjoint
+    steps, against RevVPSDE.f / .g + torch.autograd through the reference UNetModel (guided_sde_adjoint10.pt)."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("guided_sde_adjoint10.pt")
+    pur = Purifier(guided_full(precision), "guided", DEV)
+    xf = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0)
+    err_x = maxabs(xf.cpu(), g["x_final"])
+    grad = (pur.sde_vjp(xf, g["cot"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0) * pur.diffuse_scale(g["t"])).cpu()
+    torch.cuda.empty_cache()
+    scale = g["grad"].abs().max().item()
+    err_g = maxabs(grad, g["grad"])
+    print(f"guided stochastic adjoint 10+10 [{precision}]: x max-abs {err_x:.3e}; dL/dx max-abs {err_g:.3e} (largest entry {scale:.3f})")
+    assert err_x < 1e-3, err_x
+    assert err_g < 5e-3 * scale, (err_g, scale)

@@ -226,14 +226,17 @@ def test_f16x3_guided_full_forward_vs_reference_golden():
     assert abs(out.abs().mean().item() - g["out_absmean"]) < 1e-4
 
 
-def test_f16x3_config1_cifar_b4_20steps_vs_oracle():
+@pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
+def test_f16_config1_cifar_b4_20steps_vs_oracle(precision):
+    """BASELINE.json configs[0] at the fp16-matrix-core arithmetics, incl. the one the runners ship with (f16sr): dt = 5e-3 is
+    five times the product step, so every rounding perturbation enters the state five times larger."""
     from diffpure_amd import ncsnpp as pn
     from diffpure_amd.sde import Purifier
     from oracle import ncsnpp as on, solvers as osol
     g = load_golden("ncsnpp_full.pt")
     cfg = pn.parse_config(g["cfg"])
     sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
-    net = pn.NCSNpp(cfg, DEV, precision="f16x3").load_state_dict(sd)
+    net = pn.NCSNpp(cfg, DEV, precision=precision).load_state_dict(sd)
     score = osol.make_score_fn("ncsnpp", sd, on.parse_ncsnpp_config(g["cfg"]))
     gen = torch.Generator().manual_seed(1234)
     x0 = torch.rand(4, 3, 32, 32, generator=gen) * 2 - 1

@@ -163,3 +163,26 @@ def test_ldsde_f_g_vs_reference_golden():
             f = osol.ldsde_f(score, r["rec"][(name, "x")], g["x"], r["sigma2"], r["lambda_ld"])
         torch.testing.assert_close(f, r["rec"][(name, "f")], rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(osol.ldsde_g(2, r["lambda_ld"], r["eta"]), r["rec"][(name, "g")], rtol=1e-6, atol=0)
+
+
+def test_oracle_stochastic_adjoint_at_the_product_grid_vs_reference_golden():
+    """The oracle's restated SDE loop + stochastic adjoint (oracle/solvers.py sde_purify / sde_adjoint_grad) on the product grid
+    (t* = 0.1, dt = 1e-3, full-size NCSN++, B=2) against the golden the reference's own RevVPSDE.f / .g and torch.autograd through
+    the reference NCSNpp produced on the same Philox path (make_golden_loops.py ncsnpp_sde_adjoint): the whole 100-step forward
+    solve, and the first 10 adjoint steps from the golden's x_final (the golden stores the adjoint state there; the remaining 90
+    steps repeat the same update and are covered at full length on the GPU, tests/test_gpu_loops.py).  ~40 s of CPU."""
+    import refops
+    g, cfg, sd = _ncsnpp("ncsnpp_sde_adjoint100.pt")
+    score = osol.make_score_fn("ncsnpp", sd, cfg)
+    x0, t_int, dt, seed = g["x0"], g["t"], g["dt"], g["noise_seed"]
+    b, c, h, w = x0.shape
+    ph = lambda step: refops.philox_normal((b, h, w, c), seed, 0, step).permute(0, 3, 1, 2).contiguous()
+    zs = [ph(k) for k in range(g["steps"])]
+    with torch.no_grad():
+        xf = osol.sde_purify(score, x0, ph(-1), zs, t_int, dt)
+    assert (xf - g["x_final"]).abs().max() < 2e-5, (xf - g["x_final"]).abs().max()
+    snap = g["snap"]
+    assert snap["k_stop"] == g["steps"] - 10
+    a, y = osol.sde_adjoint_grad(score, g["x_final"], g["cot"], zs, t_int, dt, k_stop=snap["k_stop"], return_state=True)
+    assert (y - snap["y"]).abs().max() < 2e-5, (y - snap["y"]).abs().max()
+    assert (a - snap["a"]).abs().max() < 1e-4 * snap["a"].abs().max(), ((a - snap["a"]).abs().max(), snap["a"].abs().max())
