@@ -404,7 +404,7 @@ def main():
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "peak_note": "dense fp16 MFMA peak at the 2.4 GHz nominal clock (MI355X_MICROARCH.md); see sclk_mhz for the clock this run held",
                 "mfma_passes": passes, "sclk_mhz": sclk, "end_to_end_unet_tflops_per_gpu": unet_tflops,
-                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DP_H2_SW", "DP_H2_DW", "DP_H2_DW_UNROLL", "DP_H2_DW_PRIO", "DP_H2_HALO", "DP_H2_PP", "DP_GN_FOLD", "DIFFPURE_STREAMS") if k in os.environ}}
+                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DIFFPURE_LEAN16", "DP_H2_SW", "DP_H2_DW", "DP_H2_DW_UNROLL", "DP_H2_DW_PRIO", "DP_H2_PP", "DIFFPURE_STREAMS") if k in os.environ}}
         if prof is not None:
             dom = prof["pp3x3"] if prof["pp3x3"]["n"] else prof["other3x3"]      # f32 / tiny shapes never reach the ping-pong kernel
             if dom["ms"] > 0:

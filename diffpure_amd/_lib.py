@@ -38,9 +38,11 @@ SIGNATURES = {
     "dp_softmax_rows": [_p, _ll, _i, _p],
     "dp_gn_stats": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p],
     "dp_gn_finalize": [_p, _i, _i, _i, _ll, _f, _p, _p],
-    "dp_gn_apply": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _f, _p],
-    "dp_gn_apply_f16in": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _f, _p],
-    "dp_conv2d_nhwc_h2": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _p, _p, _p, _ll, _i, _i, _i, _i, _p],
+    "dp_gn_apply": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],
+    "dp_gn_apply_h16": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "dp_conv2d_nhwc_h2": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _p, _p, _p, _ll, _i, _i, _i, _i, _i,
+                          _p, _i, _p, _i, _p],
+    "dp_conv2d_nhwc_h2_takes_segments": [_i, _i, _i, _i, _i, _i, _i, _i],
     "dp_round_weights": [_p, _p, _ll, _i, _ull, _ll, _p],
     "dp_conv2d_nhwc_h2_workspace": [_i, _i, _i, _i, _i, _i],
     "dp_pack_h2": [_p, _ll, _i, _i, _p, _p],

@@ -39,6 +39,8 @@ struct ConvArgs {
     float scale;
     int tiles_n;
     float* colstats;   // optional [tiles_m][2][N]: per output column, sum and sum of squares over the tile's rows
+    int ofmt;          // 0: fp32 output; 1: plain fp16 output (`out` then points at fp16 elements; the column records are those of
+                       // the unrounded values) - the stem of a network whose residual stream is fp16
 };
 
 template <int TM, int TN, int LDA, int LDB>
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_f32(ConvArgs p) {
                 if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
                 if (resp) v += rv[i][r];
                 v *= p.scale;
-                outp[(size_t)row * p.ldo + col] = v;
+                if (p.ofmt) reinterpret_cast<_Float16*>(outp)[(size_t)row * p.ldo + col] = (_Float16)v;
+                else outp[(size_t)row * p.ldo + col] = v;
                 cs += v;
                 cq += v * v;
             }
@@ -557,9 +560,9 @@ extern "C" int dp_prof_collect(double* ms, long long* n, double* flop, double* b
 
 extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int KH,
                               int KW, const float* w, int ldw, int N, const float* bias, const float* temb,
-                              int temb_stride, const float* res, int ldr, float scale, float* out, int ldo,
-                              int precision, float* colstats, int* tile_rows, void* stream) {
-    DP_REQUIRE(precision == 0, "dp_conv2d_nhwc: precision %d not built (0 = fp32 MFMA)", precision);
+                              int temb_stride, const float* res, int ldr, float scale, void* out, int ldo,
+                              int out_fmt, float* colstats, int* tile_rows, void* stream) {
+    DP_REQUIRE(out_fmt == 0 || out_fmt == 1, "dp_conv2d_nhwc: out_fmt %d (0 = fp32, 1 = plain fp16)", out_fmt);
     DP_REQUIRE(x1 && w && out, "dp_conv2d_nhwc: null pointer");
     DP_REQUIRE(KH == KW && (KH == 1 || KH == 3), "dp_conv2d_nhwc: kernel %dx%d unsupported", KH, KW);
     DP_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "dp_conv2d_nhwc: bad channel split %d+%d", C1, C2);
@@ -570,7 +573,7 @@ extern "C" int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2, 
     p.x1 = x1; p.x2 = x2; p.C1 = C1; p.C2 = C2;
     p.B = B; p.H = H; p.W = W; p.KH = KH; p.KW = KW; p.pad = KH / 2;
     p.w = w; p.ldw = ldw; p.bias = bias; p.temb = temb; p.temb_stride = temb_stride;
-    p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo;
+    p.res = res; p.ldr = ldr; p.out = static_cast<float*>(out); p.ldo = ldo; p.ofmt = out_fmt;
     p.M = B * H * W; p.N = N; p.K = KH * KW * (C1 + C2);
     p.scale = scale;
     p.colstats = colstats;

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rowb + (r & 3) + 8 * (r >> 2);
-                    rv[i][r] = (cok && row < p.M) ? resp[(size_t)row * p.ldr + col] : 0.f;
+                    rv[i][r] = (cok && row < p.M) ? dp_conv_res(p, (size_t)row, col) : 0.f;
                 }
             }
             tv[i] = (tembp && hw32 && cok && rowb < p.M) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col] : 0.f;
@@ -362,9 +362,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvH2Args p) {
             for (int j = 0; j < 4; ++j) v[j] += t[j];
         }
         if (p.res) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col0);
+            if (p.rfmt) {
+                const dp_half4 r = *reinterpret_cast<const dp_half4*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)row * p.ldr + col0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j];
+                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+            } else {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += r[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -451,17 +457,38 @@ extern "C" long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, in
     return s > 1 ? (long long)s * B * H * W * N * 4 : 0;
 }
 
+// Would dp_conv2d_nhwc_h2 run this fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) on the kernel that takes 1x1 K-segments?  A function
+// of the launch shape and the process-wide switches only - the host asks BEFORE it decides between the fused and the separate skip.
+extern "C" int dp_conv2d_nhwc_h2_takes_segments(int B, int H, int W, int KS, int C, int N, int segC1, int segC2) {
+    if (dp_tune(DP_T_H2_DW) == 0 || dp_tune(DP_T_H2_PP) == 0) return 0;
+    const long long M = (long long)B * H * W;
+    if (B <= 0 || H <= 0 || W <= 0 || M >= (1ll << 31) || (KS != 1 && KS != 3)) return 0;
+    if (M % 256 != 0 || N % 256 != 0 || C <= 0 || C % 32 != 0 || (H * W) % 32 != 0) return 0;
+    if (segC1 <= 0 || segC1 % 32 != 0 || segC2 < 0 || segC2 % 32 != 0) return 0;
+    if (h2_ksplit(H, W, KS, C, N) != 1) return 0;
+    return (M / 256) * (N / 256) >= 256 ? 1 : 0;
+}
+
 extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
-                                 const float* bias, const float* temb, int temb_stride, const float* res, int ldr,
+                                 const float* bias, const float* temb, int temb_stride, const void* res, int ldr,
                                  float scale, void* out, int ldo, float* colstats, int* tile_rows, void* work,
-                                 long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, void* stream) {
+                                 long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, int res_fmt,
+                                 const void* seg1, int segC1, const void* seg2, int segC2, void* stream) {
     DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
+    DP_REQUIRE(res_fmt == 0 || (res_fmt == 1 && ldr % 2 == 0 && ((size_t)res & 3) == 0),
+               "dp_conv2d_nhwc_h2: res_fmt must be 0 (fp32) or 1 (fp16; even row stride, 4-byte aligned), got %d", res_fmt);
+    DP_REQUIRE((!seg1 && !seg2 && segC1 == 0 && segC2 == 0) ||
+                   (seg1 && segC1 > 0 && segC1 % 32 == 0 && dp_aligned16(seg1) && ((seg2 != nullptr) == (segC2 > 0)) && segC2 % 32 == 0 &&
+                    (!seg2 || dp_aligned16(seg2)) && w_fmt == 1),
+               "dp_conv2d_nhwc_h2: 1x1 K-segments are plain fp16 NHWC tensors of a multiple of 32 channels (seg2 only after seg1) on "
+               "the fp16 x fp16 path");
     DP_REQUIRE(KS == 1 || KS == 3, "dp_conv2d_nhwc_h2: kernel size %d unsupported", KS);
     DP_REQUIRE((a_fmt == 0 && (passes == 3 || passes == 12)) || (a_fmt == 1 && (passes == 2 || passes == 1)),
                "dp_conv2d_nhwc_h2: (a_fmt, passes) must be (0, 3 | 12) for h2 activations or (1, 2 | 1) for plain fp16 ones (got %d, %d)",
                a_fmt, passes);
-    DP_REQUIRE(w_fmt == 0 || (w_fmt == 1 && a_fmt == 1 && passes == 1),
-               "dp_conv2d_nhwc_h2: plain fp16 weights (w_fmt 1) go with plain fp16 activations and one pass (got a_fmt %d, passes %d)", a_fmt, passes);
+    DP_REQUIRE((w_fmt == 0 && !(a_fmt == 1 && passes == 1)) || (w_fmt == 1 && a_fmt == 1 && passes == 1),
+               "dp_conv2d_nhwc_h2: one pass means plain fp16 weights (w_fmt 1) on plain fp16 activations, and vice versa (got a_fmt %d, "
+               "w_fmt %d, passes %d)", a_fmt, w_fmt, passes);
     DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && ldo % 2 == 0 && N % 4 == 0), "dp_conv2d_nhwc_h2: out_fmt must be 0 (fp32) or 1 (fp16; even row stride, N %% 4 == 0), got %d", out_fmt);
     DP_REQUIRE(C > 0 && C % 32 == 0, "dp_conv2d_nhwc_h2: channel count must be a multiple of 32 (got %d)", C);
     DP_REQUIRE(dp_aligned16(x) && dp_aligned16(w), "dp_conv2d_nhwc_h2: misaligned operand");
@@ -470,8 +497,10 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.x = (const char*)x; p.C = C;
     p.B = B; p.H = H; p.W = W; p.KS = KS; p.pad = KS / 2;
     p.w = (const char*)w; p.bias = bias; p.temb = temb; p.temb_stride = temb_stride;
-    p.res = res; p.ldr = ldr; p.out = static_cast<float*>(out); p.ldo = ldo;
-    p.M = B * H * W; p.N = N; p.K = KS * KS * C; p.scale = scale;
+    p.res = static_cast<const float*>(res); p.ldr = ldr; p.out = static_cast<float*>(out); p.ldo = ldo;
+    p.M = B * H * W; p.N = N; p.K = KS * KS * C + segC1 + segC2; p.scale = scale;
+    p.rfmt = res_fmt;
+    p.seg1 = static_cast<const char*>(seg1); p.seg2 = static_cast<const char*>(seg2); p.segC1 = segC1; p.segC2 = segC2;
     p.zero = zero_page();
     DP_REQUIRE(p.zero, "dp_conv2d_nhwc_h2: could not allocate the zero page");
     p.colstats = colstats;
@@ -492,7 +521,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     // algorithmic HBM bytes: the activation operand once (4 or 2 bytes per element), the h2 weights once, the residual and
     // the fp32 output once
     dp_prof_begin(KS == 3 ? DP_PROF_3X3_OTHER : DP_PROF_1X1, 2.0 * p.M * (double)p.N * p.K,
-                  (double)p.M * C * (a_fmt ? 2 : 4) + (w_fmt ? 2.0 : 4.0) * p.K * N + (double)p.M * N * ((res ? 4 : 0) + (out_fmt ? 2 : 4)), s, &rec);
+                  (double)p.M * (C * (a_fmt ? 2 : 4) + 2.0 * (segC1 + segC2)) + (w_fmt ? 2.0 : 4.0) * p.K * N +
+                      (double)p.M * N * ((res ? (res_fmt ? 2 : 4) : 0) + (out_fmt ? 2 : 4)), s, &rec);
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((N + bn - 1) / bn); };
 #define DP_H2_LAUNCH(BM_, BN_, BK_, ABL_)                                                                  \
     do {                                                                                                   \
@@ -500,23 +530,22 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         p.tiles = (int)tiles(BM_, BN_);                                                                    \
         const dim3 g_((unsigned)p.tiles, (unsigned)p.ksplit);                                              \
         if (p.wfmt == 1) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 1, true, true>), g_, dim3(NT), 0, s, p);                   \
-        else if (p.afmt == 1 && p.passes == 2) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 2, true, false>), g_, dim3(NT), 0, s, p); \
-        else if (p.afmt == 1) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 1, true, false>), g_, dim3(NT), 0, s, p);             \
+        else if (p.afmt == 1) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 2, true, false>), g_, dim3(NT), 0, s, p); \
         else if (p.passes == 12) hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 12, false, false>), g_, dim3(NT), 0, s, p);        \
         else hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 3, false, false>), g_, dim3(NT), 0, s, p);                             \
     } while (0)
-    {   // fp16 x fp16: two workgroups per CU on 128x256 tiles (igemm_h2_dw.hip); DP_H2_DW = 0 never, 1 when the launch fills
-        // every CU twice, 2 wherever the shape allows.  Bit-identical to the other variants.
-        const int dw = dp_tune(DP_T_H2_DW);          // 0 off; 1 / 2: 4 waves (where the launch fills every CU twice / always); 8: the 8-wave form
-        const int dww = dw == 8 ? 8 : 4;
-        if (dw != 0 && dp_conv_dw_applies(p, dww) && (dw == 2 || (dw == 8 && tiles(256, 256) >= 256) || (dw == 1 && tiles(128, 256) >= 512))) {
-            dp_launch_conv_dw(p, s, dww);
+    {   // fp16 x fp16: the 8-wave 256x256 kernel (igemm_h2_dw.hip) on launches of at least one tile per CU; DP_H2_DW = 0 never.
+        // Bit-identical to the other variants.  The only kernel that takes 1x1 K-segments.
+        if (dp_tune(DP_T_H2_DW) != 0 && dp_tune(DP_T_H2_PP) != 0 && dp_conv_dw_applies(p) && tiles(256, 256) >= 256) {
+            dp_launch_conv_dw(p, s);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("conv_igemm_dw");
             return 0;
         }
+        DP_REQUIRE(!seg1, "dp_conv2d_nhwc_h2: 1x1 K-segments were passed for a launch the 8-wave kernel does not take (ask "
+                          "dp_conv2d_nhwc_h2_takes_segments first)");
     }
     // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
     // also fills the chip (>= one tile per CU); default 2 (dp_tune.h: read once; probes flip it with dp_set_tuning).
@@ -533,18 +562,12 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         else if (pp != 0 && p.M % 256 == 0 && N % 256 == 0 && (pp == 1 || fills(256, 256))) bn = 256;
         else if (pp != 0 && p.M % 512 == 0 && N % 128 == 0 && (pp == 1 || fills(512, 128))) bn = 128;
         if (bn) {
-            // 3x3, fp16 x fp16: the halo-tile variant (one activation DMA per channel slice instead of one per tap);
-            // DP_H2_HALO = 0: never (per-tap kernel), 1: whenever the shape allows (W >= 16), unset: where it measured
-            // faster (W >= 32).  Both kernels give identical bits.
-            const int hv = dp_tune(DP_T_H2_HALO);
             // fp16 x fp16, N % 256 == 0: the one-wave-per-SIMD software-pipelined kernel (igemm_h2_sw.hip) - measured
             // fastest on every shape of both networks (tests/probes/pp_ablate.py --w16); DP_H2_SW=0 falls back
             // (its 512x128 form only for 3x3 layers: on 1x1 layers with 128 output channels it measured 5 % slower than the
             //  ping-pong kernel; tests/probes/n128_probe.py)
             if (dp_tune(DP_T_H2_SW) != 0 && (bn == 256 || (dp_tune(DP_T_H2_SW) >= 2 && KS == 3)) && dp_conv_sw_applies(p, bn)) dp_launch_conv_sw(p, s, bn);
-            else if (bn == 256 && hv != 0 && dp_conv_halo_applies(p, hv == 1 ? 16 : 32)) dp_launch_conv_halo(p, s);
-            else
-            dp_launch_conv_h2_pp(p, s, bn);
+            else dp_launch_conv_h2_pp(p, s, bn);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);

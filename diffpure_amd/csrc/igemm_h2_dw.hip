@@ -1,32 +1,31 @@
-// fp16 x fp16 implicit-GEMM convolution, 128 (pixels) x 256 (channels) tile, TWO WORKGROUPS PER CU ("dw").
+// fp16 x fp16 implicit-GEMM convolution, 256 (pixels) x 256 (channels) tile, ONE 8-WAVE WORKGROUP PER CU with two FREE-RUNNING
+// waves per SIMD ("dw8"; the dominant kernel of the purification step since round 3).
 //
-// What bounds the one-wave-per-SIMD kernel (igemm_h2_sw.hip): (i) a lone in-order wave exposes every
-// cycle an LDS-DMA issue or a ds_read_b128 costs beyond the 32-cycle shadow of one MFMA (its k-loop runs at 61 % of the
-// matrix rate), and (ii) a tile ends in ~18 us during which the CU's matrix pipes idle: all 256 CUs store their 256 KB
-// tiles (and read their residual tiles) at the same moment - a 64 + 64 MB burst that HBM takes 13-16 us to absorb - then
-// start the next tile's prologue together.  Both are the SAME defect: nothing else is resident on the CU to use the pipe.
+// What bounds the one-wave-per-SIMD kernel (igemm_h2_sw.hip): a lone in-order wave exposes every cycle an
+// LDS-DMA issue or a ds_read_b128 costs beyond the 32-cycle shadow of one MFMA.  Here two waves share every SIMD on the SAME
+// 256 x 256 tile (wave tile 64 x 128 = 2 x 4 MFMA tiles of 32x32, 128 accumulator registers of the 256 a wave may use): the
+// operand traffic of the one-wave-per-SIMD kernel (32 KB per k-tile), and whenever one wave of a SIMD sits in an LDS-DMA issue,
+// a ds_read, its vmcnt or the barrier, the other's MFMAs take the pipe.  Unlike the ping-pong kernel (same geometry) the waves
+// are not assigned roles: every wave runs the same interleaved MFMA / read / DMA stream and meets the others at ONE barrier per
+// k-tile.  (Round 3 also built the two-workgroups-per-CU form on 128 x 256 tiles, with a per-CU ticket to stagger the two
+// epilogues: bit-identical, 811-870 vs 1 022-1 130 TFLOP/s because of 1.5x the operand traffic - removed in round 4, see git history
+// and DESIGN.md section 6.)
 //
-// This kernel halves the tile so that two workgroups fit a CU (4 waves each, one per SIMD -> two waves per SIMD; 128 of the
-// 256 registers a wave may now use are accumulators; 72 or 80 KB of LDS each) and lets them run FREE of each other: no
-// shared barrier, no role assignment (unlike the 8-wave ping-pong kernel, whose load segment outlasts its MFMA segment).
-// Whenever one wave of a SIMD waits - for an LDS-DMA issue slot, its vmcnt, its workgroup's barrier, or through its whole
-// epilogue - the other wave's MFMAs take the pipe.  The second workgroup to arrive on a CU (a ticket per CU, read from
-// HW_ID) starts half a tile late, so the two epilogues of a CU alternate instead of coinciding, and the chip's store burst is
-// halved and spread.  Price: (128 + 256) instead of (256 + 256) operand rows per 128 x 256 x 32 products - 1.5x the LDS-DMA
-// and ds_read traffic per MFMA.
+// Per k-tile (32 channels of one tap) a wave issues 16 MFMAs, 12 ds_read_b128 and 4 LDS-DMA pieces.  The two operands have
+// separate LDS rings of three stages each (prefetch distance 2).
 //
-// Wave tile 64 x 128 = 2 x 4 MFMA tiles of 32x32; per k-tile (32 channels of one tap) a wave issues 16 MFMAs, 12
-// ds_read_b128 and 6 LDS-DMA pieces.  The two operands have separate LDS rings: weights (L2-resident) three stages
-// = prefetch distance 2, activations (the operand that misses to HBM once per nine taps) ADEPTH stages = distance ADEPTH - 1.
-//
-//   iteration t:  issue DMA: weights of k-tile t+2, then activations of k-tile t+DA     | 8 MFMA (t, s=0), ds_read (t, s=1)
+//   iteration t:  issue DMA: weights of k-tile t+2, then activations of k-tile t+2          | 8 MFMA (t, s=0), ds_read (t, s=1)
 //                 4 MFMA (t, s=1, row 0) ; s_waitcnt vmcnt(in-order count: k-tile t+1 landed) ; s_barrier
 //                 ds_read fragments (t+1, s=0)                                          | 4 MFMA (t, s=1, row 1)
 //   RAW: every wave waits for its own share of k-tile t+1 before the barrier of iteration t; the reads follow it.
-//   WAR: the stages written in iteration t held k-tiles t-1 (weights) / t-1 (activations, ring of DA+1) whose last reads
-//        precede the barrier of iteration t-1.
+//   WAR: the stages written in iteration t held k-tile t-1, whose last reads precede the barrier of iteration t-1.
 // Same operand formats, reduction order and epilogue arithmetic as every other variant: bit-identical output.
-// Needs: fp16 activations and weights (a_fmt 1, w_fmt 1, passes 1), M % 128 == 0, N % 256 == 0, C % 32 == 0, >= 4 k-tiles.
+// Needs: fp16 activations and weights (a_fmt 1, w_fmt 1, passes 1), M % 256 == 0, N % 256 == 0, C % 32 == 0, >= 4 k-tiles.
+//
+// 1x1 K-SEGMENTS (round 4; the rolled kernel only): after the KS*KS*C/32 k-tiles over the zero-bordered operand the loop runs on
+// over the channels of up to two plain fp16 NHWC tensors (p.seg1, p.seg2; no border) - the raw input(s) of a ResBlock whose
+// 1x1 skip_connection is thereby folded into its second 3x3 convolution (igemm_h2.h).  Only the address of an activation
+// piece changes (a different base pointer and pixel stride per segment); the weight stream, the rings and the waits do not.
 #include <stdlib.h>
 
 #include "dp_tune.h"
@@ -39,32 +38,21 @@ constexpr int NXCD = 8;
 constexpr int BTILE = 256 * 64;                 // weight tile of one k-tile: 256 rows x 64 bytes (32 fp16)
 constexpr int BDEPTH = 3;
 
-// one arrival counter per CU (index: XCC id, then bits 15:8 of HW_ID = CU / SH / SE ids); parity decides who starts late
-__device__ unsigned dw_cu_ticket[8 * 256];
-
 template <int N>
 __device__ __forceinline__ void dw_wait_vm() {
-    static_assert(N == 8 || N == 6 || N == 4 || N == 0, "add the immediate");
-    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    static_assert(N == 4 || N == 0, "add the immediate");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // MODE (timing ablations, DP_ABLATE builds only; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait,
 // 4 = no ds_reads, 8 = no epilogue stores, 16 = no activation DMA, 32 = no weight DMA
-// NW = 4: the kernel described above (128 x 256 tile, two workgroups per CU).
-// NW = 8 (round 3, "one workgroup, two free-running waves per SIMD"): ONE workgroup of eight waves per CU on a 256 x 256 tile - the
-// operand traffic of the one-wave-per-SIMD kernel (32 KB per k-tile: the two waves of a SIMD share the tile in LDS) with two
-// waves per SIMD to fill each other's issue stalls, at 1.5x that kernel's ds_reads per MFMA (wave tile 64 x 128).  Unlike the
-// ping-pong kernel (same geometry) the waves are not assigned roles: every wave runs the interleaved MFMA / read / DMA stream
-// and meets the others at ONE barrier per k-tile.  The epilogues of its waves still coincide (one tile per CU at a time).
-template <int ADEPTH, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2Args p) {
-    constexpr int DA = ADEPTH - 1;              // prefetch distance of the activation ring (weights: 2)
-    constexpr int BMT = NW * 32;                // tile rows: every wave stages 32 of them (2 pieces) and 256 / NW weight rows
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
+    constexpr int ADEPTH = 3, DA = ADEPTH - 1;  // ring stages / prefetch distance of both operands
+    constexpr int BMT = 256;                    // tile rows: every wave stages 32 of them (2 pieces) and 32 weight rows (2 pieces)
     constexpr int ATILE = BMT * 64;             // activation tile of one k-tile
-    constexpr int NPB = 256 / NW / 16;          // weight pieces per wave and k-tile (4 | 2)
+    constexpr int NPB = 2;                      // weight pieces per wave and k-tile
     constexpr int BBASE = ADEPTH * ATILE;
     __shared__ __attribute__((aligned(1024))) char smem[ADEPTH * ATILE + BDEPTH * BTILE];
 
@@ -81,29 +69,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
 
-    // ---- de-phase the two workgroups of a CU: of the launch's first residents, the second arrival on a CU sleeps for about
-    // half a tile (p.stagger cycles per k-tile); every later workgroup inherits the phase of the one it replaces
-    if (NW == 4 && p.stagger > 0 && blockIdx.x < 512) {
-        unsigned* flag = reinterpret_cast<unsigned*>(smem + BBASE + 2 * BTILE);    // a stage nothing writes before iteration 0
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
-            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7;  // HW_REG_XCC_ID
-            *flag = atomicAdd(&dw_cu_ticket[xcc * 256 + ((hw >> 8) & 0xFF)], 1u);
-        }
-        __syncthreads();
-        const unsigned ticket = __builtin_amdgcn_readfirstlane(*flag);
-        if (ticket & 1) {
-            const long long delay = (long long)nt * p.stagger;
-            const long long t0 = __builtin_readcyclecounter();
-            while ((long long)__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
-        }
-    }
-
-    // ---- staging: wave w fills rows [32 w, 32 w + 32) of the A tile and [64 w, 64 w + 64) of the B tile, 16 rows per DMA
-    // instruction; lane -> row (lane >> 2) of the piece, physical slot lane & 3, logical slot XOR-ed with the row key
+    // ---- staging: wave w fills rows [32 w, 32 w + 32) of the A tile and of the B tile, 16 rows per DMA instruction; lane -> row
+    // (lane >> 2) of the piece, physical slot lane & 3, logical slot XOR-ed with the row key
     const int lrow = lane >> 2;
     const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
-    const char* actr[2];                        // centre pixel of the lane's A row, + slot
+    const char* actr[2];                        // centre pixel of the lane's A row (segments: the lane's pixel), + slot
     const char* bptr[NPB];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -114,23 +84,38 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
     }
 #pragma unroll
     for (int it = 0; it < NPB; ++it) {
-        const int n = n0 + wave * (256 / NW) + it * 16 + lrow;      // block layout of the fp16 panels (ops.order_conv_weight_w16)
+        const int n = n0 + wave * 32 + it * 16 + lrow;              // block layout of the fp16 panels (ops.order_conv_weight_w16)
         bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
-    int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next activation k-tile to stage
+    // (tap, slice) of the next activation k-tile to stage, inside the current K-segment: segment 0 = the KS x KS convolution over
+    // p.x (C / 32 slices of `taps` k-tiles), then the 1x1 segments over p.seg1 / p.seg2 (segC / 32 slices of one k-tile)
+    int cur_tap = 0, cur_c = 0, cur_seg = 0, seg_slices = p.C / 32;
     long long a_off = 0;
     auto pieceA = [&](int aoff, int it) {       // aoff: byte offset of the ring stage
         if (it == 0) {
-            const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;     // tap / 3 for tap < 9, no division
-            a_off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
+            if (cur_c == seg_slices) {          // (wave-uniform) this segment is staged: on to the next tensor
+                ++cur_seg;
+                const char* sb = cur_seg == 1 ? p.seg1 : p.seg2;
+                const int sc = cur_seg == 1 ? p.segC1 : p.segC2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) actr[j] = sb + (size_t)(m0 + wave * 32 + j * 16 + lrow) * sc * 2 + ls * 16;
+                seg_slices = sc / 32;
+                cur_c = 0;
+            }
+            if (cur_seg == 0) {
+                const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;     // tap / 3 for tap < 9, no division
+                a_off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
+            } else {
+                a_off = (long long)cur_c * 64;
+            }
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + a_off),
                                          (__attribute__((address_space(3))) void*)(smem + aoff + (wave * 32 + it * 16) * 64), 16, 0, 0);
-        if (it == 1 && ++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+        if (it == 1 && (cur_seg != 0 || ++cur_tap == taps)) { cur_tap = 0; ++cur_c; }
     };
     auto pieceB = [&](int boff, int it) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
-                                         (__attribute__((address_space(3))) void*)(smem + boff + (wave * (256 / NW) + it * 16) * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + boff + (wave * 32 + it * 16) * 64), 16, 0, 0);
         bptr[it] += 2048;
     };
     auto issueA = [&](int aoff) { pieceA(aoff, 0); pieceA(aoff, 1); };
@@ -171,7 +156,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
     };
 
     // ring stage offsets, rotated once per k-tile: ar[0] / br[0] hold k-tile t, ar[1] / br[1] k-tile t+1,
-    // ar[DA] / br[2] are the stages the iteration writes
+    // ar[2] / br[2] are the stages the iteration writes
     int ar[ADEPTH], br[BDEPTH];
 #pragma unroll
     for (int i = 0; i < ADEPTH; ++i) ar[i] = i * ATILE;
@@ -179,26 +164,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
     for (int i = 0; i < BDEPTH; ++i) br[i] = BBASE + i * BTILE;
     auto rotate = [&]() {
         const int a0 = ar[0], b0 = br[0];
-#pragma unroll
-        for (int i = 0; i + 1 < ADEPTH; ++i) ar[i] = ar[i + 1];
-        ar[ADEPTH - 1] = a0;
+        ar[0] = ar[1];
+        ar[1] = ar[2];
+        ar[2] = a0;
         br[0] = br[1];
         br[1] = br[2];
         br[2] = b0;
     };
 
-    // ---- prologue (nt >= 4): B(0), A(0), A(1), B(1), [A(2)] in flight - in THAT order, because vmcnt counts in issue order
+    // ---- prologue (nt >= 4): B(0), A(0), A(1), B(1) in flight - in THAT order, because vmcnt counts in issue order
     // and the steady-state wait "everything up to the weights of k-tile t+1" must leave only younger pieces outstanding
     issueB(br[0]);
     issueA(ar[0]);
     issueA(ar[1]);
     issueB(br[1]);
-    if constexpr (DA == 3) issueA(ar[2]);
-    dw_wait_vm<NPB + 2 + (DA == 3 ? 2 : 0)>();  // k-tile 0 landed; A(1), B(1), [A(2)] may fly
+    dw_wait_vm<NPB + 2>();                      // k-tile 0 landed; A(1), B(1) may fly
     SW_BARRIER();
     read_frags(0, ar[0], br[0]);
 
-    // steady state: k-tiles t+2 (weights) and t+DA (activations) exist
+    // steady state: k-tile t+2 exists
     int t = 0;
     for (; t + DA < nt; ++t) {
         // first half: 8 MFMAs on fragment set 0 | the 6 reads of set 1 and the NPB + 2 DMA pieces, one (read, piece) pair per MFMA shadow
@@ -226,8 +210,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        // outstanding in issue order: [.., B(t+1), A(t+DA-1)] from iteration t-1, [B(t+2), A(t+DA)] from this one
-        if constexpr (!(MODE & 3)) dw_wait_vm<NPB + 2 + (DA == 3 ? 2 : 0)>();
+        // outstanding in issue order: [.., B(t+1), A(t+1)] from iteration t-1, [B(t+2), A(t+2)] from this one
+        if constexpr (!(MODE & 3)) dw_wait_vm<NPB + 2>();
         if constexpr (!(MODE & 2)) SW_BARRIER();
         // second half: 4 MFMAs | the 6 reads of set 0 of k-tile t+1, two per MFMA shadow
         if constexpr (!(MODE & 4)) read_frags(0, ar[1], br[1]);
@@ -241,9 +225,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
         __builtin_amdgcn_sched_barrier(0);
         rotate();
     }
-    // tail: the last DA k-tiles; with DA == 3 the first of them still stages the weights of the last k-tile
+    // tail: the last two k-tiles, nothing left to stage
     for (; t < nt; ++t) {
-        if (DA == 3 && t + 2 < nt) issueB(br[2]);
         mfma_rows(0, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         read_frags(1, ar[0], br[0]);
@@ -252,9 +235,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        // DA == 3, t == nt-3: outstanding [B(nt-2), A(nt-1)], [B(nt-1)] -> the 2 + NPB pieces behind B(nt-2) may fly
-        if (DA == 3 && t + 2 < nt) dw_wait_vm<NPB + 2>();
-        else dw_wait_vm<0>();
+        dw_wait_vm<0>();
         SW_BARRIER();
         if (t + 1 < nt) read_frags(0, ar[1], br[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -268,7 +249,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_dw(ConvH2
 
 
 // ---- the 8-wave kernel for 3x3 convolutions with the NINE TAPS OF A CHANNEL SLICE UNROLLED ("dw8u", round 3) -------------------
-// Same tile, staging, rings, waits, instruction order and arithmetic as conv_igemm_dw<3, 0, 8> - bit-identical - but the loop
+// Same tile, staging, rings, waits, instruction order and arithmetic as conv_igemm_dw<0> - bit-identical - but the loop
 // body is one channel slice = nine k-tiles, so that everything the rolled loop recomputed per k-tile in scalar code is a
 // compile-time constant: the ring stages (9 = 0 mod 3: stage = q mod 3, so the LDS addresses of the fragment reads are
 // immediates and the M0 values of the DMA pieces are one s_add from a wave constant), the tap of the activation piece (nine
@@ -452,48 +433,34 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw8u(ConvH2Args p) {
 
 }  // namespace
 
-bool dp_conv_dw_applies(const ConvH2Args& p, int waves) {
-    return (waves == 4 || waves == 8) && p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % (waves * 32) == 0 &&
-           p.N % 256 == 0 && p.C % 32 == 0 && p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0);
+bool dp_conv_dw_applies(const ConvH2Args& p) {
+    const bool seg_ok = (!p.seg1 || (p.segC1 > 0 && p.segC1 % 32 == 0)) && (!p.seg2 || (p.seg1 && p.segC2 > 0 && p.segC2 % 32 == 0));
+    return p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % 256 == 0 && p.N % 256 == 0 && p.C % 32 == 0 &&
+           p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0) && seg_ok && (p.rfmt == 0 || p.ofmt == 1);
 }
 
-void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int waves) {
+void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s) {
     p.tiles_n = p.N / 256;
-    p.tiles = (p.M / (waves * 32)) * p.tiles_n;
-    // start-up stagger (two workgroups per CU only): only where the launch runs long enough to earn it back (rounds of 512)
-    p.stagger = waves == 4 && p.tiles >= 512 * dp_tune(DP_T_H2_DW_MINROUNDS) ? dp_tune(DP_T_H2_DW_STAGGER) : 0;
-    const int adepth = dp_tune(DP_T_H2_DW_ADEPTH);
-    const dim3 g((unsigned)p.tiles), b((unsigned)(waves * 64));
-    // 3x3, 8 waves, ring depth 3: the slice-unrolled form (DP_H2_DW_UNROLL=0: the rolled loop)
-    const bool unrolled = waves == 8 && adepth != 4 && p.KS == 3 && dp_tune(DP_T_H2_DW_UNROLL) != 0;
-#define DW_LAUNCH(M_)                                                                              \
-    do {                                                                                           \
-        if (waves == 8 && adepth == 4) hipLaunchKernelGGL((conv_igemm_dw<4, M_, 8>), g, b, 0, s, p);  \
-        else if (waves == 8) hipLaunchKernelGGL((conv_igemm_dw<3, M_, 8>), g, b, 0, s, p);            \
-        else if (adepth == 4) hipLaunchKernelGGL((conv_igemm_dw<4, M_, 4>), g, b, 0, s, p);           \
-        else hipLaunchKernelGGL((conv_igemm_dw<3, M_, 4>), g, b, 0, s, p);                            \
-    } while (0)
+    p.tiles = (p.M / 256) * p.tiles_n;
+    p.stagger = 0;
+    const dim3 g((unsigned)p.tiles), b(512u);
+    // 3x3 without K-segments: the slice-unrolled form (DP_H2_DW_UNROLL=0: the rolled loop)
+    const bool unrolled = p.KS == 3 && !p.seg1 && dp_tune(DP_T_H2_DW_UNROLL) != 0;
 #ifdef DP_ABLATE   // timing ablations (WRONG RESULTS): only in libdiffpure_hip_ablate.so (tests/probes/build_ablate.py)
     {
         const char* e = getenv("DP_H2_DW_MODE");
         switch (e ? atoi(e) : 0) {
-            case 1: DW_LAUNCH(1); return;
-            case 2: DW_LAUNCH(2); return;
-            case 3: DW_LAUNCH(3); return;
-            case 6: DW_LAUNCH(6); return;
-            case 4: DW_LAUNCH(4); return;
-            case 7: DW_LAUNCH(7); return;
-            case 8: DW_LAUNCH(8); return;
-            case 16: DW_LAUNCH(16); return;
-            case 32: DW_LAUNCH(32); return;
+#define DW_CASE(M_) case M_: hipLaunchKernelGGL((conv_igemm_dw<M_>), g, b, 0, s, p); return
+            DW_CASE(1); DW_CASE(2); DW_CASE(3); DW_CASE(6); DW_CASE(4); DW_CASE(7); DW_CASE(8); DW_CASE(16); DW_CASE(32);
+#undef DW_CASE
             default: break;
         }
     }
 #endif
     if (unrolled) {
-        p.stagger = dp_tune(DP_T_H2_DW_PRIO);       // (the start-up stagger belongs to the two-workgroups-per-CU form only)
+        p.stagger = dp_tune(DP_T_H2_DW_PRIO);
         hipLaunchKernelGGL(conv_igemm_dw8u, g, b, 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_dw<0>), g, b, 0, s, p);
     }
-    else DW_LAUNCH(0);
-#undef DW_LAUNCH
 }

@@ -47,7 +47,6 @@ namespace {
 constexpr int NT = 512;
 constexpr int NXCD = 8;
 constexpr int ROWB = 128;               // bytes per LDS row: 32 channels as (hi, lo) fp16 octets
-// DP_H2_PP_SCHED default 1 (dp_tune.h): measured (tests/probes/pp_ablate.py, B=16): 621-661 vs 495-635 TFLOP/s, bit-identical
 
 // MODE (timing experiments, DP_H2_PP_MODE): bit 0 = no s_setprio; bit 1 = no operand traffic after k-tile 0 (WRONG
 // RESULTS); bit 2 = no barriers in the k-loop (WRONG RESULTS); bit 3 = no ds_reads / bit 4 = no DMA after k-tile 0 / bit 5 = no vmcnt waits (WRONG RESULTS)
@@ -100,18 +99,9 @@ __global__ __launch_bounds__(NT) void conv_igemm_h2_pp(ConvH2Args p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
-    // De-phase the CUs.  Every CU runs its tiles back to back, so without this all 256 reach their epilogues - 256 KB of
-    // stores plus the residual reads each - at the same moments and HBM alternates between bursts and idling.  The first
-    // tile of every CU (the first 256 workgroups) starts (b / 8) % 8 eighths of a tile late; the offset persists for the
-    // rest of the launch.  Only for launches of >= 16 rounds of tiles (the start-up / tail cost is a fraction of one tile).
-    // Measured: +1.5 ... +9 % on isolated back-to-back launches of one shape (tests/probes/pp_ablate.py, B=64) but +0.5 % =
-    // noise on the whole purification (bench.py: 2.989 vs 3.004 images/s), where consecutive launches differ in shape and
-    // other kernels sit between them.  OFF by default (DP_H2_PP_STAGGER=200 switches it on).  Results are unaffected.
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        const long long delay = (long long)((blockIdx.x >> 3) & 7) * nt * p.stagger;
-        const long long t0 = __builtin_readcyclecounter();
-        while ((long long)__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(16);
-    }
+    // (A start-up stagger that de-phased the CUs' epilogues - the first tile of every CU starting (b / 8) % 8 eighths of a tile late -
+    //  measured +1.5 ... +9 % on isolated back-to-back launches of one shape and +0.5 % = noise on the whole purification; it was off by
+    //  default since round 2 and is removed in round 4.)
     // ---- staging geometry: a B unit is 128 rows = 2 pieces of 64 rows; lane -> row u of the piece, physical slot tid & 7.
     // An A unit is the rows {blk*128 + unit*64 + 0..63} of every 128-row block blk of the tile.  h2 operand: one piece per
     // block (64 rows x 128 B, lane -> row u, slot tid & 7); h1 operand: one piece per TWO blocks (128 rows x 64 B, lane ->
@@ -449,20 +439,16 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
 #endif
 #define PP_LAUNCH1(BM_, BN_, M_, P_, A_, S_, W_) \
     hipLaunchKernelGGL((conv_igemm_h2_pp<BM_, BN_, M_, P_, A_, S_, W_>), dim3((unsigned)p.tiles), dim3(NT), 0, s, p)
-    // DP_H2_PP_SCHED: schedule of the fp16-operand kernels (0 = four phases per k-tile, 1 = two); A/B switch
-    const int sched = dp_tune(DP_T_H2_PP_SCHED);
+    // fp16-operand kernels run the two-phase schedule (SCHED 1; the four-phase form measured 495-635 vs 621-661 TFLOP/s and is no
+    // longer instantiated); (a_fmt 1, passes 1) exists with fp16 weights only (dp_conv2d_nhwc_h2 checks)
 #define PP_LAUNCH(BM_, BN_, M_)                                          \
     do {                                                                 \
         if (p.wfmt == 1) PP_LAUNCH1(BM_, BN_, M_, 1, true, 1, true);     \
-        else if (p.afmt == 1 && p.passes == 2 && sched == 1) PP_LAUNCH1(BM_, BN_, M_, 2, true, 1, false);   \
-        else if (p.afmt == 1 && p.passes == 2) PP_LAUNCH1(BM_, BN_, M_, 2, true, 0, false);   \
-        else if (p.afmt == 1 && sched == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 1, false); \
-        else if (p.afmt == 1) PP_LAUNCH1(BM_, BN_, 0, 1, true, 0, false);       \
+        else if (p.afmt == 1) PP_LAUNCH1(BM_, BN_, M_, 2, true, 1, false);   \
         else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false, 0, false); \
         else PP_LAUNCH1(BM_, BN_, M_, 3, false, 0, false);                      \
     } while (0)
-    // start-up stagger (see the kernel): cycles per k-tile and phase; off unless DP_H2_PP_STAGGER is set
-    p.stagger = p.tiles >= 4096 ? dp_tune(DP_T_H2_PP_STAGGER) : 0;
+    p.stagger = 0;
     if (bn == 128) {
         PP_LAUNCH(512, 128, 0);
         return;

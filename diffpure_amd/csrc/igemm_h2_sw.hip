@@ -1,6 +1,6 @@
 // fp16 x fp16 implicit-GEMM convolution, 256x256 tile, ONE WAVE PER SIMD, software-pipelined ("sw").
 //
-// The 8-wave ping-pong kernels (igemm_h2_pp.hip, igemm_h2_halo.hip) are bound, with one MFMA pass per product, by the load
+// The 8-wave ping-pong kernel (igemm_h2_pp.hip) is bound, with one MFMA pass per product, by the load
 // segment of a phase: per k-tile a wave has 16 MFMAs (512 cycles) against 12 ds_read_b128, 2-4 LDS-DMA issues and two
 // barrier pairs, and the partner wave's load segment outlasts its own MFMA segment.  This kernel
 // changes the ratio instead of the schedule: 4 waves per workgroup, one per SIMD, each owning a 128 x 128 wave tile
@@ -53,11 +53,10 @@ __device__ __forceinline__ void sw_wait_vm() {
 // The DMA issues of a k-tile are SPREAD - behind every second fragment read, the activation pieces in the first half of the
 // k-tile and the weight pieces in the second - instead of back to back in consecutive MFMA shadows (an LDS-DMA issue costs
 // more than one 32-cycle shadow; consecutive ones queue up in front of the next MFMA: +1...2.5 % measured in round 2).
-// PERSIST: the grid is one workgroup per CU and every workgroup walks its tiles itself; the operands of the NEXT tile's first
-// three k-tiles are put in flight BEFORE the epilogue of the current tile (the LDS ring is idle there: the last fragment read
-// of a tile precedes the last barrier of its k-loop), so that the ~2 us a tile used to wait for its first operands - and the
-// dispatch of a new workgroup - sit under the epilogue's stores.
-template <int MODE, int BN, bool PERSIST>
+// (Round 3 also built a persistent form - one workgroup per CU walking its tiles, the next tile's first three k-tiles put in
+//  flight before the epilogue: bit-identical, measured 2-3 % SLOWER (the hardware's own dispatch re-balances and de-phases the
+//  CUs), removed in round 4: git history, profiles/r03/sw_persistent_ab.log.)
+template <int MODE, int BN>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_sw(ConvH2Args p) {
     constexpr int BM = BN == 256 ? 256 : 512;
     constexpr int TILE_A = BM * 64, TILE_B = BN * 64;       // one operand tile of a k-tile: rows x 64 bytes (32 fp16)
@@ -70,8 +69,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int wr = BN == 256 ? wave >> 1 : wave, wc = BN == 256 ? wave & 1 : 0;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
-    // XCD-aware bijective remap of a (virtual) workgroup id to a tile (speed only); a persistent workgroup b takes the ids
-    // b, b + gridDim.x, ... - all on its own XCD, because gridDim.x is a multiple of 8
+    // XCD-aware bijective remap of the workgroup id to a tile (speed only)
     auto tile_of = [&](int v) {
         const int x = v % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
         return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + v / NXCD;
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     };
     stage_setup(tile_of(blockIdx.x));
     prologue_issue();
-  for (int vid = blockIdx.x;;) {                // one iteration per tile (exactly one without PERSIST)
     adopt();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -277,35 +274,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // every fragment read of this tile precedes the last barrier of its k-loop: the ring is free for the next tile's operands
-    bool more = false;
-    if constexpr (PERSIST) {
-        vid += gridDim.x;
-        more = vid < p.tiles;
-        if (more) {
-            stage_setup(tile_of(vid));
-            prologue_issue();
-        }
-    }
     sw_epilogue_any<2, 1>(p, acc, m0 + wr * 128, n0 + wc * 128, tile_m * (BM / 64) + wr * 2, lr, lk, HW);
-    if (!more) break;
-    if constexpr (PERSIST) {
-        // The staging pointers of the next tile are REBUILT here instead of being kept live across the epilogue (16 registers
-        // more there make the register allocator spill an accumulator tile): same arithmetic on an id the optimiser cannot
-        // see through, then moved past the DIST k-tiles that are already in flight.
-        int v2 = vid;
-        asm volatile("" : "+s"(v2));
-        stage_setup(tile_of(v2));
-        const int adv = nt < DIST ? nt : DIST;
-#pragma unroll
-        for (int it = 0; it < NPB; ++it) bptr[it] += 2048 * adv;
-        cur_tap = adv;
-        while (cur_tap >= taps) {
-            cur_tap -= taps;
-            ++cur_c;
-        }
-    }
-  }
 }
 
 
@@ -313,7 +282,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 //   * weight fragments fetched straight from global memory into registers (the block layout of the fp16 panels makes a B
 //     fragment 1 KB of contiguous memory): no LDS write / read / barrier dependence for B, but the two waves that share a column
 //     block fetch the same bytes - 48 KB instead of 32 KB per k-tile through the vector-memory path: 891-972 vs 918-1003 TFLOP/s;
-//   * activation operand as a 2-D halo tile (as igemm_h2_halo.hip; 21.5 KB instead of 32 KB per k-tile): 885-1022 vs 946-1131
+//   * activation operand as a 2-D halo tile (as round 2's halo-tile ping-pong kernel; 21.5 KB instead of 32 KB per k-tile): 885-1022 vs 946-1131
 //     TFLOP/s - the per-tap address arithmetic, the data-dependent vmcnt variants and the 160 KB of LDS cost more than the
 //     bytes save (its no-loads-at-all ablation is already slower than this kernel's: 1277-1599 vs 1498-1880);
 //   * the x-halo form (one activation run of R x (W + 2) pixels per (channel slice, ky) serves the three kx taps: 65 DMA pieces
@@ -325,21 +294,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 bool dp_conv_sw_applies(const ConvH2Args& p, int bn) {
     return (bn == 256 || bn == 128) && p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % (bn == 256 ? 256 : 512) == 0 &&
-           p.N % bn == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0);
+           p.N % bn == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0) && !p.seg1 && (p.rfmt == 0 || p.ofmt == 1);
 }
 
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn) {
     p.tiles_n = p.N / bn;
     p.tiles = (p.M / (bn == 256 ? 256 : 512)) * p.tiles_n;
-    // persistent form: one workgroup per CU, each walking tiles b, b + 256, ... (only when there is more than one round)
-    const bool persist = dp_tune(DP_T_H2_SW_PERSIST) != 0 && p.tiles > 256;
-    const dim3 g((unsigned)(persist ? 256 : p.tiles)), b(NT);
-#define SW_LAUNCH(M_)                                                                               \
-    do {                                                                                            \
-        if (bn == 256 && persist) hipLaunchKernelGGL((conv_igemm_sw<M_, 256, true>), g, b, 0, s, p);  \
-        else if (bn == 256) hipLaunchKernelGGL((conv_igemm_sw<M_, 256, false>), g, b, 0, s, p);       \
-        else if (persist) hipLaunchKernelGGL((conv_igemm_sw<M_, 128, true>), g, b, 0, s, p);          \
-        else hipLaunchKernelGGL((conv_igemm_sw<M_, 128, false>), g, b, 0, s, p);                      \
+    const dim3 g((unsigned)p.tiles), b(NT);
+#define SW_LAUNCH(M_)                                                                       \
+    do {                                                                                    \
+        if (bn == 256) hipLaunchKernelGGL((conv_igemm_sw<M_, 256>), g, b, 0, s, p);          \
+        else hipLaunchKernelGGL((conv_igemm_sw<M_, 128>), g, b, 0, s, p);                    \
     } while (0)
 #ifdef DP_ABLATE   // timing ablations (WRONG RESULTS): only in libdiffpure_hip_ablate.so (tests/probes/build_ablate.py)
     {

@@ -1,4 +1,4 @@
-// Pieces shared by the 8-wave ping-pong convolution kernels (igemm_h2_pp.hip, igemm_h2_halo.hip): LDS-DMA issue with scalar
+// Pieces shared by the 8-wave ping-pong convolution kernel (igemm_h2_pp.hip; round 2 also had a halo-tile form, removed in round 4): LDS-DMA issue with scalar
 // base + lane offset, the barrier spelling, and the fused epilogue.
 #pragma once
 #include "igemm_h2.h"
@@ -57,9 +57,9 @@ __device__ __forceinline__ void pp_epilogue_t(const ConvH2Args& p, f32x16 (&acc)
         if (resp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float* rp = resp + (size_t)(rowb + (r & 3) + 8 * (r >> 2)) * p.ldr + col0;
-                rv[0][r] = rp[0];
-                rv[1][r] = rp[32];
+                const size_t rrow = (size_t)(rowb + (r & 3) + 8 * (r >> 2));
+                rv[0][r] = dp_conv_res(p, rrow, col0);
+                rv[1][r] = dp_conv_res(p, rrow, col0 + 32);
             }
         }
 #pragma unroll

@@ -1,5 +1,5 @@
-// Epilogue of the 4-wave fp16 x fp16 convolution kernels: igemm_h2_sw.hip (one workgroup per CU, 128 x 128 wave tiles = 4 x 4
-// MFMA tiles of 32 x 32, NQ = 2 column records of 64 rows per wave) and igemm_h2_dw.hip (two workgroups per CU, 64 x 128 wave
+// Epilogue of the fp16 x fp16 convolution kernels: igemm_h2_sw.hip (four waves, one per SIMD, 128 x 128 wave tiles = 4 x 4
+// MFMA tiles of 32 x 32, NQ = 2 column records of 64 rows per wave) and igemm_h2_dw.hip (eight waves, 64 x 128 wave
 // tiles = 2 x 4 MFMA tiles, NQ = 1).
 #pragma once
 #include "igemm_h2.h"
@@ -26,6 +26,11 @@ __device__ __forceinline__ float sw_swap1(float v) {
 // a lane's first row is ONE register per tensor, the row of each accumulator register is a wave-uniform addend of the base; the
 // per-element 64-bit multiply-adds of the first version of this epilogue (two VALU instructions and a register pair per
 // element) are gone - which is also what lets the 256-register kernel keep its accumulators out of scratch.
+// p.rfmt 1 (with OUT16 only: the callers send an fp16 residual under an fp32 output - which no network produces - to the generic
+// tiles): the residual is plain fp16, the fp16 residual stream of the fp16 x fp16 modes.  It is read the way the output is stored -
+// one dword = two adjacent columns of one row per lane, then the same lane-pair exchange - 8 loads per 32 x 32 tile instead of 16.
+// A wave-uniform run-time branch inside the OUT16 instantiation (a third instantiation of the whole epilogue made the 512-register
+// kernel spill its accumulators).
 template <bool OUT16, int NQ, int JP>
 __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2 * NQ][4], int row0, int colw, int rec0, int lr, int lk,
                                             int HW) {
@@ -45,10 +50,12 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
     // lane offsets (bytes) inside a 32-row tile: the lane's FIRST row (4 lk) and column lr - one register per tensor; the row
     // the r-th accumulator register belongs to, 4 lk + (r & 3) + 8 (r >> 2), adds a wave-uniform (r & 3) + 8 (r >> 2) rows,
     // which goes into the scalar base of the access
-    const unsigned vr0 = ((unsigned)(4 * lk) * (unsigned)p.ldr + (unsigned)lr) * 4u;
+    const bool res16 = OUT16 && p.rfmt != 0;
+    const unsigned vr0 = res16 ? ((unsigned)(4 * lk + odd) * (unsigned)p.ldr + (unsigned)(lr - odd)) * 2u      // pair load
+                               : ((unsigned)(4 * lk) * (unsigned)p.ldr + (unsigned)lr) * 4u;
     const unsigned vo0 = OUT16 ? ((unsigned)(4 * lk + odd) * (unsigned)p.ldo + (unsigned)(lr - odd)) * 2u     // pair store, below
                                : ((unsigned)(4 * lk) * (unsigned)p.ldo + (unsigned)lr) * 4u;
-    const size_t ldr_b = (size_t)p.ldr * 4, ldo_b = (size_t)p.ldo * (OUT16 ? 2 : 4);
+    const size_t ldr_b = (size_t)p.ldr * (res16 ? 2 : 4), ldo_b = (size_t)p.ldo * (OUT16 ? 2 : 4);
     auto rows_of = [](int r) { return (r & 3) + 8 * (r >> 2); };
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {                  // one 64-row column record = two 32-row MFMA tiles
@@ -70,10 +77,23 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                 if (p.res) {
 #pragma unroll
                     for (int jj = 0; jj < JP; ++jj) {
-                        gptr rb = (gptr)(p.res + (size_t)rowt * p.ldr + colw + (jh * JP + jj) * 32);
+                        if (res16) {
+                            gptr rb = (gptr)(reinterpret_cast<const _Float16*>(p.res) + (size_t)rowt * p.ldr + colw + (jh * JP + jj) * 32);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            rv[jj][r] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(rb + rows_of(r) * ldr_b + vr0);
+                            for (int k = 0; k < 8; ++k) {
+                                // even lane: row r = 2k, columns (lr, lr + 1); odd lane: row 2k + 1, columns (lr - 1, lr)
+                                const dp_half2 h = *reinterpret_cast<const __attribute__((address_space(1))) dp_half2*>(rb + rows_of(2 * k) * ldr_b + vr0);
+                                const float mine = odd ? (float)h[1] : (float)h[0];
+                                const float other = sw_swap1(odd ? (float)h[0] : (float)h[1]);
+                                rv[jj][2 * k] = odd ? other : mine;
+                                rv[jj][2 * k + 1] = odd ? mine : other;
+                            }
+                        } else {
+                            gptr rb = (gptr)(p.res + (size_t)rowt * p.ldr + colw + (jh * JP + jj) * 32);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                rv[jj][r] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(rb + rows_of(r) * ldr_b + vr0);
+                        }
                     }
                 }
                 float vv[JP][16];

@@ -129,12 +129,11 @@ __global__ void gn_finalize_cols_kernel(const float* cs1, int C1, int tr1, const
 // used whole instead of 32 .. 64 bytes of it).  Isolated, back to back at 256^2 x 256, B=64: 45 us instead of 82 us per launch; in
 // the purification itself (rocprofv3, 10 100 launches) 20.7 us average instead of 18.9 us: a quarter of the workgroups, each with
 // a four times longer dependent sweep - the launch is latency-bound, not byte-bound.
-// GroupNorm-apply WITHOUT a finalize launch ("fold", small feature maps): instead of reading (mean, rstd) that
-// gn_finalize_cols_kernel wrote, every workgroup of an apply kernel reduces the column records of ITS sample itself - a sample
-// of <= FOLD_MAX_TILES record tiles is a few KB..tens of KB of L2-resident floats, against one more dependent launch
-// (11-19 us each, 122 per NCSN++ call = 5 % of a CIFAR purification).  Thread c sums channel c over the sample's tiles in
-// double (coalesced: consecutive threads, consecutive floats), group g then adds its C/G channel sums in order.  The values
-// are a function of the sample's records only - batch composition and sharding cannot change them.
+// Per-sample reduction of the column records (small feature maps: a sample of <= FOLD_MAX_TILES record tiles is a few KB..tens of
+// KB of L2-resident floats).  Thread c sums channel c over the sample's tiles in double (coalesced: consecutive threads,
+// consecutive floats), group g then adds its C/G channel sums in order.  The values are a function of the sample's records only -
+// batch composition and sharding cannot change them.  (Round 3 also let the GroupNorm-APPLY kernels run this reduction themselves
+// instead of a finalize launch: bit-identical, 4.5 % slower on the CIFAR purification, removed in round 4.)
 struct FoldSrc {
     const float* cs1;   // [tiles][2][C1] records of source 1 (null: no fold, statistics come from `stats`)
     const float* cs2;   // ... of source 2 (channel concat) or null
@@ -180,14 +179,8 @@ __device__ __forceinline__ float* gn_fold_reduce(const FoldSrc& f, int b, int C1
     return st;
 }
 
-// -> pointer to this sample's [G][2] (mean, rstd): global memory, or the workgroup's LDS copy it has just computed
-__device__ __forceinline__ const float* gn_stats_of(const FoldSrc& f, const float* stats, int b, int C1, int C2, int G, double* sh) {
-    if (!f.cs1) return stats + (size_t)b * G * 2;
-    return gn_fold_reduce(f, b, C1, C2, G, sh);
-}
-
 // gn_finalize_cols for small feature maps (a sample of <= FOLD_MAX_TILES record tiles): ONE workgroup per sample reduces all G
-// groups with the arithmetic of gn_stats_of - B workgroups instead of B * G (8192 workgroups of a 256-wide tree for a few hundred
+// groups - B workgroups instead of B * G (8192 workgroups of a 256-wide tree for a few hundred
 // floats each at CIFAR sizes: the launch was pure overhead, 11 us x 122 per NCSN++ call).
 __global__ __launch_bounds__(256) void gn_finalize_cols_sample_kernel(FoldSrc f, int C1, int C2, int G, float* stats) {
     extern __shared__ double fold_lds[];
@@ -208,9 +201,8 @@ struct ApplyArgs {
     int film_stride, act, resample;
     float* y;
     int C4, cpg, Ho, Wo;
-    char* y_raw;     // optional second output (H2 kernels, resample == 0): the UN-normalised input in bordered h2 form
+    char* y_raw;     // optional second output (operand kernels, resample == 0): the UN-normalised input in bordered operand form
     float fir[4];    // resample 3 / 4: the 1-D FIR taps k[0..3] (sum 1) of upfirdn2d's separable filter
-    FoldSrc fold;
 };
 
 // FIR resampling of score_sde's `fir: True` networks (up_or_down_sampling.py:203-265 -> upfirdn2d, op/upfirdn2d_kernel.cu:107-207)
@@ -280,8 +272,7 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
     const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
     const int oy = qy - 1;
     const bool zrow = (unsigned)oy >= (unsigned)p.Ho;
-    extern __shared__ double fold_lds[];
-    const float* st = p.gamma ? gn_stats_of(p.fold, p.stats, b, p.C1, p.C2, p.G, fold_lds) : nullptr;
+    const float* st = p.gamma ? p.stats + (size_t)b * p.G * 2 : nullptr;
     const int slot = threadIdx.x / CQT;
     const bool odd = threadIdx.x & 1;                    // CQT is even: lane parity == quad parity
     const size_t orow = ((size_t)b * Hq + qy) * Wq;
@@ -399,34 +390,120 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
     }
 }
 
-// One work item = VEC channels of one OUTPUT pixel: VEC = 4 (fp32 out, one float4) or 8 (h2 out:
-// 8 fp16 hi | 8 fp16 lo = 32 bytes, the operand format of csrc/igemm_h2.hip).
-// H2 output carries a one-pixel zero border ([B][Ho+2][Wo+2][C]): the operand format of
-// csrc/igemm_h2.hip, whose loader then needs no bounds tests.
-// One workgroup = one (bordered) output row of one sample; a thread owns ONE channel vector (its
-// normalisation / FiLM coefficients are formed once, not per pixel) and walks the row's pixels in
-// steps of `slots`, so the inner loop has no integer division: load, fma, SiLU, convert, store.
-// Lanes run along the channels: a wave touches 64 * VEC * 4 contiguous bytes per step.
-template <bool H2, bool ACT, bool FIR>
+// fp32 -> fp32 form (the tape of the adjoint passes, the resampled identity skip of the fp32 residual stream): one work item =
+// 4 channels of one OUTPUT pixel (one float4).  One workgroup = one output row of one sample; a thread owns ONE channel quad (its
+// normalisation / FiLM coefficients are formed once, not per pixel) and walks the row's pixels in steps of `slots`, so the inner
+// loop has no integer division: load, fma, SiLU, store.  Lanes run along the channels: a wave touches 64 * 16 contiguous bytes
+// per step.  (The operand formats are written by gn_apply_h2q_kernel above; the octet-per-thread h2 form of round 1 is gone.)
+template <bool ACT, bool FIR>
 __global__ __launch_bounds__(256) void gn_apply_kernel(ApplyArgs p, int CVT, int slots) {      // CVT * slots <= 256 threads
-    constexpr int VEC = H2 ? 8 : 4, NQ = VEC / 4;
-    constexpr int BORDER = H2 ? 1 : 0;
-    const int CV = p.C4 * 4 / VEC;
+    const int CV = p.C4;
+    const int b = blockIdx.x / p.Ho, oy = blockIdx.x - b * p.Ho;
+    const float* st = p.gamma ? p.stats + (size_t)b * p.G * 2 : nullptr;
+    const int slot = threadIdx.x / CVT;
+    const size_t orow = ((size_t)b * p.Ho + oy) * p.Wo;     // first pixel of this row in the output
+    for (int cv = threadIdx.x - slot * CVT; cv < CV; cv += CVT) {
+        const int c = cv * 4;
+        f32x4 a = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};       // y = x*a + d before act
+        if (p.gamma) {
+            const int g = c / p.cpg;
+            const float mean = st[g * 2], rstd = st[g * 2 + 1];
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = rstd * ga[j];
+                d[j] = be[j] - mean * a[j];
+            }
+        }
+        if (p.fscale) {
+            const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
+            const f32x4 fh = *reinterpret_cast<const f32x4*>(p.fshift + (size_t)b * p.film_stride + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m = 1.f + fs[j];
+                a[j] *= m;
+                d[j] = d[j] * m + fh[j];
+            }
+        }
+        auto xf = [&](size_t pix) {
+            f32x4 v = gn_load(p, pix, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = v[j] * a[j] + d[j];
+                v[j] = ACT ? dp_silu_f(u) : u;
+            }
+            return v;
+        };
+        for (int ox = slot; ox < p.Wo; ox += slots) {
+            f32x4 o;
+            if (p.resample == 0) {
+                o = xf(((size_t)b * p.H + oy) * p.W + ox);
+            } else if (p.resample == 1) {
+                o = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
+            } else if (FIR && p.resample >= 3) {
+                auto src = [&](int y, int x) { return xf(((size_t)b * p.H + y) * p.W + x); };
+                o = p.resample == 3 ? fir_up2(p, oy, ox, src) : fir_down2(p, oy, ox, src);
+            } else {
+                const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
+                const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
+            }
+            *reinterpret_cast<f32x4*>(p.y + (orow + ox) * (p.C4 * 4) + c) = o;
+        }
+    }
+}
+
+// fp16 in -> fp16 out ("h16"): GroupNorm-apply over tensors that are stored as PLAIN fp16 [B][H][W][C] (no border) - the output of a
+// ResBlock's first convolution (round 3) and, since round 4, the whole residual stream of the fp16 x fp16 modes (the reference's
+// own `use_fp16` torso keeps h in fp16: guided_diffusion/unet.py:626-632).  Everything gn_apply_h2q_kernel does for an fp32
+// input: two sources (the skip concatenation, never materialised), optional normalisation + FiLM + SiLU, 2x nearest-up / 2x2
+// mean-down resampling, and the raw input as a second operand - at 4 instead of 6 HBM bytes per element.  Output: the
+// zero-bordered "h1" operand [B][Ho+2][Wo+2][C] (BORDER 1) or a plain fp16 tensor [B][Ho][Wo][C] (BORDER 0: the resampled
+// identity skip of an up / down ResBlock, unet.py:245-250 - the residual of its second convolution).
+// A thread owns one channel OCTET: 16-byte loads, 16-byte stores, lanes along the channels.  Per element the arithmetic is
+// gn_apply_h2q_kernel's on the (exactly representable) fp32 value of the fp16 input: identical bytes to dp_gn_apply(out_fmt 2)
+// of the up-converted tensor (tests/test_gpu_ops.py).
+struct Apply16Args {
+    const _Float16* x1;
+    const _Float16* x2;
+    int C1, C2, B, H, W, G;
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    const float* fscale;
+    const float* fshift;
+    int film_stride, resample;
+    char* y;
+    char* y_raw;
+    int cpg, Ho, Wo;
+};
+
+template <bool ACT, int BORDER>
+__global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int COT, int slots) {
+    const int C = p.C1 + p.C2, CO = C / 8;
     const int Hq = p.Ho + 2 * BORDER, Wq = p.Wo + 2 * BORDER;
     const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
     const int oy = qy - BORDER;
-    const bool zrow = H2 && (unsigned)oy >= (unsigned)p.Ho;
-    extern __shared__ double fold_lds[];
-    const float* st = p.gamma ? gn_stats_of(p.fold, p.stats, b, p.C1, p.C2, p.G, fold_lds) : nullptr;
-    const int slot = threadIdx.x / CVT;
-    const size_t orow = ((size_t)b * Hq + qy) * Wq;     // first pixel of this row in the (bordered) output
-    for (int cv = threadIdx.x - slot * CVT; cv < CV; cv += CVT) {
-        f32x4 a[NQ], d[NQ];                             // y = x*a + d before act
+    const bool zrow = BORDER && (unsigned)oy >= (unsigned)p.Ho;
+    const float* st = p.gamma ? p.stats + (size_t)b * p.G * 2 : nullptr;
+    const int slot = threadIdx.x / COT;
+    const size_t orow = ((size_t)b * Hq + qy) * Wq;
+    half8 zero8;
 #pragma unroll
-        for (int qd = 0; qd < NQ; ++qd) {
-            const int c = cv * VEC + qd * 4;
-            a[qd] = f32x4{1.f, 1.f, 1.f, 1.f};
-            d[qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.f;
+    for (int co = threadIdx.x - slot * COT; co < CO; co += COT) {
+        const int c0 = co * 8;
+        float a[8], d[8];                                  // y = x*a + d before act
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+            const int c = c0 + qd * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[qd * 4 + j] = 1.f;
+                d[qd * 4 + j] = 0.f;
+            }
             if (p.gamma) {
                 const int g = c / p.cpg;
                 const float mean = st[g * 2], rstd = st[g * 2 + 1];
@@ -434,142 +511,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(ApplyArgs p, int CVT, int
                 const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a[qd][j] = rstd * ga[j];
-                    d[qd][j] = be[j] - mean * a[qd][j];
+                    a[qd * 4 + j] = rstd * ga[j];
+                    d[qd * 4 + j] = be[j] - mean * a[qd * 4 + j];
                 }
-            }
-            if (p.fscale) {
-                const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
-                const f32x4 fh = *reinterpret_cast<const f32x4*>(p.fshift + (size_t)b * p.film_stride + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float m = 1.f + fs[j];
-                    a[qd][j] *= m;
-                    d[qd][j] = d[qd][j] * m + fh[j];
-                }
-            }
-        }
-        for (int qx = slot; qx < Wq; qx += slots) {
-            const int ox = qx - BORDER;
-            const size_t opix = orow + qx;
-            if (H2 && (zrow || (unsigned)ox >= (unsigned)p.Wo)) {
-                half8 z;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
-                half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CV + cv) * 32);
-                dst[0] = z;
-                dst[1] = z;
-                if (p.y_raw) {
-                    half8* dr = reinterpret_cast<half8*>(p.y_raw + (opix * CV + cv) * 32);
-                    dr[0] = z;
-                    dr[1] = z;
-                }
-                continue;
-            }
-            f32x4 o[NQ];
-            f32x4 raw[NQ];
-#pragma unroll
-            for (int qd = 0; qd < NQ; ++qd) {
-                const int c = cv * VEC + qd * 4;
-                auto xf = [&](size_t pix) {
-                    f32x4 v = gn_load(p, pix, c);
-                    raw[qd] = v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float u = v[j] * a[qd][j] + d[qd][j];
-                        v[j] = ACT ? dp_silu_f(u) : u;
-                    }
-                    return v;
-                };
-                if (p.resample == 0) {
-                    o[qd] = xf(((size_t)b * p.H + oy) * p.W + ox);
-                } else if (p.resample == 1) {
-                    o[qd] = xf(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1));
-                } else if (FIR && p.resample >= 3) {
-                    auto src = [&](int y, int x) { return xf(((size_t)b * p.H + y) * p.W + x); };
-                    o[qd] = p.resample == 3 ? fir_up2(p, oy, ox, src) : fir_down2(p, oy, ox, src);
-                } else {
-                    const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
-                    const f32x4 v00 = xf(r0), v01 = xf(r0 + 1), v10 = xf(r0 + p.W), v11 = xf(r0 + p.W + 1);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[qd][j] = ((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f;
-                }
-            }
-            if constexpr (H2) {
-                half8 hi, lo;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = o[j >> 2][j & 3];
-                    hi[j] = (_Float16)v;
-                    lo[j] = (_Float16)(v - (float)hi[j]);
-                }
-                half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.y) + (opix * CV + cv) * 32);
-                dst[0] = hi;
-                dst[1] = lo;
-                if (p.y_raw) {       // resample == 0 here: raw[] holds this very pixel
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float v = raw[j >> 2][j & 3];
-                        hi[j] = (_Float16)v;
-                        lo[j] = (_Float16)(v - (float)hi[j]);
-                    }
-                    half8* dr = reinterpret_cast<half8*>(p.y_raw + (opix * CV + cv) * 32);
-                    dr[0] = hi;
-                    dr[1] = lo;
-                }
-            } else {
-                *reinterpret_cast<f32x4*>(p.y + opix * (p.C4 * 4) + cv * 4) = o[0];   // BORDER == 0: opix is the pixel
-            }
-        }
-    }
-}
-
-// fp16 in -> "h1" operand out: GroupNorm-apply over a tensor the producing convolution stored as plain fp16 (dp_conv2d_nhwc_h2
-// out_fmt 1: [B][H][W][C] fp16, no border) - the second GroupNorm of a ResBlock (FiLM + SiLU, no resampling, one source).
-// 4 HBM bytes per element instead of 6.  A thread owns one channel OCTET: 16-byte loads, 16-byte stores, lanes along the
-// channels.  Per element the arithmetic is gn_apply_h2q_kernel's on the (exactly representable) fp32 value of the fp16
-// input: identical bytes to dp_gn_apply(out_fmt 2) of the up-converted tensor.
-struct Apply16Args {
-    const _Float16* x;
-    int C, B, H, W, G;
-    const float* stats;
-    const float* gamma;
-    const float* beta;
-    const float* fscale;
-    const float* fshift;
-    int film_stride;
-    char* y;
-    int cpg;
-    FoldSrc fold;
-};
-
-template <bool ACT>
-__global__ __launch_bounds__(256) void gn_apply_f16in_kernel(Apply16Args p, int COT, int slots) {
-    const int CO = p.C / 8;
-    const int Hq = p.H + 2, Wq = p.W + 2;
-    const int b = blockIdx.x / Hq, qy = blockIdx.x - b * Hq;
-    const int oy = qy - 1;
-    const bool zrow = (unsigned)oy >= (unsigned)p.H;
-    extern __shared__ double fold_lds[];
-    const float* st = gn_stats_of(p.fold, p.stats, b, p.C, 0, p.G, fold_lds);
-    const int slot = threadIdx.x / COT;
-    const size_t orow = ((size_t)b * Hq + qy) * Wq;
-    half8 zero8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.f;
-    for (int co = threadIdx.x - slot * COT; co < CO; co += COT) {
-        float a[8], d[8];                                  // y = x*a + d before act
-#pragma unroll
-        for (int qd = 0; qd < 2; ++qd) {
-            const int c = co * 8 + qd * 4;
-            const int g = c / p.cpg;
-            const float mean = st[g * 2], rstd = st[g * 2 + 1];
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a[qd * 4 + j] = rstd * ga[j];
-                d[qd * 4 + j] = be[j] - mean * a[qd * 4 + j];
             }
             if (p.fscale) {
                 const f32x4 fs = *reinterpret_cast<const f32x4*>(p.fscale + (size_t)b * p.film_stride + c);
@@ -582,37 +526,78 @@ __global__ __launch_bounds__(256) void gn_apply_f16in_kernel(Apply16Args p, int 
                 }
             }
         }
-        auto xf = [&](half8 v) {
-            half8 o;
+        // this octet's source tensor (the channel split C1 is a multiple of 8) and its octet stride per pixel
+        const bool first = c0 < p.C1;
+        const half8* src = first ? reinterpret_cast<const half8*>(p.x1) + co : reinterpret_cast<const half8*>(p.x2) + (co - p.C1 / 8);
+        const int so = (first ? p.C1 : p.C2) / 8;
+        auto xf32 = [&](half8 v, float (&o)[8]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float u = (float)v[j] * a[j] + d[j];
-                o[j] = (_Float16)(ACT ? dp_silu_f(u) : u);
+                const float u = (float)v[j] * a[j] + d[j];
+                o[j] = ACT ? dp_silu_f(u) : u;
             }
-            return o;
+        };
+        auto xf = [&](half8 v) {
+            float o[8];
+            xf32(v, o);
+            half8 h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (_Float16)o[j];
+            return h;
         };
         half8* yrow = reinterpret_cast<half8*>(p.y) + orow * CO + co;
+        half8* rrow = p.y_raw ? reinterpret_cast<half8*>(p.y_raw) + orow * CO + co : nullptr;
         if (zrow) {
-            for (int qx = slot; qx < Wq; qx += slots) yrow[(size_t)qx * CO] = zero8;
+            for (int qx = slot; qx < Wq; qx += slots) {
+                yrow[(size_t)qx * CO] = zero8;
+                if (rrow) rrow[(size_t)qx * CO] = zero8;
+            }
             continue;
         }
-        const half8* xrow = reinterpret_cast<const half8*>(p.x) + ((size_t)b * p.H + oy) * p.W * CO + co;
         int qx = slot;
-        for (; qx + 3 * slots < Wq; qx += 4 * slots) {       // four pixels at a time: all loads issued before the first use
-            half8 rv[4];
-            bool in[4];
+        if (p.resample == 0) {
+            const half8* xrow = src + ((size_t)b * p.H + oy) * p.W * so;
+            for (; qx + 3 * slots < Wq; qx += 4 * slots) {       // four pixels at a time: all loads issued before the first use
+                half8 rv[4];
+                bool in[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ox = qx + k * slots - 1;
-                in[k] = (unsigned)ox < (unsigned)p.W;
-                rv[k] = in[k] ? xrow[(size_t)ox * CO] : zero8;
+                for (int k = 0; k < 4; ++k) {
+                    const int ox = qx + k * slots - BORDER;
+                    in[k] = (unsigned)ox < (unsigned)p.Wo;
+                    rv[k] = in[k] ? xrow[(size_t)ox * so] : zero8;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    yrow[(size_t)(qx + k * slots) * CO] = in[k] ? xf(rv[k]) : zero8;
+                    if (rrow) rrow[(size_t)(qx + k * slots) * CO] = rv[k];
+                }
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) yrow[(size_t)(qx + k * slots) * CO] = in[k] ? xf(rv[k]) : zero8;
         }
         for (; qx < Wq; qx += slots) {
-            const int ox = qx - 1;
-            yrow[(size_t)qx * CO] = (unsigned)ox < (unsigned)p.W ? xf(xrow[(size_t)ox * CO]) : zero8;
+            const int ox = qx - BORDER;
+            if ((unsigned)ox >= (unsigned)p.Wo) {
+                yrow[(size_t)qx * CO] = zero8;
+                if (rrow) rrow[(size_t)qx * CO] = zero8;
+                continue;
+            }
+            half8 o;
+            if (p.resample == 0) {
+                const half8 v = src[(((size_t)b * p.H + oy) * p.W + ox) * so];
+                o = xf(v);
+                if (rrow) rrow[(size_t)qx * CO] = v;
+            } else if (p.resample == 1) {
+                o = xf(src[(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1)) * so]);
+            } else {
+                const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
+                float v00[8], v01[8], v10[8], v11[8];
+                xf32(src[r0 * so], v00);
+                xf32(src[(r0 + 1) * so], v01);
+                xf32(src[(r0 + p.W) * so], v10);
+                xf32(src[(r0 + p.W + 1) * so], v11);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f);
+            }
+            yrow[(size_t)qx * CO] = o;
         }
     }
 }
@@ -669,17 +654,12 @@ extern "C" int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, con
 extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                            const float* stats, const float* gamma, const float* beta, const float* fscale,
                            const float* fshift, int film_stride, int act, int resample, int out_fmt, void* y,
-                           void* y_raw, const float* fir4, const float* cs1, int tile_rows1, const float* cs2, int tile_rows2,
-                           float eps, void* stream) {
+                           void* y_raw, const float* fir4, void* stream) {
     const int C = C1 + C2;
     DP_REQUIRE(x1 && y && B > 0 && H > 0 && W > 0, "dp_gn_apply: bad args");
     DP_REQUIRE(C2 == 0 || x2, "dp_gn_apply: x2 missing");
     DP_REQUIRE(C % 4 == 0 && C1 % 4 == 0, "dp_gn_apply: channel counts must be multiples of 4");
-    DP_REQUIRE(!gamma || (beta && (stats || cs1) && G > 0 && C % (4 * G) == 0), "dp_gn_apply: need beta, stats (or column records) and C %% (4*G) == 0");
-    DP_REQUIRE(!cs1 || (gamma && !stats && tile_rows1 > 0 && (H * W) % tile_rows1 == 0 && (H * W) / tile_rows1 <= FOLD_MAX_TILES &&
-                        (C2 == 0 || (cs2 && tile_rows2 > 0 && (H * W) % tile_rows2 == 0 && (H * W) / tile_rows2 <= FOLD_MAX_TILES)) && G <= 256),
-               "dp_gn_apply: folded statistics need the column records of every source, whole record tiles per sample and at most %d "
-               "tiles per sample (H*W = %d)", FOLD_MAX_TILES, H * W);
+    DP_REQUIRE(!gamma || (beta && stats && G > 0 && C % (4 * G) == 0), "dp_gn_apply: need beta, stats and C %% (4*G) == 0");
     DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply: FiLM scale and shift come together");
     DP_REQUIRE(resample >= 0 && resample <= 4, "dp_gn_apply: resample mode %d", resample);
     DP_REQUIRE((resample != 2 && resample != 4) || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply: 2x down-sampling needs even H, W");
@@ -690,40 +670,30 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     DP_REQUIRE(!y_raw || (out_fmt != 0 && resample == 0), "dp_gn_apply: the raw operand output needs out_fmt=1|2 and no resampling");
     ApplyArgs p{x1, x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, act, resample, (float*)y,
                 C / 4, gamma ? C / G : C, (resample == 1 || resample == 3) ? 2 * H : ((resample == 2 || resample == 4) ? H / 2 : H),
-                (resample == 1 || resample == 3) ? 2 * W : ((resample == 2 || resample == 4) ? W / 2 : W), (char*)y_raw, {0.f, 0.f, 0.f, 0.f},
-                FoldSrc{cs1, cs2, tile_rows1, C2 ? tile_rows2 : 1, H * W, eps}};
-    const size_t shm = cs1 ? (size_t)C * 16 + (size_t)G * 8 : 0;      // folded statistics: 2 C doubles + G (mean, rstd) pairs
+                (resample == 1 || resample == 3) ? 2 * W : ((resample == 2 || resample == 4) ? W / 2 : W), (char*)y_raw, {0.f, 0.f, 0.f, 0.f}};
     if (resample >= 3)
         for (int i = 0; i < 4; ++i) p.fir[i] = fir4[i];
-    const int CV = out_fmt ? C / 8 : C / 4;
-    const int CVT = CV < 256 ? CV : 256, slots = 256 / CVT;
+    const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;     // operand formats: C % 8 == 0, so CQ and CQT are even
     const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));
-#define GN_APPLY_LAUNCH(H2_, ACT_) \
+#define GN_APPLY_LAUNCH(ACT_) \
     do {                                                                                                                              \
-        if (resample >= 3) hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_, true>), dim3(rows), dim3(CVT * slots), shm, (hipStream_t)stream, p, CVT, slots);   \
-        else hipLaunchKernelGGL((gn_apply_kernel<H2_, ACT_, false>), dim3(rows), dim3(CVT * slots), shm, (hipStream_t)stream, p, CVT, slots);              \
+        if (resample >= 3) hipLaunchKernelGGL((gn_apply_kernel<ACT_, true>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);   \
+        else hipLaunchKernelGGL((gn_apply_kernel<ACT_, false>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);              \
     } while (0)
 #define GN_H2Q_LAUNCH(ACT_, FMT_)                                                                                                      \
     do {                                                                                                                              \
-        if (resample >= 3) hipLaunchKernelGGL((gn_apply_h2q_kernel<ACT_, FMT_, true>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);  \
-        else hipLaunchKernelGGL((gn_apply_h2q_kernel<ACT_, FMT_, false>), dim3(rows), dim3(CQT * qslots), shm, (hipStream_t)stream, p, CQT, qslots);             \
+        if (resample >= 3) hipLaunchKernelGGL((gn_apply_h2q_kernel<ACT_, FMT_, true>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);  \
+        else hipLaunchKernelGGL((gn_apply_h2q_kernel<ACT_, FMT_, false>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);             \
     } while (0)
-    // h2 output: the lane-contiguous quad kernel unless DP_GN_APPLY_QUAD=0 (A/B switch; both give identical bytes)
-    const bool quad = dp_tune(DP_T_GN_APPLY_QUAD) != 0;
     if (out_fmt == 2) {
-        const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;
         if (act) GN_H2Q_LAUNCH(true, 2);
         else GN_H2Q_LAUNCH(false, 2);
-    } else if (out_fmt && quad) {
-        const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;     // C % 8 == 0: CQ and CQT are even
+    } else if (out_fmt == 1) {
         if (act) GN_H2Q_LAUNCH(true, 1);
         else GN_H2Q_LAUNCH(false, 1);
-    } else if (out_fmt) {
-        if (act) GN_APPLY_LAUNCH(true, true);
-        else GN_APPLY_LAUNCH(true, false);
     } else {
-        if (act) GN_APPLY_LAUNCH(false, true);
-        else GN_APPLY_LAUNCH(false, false);
+        if (act) GN_APPLY_LAUNCH(true);
+        else GN_APPLY_LAUNCH(false);
     }
 #undef GN_APPLY_LAUNCH
 #undef GN_H2Q_LAUNCH
@@ -731,23 +701,38 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     return 0;
 }
 
-extern "C" int dp_gn_apply_f16in(const void* x16, int C, int B, int H, int W, int G, const float* stats, const float* gamma,
-                                 const float* beta, const float* fscale, const float* fshift, int film_stride, int act, void* y,
-                                 const float* cs1, int tile_rows1, float eps, void* stream) {
-    DP_REQUIRE(x16 && y && (stats || cs1) && gamma && beta && B > 0 && H > 0 && W > 0 && G > 0, "dp_gn_apply_f16in: bad args");
-    DP_REQUIRE(!cs1 || (!stats && tile_rows1 > 0 && (H * W) % tile_rows1 == 0 && (H * W) / tile_rows1 <= FOLD_MAX_TILES && G <= 256),
-               "dp_gn_apply_f16in: folded statistics need whole record tiles per sample, at most %d of them (H*W = %d)", FOLD_MAX_TILES, H * W);
-    DP_REQUIRE(C % 8 == 0 && C % (4 * G) == 0, "dp_gn_apply_f16in: need C %% 8 == 0 and C %% (4*G) == 0 (C=%d, G=%d)", C, G);
-    DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply_f16in: FiLM scale and shift come together");
-    DP_REQUIRE(dp_aligned16(x16) && dp_aligned16(y) && dp_aligned16(gamma) && dp_aligned16(beta), "dp_gn_apply_f16in: misaligned tensor");
-    DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply_f16in: misaligned FiLM rows");
-    Apply16Args p{(const _Float16*)x16, C, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, (char*)y, C / G,
-                  FoldSrc{cs1, nullptr, tile_rows1, 1, H * W, eps}};
-    const size_t shm = cs1 ? (size_t)C * 16 + (size_t)G * 8 : 0;
+// GroupNorm-apply over PLAIN fp16 tensors (the fp16 residual stream / a first convolution's fp16 output): see gn_apply_h16_kernel.
+// out_fmt 2 = the zero-bordered "h1" operand [B][Ho+2][Wo+2][C]; 3 = a plain fp16 tensor [B][Ho][Wo][C].  resample: 0 | 1 (2x
+// nearest up) | 2 (2x2 mean down).  gamma == NULL: no normalisation (conversion / resampling only).
+extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, int B, int H, int W, int G, const float* stats,
+                               const float* gamma, const float* beta, const float* fscale, const float* fshift, int film_stride,
+                               int act, int resample, int out_fmt, void* y, void* y_raw, void* stream) {
+    const int C = C1 + C2;
+    DP_REQUIRE(x1 && y && B > 0 && H > 0 && W > 0, "dp_gn_apply_h16: bad args");
+    DP_REQUIRE(C2 == 0 || x2, "dp_gn_apply_h16: x2 missing");
+    DP_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "dp_gn_apply_h16: channel counts must be multiples of 8 (C1=%d, C2=%d)", C1, C2);
+    DP_REQUIRE(!gamma || (beta && stats && G > 0 && C % (4 * G) == 0), "dp_gn_apply_h16: need beta, stats and C %% (4*G) == 0");
+    DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "dp_gn_apply_h16: FiLM scale and shift come together");
+    DP_REQUIRE(resample >= 0 && resample <= 2, "dp_gn_apply_h16: resample mode %d (0 | 1 | 2; the FIR modes run on the fp32 stream)", resample);
+    DP_REQUIRE(resample != 2 || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply_h16: 2x down-sampling needs even H, W");
+    DP_REQUIRE(out_fmt == 2 || out_fmt == 3, "dp_gn_apply_h16: out_fmt must be 2 (bordered fp16 operand) or 3 (plain fp16), got %d", out_fmt);
+    DP_REQUIRE(!y_raw || (out_fmt == 2 && resample == 0), "dp_gn_apply_h16: the raw operand output needs out_fmt=2 and no resampling");
+    DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(y) && (!y_raw || dp_aligned16(y_raw)) &&
+                   (!gamma || (dp_aligned16(gamma) && dp_aligned16(beta))), "dp_gn_apply_h16: misaligned tensor");
+    DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply_h16: misaligned FiLM rows");
+    Apply16Args p{(const _Float16*)x1, (const _Float16*)x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, resample,
+                  (char*)y, (char*)y_raw, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
+                  resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W)};
     const int CO = C / 8, COT = CO < 256 ? CO : 256, slots = 256 / COT;
-    const unsigned rows = (unsigned)(B * (H + 2));
-    if (act) hipLaunchKernelGGL((gn_apply_f16in_kernel<true>), dim3(rows), dim3(COT * slots), shm, (hipStream_t)stream, p, COT, slots);
-    else hipLaunchKernelGGL((gn_apply_f16in_kernel<false>), dim3(rows), dim3(COT * slots), shm, (hipStream_t)stream, p, COT, slots);
-    DP_LAUNCH_CHECK("gn_apply_f16in");
+    const unsigned rows = (unsigned)(B * (out_fmt == 2 ? p.Ho + 2 : p.Ho));
+    const dim3 g(rows), blk((unsigned)(COT * slots));
+    if (out_fmt == 2) {
+        if (act) hipLaunchKernelGGL((gn_apply_h16_kernel<true, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
+        else hipLaunchKernelGGL((gn_apply_h16_kernel<false, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
+    } else {
+        if (act) hipLaunchKernelGGL((gn_apply_h16_kernel<true, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
+        else hipLaunchKernelGGL((gn_apply_h16_kernel<false, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
+    }
+    DP_LAUNCH_CHECK("gn_apply_h16");
     return 0;
 }

@@ -91,7 +91,8 @@ std::tuple<Tensor, Tensor> conv2d_h2_impl(const Tensor& xh, const Tensor& wh, co
     DP_CALL(dp_conv2d_nhwc_h2(xh.data_ptr(), (int)C, (int)B, (int)H, (int)W, (int)ksize, wh.data_ptr(), (int)n_out,
                               opt_ptr(bias, "bias"), nullptr, 0, nullptr, 0, 1.f, out.data_ptr<float>(), (int)n_out,
                               want_stats ? cols.data_ptr<float>() : nullptr, want_stats ? &tile_rows : nullptr,
-                              wbytes ? work.data_ptr() : nullptr, wbytes, (int)passes, a_fmt, (int)w_fmt, /*out_fmt=*/0, cur_stream(xh)));
+                              wbytes ? work.data_ptr() : nullptr, wbytes, (int)passes, a_fmt, (int)w_fmt, /*out_fmt=*/0, /*res_fmt=*/0,
+                              /*1x1 K-segments: none*/ nullptr, 0, nullptr, 0, cur_stream(xh)));
     return {out, cols};
 }
 Tensor conv2d_h2(const Tensor& xh, const Tensor& wh, const c10::optional<Tensor>& bias, int64_t n_out, int64_t ksize, int64_t passes,
@@ -138,7 +139,7 @@ Tensor group_norm_silu(const Tensor& x, const Tensor& gamma, const Tensor& beta,
                             : at::empty({B, H + 2, W + 2, out_fmt == 1 ? 2 * C : C}, x.options().dtype(at::kHalf));
     DP_CALL(dp_gn_apply(x.data_ptr<float>(), (int)C, nullptr, 0, (int)B, (int)H, (int)W, (int)groups, stats.data_ptr<float>(),
                         gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr, nullptr, 0, act ? 1 : 0, 0, (int)out_fmt,
-                        y.data_ptr(), nullptr, nullptr, /*folded statistics: no*/ nullptr, 0, nullptr, 0, 0.f, s));
+                        y.data_ptr(), nullptr, nullptr, s));
     return y;
 }
 

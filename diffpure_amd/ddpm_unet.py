@@ -225,7 +225,7 @@ class DdpmUNet:
         P, n, co = self.p, r["name"], r["cout"]
         conv0 = self._ch2 if r["h2_0"] else ops.conv2d
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
-        st0 = ops.group_norm_stats(xa, GN_GROUPS, GN_EPS, x2a, fold=True)
+        st0 = ops.group_norm_stats(xa, GN_GROUPS, GN_EPS, x2a)
         want_raw = r.get("h2_s", False)
         h = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True, split=r["h2_0"] and self._ofmt, stats=st0,
                            raw=want_raw)
@@ -233,7 +233,7 @@ class DdpmUNet:
             h, xraw = h
         off = r["dense_off"]
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True)
-        st1 = ops.group_norm_stats(h, GN_GROUPS, GN_EPS, fold=True)
+        st1 = ops.group_norm_stats(h, GN_GROUPS, GN_EPS)
         h = h.t
         h = ops.group_norm(h, GN_GROUPS, GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
         if want_raw:
@@ -248,7 +248,7 @@ class DdpmUNet:
         P, n, c = self.p, r["name"], r["ch"]
         x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(xa, GN_GROUPS, GN_EPS, fold=True)
+        st = ops.group_norm_stats(xa, GN_GROUPS, GN_EPS)
         hn = ops.group_norm(x, GN_GROUPS, GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")           # one head of dimension C, scale C^-1/2
@@ -304,7 +304,7 @@ class DdpmUNet:
             else:
                 h = self._res(r, h, hs.pop(), dense)
         assert not hs
-        sth = ops.group_norm_stats(h, GN_GROUPS, GN_EPS, fold=True)
+        sth = ops.group_norm_stats(h, GN_GROUPS, GN_EPS)
         h = ops.tensor_of(h)
         h = ops.group_norm(h, GN_GROUPS, GN_EPS, P["out.g"], P["out.b"], act=True, split=self._out_h2 and self._ofmt, stats=sth)
         conv = self._ch2 if self._out_h2 else ops.conv2d

@@ -192,6 +192,12 @@ class GuidedUNet:
         # fp16 x fp16 modes: a ResBlock's first convolution stores its output as fp16 (its only reader is the GroupNorm-apply
         # that emits the fp16 operand of the second one) and the attention output reaches proj_out as an fp16 operand
         self._lean = self._pool is not None and os.environ.get("DIFFPURE_LEAN", "1") != "0"
+        # ... and (round 4, DIFFPURE_LEAN16=0 switches it off) the RESIDUAL STREAM itself travels as plain fp16 between the blocks -
+        # the reference's own arithmetic for this network (`use_fp16: True`, configs/imagenet.yml:18: convert_to_fp16 casts the
+        # whole torso, unet.py:626-632, so h IS fp16 there) with fp32 accumulation / epilogues / GroupNorm statistics on top.
+        # Decided in load_state_dict (every convolution on the stream must be on the fp16 matrix path); forward passes that keep a
+        # tape (the adjoints) stay fp32.
+        self._lean16 = False
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -273,6 +279,18 @@ class GuidedUNet:
         P["out.g"], P["out.b"] = vec("out.0.weight"), vec("out.0.bias")
         P["out.w"], self._out_h2 = conv_w("out.2.weight", self.plan["final_ch"])
         P["out.c"] = vec("out.2.bias")
+        res_blocks = [r for r in blocks if r["kind"] == "res"]
+        self._lean16 = (self._lean and os.environ.get("DIFFPURE_LEAN16", "1") != "0" and self._out_h2
+                        and all(r["h2_1"] and r["h2_2"] and (r["cin"] == r["cout"] or r.get("h2_s", False)) for r in res_blocks)
+                        and all(r["h2"] for r in blocks if r["kind"] == "attn"))
+        if self._lean16:
+            # the 1x1 skip_connection of a channel-changing ResBlock as 1x1 K-segments of its second 3x3 convolution (one panel
+            # [w2 | ws] next to the separate ones, which small launches and the taped forward keep using)
+            for r in res_blocks:
+                if r["cin"] != r["cout"] and not r["mode"]:
+                    n = r["name"]
+                    P[n + ".w2s"] = self._pack_h2w(ops.fuse_skip_weight(sd[n + ".out_layers.3.weight"], sd[n + ".skip_connection.weight"]))
+                    P[n + ".c2s"] = (sd[n + ".out_layers.3.bias"].detach().float() + sd[n + ".skip_connection.bias"].detach().float()).contiguous().to(dev)
         self._resolve_pool(P)
         self.p = P
         return self
@@ -302,49 +320,62 @@ class GuidedUNet:
         if getattr(self, "_gpool", None) is not None:
             self._gpool.round(key)
 
+    def _o16(self, hw, tape):
+        """is a residual-stream tensor of `hw` pixels per sample stored as plain fp16?  (fp16 x fp16 modes, no tape, and whole
+        column records per sample - an fp16 tensor's GroupNorm statistics exist only as its producer's records)"""
+        return self._lean16 and tape is None and hw % 64 == 0
+
     def _res(self, r, xa, x2a, film_table, tape=None):
-        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
+        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors; fp32, or plain
+        fp16 on the fp16 residual stream"""
         x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
         P, n, co = self.p, r["name"], r["cout"]
         G, eps = self.GN_GROUPS, self.GN_EPS
         mode = r["mode"]
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
         conv2 = self._ch2 if r["h2_2"] else ops.conv2d
-        st1 = ops.group_norm_stats(xa, G, eps, x2a, fold=tape is None)
-        want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False)
+        b = x.shape[0]
+        ho, wo = ops._out_hw(x.shape[1], x.shape[2], mode)
+        out16 = self._o16(ho * wo, tape)
+        st1 = ops.group_norm_stats(xa, G, eps, x2a)
+        # channel-changing block: the 1x1 skip as K-segments of the second convolution (fp16 stream, launches the 8-wave kernel takes)
+        c1 = x.shape[3]
+        fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w2s") in P
+                 and ops.takes_segments(b, ho, wo, 3, co, co, c1, r["cin"] - c1))
+        want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False) and not fused
         h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
                            raw=want_raw)
         if want_raw:
             h, xraw = h
         # (the taped forward keeps fp32 for the backward pass; below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
-        mid16 = self._lean and tape is None and r["h2_1"] and r["h2_2"] and ((h.shape[1] - 2) * (h.shape[2] - 2)) % 64 == 0
+        mid16 = self._lean and tape is None and r["h2_1"] and r["h2_2"] and (ho * wo) % 64 == 0
         h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True, **({"out_f16": True} if mid16 else {}))
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
-        st2 = ops.group_norm_stats(h, G, eps, fold=tape is None)
+        st2 = ops.group_norm_stats(h, G, eps)
         h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
-        if mid16:
-            h = ops.group_norm_f16in(h, G, P[n + ".g2"], P[n + ".b2"], st2, film=film, act=True)
-        else:
-            h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
+        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
+        o16 = {"out_f16": True} if out16 else {}
+        if fused:
+            return conv2(h, P[n + ".w2s"], co, 3, bias=P[n + ".c2s"], segs=(x,) if x2 is None else (x, x2), colstats=True, **o16)
         if mode:
             skip = ops.resample(x, mode)
         elif want_raw:
-            skip = self._ch2(xraw, P[n + ".ws"], co, 1, bias=P[n + ".cs"])
+            skip = self._ch2(xraw, P[n + ".ws"], co, 1, bias=P[n + ".cs"], **o16)
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".ws"], co, 1, bias=P[n + ".cs"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip, colstats=True)
+        return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip, colstats=True, **o16)
 
     def _attn(self, r, xa, tape=None):
         P, n, c = self.p, r["name"], r["ch"]
         x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS, fold=tape is None)
+        st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS)
         xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
@@ -355,9 +386,12 @@ class GuidedUNet:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv, layout=layout))
         if r.get("proj16") and ops.attention_fused_ok(hh * ww, c // r["heads"]):
             ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), r["heads"], layout, operand_hw=(hh, ww))
-            return self._ch2(ah, P[n + ".wproj16"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True)
+            return self._ch2(ah, P[n + ".wproj16"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True,
+                             **({"out_f16": True} if self._o16(hh * ww, tape) else {}))
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
-        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True)
+        # shapes the fused kernel does not cover: proj_out on the fp32 path (fp32 residual), the result in the stream's format of this level
+        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".wproj"], c, 1, bias=P[n + ".cproj"], res=x.float() if x.dtype == torch.float16 else x,
+                          colstats=True, out_f16=self._o16(hh * ww, tape))
 
     def _run(self, blk, h, h2, film, tape=None):
         for r in blk:
@@ -389,7 +423,8 @@ class GuidedUNet:
         P = self.p
         hs = []
         stem = self.plan["inp"][0][0]
-        h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"], colstats=True)
+        h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"], colstats=True,
+                       out_f16=self._o16(x.shape[1] * x.shape[2], tape))
         hs.append(h)
         for blk in self.plan["inp"][1:]:
             h = self._run(blk, h, None, film, tape)
@@ -397,7 +432,7 @@ class GuidedUNet:
         h = self._run(self.plan["mid"], h, None, film, tape)
         for blk in self.plan["out"]:
             h = self._run(blk, h, hs.pop(), film, tape)
-        st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS, fold=tape is None)
+        st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS)
         h = ops.tensor_of(h)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=st))

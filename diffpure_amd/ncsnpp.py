@@ -153,6 +153,7 @@ class NCSNpp:
         self._ch2 = functools.partial(ops.conv2d_h2, passes=passes, w_fmt=1 if self._pool is not None else 0)
         # fp16 x fp16 modes: the first convolution of a ResBlock stores its output as fp16 (see GuidedUNet)
         self._lean = self._pool is not None and os.environ.get("DIFFPURE_LEAN", "1") != "0"
+        self._lean16 = False         # fp16 residual stream: decided in load_state_dict
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -232,6 +233,18 @@ class NCSNpp:
         P["dense.w"] = ops.pack_linear_weight(torch.cat(dw, dim=0)).to(dev)
         P["dense.b"] = torch.cat(db, dim=0).contiguous().to(dev)
         self.dense_cols = off
+        # fp16 residual stream (round 4; see GuidedUNet.__init__): every convolution on the stream on the fp16 matrix path, no FIR
+        # resampling (its stencils live in the fp32 GroupNorm-apply kernels); DIFFPURE_LEAN16=0 switches it off
+        res_recs = [r for r in recs if r["kind"] == "res"]
+        self._lean16 = (self._lean and os.environ.get("DIFFPURE_LEAN16", "1") != "0" and not self._fir
+                        and all(r["h2_0"] and r["h2_1"] and ((r["cin"] == r["cout"] and not r["mode"]) or r.get("h2_s", False)) for r in res_recs)
+                        and all(r["h2"] for r in recs if r["kind"] == "attn"))
+        if self._lean16:
+            for r in res_recs:      # Conv_2 (1x1 shortcut) as K-segments of Conv_1: one fused panel next to the separate ones
+                if r["cin"] != r["cout"] and not r["mode"]:
+                    p, n = M + str(r["idx"]), str(r["idx"])
+                    P[n + ".w1s"] = self._pack_h2w(ops.fuse_skip_weight(sd[p + ".Conv_1.weight"], sd[p + ".Conv_2.weight"]))
+                    P[n + ".c1s"] = (sd[p + ".Conv_1.bias"].detach().float() + sd[p + ".Conv_2.bias"].detach().float()).contiguous().to(dev)
         gi, ci = self.plan["gn_idx"], self.plan["conv_idx"]
         P["out.g"], P["out.b"] = vec(M + f"{gi}.weight"), vec(M + f"{gi}.bias")
         (P["out.w"], self._out_h2), P["out.c"] = conv_w(M + f"{ci}.weight", self.plan["final_ch"]), vec(M + f"{ci}.bias")
@@ -269,17 +282,30 @@ class NCSNpp:
         if getattr(self, "_gpool", None) is not None:
             self._gpool.round(key)
 
+    def _o16(self, hw, tape):
+        """is a residual-stream tensor of `hw` pixels per sample stored as plain fp16?  (see GuidedUNet._o16)"""
+        return self._lean16 and tape is None and hw % 64 == 0
+
     def _res(self, r, xa, x2a, dense, tape=None):
-        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors"""
+        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors; fp32, or plain
+        fp16 on the fp16 residual stream"""
         x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
         P, n, co = self.p, str(r["idx"]), r["cout"]
         mode = self._rmode(r["mode"])
         fir = self._fir
         conv0 = self._ch2 if r["h2_0"] else ops.conv2d
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
-        st0 = ops.group_norm_stats(xa, self._groups(r["cin"]), self.GN_EPS, x2a, fold=tape is None)
+        b = x.shape[0]
+        ho, wo = ops._out_hw(x.shape[1], x.shape[2], mode)
+        out16 = self._o16(ho * wo, tape)
+        o16 = {"out_f16": True} if out16 else {}
+        st0 = ops.group_norm_stats(xa, self._groups(r["cin"]), self.GN_EPS, x2a)
         h2s = r.get("h2_s", False)
-        want_raw = h2s and not mode
+        # channel-changing block without resampling: Conv_2 (the 1x1 shortcut, layerspp.py:268-272) as K-segments of Conv_1
+        c1 = x.shape[3]
+        fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
+                 and ops.takes_segments(b, ho, wo, 3, co, co, c1, r["cin"] - c1))
+        want_raw = h2s and not mode and not fused
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
                            resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw, fir=fir)
         if want_raw:
@@ -287,35 +313,34 @@ class NCSNpp:
         off = r["dense_off"]
         # (the taped forward keeps fp32 for the backward pass; below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
-        mid16 = (self._lean and tape is None and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0
-                 and ((h.shape[1] - 2) * (h.shape[2] - 2)) % 64 == 0)
+        mid16 = (self._lean and tape is None and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0 and (ho * wo) % 64 == 0)
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True, **({"out_f16": True} if mid16 else {}))
-        st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS, fold=tape is None)
+        st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
         h = h.t
         if tape is not None:
             tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
-        if mid16:
-            h = ops.group_norm_f16in(h, self._groups(co), P[n + ".g1"], P[n + ".b1"], st1, act=True)
-        else:
-            h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
+        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
+        if fused:
+            return conv1(h, P[n + ".w1s"], co, 3, bias=P[n + ".c1s"], segs=(x,) if x2 is None else (x, x2), scale=INV_SQRT2,
+                         colstats=True, **o16)
         if mode:
             if h2s:
-                skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+                skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"], **o16)
             else:
                 skip = ops.conv2d(ops.resample(x, mode, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"])
         elif want_raw:
-            skip = self._ch2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"])
+            skip = self._ch2(xraw, P[n + ".w2"], co, 1, bias=P[n + ".c2"], **o16)
         elif r["cin"] != co:
             skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2, colstats=True)
+        return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2, colstats=True, **o16)
 
     def _attn(self, r, xa, tape=None):
         P, n, c = self.p, str(r["idx"]), r["ch"]
         x = ops.tensor_of(xa)
         b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS, fold=tape is None)
+        st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS)
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
         # the taped forward keeps only qkv; the probabilities are recomputed per block in the backward pass (see GuidedUNet._attn)
@@ -323,9 +348,12 @@ class NCSNpp:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv))
         if r.get("proj16") and ops.attention_fused_ok(hh * ww, c):      # with or without a tape, as GuidedUNet._attn
             ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), 1, "split", operand_hw=(hh, ww))
-            return self._ch2(ah, P[n + ".w3h"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True)
+            return self._ch2(ah, P[n + ".w3h"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True,
+                             **({"out_f16": True} if self._o16(hh * ww, tape) else {}))
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), 1, "split")
-        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True)
+        # shapes the fused kernel does not cover: NIN_3 on the fp32 path (fp32 residual), the result in the stream's format of this level
+        return ops.conv2d(a.view(b, hh, ww, c), P[n + ".w3"], c, 1, bias=P[n + ".c3"], res=x.float() if x.dtype == torch.float16 else x,
+                          scale=INV_SQRT2, colstats=True, out_f16=self._o16(hh * ww, tape))
 
     def time_table(self, labels):
         """labels: float32 GPU tensor [R] (= 999*s). -> Dense_0 rows of every ResBlock [R, sum(cout)]."""
@@ -341,7 +369,7 @@ class NCSNpp:
         P = self.p
         dense = table_row if table_row is not None else self.time_table(labels)
         st = self.plan["stem"]
-        hs = [ops.conv2d(x, P["stem.w"], st["cout"], 3, bias=P["stem.b"], colstats=True)]
+        hs = [ops.conv2d(x, P["stem.w"], st["cout"], 3, bias=P["stem.b"], colstats=True, out_f16=self._o16(x.shape[1] * x.shape[2], tape))]
         for blk in self.plan["down"]:
             h = hs[-1]
             for r in blk:
@@ -359,7 +387,7 @@ class NCSNpp:
                 h = self._res(r, h, None, dense, tape)
         assert not hs
         g = self._groups(self.plan["final_ch"])
-        sth = ops.group_norm_stats(h, g, self.GN_EPS, fold=tape is None)
+        sth = ops.group_norm_stats(h, g, self.GN_EPS)
         h = ops.tensor_of(h)
         if tape is not None:
             tape.append(dict(head=True, x=h, st=sth))

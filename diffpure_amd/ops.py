@@ -108,12 +108,32 @@ def order_conv_weight_w16(w):
     so that the (lane-ordered) B fragment of one 32x32x16 MFMA - 32 rows x 2 groups - is 1 KB of contiguous memory (a wave loads
     it with one coalesced 16-byte-per-lane instruction, igemm_h2_sw.hip) and a 64-byte LDS row of a 32-channel k-tile is four
     16-byte pieces 512 bytes apart (the LDS-DMA loaders gather them: every lane has its own address anyway)."""
-    wk = order_conv_weight_h2(w)                        # [N, K] in reduction order
+    wk = w.t if isinstance(w, PreOrdered) else order_conv_weight_h2(w)   # [N, K] in reduction order
     n, k = wk.shape
     n32 = (n + 31) // 32 * 32
     if n32 != n:
         wk = torch.cat([wk, wk.new_zeros(n32 - n, k)], dim=0)
     return wk.reshape(n32 // 32, 32, k // 8, 8).permute(0, 2, 1, 3).reshape(n32, k).contiguous()
+
+
+class PreOrdered:
+    """an fp32 weight matrix [N, K] that is ALREADY in the reduction order of the kernels (fuse_skip_weight)"""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def fuse_skip_weight(w3, ws):
+    """[N, KS*KS*C | C_skip] in reduction order: the k' order of the KS x KS convolution `w3`, then the input channels of the
+    1x1 skip convolution `ws` (OI / OI11; its channels in their own order - the 1x1 K-segments of conv2d_h2 run over the raw
+    input tensors channel by channel).  -> PreOrdered, which order_conv_weight_w16 / WeightPool.add take as already ordered."""
+    if ws.dim() == 4:
+        ws = ws[:, :, 0, 0]
+    elif ws.dim() == 3:
+        ws = ws[:, :, 0]
+    assert ws.shape[1] % 32 == 0 and ws.shape[0] == w3.shape[0], (ws.shape, w3.shape)
+    return PreOrdered(torch.cat([order_conv_weight_h2(w3.detach()), ws.detach().float()], dim=1).contiguous())
 
 
 def unorder_conv_weight_w16(panel, n_out):
@@ -144,7 +164,7 @@ class WeightPool:
 
     def add(self, name, w):
         """register the OIHW / OI / OIk weight `w` under `name`; the panel view is available after finalize()"""
-        self._pending.append((name, order_conv_weight_w16(w.detach())))
+        self._pending.append((name, order_conv_weight_w16(w if isinstance(w, PreOrdered) else w.detach())))
 
     def finalize(self):
         total = sum(p.numel() for _, p in self._pending)
@@ -249,7 +269,8 @@ def _fmt_of(split):
     raise ValueError(f"unknown operand format {split!r}")
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False,
+              segs=None):
     """conv2d on the fp16 matrix cores; same epilogue contract as conv2d.  wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2),
     or with w_fmt=1 the plain fp16 panel [N32, K] in the block layout of order_conv_weight_w16 (WeightPool; one pass, h1
     activations).
@@ -257,11 +278,24 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     product, `passes` 3, or 12 for the weights-rounded study mode) or h1 [B, H+2, W+2, C] fp16 (`passes` 2 or 1).
     The activation format is read off the shapes; `passes` defaults to the full arithmetic of the formats (3 / 2 / 1).
     out_f16=True: the result is stored as PLAIN fp16 [B, H, W, N] (rounded to nearest; the column statistics are those of
-    the unrounded values) - for a tensor whose only consumer is `group_norm_f16in` (the first convolution of a ResBlock)."""
+    the unrounded values).  res: fp32 or plain fp16 [B, H, W, N] (the fp16 residual stream).
+    segs=(s1,) | (s1, s2): 1x1 K-segments - plain fp16 NHWC tensors [B, H, W, Cs] whose weight columns follow the KS x KS
+    part in `wh` (fuse_skip_weight): out += cat(s1, s2) . wh[:, KS*KS*C:] - a ResBlock's 1x1 skip folded into this
+    convolution.  Only where takes_segments(...) says so."""
     _chk_h2(x, "conv2d_h2.x")
     _chk_h2(wh, "conv2d_h2.w")
     b, h, w = x.shape[0], x.shape[1] - 2, x.shape[2] - 2
-    c = wh.shape[1] // ((1 if w_fmt else 2) * ksize * ksize)
+    sc = [0, 0]
+    sp = [None, None]
+    if segs:
+        assert w_fmt == 1 and 1 <= len(segs) <= 2
+        for i, sg in enumerate(segs):
+            if not (isinstance(sg, torch.Tensor) and sg.is_cuda and sg.dtype == torch.float16 and sg.is_contiguous() and sg.dim() == 4
+                    and tuple(sg.shape[:3]) == (b, h, w)):
+                raise _lib.DiffpureHipError(f"conv2d_h2: K-segment {i} must be a contiguous fp16 GPU tensor [B, H, W, Cs] at the output resolution")
+            sc[i], sp[i] = sg.shape[3], sg.data_ptr()
+    kk = wh.shape[1] // (1 if w_fmt else 2) - sc[0] - sc[1]
+    c = kk // (ksize * ksize)
     if x.shape[3] == 2 * c:
         a_fmt = 0
     elif x.shape[3] == c:
@@ -271,7 +305,7 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     if passes is None:
         passes = 1 if w_fmt else (2 if a_fmt else 3)
     if w_fmt:
-        assert wh.shape == ((n_out + 31) // 32 * 32, ksize * ksize * c), (wh.shape, n_out, ksize, c)
+        assert wh.shape == ((n_out + 31) // 32 * 32, ksize * ksize * c + sc[0] + sc[1]), (wh.shape, n_out, ksize, c, sc)
     else:
         assert wh.shape == (n_out, 2 * ksize * ksize * c), (wh.shape, n_out, ksize, c)
     if bias is not None:
@@ -282,10 +316,15 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
         assert temb.shape[0] in (1, b) and temb.shape[1] >= n_out
         ts = 0 if temb.shape[0] == 1 else temb.stride(0)
     out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
-    ldr = 0
+    ldr, rfmt = 0, 0
     if res is not None:
-        _chk(res, "conv2d_h2.res", 4)
-        assert res.shape == out.shape
+        if res.dtype == torch.float16:
+            if not (res.is_cuda and res.is_contiguous() and res.dim() == 4):
+                raise _lib.DiffpureHipError("conv2d_h2.res: expected a contiguous fp16 GPU tensor")
+            rfmt = 1
+        else:
+            _chk(res, "conv2d_h2.res", 4)
+        assert res.shape == out.shape, (res.shape, out.shape)
         ldr = n_out
     cs, tr = _colstats_alloc(b * h * w, n_out, x.device) if colstats else (None, None)
     # low-resolution levels are reduced with split-K (factor fixed by the layer shape): scratch for the partial sums
@@ -293,14 +332,20 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     work = torch.empty((wbytes // 4,), device=x.device, dtype=torch.float32) if wbytes else None
     _lib.call("dp_conv2d_nhwc_h2", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(bias), _ptr(temb), ts, _ptr(res),
               ldr, float(scale), _ptr(out), n_out, _ptr(cs), None if tr is None else ctypes.addressof(tr), _ptr(work), wbytes,
-              int(passes), a_fmt, int(w_fmt), 1 if out_f16 else 0, _stream())
+              int(passes), a_fmt, int(w_fmt), 1 if out_f16 else 0, rfmt, sp[0], sc[0], sp[1], sc[1], _stream())
     return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
 
-def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False):
+def takes_segments(b, h, w, ksize, c, n_out, c1, c2=0):
+    """would conv2d_h2 (fp16 x fp16) run this launch on the kernel that accepts 1x1 K-segments of c1 (+ c2) channels?"""
+    return bool(_lib.load().dp_conv2d_nhwc_h2_takes_segments(b, h, w, ksize, c, n_out, c1, c2))
+
+
+def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False, out_f16=False):
     """out = scale * (res + bias + temb[b] + conv_{ksize x ksize, same}(cat(x, x2)))   (NHWC).
     colstats=True: the epilogue also reduces per-column partial sums and the call returns Act(out, records), which
-    `group_norm_stats` turns into GroupNorm statistics without reading the tensor again."""
+    `group_norm_stats` turns into GroupNorm statistics without reading the tensor again.
+    out_f16=True: the result is stored as plain fp16 (the stem of a network whose residual stream is fp16)."""
     _chk(x, "conv2d.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0
@@ -320,7 +365,8 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
         assert temb.shape[0] in (1, b) and temb.shape[1] >= n_out
         ts = 0 if temb.shape[0] == 1 else temb.stride(0)
     if out is None:
-        out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float32)
+        out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
+    assert out.dtype == (torch.float16 if out_f16 else torch.float32)
     ldr = 0
     if res is not None:
         _chk(res, "conv2d.res", 4)
@@ -328,7 +374,7 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
         ldr = n_out
     cs, tr = _colstats_alloc(b * h * w, n_out, x.device) if colstats else (None, None)
     _lib.call("dp_conv2d_nhwc", _ptr(x), c1, _ptr(x2), c2, b, h, w, ksize, ksize, _ptr(wp), wp.shape[1], n_out,
-              _ptr(bias), _ptr(temb), ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, 0, _ptr(cs),
+              _ptr(bias), _ptr(temb), ts, _ptr(res), ldr, float(scale), _ptr(out), n_out, 1 if out_f16 else 0, _ptr(cs),
               None if tr is None else ctypes.addressof(tr), _stream())
     return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
@@ -380,45 +426,25 @@ def _nsplit(hw):
     return max(1, min(hw // 256, 128))
 
 
-class FoldedStats:
-    """GroupNorm statistics that are NOT finalized by a launch of their own: the GroupNorm-apply kernel reduces the column
-    records of its sample itself (dp_gn_apply with cs1 != NULL).  Returned by group_norm_stats(fold=True) for small feature
-    maps (a sample of at most FOLD_MAX_TILES record tiles), where the finalize launch costs more than it computes: 122
-    launches of 11 us per NCSN++ call = 5 % of a CIFAR-10 purification."""
-    __slots__ = ("k1", "k2", "eps", "groups")
-
-    def __init__(self, k1, k2, eps, groups):
-        self.k1, self.k2, self.eps, self.groups = k1, k2, eps, groups
-
-
-FOLD_MAX_TILES = 16     # csrc/norm.hip
-
-
-def _fold_wanted():
-    return get_tuning("DP_GN_FOLD") != 0
-
-
-def group_norm_stats(x, groups, eps, x2=None, fold=False):
+def group_norm_stats(x, groups, eps, x2=None):
     """-> stats [B, G, 2] = (mean, rstd) of cat(x, x2) per (sample, group).  x / x2: tensors, or `Act` pairs whose
-    column records (from the producing convolutions' epilogues) make the pass over the data unnecessary.
-    fold=True (forward passes that keep no tape): where the feature map is small enough, return a `FoldedStats` handle
-    instead - `group_norm` / `group_norm_f16in` accept it in place of the tensor and no finalize kernel is launched."""
+    column records (from the producing convolutions' epilogues) make the pass over the data unnecessary.  fp16 tensors
+    (a convolution's fp16 output, the fp16 residual stream) exist ONLY with their records: their statistics are those of the
+    unrounded values the epilogue summed."""
     k1 = x.cols if isinstance(x, Act) else None
     k2 = x2.cols if isinstance(x2, Act) else None
     x, x2 = tensor_of(x), tensor_of(x2)
-    if fold and k1 is not None and (x2 is None or k2 is not None) and x.dim() == 4 and _fold_wanted():
-        hw_ = x.shape[1] * x.shape[2]
-        ok = lambda k: hw_ % k.tile_rows == 0 and hw_ // k.tile_rows <= FOLD_MAX_TILES
-        if ok(k1) and (k2 is None or ok(k2)):
-            return FoldedStats(k1, k2, float(eps), groups)
-    if x.dtype == torch.float16 and x2 is None:
-        # a convolution's fp16 output (conv2d_h2 out_f16): its statistics exist only as the epilogue's column records
-        if k1 is None or not x.is_cuda or x.dim() != 4 or (x.shape[1] * x.shape[2]) % k1.tile_rows != 0:
-            raise _lib.DiffpureHipError("gn.x: an fp16 activation needs the column records of its producing convolution")
+    half = x.dtype == torch.float16
+    if half:
+        ok = x.is_cuda and x.dim() == 4 and k1 is not None and (x.shape[1] * x.shape[2]) % k1.tile_rows == 0
+        if x2 is not None:
+            ok = ok and x2.dtype == torch.float16 and k2 is not None and (x.shape[1] * x.shape[2]) % k2.tile_rows == 0
+        if not ok:
+            raise _lib.DiffpureHipError("gn.x: an fp16 activation needs the column records of its producing convolution (both sources)")
     else:
         _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
-    c2 = 0 if x2 is None else _chk(x2, "gn.x2", 4).shape[3]
+    c2 = 0 if x2 is None else (x2.shape[3] if half else _chk(x2, "gn.x2", 4).shape[3])
     hw = h * w
     stats = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
     s = _stream()
@@ -434,6 +460,22 @@ def group_norm_stats(x, groups, eps, x2=None, fold=False):
     return stats
 
 
+def _film_args(film, b, c):
+    if film is None:
+        return None, None, 0
+    fs, fh = film
+    assert fs.is_cuda and fs.dtype == torch.float32 and fs.shape[-1] == c and fs.stride(-1) == 1
+    assert fh.shape == fs.shape and fh.stride() == fs.stride()
+    assert fs.shape[0] in (1, b)
+    return fs, fh, (0 if fs.shape[0] == 1 else fs.stride(0))
+
+
+def _chk_f16(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous() or t.dim() != 4:
+        raise _lib.DiffpureHipError(f"{name}: expected a contiguous fp16 GPU tensor [B, H, W, C]")
+    return t
+
+
 def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
                split=False, raw=False, fir=None):
     """y = resample(act(FiLM(GroupNorm(cat(x, x2))))).  film = (scale [R,C], shift [R,C]) with R in
@@ -441,21 +483,20 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     split=True / "h2" writes the split-fp16 operand format of conv2d_h2 with its one-pixel zero border
     ([B, Ho+2, Wo+2, 2C] fp16), split="h1" the plain-fp16 operand ([B, Ho+2, Wo+2, C] fp16).  raw=True (with
     split, no resampling) additionally returns the un-normalised cat(x, x2) in the same operand format (input of
-    a 1x1 skip convolution)."""
+    a 1x1 skip convolution).
+    x (and x2) may be PLAIN fp16 tensors [B, H, W, C] (a convolution's fp16 output / the fp16 residual stream): then `stats`
+    is required, split must be "h1", and the pass moves 4 instead of 6 bytes per element (dp_gn_apply_h16)."""
+    if isinstance(x, torch.Tensor) and x.dtype == torch.float16:
+        if _fmt_of(split) != FMT_H1 or stats is None:
+            raise _lib.DiffpureHipError("group_norm: an fp16 input goes to the 'h1' operand format and needs its statistics")
+        return _group_norm_h16(x, groups, gamma, beta, stats, x2, film, act, resample, 2, raw)
     _chk(x, "gn.x", 4)
     b, h, w, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
     c = c1 + c2
     if stats is None:
         stats = group_norm_stats(x, groups, eps, x2)
-    fs = fh = None
-    fstride = 0
-    if film is not None:
-        fs, fh = film
-        assert fs.is_cuda and fs.dtype == torch.float32 and fs.shape[-1] == c and fs.stride(-1) == 1
-        assert fh.shape == fs.shape and fh.stride() == fs.stride()
-        assert fs.shape[0] in (1, b)
-        fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
+    fs, fh, fstride = _film_args(film, b, c)
     ho, wo = _out_hw(h, w, resample)
     fmt = _fmt_of(split)
     fkeep, fptr = _fir_arg(resample, fir)
@@ -467,15 +508,32 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     if raw:
         assert fmt and resample == RESAMPLE_NONE
         yr = torch.empty_like(y)
-    if isinstance(stats, FoldedStats):
-        f = stats
-        assert f.groups == groups and (f.k2 is None) == (x2 is None)
-        fold = (_ptr(f.k1.buf), f.k1.tile_rows, None if f.k2 is None else _ptr(f.k2.buf), 0 if f.k2 is None else f.k2.tile_rows, f.eps)
-        stats = None
-    else:
-        fold = (None, 0, None, 0, 0.0)
     _lib.call("dp_gn_apply", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta),
-              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), fptr, *fold, _stream())
+              _ptr(fs), _ptr(fh), fstride, 1 if act else 0, resample, fmt, _ptr(y), _ptr(yr), fptr, _stream())
+    return (y, yr) if raw else y
+
+
+def _group_norm_h16(x, groups, gamma, beta, stats, x2, film, act, resample, out_fmt, raw=False):
+    """dp_gn_apply_h16: fp16 [B, H, W, C1 (+ C2)] -> out_fmt 2: the zero-bordered 'h1' operand; 3: a plain fp16 tensor"""
+    _chk_f16(x, "gn.x16")
+    b, h, w, c1 = x.shape
+    c2 = 0
+    if x2 is not None:
+        _chk_f16(x2, "gn.x2_16")
+        assert x2.shape[:3] == x.shape[:3], (x.shape, x2.shape)
+        c2 = x2.shape[3]
+    c = c1 + c2
+    if resample not in (RESAMPLE_NONE, RESAMPLE_UP, RESAMPLE_DOWN):
+        raise _lib.DiffpureHipError("group_norm: the FIR resampling modes run on the fp32 residual stream")
+    fs, fh, fstride = _film_args(film, b, c)
+    ho, wo = _out_hw(h, w, resample)
+    y = torch.empty((b, ho + 2, wo + 2, c) if out_fmt == 2 else (b, ho, wo, c), device=x.device, dtype=torch.float16)
+    yr = None
+    if raw:
+        assert out_fmt == 2 and resample == RESAMPLE_NONE
+        yr = torch.empty_like(y)
+    _lib.call("dp_gn_apply_h16", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
+              fstride, 1 if act else 0, resample, out_fmt, _ptr(y), _ptr(yr), _stream())
     return (y, yr) if raw else y
 
 
@@ -483,26 +541,7 @@ def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
     """GroupNorm-apply (+FiLM) (+SiLU) of a tensor its producing convolution stored as plain fp16 (conv2d_h2 out_f16=True):
     x16 [B, H, W, C] fp16 -> the zero-bordered "h1" operand [B, H+2, W+2, C] fp16 of the next convolution.  Same values as
     group_norm(x16.float(), ..., split="h1") at 4 instead of 6 HBM bytes per element."""
-    if not isinstance(x16, torch.Tensor) or not x16.is_cuda or x16.dtype != torch.float16 or not x16.is_contiguous() or x16.dim() != 4:
-        raise _lib.DiffpureHipError("group_norm_f16in.x16: expected a contiguous fp16 GPU tensor [B, H, W, C]")
-    b, h, w, c = x16.shape
-    fs = fh = None
-    fstride = 0
-    if film is not None:
-        fs, fh = film
-        assert fs.is_cuda and fs.dtype == torch.float32 and fs.shape[-1] == c and fs.stride(-1) == 1
-        assert fh.shape == fs.shape and fh.stride() == fs.stride()
-        assert fs.shape[0] in (1, b)
-        fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
-    y = torch.empty((b, h + 2, w + 2, c), device=x16.device, dtype=torch.float16)
-    if isinstance(stats, FoldedStats):
-        assert stats.groups == groups and stats.k2 is None
-        fold, stats = (_ptr(stats.k1.buf), stats.k1.tile_rows, stats.eps), None
-    else:
-        fold = (None, 0, 0.0)
-    _lib.call("dp_gn_apply_f16in", _ptr(x16), c, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh), fstride,
-              1 if act else 0, _ptr(y), *fold, _stream())
-    return y
+    return _group_norm_h16(x16, groups, gamma, beta, stats, None, film, act, RESAMPLE_NONE, 2)
 
 
 def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False,
@@ -591,7 +630,12 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
 
 def to_h2(x, mode=RESAMPLE_NONE, fmt="h2", fir=None):
     """fp32 NHWC -> zero-bordered convolution operand without normalisation, optionally through the 2x resampler
-    (`mode`): fmt "h2" -> [B, H'+2, W'+2, 2C] fp16 (hi|lo octets), "h1" -> [B, H'+2, W'+2, C] plain fp16."""
+    (`mode`): fmt "h2" -> [B, H'+2, W'+2, 2C] fp16 (hi|lo octets), "h1" -> [B, H'+2, W'+2, C] plain fp16.  A plain fp16
+    input (the fp16 residual stream) goes to "h1"."""
+    if isinstance(x, torch.Tensor) and x.dtype == torch.float16:
+        if _fmt_of(fmt) != FMT_H1:
+            raise _lib.DiffpureHipError("to_h2: an fp16 input goes to the 'h1' operand format")
+        return _group_norm_h16(x, 1, None, None, None, None, None, False, mode, 2)
     _chk(x, "to_h2.x", 4)
     b, h, w, c = x.shape
     f = _fmt_of(fmt)
@@ -599,7 +643,7 @@ def to_h2(x, mode=RESAMPLE_NONE, fmt="h2", fir=None):
     ho, wo = _out_hw(h, w, mode)
     fkeep, fptr = _fir_arg(mode, fir)
     y = torch.empty((b, ho + 2, wo + 2, (2 * c) if f == FMT_H2 else c), device=x.device, dtype=torch.float16)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, f, _ptr(y), None, fptr, None, 0, None, 0, 0.0, _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, f, _ptr(y), None, fptr, _stream())
     return y
 
 
@@ -615,13 +659,15 @@ def dgrad_weight(w):
 
 def resample(x, mode, fir=None):
     """Nearest x2 up (mode 1), 2x2 mean down (2) or the FIR x2 up / down of `fir: True` networks (3 / 4, taps `fir`) of an
-    NHWC tensor, no normalisation."""
+    NHWC tensor, no normalisation.  A plain fp16 tensor (the fp16 residual stream) stays fp16."""
+    if isinstance(x, torch.Tensor) and x.dtype == torch.float16:
+        return _group_norm_h16(x, 1, None, None, None, None, None, False, mode, 3)
     _chk(x, "resample.x", 4)
     b, h, w, c = x.shape
     ho, wo = _out_hw(h, w, mode)
     fkeep, fptr = _fir_arg(mode, fir)
     y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
-    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), None, fptr, None, 0, None, 0, 0.0, _stream())
+    _lib.call("dp_gn_apply", _ptr(x), c, None, 0, b, h, w, 1, None, None, None, None, None, 0, 0, mode, 0, _ptr(y), None, fptr, _stream())
     return y
 
 

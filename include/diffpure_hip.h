@@ -64,7 +64,9 @@ int dp_prof_collect(double* ms, long long* n, double* flop, double* bytes, long 
  *   never materialised;  w is [K][ldw] row-major (ldw >= N, ldw % 4 == 0, pad columns zero);
  *   bias [N] or NULL; temb [B][temb_stride] or NULL (temb_stride 0 broadcasts one row);
  *   res [M][ldr] or NULL; out [M][ldo].
- * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation).
+ * Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation).
+ * out_fmt: 0 = `out` is fp32 [M][ldo]; 1 = `out` is PLAIN fp16 [M][ldo] (final value rounded to nearest; the stem convolution of a
+ *   network whose residual stream is fp16, unet.py:478-484 under use_fp16).  colstats are those of the unrounded values.
  * colstats (optional): [ceil(M/512)*8][2][N] floats (one record per 64 rows, ROUNDED UP to whole 512-row tiles: a tile writes all
  *   the records of its rows, also those wholly beyond a ragged M); for every record of 64 consecutive output rows the
  *   per-column sum and sum of squares of the FINAL values, reduced inside the epilogue in an order that
@@ -77,7 +79,7 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
                    const float* w, int ldw, int N,
                    const float* bias, const float* temb, int temb_stride,
                    const float* res, int ldr, float scale,
-                   float* out, int ldo, int precision,
+                   void* out, int ldo, int out_fmt,
                    float* colstats, int* tile_rows, void* stream);
 
 /* Same contract on the fp16 matrix cores with fp32-class accuracy ("f16x3"): every operand is a
@@ -117,13 +119,30 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
  *             and scale applied - rounded to nearest even; ldo even, N % 4 == 0).  For a tensor whose only consumer is a
  *             GroupNorm-apply pass that emits an fp16 operand anyway (the first convolution of every ResBlock:
  *             guided_diffusion/unet.py:244-264 in_layers -> out_layers[0]): half the store bytes here, half the load bytes
- *             there (dp_gn_apply_f16in).  `colstats` are the sums of the UNROUNDED values in both formats. */
+ *             there (dp_gn_apply_h16).  `colstats` are the sums of the UNROUNDED values in both formats.
+ *   res_fmt 0 = `res` is fp32 [M][ldr]; res_fmt 1 = `res` is PLAIN fp16 [M][ldr] (ldr even).  Together with out_fmt 1 this is the
+ *             fp16 RESIDUAL STREAM of the fp16 x fp16 modes (ABI 6): the block outputs h of the UNet travel as fp16, which is the
+ *             reference's own arithmetic for the ImageNet model (`use_fp16: True`, configs/imagenet.yml:18; convert_to_fp16 casts
+ *             the torso, guided_diffusion/unet.py:626-632, fp16_util.py:23-40) - here with fp32 accumulation, fp32 epilogue
+ *             arithmetic and fp32 GroupNorm statistics on top.
+ *   seg1 / seg2 (ABI 6, with w_fmt 1): 1x1 "skip" K-SEGMENTS.  After the KS*KS*C reduction over x the k-loop continues over the
+ *             segC1 (+ segC2) channels of up to two PLAIN fp16 NHWC tensors [B][H][W][segC] (no border; segC % 32 == 0), whose
+ *             weight columns FOLLOW in the same panel: w is [N32][KS*KS*C + segC1 + segC2] in the block layout above, and
+ *             out += [seg1 | seg2] . w[:, KS*KS*C:].  This folds a ResBlock's 1x1 skip_connection (unet.py:223-230, 262-264;
+ *             layerspp.py:268-272: Conv_2 / NIN shortcut) over its raw input - the channel concatenation of the two skip
+ *             sources - into its second 3x3 convolution: the skip tensor is never written or re-read (`bias` then carries the sum
+ *             of both biases).  Only the 8-wave 256x256 kernel takes segments: ask dp_conv2d_nhwc_h2_takes_segments() first;
+ *             passing segments for a launch it refuses is an error. */
 int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
-                      const float* res, int ldr, float scale,
+                      const void* res, int ldr, float scale,
                       void* out, int ldo, float* colstats, int* tile_rows,
-                      void* work, long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, void* stream);
+                      void* work, long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, int res_fmt,
+                      const void* seg1, int segC1, const void* seg2, int segC2, void* stream);
+/* 1 when dp_conv2d_nhwc_h2 would run an fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) of this shape on the kernel that takes 1x1
+ * K-segments (a function of the shape and of the process-wide tuning switches only), else 0. */
+int dp_conv2d_nhwc_h2_takes_segments(int B, int H, int W, int KS, int C, int N, int segC1, int segC2);
 /* Scratch the call above needs for this layer shape (0 for most): low-resolution levels (H*W <= 64) are reduced with
  * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
  * layer shape only, never on B, so that results do not depend on how a batch is sharded. */
@@ -184,23 +203,22 @@ int dp_gn_finalize(const float* partial, int B, int nsplit, int G, long long cou
  * convolutions wrote (dp_conv2d_nhwc[_h2] colstats).  HW % tile_rows == 0 for every source. */
 int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, const float* cs2, int C2, int tile_rows2,
                         int B, int HW, int G, float eps, float* stats, void* stream);
-/* "Fold" (small feature maps): pass stats = NULL and the column records instead (cs1 / tile_rows1 [/ cs2 / tile_rows2 for the
- * second source] and eps, exactly the arguments of dp_gn_finalize_cols): every workgroup of the apply kernel then reduces the
- * records of its own sample itself and no finalize launch is needed.  Allowed while a sample spans at most 16 record tiles
- * (H*W / tile_rows <= 16); cs1 = NULL is the three-step form above. */
 int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta,
                 const float* fscale, const float* fshift, int film_stride,
-                int act, int resample, int out_fmt, void* y, void* y_raw, const float* fir4,
-                const float* cs1, int tile_rows1, const float* cs2, int tile_rows2, float eps, void* stream);
-/* Step 3 for a tensor its producing convolution stored as plain fp16 (dp_conv2d_nhwc_h2 out_fmt 1): x16 is [B][H][W][C] fp16
- * (no border), y the zero-bordered "h1" operand [B][H+2][W+2][C] fp16; one source, no resampling - the out_layers GroupNorm
- * of a ResBlock (guided_diffusion/unet.py:251-258 scale-shift norm + SiLU; score_sde layerspp.py:246 GroupNorm_1 + act).
- * Same arithmetic per element as dp_gn_apply(out_fmt 2) on the up-converted tensor (identical bytes), 4 HBM bytes per element
- * instead of 6. */
-int dp_gn_apply_f16in(const void* x16, int C, int B, int H, int W, int G, const float* stats, const float* gamma,
-                      const float* beta, const float* fscale, const float* fshift, int film_stride, int act, void* y,
-                      const float* cs1, int tile_rows1, float eps, void* stream);
+                int act, int resample, int out_fmt, void* y, void* y_raw, const float* fir4, void* stream);
+/* Step 3 over PLAIN fp16 tensors (ABI 6; replaces dp_gn_apply_f16in): x1 / x2 are [B][H][W][C1 | C2] fp16 without a border - a
+ * first convolution's fp16 output (dp_conv2d_nhwc_h2 out_fmt 1) or, in the fp16 x fp16 modes, the residual stream itself (the
+ * reference's own use_fp16 arithmetic keeps h in fp16: guided_diffusion/unet.py:626-632) and the skip tensors of the up path
+ * (the th.cat of unet.py:667 is two source pointers).  Same contract as dp_gn_apply otherwise: optional normalisation (gamma ==
+ * NULL: none) + FiLM + SiLU, resample 0 | 1 (nearest x2) | 2 (mean 2x2) - the FIR modes stay on the fp32 stream -, optional raw
+ * second output.  out_fmt 2 = the zero-bordered "h1" operand [B][Ho+2][Wo+2][C]; out_fmt 3 = a plain fp16 tensor [B][Ho][Wo][C]
+ * (the resampled identity skip of an up / down ResBlock, unet.py:245-250: the residual of its second convolution, res_fmt 1).
+ * C1 % 8 == 0, C % 8 == 0.  Same arithmetic per element as dp_gn_apply(out_fmt 2) on the up-converted tensors (identical bytes):
+ * 4 HBM bytes per element instead of 6. */
+int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, int B, int H, int W, int G, const float* stats,
+                    const float* gamma, const float* beta, const float* fscale, const float* fshift, int film_stride,
+                    int act, int resample, int out_fmt, void* y, void* y_raw, void* stream);
 
 /* ---- small elementwise pieces ----------------------------------------------------------------*/
 /* y = x * sigmoid(x)   (nn.SiLU on the embedding vector, unet.py:211, layerspp.py:265) */

@@ -327,4 +327,4 @@ def ldsde_adjoint_grad(score_fn, x_final, grad_out, x_init, noises, t_int, sigma
         g = ldsde_g(y.shape[0], lambda_ld, eta)[:, None, None, None]
         y = y - f.detach() * h - g * (noises[k] * torch.sqrt(h))
         a = a + h * vjp
-    return (a, y) if return_state else a
+    return a

@@ -30,7 +30,7 @@ def timeit(fn, iters):
 
 def main():
     B = 64
-    ops.set_tuning("DP_H2_DW", 8)
+    ops.set_tuning("DP_H2_DW", 1)
     ops.set_tuning("DP_H2_DW_UNROLL", 0)        # the ablation modes live in the rolled loop
     for (H, ci, co) in [(256, 256, 256), (128, 512, 512), (64, 512, 512)]:
         x = torch.randn(B, H, H, ci)
@@ -42,7 +42,6 @@ def main():
         fn = lambda: ops.conv2d_h2(xh, wh, co, 3, bias=bias, colstats=True, w_fmt=1)
         line = f"{H:4d} {ci:5d}->{co:4d} B={B} |"
         for adepth in (3, 4):
-            ops.set_tuning("DP_H2_DW_ADEPTH", adepth)
             line += f" a{adepth}:"
             for m in (0, 2, 1, 3, 4, 6, 7, 0):
                 os.environ["DP_H2_DW_MODE"] = str(m)

@@ -55,14 +55,21 @@ def _h2_hi(t):
     return t.reshape(-1, shp[-1] // 16, 2, 8).double()[:, :, 0].reshape(*shp[:-1], shp[-1] // 2)
 
 
-def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False):
+def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False,
+              segs=None):
     """Statement of the fp16-matrix-core contract (include/diffpure_hip.h, dp_conv2d_nhwc_h2): exact products of the
     operands each mode keeps - f16x3 (h2 activations, passes 3): (hi+lo) x (hi+lo) (the dropped lo*lo term is ~2^-22
     relative, below the test tolerance); passes 12: (hi+lo) x w_hi; h1 activations (plain fp16): passes 2: a x (w_hi+w_lo),
-    passes 1: a x w_hi.  x carries a one-pixel zero border.  out_f16: the result rounded to fp16 (out_fmt 1)."""
+    passes 1: a x w_hi.  x carries a one-pixel zero border.  out_f16: the result rounded to fp16 (out_fmt 1).  res: fp32 or fp16.
+    segs: 1x1 K-segments - plain fp16 NHWC tensors whose weight columns follow the KS x KS part in the panel."""
+    wseg = None
     if w_fmt:
         from diffpure_amd import ops
         wh = ops.unorder_conv_weight_w16(wh, n_out)          # block layout of the fp16 panels -> [N, K'] reduction order
+    if segs:
+        assert w_fmt == 1
+        cs = sum(sg.shape[3] for sg in segs)
+        wh, wseg = wh[:, :wh.shape[1] - cs], wh[:, wh.shape[1] - cs:]
     cin = wh.shape[1] // ((1 if w_fmt else 2) * ksize * ksize)
     h1 = x.shape[3] == cin
     if passes is None:
@@ -74,16 +81,24 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     wf = wdec.reshape(n_out, cin // 32, ksize, ksize, 32)       # [N, c32, ky, kx, 32]
     wt = wf.permute(0, 1, 4, 2, 3).reshape(n_out, cin, ksize, ksize).contiguous()
     y = F.conv2d(xin.permute(0, 3, 1, 2), wt, None, padding=ksize // 2).permute(0, 2, 3, 1)
+    if wseg is not None:
+        y = y + torch.cat([sg.double() for sg in segs], dim=3) @ wseg.double().t()
     if bias is not None:
         y = y + bias[:n_out]
     if temb is not None:
         y = y + temb[:, :n_out].reshape(-1, 1, 1, n_out)
     if res is not None:
-        y = y + res
+        y = y + res.double()
     y = (y * scale).float().contiguous()
     if out_f16:
         y = y.half()
     return _act(y) if colstats else y
+
+
+def takes_segments(b, h, w, ksize, c, n_out, c1, c2=0):
+    """host-logic tests: every fp16 x fp16 launch with whole 32-channel slices takes K-segments (on the GPU: only the launches of
+    the 8-wave kernel, dp_conv2d_nhwc_h2_takes_segments)"""
+    return c % 32 == 0 and c1 > 0 and c1 % 32 == 0 and c2 % 32 == 0
 
 
 def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
@@ -136,7 +151,7 @@ def _act(y):
     return ops.Act(y, None)
 
 
-def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False):
+def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False, out_f16=False):
     xin = _cat(x, x2)
     b, h, w, cin = xin.shape
     wt = wp[:, :n_out].reshape(ksize, ksize, cin, n_out).permute(3, 2, 0, 1).contiguous()
@@ -148,6 +163,8 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
     if res is not None:
         y = y + res
     y = (y * scale).contiguous()
+    if out_f16:
+        y = y.half()
     if out is not None:
         out.copy_(y)
         y = out
@@ -159,9 +176,9 @@ def linear(x, wp, n_out, bias=None):
     return conv2d(x.view(m, 1, 1, k), wp, n_out, 1, bias=bias).view(m, n_out)
 
 
-def group_norm_stats(x, groups, eps, x2=None, fold=False):
+def group_norm_stats(x, groups, eps, x2=None):
     from diffpure_amd import ops
-    xin = _cat(ops.tensor_of(x), ops.tensor_of(x2))
+    xin = _cat(ops.tensor_of(x), ops.tensor_of(x2)).float()      # (fp16 stream tensors: statistics of the rounded values here)
     b, h, w, c = xin.shape
     v = xin.reshape(b, h * w, groups, c // groups).double()
     mean = v.mean(dim=(1, 3))
@@ -206,7 +223,7 @@ def _resample(y, mode, fir=None):
 
 def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
                split=False, raw=False, fir=None):
-    xin = _cat(x, x2)
+    xin = _cat(x, x2).float()                                    # fp32, or plain fp16 on the fp16 residual stream
     y = F.group_norm(xin.permute(0, 3, 1, 2), groups, gamma, beta, eps).permute(0, 2, 3, 1)
     if film is not None:
         fs, fh = film
@@ -228,6 +245,8 @@ def _operand_encoder(split):
 
 
 def resample(x, mode, fir=None):
+    if x.dtype == torch.float16:                                 # the fp16 residual stream stays fp16 (dp_gn_apply_h16 out_fmt 3)
+        return _resample(x.float(), mode, fir).half().contiguous()
     return _resample(x, mode, fir).contiguous()
 
 
@@ -323,7 +342,7 @@ def add(a, b):
 
 
 def to_h2(x, mode=RESAMPLE_NONE, fmt="h2", fir=None):
-    return _operand_encoder(fmt)(F.pad(_resample(x, mode, fir), (0, 0, 1, 1, 1, 1)))
+    return _operand_encoder(fmt)(F.pad(_resample(x.float(), mode, fir), (0, 0, 1, 1, 1, 1)))
 
 
 def silu(x):
@@ -439,7 +458,7 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
 
 PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd",
            "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "group_norm_f16in", "resample", "attention", "attention_fused",
-           "attention_fused_ok", "silu", "axpby",
+           "attention_fused_ok", "silu", "axpby", "takes_segments",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
 
 

@@ -422,19 +422,17 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
     tune.setenv("DP_H2_PP", "0")
     base, base_cs = run()
     close(base, ref, rtol=2e-5, atol=2e-5)
-    # every 256x256 variant: per-tap ping-pong, halo-tile ping-pong, one-wave-per-SIMD software-pipelined
+    # every 256x256 variant: ping-pong (DP_H2_SW=0), one-wave-per-SIMD software-pipelined (DP_H2_SW=1), both with the 8-wave kernel off
     if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64):
         tune.setenv("DP_H2_PP", "1")
         tune.setenv("DP_H2_DW", "0")
-        for sw, halo, persist in (("0", "0", 0), ("0", "1", 0), ("1", "0", 0), ("1", "0", 1)):
+        for sw in ("0", "1"):
             tune.setenv("DP_H2_SW", sw)
-            tune.setenv("DP_H2_HALO", halo)
-            tune.setenv("DP_H2_SW_PERSIST", persist)      # one persistent workgroup per CU walking the tiles (> 256 tiles only)
             for _ in range(3):
                 got, got_cs = run()
-                assert torch.equal(got, base), (sw, halo)
-                assert torch.equal(got_cs, base_cs), (sw, halo)
-        for name in ("DP_H2_SW", "DP_H2_HALO", "DP_H2_DW", "DP_H2_SW_PERSIST"):
+                assert torch.equal(got, base), sw
+                assert torch.equal(got_cs, base_cs), sw
+        for name in ("DP_H2_SW", "DP_H2_DW"):
             tune.delenv(name)
         tune.setenv("DP_H2_PP", "0")
     # the 512x128 form of the one-wave-per-SIMD kernel (layers with 128 output channels; DP_H2_SW=2)
@@ -442,46 +440,29 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
         tune.setenv("DP_H2_PP", "1")
         tune.setenv("DP_H2_DW", "0")
         tune.setenv("DP_H2_SW", "2")
-        for persist in (0, 1):
-            tune.setenv("DP_H2_SW_PERSIST", persist)
-            for _ in range(3):
-                got, got_cs = run()
-                assert torch.equal(got, base), ("sw 512x128", persist)
-                assert torch.equal(got_cs, base_cs), ("sw 512x128", persist)
-        for name in ("DP_H2_SW", "DP_H2_DW", "DP_H2_SW_PERSIST"):
+        for _ in range(3):
+            got, got_cs = run()
+            assert torch.equal(got, base), "sw 512x128"
+            assert torch.equal(got_cs, base_cs), "sw 512x128"
+        for name in ("DP_H2_SW", "DP_H2_DW"):
             tune.delenv(name)
         tune.setenv("DP_H2_PP", "0")
-    # the two-workgroups-per-CU kernel (igemm_h2_dw.hip: 128x256 tiles; both activation-ring depths, with and without the
-    # start-up stagger of a CU's second workgroup - the stagger changes timing only)
-    if B * H * W % 128 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
-        tune.setenv("DP_H2_DW", "2")
-        tune.setenv("DP_H2_DW_MINROUNDS", "0")
-        for adepth, stagger in ((3, 0), (4, 0), (3, 300), (4, 300)):
-            tune.setenv("DP_H2_DW_ADEPTH", adepth)
-            tune.setenv("DP_H2_DW_STAGGER", stagger)
+    # the 8-wave kernel (igemm_h2_dw.hip: one workgroup per CU on 256x256 tiles, two free-running waves per SIMD); taken only where
+    # the launch has >= 256 tiles, elsewhere the other variants run.  The 3x3 launches run the slice-unrolled loop by default,
+    # DP_H2_DW_UNROLL=0 the rolled one; DP_H2_DW_PRIO (static priority of waves 4-7) changes timing only.
+    if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
+        tune.setenv("DP_H2_DW", "1")
+        tune.setenv("DP_H2_PP", "1")
+        for unroll, prio in ((1, 0), (1, 1), (0, 0)):
+            tune.setenv("DP_H2_DW_UNROLL", unroll)
+            tune.setenv("DP_H2_DW_PRIO", prio)
             for _ in range(3):
                 got, got_cs = run()
-                assert torch.equal(got, base), ("dw", adepth, stagger)
-                assert torch.equal(got_cs, base_cs), ("dw", adepth, stagger)
-        if B * H * W % 256 == 0:        # its 8-wave form: one workgroup per CU on 256x256 tiles, two free-running waves per SIMD
-            tune.setenv("DP_H2_DW", "8")
-            tune.setenv("DP_H2_PP", "1")    # (DP_H2_DW=8 is taken only where the launch has >= 256 tiles; elsewhere the other variants run)
-            # (depth 3: the 3x3 launches run the slice-unrolled loop by default, DP_H2_DW_UNROLL=0 the rolled one)
-            for adepth, unroll, prio in ((3, 1, 0), (3, 1, 1), (3, 0, 0), (4, 1, 0)):
-                tune.setenv("DP_H2_DW_ADEPTH", adepth)
-                tune.setenv("DP_H2_DW_UNROLL", unroll)
-                tune.setenv("DP_H2_DW_PRIO", prio)       # static priority of waves 4-7: timing only
-                for _ in range(3):
-                    got, got_cs = run()
-                    assert torch.equal(got, base), ("dw8", adepth, unroll)
-                    assert torch.equal(got_cs, base_cs), ("dw8", adepth, unroll)
-            tune.delenv("DP_H2_PP")
-        for name in ("DP_H2_DW", "DP_H2_DW_MINROUNDS", "DP_H2_DW_ADEPTH", "DP_H2_DW_STAGGER", "DP_H2_DW_UNROLL", "DP_H2_DW_PRIO"):
+                assert torch.equal(got, base), ("dw8", unroll, prio)
+                assert torch.equal(got_cs, base_cs), ("dw8", unroll, prio)
+        for name in ("DP_H2_DW", "DP_H2_DW_UNROLL", "DP_H2_DW_PRIO"):
             tune.delenv(name)
-    # the same bits as the hi|lo panel with one pass (a_hi * w_hi): the fp16 panel IS its hi half
-    y1 = ops.conv2d_h2(xh, ops.pack_conv_weight_h2(w, dev), N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N],
-                       res=res, scale=scale, passes=1)
-    assert torch.equal(y1, base)
+        tune.setenv("DP_H2_PP", "0")
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
         tune.setenv("DP_H2_PP", "1")
         for _ in range(4):
@@ -570,68 +551,6 @@ def test_group_norm_h1_output_is_the_fp16_rounding_of_the_fp32_output(dev):
     y, yr = ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, split="h1", raw=True)
     assert torch.equal(y, ops.group_norm(x, 32, 1e-5, gamma, beta, x2=x2, act=True, split="h1"))
     assert torch.equal(yr.cpu(), torch.nn.functional.pad(torch.cat([x, x2], dim=3).cpu(), (0, 0, 1, 1, 1, 1)).half())
-
-
-FOLD_CASES = [(3, 16, 16, 128, 0), (2, 32, 32, 128, 0), (2, 16, 16, 256, 128), (3, 8, 8, 256, 256), (2, 32, 32, 384, 0), (1, 16, 16, 512, 256)]
-
-
-@pytest.mark.parametrize("case", FOLD_CASES, ids=[str(c) for c in FOLD_CASES])
-def test_group_norm_folded_statistics_equal_the_finalize_launch(dev, case, tune):
-    """GroupNorm-apply that reduces the column records of its own sample (no finalize launch; small feature maps) against the
-    three-step form: one / two sources (channel concat: a group may straddle them), every output format, FiLM, up-sampling, the
-    fp16-input kernel, 1 .. 16 record tiles per sample."""
-    from diffpure_amd import ops
-    tune.setenv("DP_GN_FOLD", 1)
-    B, H, W, C1, C2 = case
-    C, G, eps = C1 + C2, 32, 1e-5
-
-    def conv_out(cin, cout, seed, f16=False):
-        x = rnd(B, H, W, cin, seed=seed)
-        w = rnd(cout, cin, 3, 3, seed=seed + 1, scale=1.0 / math.sqrt(9 * cin))
-        return ops.conv2d_h2(_h1_bordered(x, dev), ops.order_conv_weight_w16(w).half().to(dev), cout, 3, bias=rnd(cout, seed=seed + 2).to(dev),
-                             colstats=True, w_fmt=1, out_f16=f16)
-
-    a1 = conv_out(64, C1, 10)
-    a2 = conv_out(32, C2, 20) if C2 else None
-    gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
-    tab = (0.3 * rnd(B, 2 * C, seed=5)).to(dev)
-    film = (tab[:, :C], tab[:, C:])
-    tune.setenv("DP_GN_FINALIZE_SAMPLE", 0)          # one workgroup per (sample, group)
-    st = ops.group_norm_stats(a1, G, eps, a2)
-    tune.setenv("DP_GN_FINALIZE_SAMPLE", 1)          # small feature maps: one workgroup per sample
-    assert torch.equal(ops.group_norm_stats(a1, G, eps, a2), st)
-    fs = ops.group_norm_stats(a1, G, eps, a2, fold=True)
-    assert isinstance(fs, ops.FoldedStats) and isinstance(st, torch.Tensor)
-    x1, x2 = a1.t, None if a2 is None else a2.t
-    worst, flips = 0.0, 0.0
-
-    def compare(got, want):
-        nonlocal worst, flips
-        assert got.shape == want.shape and got.dtype == want.dtype
-        if got.dtype == torch.float32:
-            worst = max(worst, (got - want).abs().max().item())
-        else:       # fp16 operand formats: a last-bit difference of (mean, rstd) can flip the fp16 rounding of an element
-            flips = max(flips, (got != want).float().mean().item())
-            worst = max(worst, (got.float() - want.float()).abs().max().item() * 1e-3)
-
-    for split, act, rs, fl in ((False, True, 0, None), ("h1", True, 0, film), ("h2", False, 0, None), ("h1", True, 1, None), (False, False, 2, film)):
-        compare(ops.group_norm(x1, G, eps, gamma, beta, x2=x2, film=fl, act=act, resample=rs, split=split, stats=fs),
-                ops.group_norm(x1, G, eps, gamma, beta, x2=x2, film=fl, act=act, resample=rs, split=split, stats=st))
-    if C2 == 0:
-        h16 = conv_out(64, C1, 10, f16=True)
-        st16 = ops.group_norm_stats(h16, G, eps)
-        fs16 = ops.group_norm_stats(h16, G, eps, fold=True)
-        assert isinstance(fs16, ops.FoldedStats)
-        compare(ops.group_norm_f16in(h16.t, G, gamma, beta, fs16, film=film, act=True),
-                ops.group_norm_f16in(h16.t, G, gamma, beta, st16, film=film, act=True))
-    print(f"folded GroupNorm statistics {case}: max difference to the finalize launch {worst:.3e}, fp16 elements that differ {flips:.2e}")
-    # the same sums in double, added in a different order: (mean, rstd) agree to the last float bit or the one before it
-    assert worst < 4e-6 and flips < 1e-3, (worst, flips)
-    # large feature maps keep the finalize launch
-    big = ops.Act(torch.empty(1, 64, 64, 128, device=dev), ops.ColStats(torch.empty(64, 2, 128, device=dev), 64, 128))
-    assert isinstance(ops.group_norm_stats(big, G, eps, fold=True), torch.Tensor)     # 64 record tiles per sample > 16
-    tune.setenv("DP_GN_FOLD", 0)
-    assert isinstance(ops.group_norm_stats(a1, G, eps, a2, fold=True), torch.Tensor)
 
 
 def test_group_norm_split_output_is_bordered_h2_of_fp32_output(dev):
@@ -790,49 +709,147 @@ def test_conv2d_fp16_output_is_the_rounded_fp32_output(dev, case, tune):
                           colstats=True, w_fmt=1, out_f16=f16)
         return y.t, y.cols.buf.clone()
 
-    base32 = basecs = None
-    combos = [("0", None, None, None)]
+    res16 = None if res is None else res.half()
+    res16f = None if res is None else res16.float()
+
+    def run_res16(fp16_res):
+        # the same residual VALUES (fp16-representable) as an fp16 tensor (res_fmt 1) and as an fp32 tensor: identical bits
+        y = ops.conv2d_h2(xh, w16, N, k, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res16 if fp16_res else res16f,
+                          scale=scale, colstats=True, w_fmt=1, out_f16=True)
+        return y.t, y.cols.buf.clone()
+
+    base32 = basecs = base_r = None
+    combos = [("0", None, "0")]                                     # generic tiles only
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
-        combos += [("1", "0", "0", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"), ("1", "2", "0", "0")]
-    if B * H * W % 128 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
-        combos += [("0", None, None, "3"), ("0", None, None, "4")]           # the two-workgroups-per-CU kernel
-    for pp, sw, halo, dw in combos:
+        combos += [("1", "0", "0"), ("1", "1", "0"), ("1", "2", "0")]      # ping-pong / one-wave-per-SIMD 256x256 / + 512x128
+    if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
+        combos += [("1", "2", "1")]                                 # the 8-wave kernel (where the launch has >= 256 tiles)
+    for pp, sw, dw in combos:
         tune.setenv("DP_H2_PP", pp)
-        for name, val in (("DP_H2_SW", sw), ("DP_H2_HALO", halo)):
-            if val is None:
-                tune.delenv(name, raising=False)
-            else:
-                tune.setenv(name, val)
-        tune.setenv("DP_H2_DW", "2" if dw else "0")
-        if dw:
-            tune.setenv("DP_H2_DW_ADEPTH", dw)
-        var = dw
+        if sw is None:
+            tune.delenv("DP_H2_SW", raising=False)
+        else:
+            tune.setenv("DP_H2_SW", sw)
+        tune.setenv("DP_H2_DW", dw)
         y32, cs32 = run(False)
         y16, cs16 = run(True)
         assert y16.dtype == torch.float16 and y16.shape == y32.shape
-        assert torch.equal(y16, y32.half()), (pp, sw, halo, var)
-        assert torch.equal(cs16, cs32), (pp, sw, halo, var)
+        assert torch.equal(y16, y32.half()), (pp, sw, dw)
+        assert torch.equal(cs16, cs32), (pp, sw, dw)
         if base32 is None:
             base32, basecs = y32, cs32
-        assert torch.equal(y32, base32) and torch.equal(cs32, basecs), (pp, sw, halo, var)
+        assert torch.equal(y32, base32) and torch.equal(cs32, basecs), (pp, sw, dw)
+        if res is not None:             # fp16 residual stream: res_fmt 1 == the same values as fp32, in every variant
+            ya, csa = run_res16(True)
+            yb, csb = run_res16(False)
+            assert torch.equal(ya, yb) and torch.equal(csa, csb), (pp, sw, dw)
+            if base_r is None:
+                base_r = (ya, csa)
+            assert torch.equal(ya, base_r[0]) and torch.equal(csa, base_r[1]), (pp, sw, dw)
 
 
-def test_group_norm_f16in_equals_group_norm_of_the_upconverted_tensor(dev):
-    """dp_gn_apply_f16in (fp16 NHWC in -> bordered fp16 operand out) gives the bytes of dp_gn_apply(out_fmt 2) on the same
-    values held as fp32: with FiLM rows per sample / broadcast / absent, with and without SiLU, narrow and wide channel counts."""
+SEG_CASES = [
+    # B, H, W, C (3x3 input = output channels of the block), N, C1, C2, scale
+    (64, 32, 32, 256, 256, 256, 256, 1.0),          # decoder ResBlock (512 -> 256): two skip sources
+    (32, 32, 32, 512, 512, 512, 256, 1.0),          # 768 -> 512
+    (64, 32, 32, 256, 256, 128, 0, 0.70710678),     # encoder channel change (128 -> 256), NCSN++ skip_rescale
+    (256, 16, 16, 256, 256, 256, 128, 0.70710678),  # NCSN++ 16x16 up path (384 -> 256) at the benchmarked batch
+]
+
+
+@pytest.mark.parametrize("case", SEG_CASES, ids=[str(c) for c in SEG_CASES])
+def test_conv2d_with_1x1_skip_k_segments(dev, case, tune):
+    """A ResBlock's 1x1 skip_connection over its raw input folded into its second 3x3 convolution (ABI 6, K-segments): against the
+    exact fp64 sum of the two convolutions of the fp16-rounded operands, and against the un-fused pair of launches (3x3 with the 1x1's
+    fp16 output as residual) - which differ only by the rounding of that intermediate tensor."""
     from diffpure_amd import ops
-    for (B, H, W, C, G) in ((2, 8, 8, 256, 32), (3, 5, 7, 64, 16), (1, 16, 16, 1024, 32), (2, 4, 4, 384, 32), (1, 3, 260, 128, 32)):
-        x16 = (rnd(B, H, W, C, seed=1) * 2 + 0.5).half().to(dev)
-        gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
-        stats = ops.group_norm_stats(x16.float(), G, 1e-5)
-        for film_rows in (0, 1, B):
-            table = rnd(film_rows, 2 * C + 8, seed=7).to(dev) if film_rows else None
-            film = None if table is None else (table[:, 4:4 + C], table[:, 4 + C:4 + 2 * C])
-            for act in (True, False):
-                ref = ops.group_norm(x16.float(), G, 1e-5, gamma, beta, film=film, act=act, split="h1", stats=stats)
-                got = ops.group_norm_f16in(x16, G, gamma, beta, stats, film=film, act=act)
+    B, H, W, C, N, C1, C2, scale = case
+    h = rnd(B, H, W, C, seed=1)
+    s1 = rnd(B, H, W, C1, seed=2).half()
+    s2 = rnd(B, H, W, C2, seed=3).half() if C2 else None
+    w3 = rnd(N, C, 3, 3, seed=4, scale=1.0 / math.sqrt(9 * C))
+    ws = rnd(N, C1 + C2, 1, 1, seed=5, scale=1.0 / math.sqrt(C1 + C2))
+    b3, bs = rnd(N, seed=6), rnd(N, seed=7)
+    assert ops.takes_segments(B, H, W, 3, C, N, C1, C2)
+    hh = _h1_bordered(h, dev)
+    wf = ops.order_conv_weight_w16(ops.fuse_skip_weight(w3, ws)).half().to(dev)
+    segs = (s1.to(dev),) if s2 is None else (s1.to(dev), s2.to(dev))
+    got = ops.conv2d_h2(hh, wf, N, 3, bias=(b3 + bs).to(dev), scale=scale, colstats=True, w_fmt=1, out_f16=True, segs=segs)
+    raw = torch.cat([s1] + ([] if s2 is None else [s2]), dim=3)
+    sub = slice(0, 2)                   # fp64 reference on two samples
+    ref = torch.nn.functional.conv2d(h[sub].half().double().permute(0, 3, 1, 2), w3.half().double(), None, padding=1).permute(0, 2, 3, 1)
+    ref = ref + raw[sub].double() @ ws[:, :, 0, 0].half().double().t() + (b3 + bs).double()
+    ref = (ref * scale).float()
+    err = (got.t[sub].float().cpu() - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err          # one fp16 rounding of the output
+    # the un-fused pair: skip = 1x1(raw) stored as fp16, then the 3x3 with it as residual
+    sraw = torch.nn.functional.pad(raw, (0, 0, 1, 1, 1, 1)).to(dev).contiguous()
+    skip = ops.conv2d_h2(sraw, ops.order_conv_weight_w16(ws).half().to(dev), N, 1, bias=bs.to(dev), w_fmt=1, out_f16=True)
+    two = ops.conv2d_h2(hh, ops.order_conv_weight_w16(w3).half().to(dev), N, 3, bias=b3.to(dev), res=skip, scale=scale, colstats=True,
+                        w_fmt=1, out_f16=True)
+    d = (got.t.float() - two.t.float()).abs().max().item()
+    print(f"K-segment fusion {case}: max-abs vs fp64 {err:.2e}, vs the un-fused pair {d:.2e}")
+    assert d < 4e-3 * max(1.0, ref.abs().max().item()), d
+    # the column records describe the stored tensor's unrounded values: GroupNorm statistics of the two agree
+    close(ops.group_norm_stats(got, 32, 1e-5), ops.group_norm_stats(two, 32, 1e-5).cpu(), rtol=2e-3, atol=2e-3)
+    # a launch the 8-wave kernel does not take refuses segments loudly
+    tune.setenv("DP_H2_DW", "0")
+    assert not ops.takes_segments(B, H, W, 3, C, N, C1, C2)
+    from diffpure_amd import _lib
+    with pytest.raises(_lib.DiffpureHipError):
+        ops.conv2d_h2(hh, wf, N, 3, bias=(b3 + bs).to(dev), w_fmt=1, out_f16=True, segs=segs)
+
+
+def test_stem_convolution_fp16_output(dev):
+    """dp_conv2d_nhwc out_fmt 1: the fp32-MFMA stem writes the first tensor of the fp16 residual stream; records as the fp32 run's."""
+    from diffpure_amd import ops
+    x = rnd(3, 32, 32, 3, seed=1).to(dev)
+    wp = ops.pack_conv_weight(rnd(128, 3, 3, 3, seed=2, scale=0.2)).to(dev)
+    b = rnd(128, seed=3).to(dev)
+    y32 = ops.conv2d(x, wp, 128, 3, bias=b, colstats=True)
+    y16 = ops.conv2d(x, wp, 128, 3, bias=b, colstats=True, out_f16=True)
+    assert y16.t.dtype == torch.float16 and torch.equal(y16.t, y32.t.half()) and torch.equal(y16.cols.buf, y32.cols.buf)
+
+
+H16_CASES = [(2, 8, 8, 256, 0, 32), (3, 6, 10, 64, 0, 16), (1, 16, 16, 1024, 0, 32), (2, 8, 8, 256, 128, 32), (2, 16, 16, 128, 128, 32),
+             (1, 4, 260, 128, 0, 32), (2, 8, 8, 512, 1024, 32)]
+
+
+@pytest.mark.parametrize("case", H16_CASES, ids=[str(c) for c in H16_CASES])
+def test_group_norm_fp16_input_equals_group_norm_of_the_upconverted_tensors(dev, case):
+    """dp_gn_apply_h16 (plain fp16 NHWC in - a first convolution's fp16 output, the fp16 residual stream, the two sources of a skip
+    concatenation - -> bordered fp16 operand, or a plain fp16 tensor) gives the bytes of dp_gn_apply(out_fmt 2) on the same values held
+    as fp32: FiLM rows per sample / broadcast / absent, with and without SiLU, 2x nearest-up / 2x2 mean-down, the raw second output, no
+    normalisation at all (resampled identity skip, raw operand of a 1x1 convolution)."""
+    from diffpure_amd import ops
+    B, H, W, C1, C2, G = case
+    C = C1 + C2
+    x16 = (rnd(B, H, W, C1, seed=1) * 2 + 0.5).half().to(dev)
+    x2_16 = (rnd(B, H, W, C2, seed=2) - 0.3).half().to(dev) if C2 else None
+    xf, x2f = x16.float(), None if x2_16 is None else x2_16.float()
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
+    stats = ops.group_norm_stats(xf, G, 1e-5, x2f)
+    for film_rows in (0, 1, B):
+        table = rnd(film_rows, 2 * C + 8, seed=7).to(dev) if film_rows else None
+        film = None if table is None else (table[:, 4:4 + C], table[:, 4 + C:4 + 2 * C])
+        for act in (True, False):
+            for rs in (0, 1, 2) if H % 2 == 0 and W % 2 == 0 else (0, 1):
+                ref = ops.group_norm(xf, G, 1e-5, gamma, beta, x2=x2f, film=film, act=act, resample=rs, split="h1", stats=stats)
+                got = ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, film=film, act=act, resample=rs, split="h1", stats=stats)
                 assert got.dtype == torch.float16 and got.shape == ref.shape
-                assert torch.equal(got, ref), (B, H, W, C, film_rows, act)
+                assert torch.equal(got, ref), (case, film_rows, act, rs)
+    y, yr = ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, act=True, split="h1", stats=stats, raw=True)
+    y0, yr0 = ops.group_norm(xf, G, 1e-5, gamma, beta, x2=x2f, act=True, split="h1", stats=stats, raw=True)
+    assert torch.equal(y, y0) and torch.equal(yr, yr0)
+    if C2 == 0:
+        assert torch.equal(ops.group_norm_f16in(x16, G, gamma, beta, stats, act=True), y0)
+        for rs in (0, 1, 2) if H % 2 == 0 and W % 2 == 0 else (0, 1):
+            assert torch.equal(ops.to_h2(x16, rs, fmt="h1"), ops.to_h2(xf, rs, fmt="h1")), rs
+            if rs:
+                r16 = ops.resample(x16, rs)
+                assert r16.dtype == torch.float16 and torch.equal(r16, ops.resample(xf, rs).half()), rs
+    with pytest.raises(Exception):
+        ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, act=True, split="h2", stats=stats)      # fp16 in -> "h1" only
 
 
 def test_attention_fused_operand_output(dev):

@@ -176,6 +176,66 @@ def test_f16x3_mode_engine_wiring(kind, precision):
         assert (out - g["out"]).abs().max() > 1e-6       # the mode really rounds its operands
 
 
+@pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
+def test_fp16_residual_stream_and_fused_skip_wiring(kind, monkeypatch):
+    """Round 4, fp16 x fp16 modes: the residual stream travels as plain fp16 wherever a level has whole column records per sample
+    (H*W % 64 == 0), every channel-changing ResBlock without resampling folds its 1x1 skip into its second convolution as
+    K-segments over the raw fp16 input(s), and the taped forward (adjoints) keeps fp32.  Traced on the torch statements of the ops:
+    dtypes of every convolution's residual / output, the K-segment calls, and the result against the reference golden with the
+    fp16 stream on and off (DIFFPURE_LEAN16=0)."""
+    from diffpure_amd import ops
+    if kind == "ncsnpp":
+        g = load_golden("ncsnpp_small.pt")
+        mod, cfg = pn, pn.parse_config(g["cfg"])
+        build = lambda: pn.NCSNpp(cfg, "cpu", precision="f16sr").load_state_dict(synth_state_dict(pn.param_shapes(cfg), g["seed"]))
+        run = lambda net, **kw: net.forward(nhwc(g["x"]), g["labels"], **kw)
+    else:
+        g = load_golden("guided_small.pt")
+        mod, cfg = pg, pg.parse_config(g["cfg"])
+        build = lambda: pg.GuidedUNet(cfg, "cpu", precision="f16sr").load_state_dict(synth_state_dict(pg.param_shapes(cfg), g["seed"]))
+        run = lambda net, **kw: net.forward(nhwc(g["x"]), g["t"].float(), **kw)
+    calls = []
+    real = ops.conv2d_h2
+
+    def spy(x, wh, n_out, ksize, **kw):
+        y = real(x, wh, n_out, ksize, **kw)
+        t = ops.tensor_of(y)
+        calls.append(dict(k=ksize, hw=t.shape[1] * t.shape[2], out=t.dtype, res=None if kw.get("res") is None else kw["res"].dtype,
+                          segs=None if not kw.get("segs") else [s.dtype for s in kw["segs"]]))
+        return y
+
+    monkeypatch.setattr(ops, "conv2d_h2", spy)
+    net = build()
+    assert net._lean16
+    out = nchw(run(net))
+    torch.testing.assert_close(out, g["out"], rtol=1e-2, atol=1e-2)
+    stream = [c for c in calls if c["k"] == 3 and (c["res"] is not None or c["segs"])]      # second convolutions of the ResBlocks
+    assert stream and all(c["out"] == (torch.float16 if c["hw"] % 64 == 0 else torch.float32) for c in stream)
+    assert any(c["out"] == torch.float16 for c in stream)
+    fused = [c for c in calls if c["segs"]]
+    assert fused and all(all(d == torch.float16 for d in c["segs"]) and c["res"] is None for c in fused)
+    assert any(len(c["segs"]) == 2 for c in fused)                     # a decoder block: two skip sources
+    n_fusable = sum(1 for r in ([r for b in net.plan["down"] for r in b] + net.plan["mid"] + net.plan["up"] if kind == "ncsnpp" else
+                                [r for b in net.plan["inp"] for r in b] + net.plan["mid"] + [r for b in net.plan["out"] for r in b])
+                    if r["kind"] == "res" and r["cin"] != r["cout"] and not r["mode"])
+    assert len(fused) <= n_fusable and len(fused) >= 1
+    # the taped forward keeps the fp32 stream (the backward kernels read fp32) and never fuses
+    calls.clear()
+    tape = []
+    run(net, tape=tape)
+    assert all(c["out"] == torch.float32 or c["res"] is None for c in calls if c["k"] == 3 and c["res"] is not None)
+    assert not any(c["segs"] for c in calls)
+    # switch: DIFFPURE_LEAN16=0 -> round 3's fp32 stream, same function to the same tolerance
+    monkeypatch.setenv("DIFFPURE_LEAN16", "0")
+    net0 = build()
+    assert not net0._lean16
+    calls.clear()
+    out0 = nchw(run(net0))
+    assert not any(c["segs"] or c["res"] == torch.float16 for c in calls)
+    torch.testing.assert_close(out0, g["out"], rtol=1e-2, atol=1e-2)
+    assert (out0 - out).abs().max() < 2e-2
+
+
 def test_h2_format_roundtrip():
     x = torch.randn(3, 5, 64) * 3
     enc = refops.h2_encode(x)
