@@ -32,7 +32,7 @@ struct ConvH2Args {
     int rfmt;           // residual: 0 = fp32 [M][ldr]; 1 = plain fp16 [M][ldr] (`res` then points at fp16 elements) - the fp16
                         // residual stream of the fp16 x fp16 modes (the reference's own `use_fp16` torso keeps h in fp16,
                         // guided_diffusion/unet.py:626-632, fp16_util.py:23-40)
-    // 1x1 "skip" K-segments (igemm_h2_dw.hip only; dp_conv_seg_applies): after the KS*KS*C reduction over `x` the k-loop runs on
+    // 1x1 "skip" K-segments (fp16 x fp16 kernels: igemm_h2_dw.hip, igemm_h2_sw.hip, the generic tiles incl. split-K): after the KS*KS*C reduction over `x` the k-loop runs on
     // over the channels of up to two PLAIN fp16 NHWC tensors [B][H][W][Cs] (no border: a 1x1 tap never leaves the image) whose
     // weight columns follow in the same panel: out += [seg1 | seg2] . W[:, KS*KS*C :].  K counts all of it.  This is the 1x1
     // skip_connection of a ResBlock (unet.py:223-230, 262-264; layerspp.py:268-272) folded into its second 3x3 convolution.
@@ -65,7 +65,7 @@ bool dp_conv_sw_applies(const ConvH2Args& p, int bn);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn);
 
 // One 8-wave workgroup per CU on 256x256 tiles, two free-running waves per SIMD sharing the tile (igemm_h2_dw.hip): fp16 x fp16;
-// the launcher fills p.tiles / p.stagger.  The only kernel that takes 1x1 K-segments (p.seg1).
+// the launcher fills p.tiles / p.stagger.
 bool dp_conv_dw_applies(const ConvH2Args& p);
 void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s);
 

@@ -138,14 +138,40 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
     // workgroup-uniform cursor of the k-stage being staged, in weight order: 32-channel slice c32 outermost,
     // then the tap, then (BKH == 16) the half of the slice
     // split-K: this workgroup reduces k-stages [t0, t0 + nt) of the layer's K / BKH
-    const int nt = (p.K / BKH) / p.ksplit;
-    const int t0 = (int)blockIdx.y * nt;
+    // (with 1x1 K-segments the total is not always a multiple of the split factor: floor boundaries - equal parts whenever it is)
+    const int ntot = p.K / BKH;
+    const int t0 = (int)(((long long)blockIdx.y * ntot) / p.ksplit);
+    const int nt = (int)(((long long)(blockIdx.y + 1) * ntot) / p.ksplit) - t0;
     int cur_h = t0 % NSUB, cur_tap = (t0 / NSUB) % taps, cur_c = (t0 / NSUB) / taps;
+    // K-segments (fp16 x fp16 only; igemm_h2.h): after the C / 32 slices of the KS x KS convolution the cursor runs over the slices of
+    // the plain fp16 NHWC tensors p.seg1 / p.seg2, one k-stage per slice, no tap offset; the row pointers are re-based per segment
+    int cur_seg = 0, seg_slices = p.C / 32;
+    auto enter_segment = [&](int seg, int slice) {
+        cur_seg = seg;
+        const char* sb = seg == 1 ? p.seg1 : p.seg2;
+        const int sc = seg == 1 ? p.segC1 : p.segC2;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) ctr[it] = sb + (size_t)min(m0 + r0a + it * ARPP, p.M - 1) * sc * ESZ + lsa * 16;
+        seg_slices = sc / 32;
+        cur_c = slice;
+        cur_tap = 0;
+    };
+    if constexpr (W16) {
+        if (p.seg1 && cur_c >= seg_slices) {        // a split-K part that starts inside a segment
+            int rem = cur_c * taps + cur_tap - seg_slices * taps;       // stages behind the KS x KS part (NSUB == 1)
+            if (rem < p.segC1 / 32) enter_segment(1, rem);
+            else enter_segment(2, rem - p.segC1 / 32);
+        }
+    }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) bptr[it] += (size_t)t0 * bstep[it];
     auto issue = [&](int stage) {
+        if constexpr (W16) {
+            if (cur_c == seg_slices && p.seg1) enter_segment(cur_seg + 1, 0);      // (workgroup-uniform) on to the next tensor
+        }
         const int ky = cur_tap / p.KS, kx = cur_tap - ky * p.KS;
-        const long long off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * ESZ + (long long)cur_c * (32 * ESZ) + cur_h * AROWB;
+        const long long off = cur_seg ? (long long)cur_c * (32 * ESZ)
+                                      : ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * ESZ + (long long)cur_c * (32 * ESZ) + cur_h * AROWB;
         char* As = smem + stage * STAGE + wave_u * ARPI * AROWB;
         char* Bs = smem + stage * STAGE + BM * AROWB + wave_u * RPI * ROWB;
 #pragma unroll
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
         }
         if (NSUB == 1 || ++cur_h == NSUB) {
             cur_h = 0;
-            if (++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+            if (cur_seg != 0 || ++cur_tap == taps) { cur_tap = 0; ++cur_c; }
         }
     };
 
@@ -457,16 +483,13 @@ extern "C" long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, in
     return s > 1 ? (long long)s * B * H * W * N * 4 : 0;
 }
 
-// Would dp_conv2d_nhwc_h2 run this fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) on the kernel that takes 1x1 K-segments?  A function
-// of the launch shape and the process-wide switches only - the host asks BEFORE it decides between the fused and the separate skip.
-extern "C" int dp_conv2d_nhwc_h2_takes_segments(int B, int H, int W, int KS, int C, int N, int segC1, int segC2) {
-    if (dp_tune(DP_T_H2_DW) == 0 || dp_tune(DP_T_H2_PP) == 0) return 0;
-    const long long M = (long long)B * H * W;
-    if (B <= 0 || H <= 0 || W <= 0 || M >= (1ll << 31) || (KS != 1 && KS != 3)) return 0;
-    if (M % 256 != 0 || N % 256 != 0 || C <= 0 || C % 32 != 0 || (H * W) % 32 != 0) return 0;
-    if (segC1 <= 0 || segC1 % 32 != 0 || segC2 < 0 || segC2 % 32 != 0) return 0;
-    if (h2_ksplit(H, W, KS, C, N) != 1) return 0;
-    return (M / 256) * (N / 256) >= 256 ? 1 : 0;
+// May an fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) of this LAYER shape carry 1x1 K-segments?  A function of the layer shape
+// only - never of the batch - so that any sharding of a batch takes the same arithmetic (fused or not); every fp16 x fp16 tile variant
+// but the ping-pong kernel has a segment loader (the dispatcher routes around that one), and all of them give identical bits.
+extern "C" int dp_conv2d_nhwc_h2_takes_segments(int H, int W, int KS, int C, int N, int segC1, int segC2) {
+    if (H <= 0 || W <= 0 || (KS != 1 && KS != 3) || N <= 0 || N % 4 != 0) return 0;
+    if (C <= 0 || C % 32 != 0 || segC1 <= 0 || segC1 % 32 != 0 || segC2 < 0 || segC2 % 32 != 0) return 0;
+    return 1;
 }
 
 extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
@@ -535,7 +558,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         else hipLaunchKernelGGL((conv_igemm_h2<BM_, BN_, BK_, ABL_, 3, false, false>), g_, dim3(NT), 0, s, p);                             \
     } while (0)
     {   // fp16 x fp16: the 8-wave 256x256 kernel (igemm_h2_dw.hip) on launches of at least one tile per CU; DP_H2_DW = 0 never.
-        // Bit-identical to the other variants.  The only kernel that takes 1x1 K-segments.
+        // Bit-identical to the other variants.
         if (dp_tune(DP_T_H2_DW) != 0 && dp_tune(DP_T_H2_PP) != 0 && dp_conv_dw_applies(p) && tiles(256, 256) >= 256) {
             dp_launch_conv_dw(p, s);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
@@ -544,8 +567,6 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             DP_LAUNCH_CHECK("conv_igemm_dw");
             return 0;
         }
-        DP_REQUIRE(!seg1, "dp_conv2d_nhwc_h2: 1x1 K-segments were passed for a launch the 8-wave kernel does not take (ask "
-                          "dp_conv2d_nhwc_h2_takes_segments first)");
     }
     // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
     // also fills the chip (>= one tile per CU); default 2 (dp_tune.h: read once; probes flip it with dp_set_tuning).
@@ -561,12 +582,14 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         if (p.ksplit > 1) bn = 0;            // split-K layers never take the ping-pong variants (shape-only rule)
         else if (pp != 0 && p.M % 256 == 0 && N % 256 == 0 && (pp == 1 || fills(256, 256))) bn = 256;
         else if (pp != 0 && p.M % 512 == 0 && N % 128 == 0 && (pp == 1 || fills(512, 128))) bn = 128;
+        const bool use_sw = bn && dp_tune(DP_T_H2_SW) != 0 && (bn == 256 || (dp_tune(DP_T_H2_SW) >= 2 && KS == 3)) && dp_conv_sw_applies(p, bn);
+        if (seg1 && !use_sw) bn = 0;         // 1x1 K-segments: the ping-pong kernel has no segment loader - the generic tiles take the launch
         if (bn) {
             // fp16 x fp16, N % 256 == 0: the one-wave-per-SIMD software-pipelined kernel (igemm_h2_sw.hip) - measured
             // fastest on every shape of both networks (tests/probes/pp_ablate.py --w16); DP_H2_SW=0 falls back
             // (its 512x128 form only for 3x3 layers: on 1x1 layers with 128 output channels it measured 5 % slower than the
             //  ping-pong kernel; tests/probes/n128_probe.py)
-            if (dp_tune(DP_T_H2_SW) != 0 && (bn == 256 || (dp_tune(DP_T_H2_SW) >= 2 && KS == 3)) && dp_conv_sw_applies(p, bn)) dp_launch_conv_sw(p, s, bn);
+            if (use_sw) dp_launch_conv_sw(p, s, bn);
             else dp_launch_conv_h2_pp(p, s, bn);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;
@@ -576,7 +599,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         }
     }
     {   // few output channels (the 6-channel head): 256 x 32 tiles over x-halo runs; DP_H2_NN=0 falls back to the generic tiles
-        if (dp_tune(DP_T_H2_NN) != 0 && dp_conv_nn_applies(p)) {
+        if (dp_tune(DP_T_H2_NN) != 0 && !seg1 && dp_conv_nn_applies(p)) {
             dp_launch_conv_nn(p, s);
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("conv_igemm_nn");

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
     const char* actr[NPA];                      // centre pixel of the lane's A row, + slot
     const char* bptr[NPB];
-    int cur_tap = 0, cur_c = 0;                 // (tap, slice) of the next k-tile to stage
+    // (tap, slice) of the next k-tile to stage inside the current K-segment: segment 0 = the KS x KS convolution over p.x, then the
+    // 1x1 segments over the plain fp16 tensors p.seg1 / p.seg2 (igemm_h2.h; one k-tile per 32-channel slice)
+    int cur_tap = 0, cur_c = 0, cur_seg = 0, seg_slices = p.C / 32;
     int nm0 = 0, nn0 = 0, ntile_m = 0, ntile_n = 0;     // the tile the staging pointers belong to
     auto stage_setup = [&](int tile) {
         ntile_n = tile % p.tiles_n;
@@ -103,6 +105,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         cur_tap = 0;
         cur_c = 0;
+        cur_seg = 0;
+        seg_slices = p.C / 32;
     };
     auto adopt = [&]() { tile_m = ntile_m; tile_n = ntile_n; m0 = nm0; n0 = nn0; };
     // one piece at a time, in PROGRAM order between the fragment reads (an LDS-DMA write and a ds_read may alias as far
@@ -110,12 +114,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     long long a_off = 0;
     auto pieceA = [&](int stage, int it) {
         if (it == 0) {
-            const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;       // tap / 3 for tap < 9, no division
-            a_off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
+            if (cur_c == seg_slices) {          // (wave-uniform) this segment is staged: on to the next tensor
+                ++cur_seg;
+                const char* sb = cur_seg == 1 ? p.seg1 : p.seg2;
+                const int sc = cur_seg == 1 ? p.segC1 : p.segC2;
+#pragma unroll
+                for (int j = 0; j < NPA; ++j) actr[j] = sb + (size_t)(nm0 + wave * (BM / 4) + j * 16 + lrow) * sc * 2 + ls * 16;
+                seg_slices = sc / 32;
+                cur_c = 0;
+            }
+            if (cur_seg == 0) {
+                const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;       // tap / 3 for tap < 9, no division
+                a_off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
+            } else {
+                a_off = (long long)cur_c * 64;
+            }
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + a_off),
                                          (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (wave * (BM / 4) + it * 16) * 64), 16, 0, 0);
-        if (it == NPA - 1 && ++cur_tap == taps) { cur_tap = 0; ++cur_c; }
+        if (it == NPA - 1 && (cur_seg != 0 || ++cur_tap == taps)) { cur_tap = 0; ++cur_c; }
     };
     auto pieceB = [&](int stage, int it) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 bool dp_conv_sw_applies(const ConvH2Args& p, int bn) {
     return (bn == 256 || bn == 128) && p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % (bn == 256 ? 256 : 512) == 0 &&
-           p.N % bn == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0) && !p.seg1 && (p.rfmt == 0 || p.ofmt == 1);
+           p.N % bn == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0) && (p.rfmt == 0 || p.ofmt == 1);
 }
 
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn) {

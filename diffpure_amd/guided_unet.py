@@ -341,7 +341,7 @@ class GuidedUNet:
         # channel-changing block: the 1x1 skip as K-segments of the second convolution (fp16 stream, launches the 8-wave kernel takes)
         c1 = x.shape[3]
         fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w2s") in P
-                 and ops.takes_segments(b, ho, wo, 3, co, co, c1, r["cin"] - c1))
+                 and ops.takes_segments(ho, wo, 3, co, co, c1, r["cin"] - c1))
         want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False) and not fused
         h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
                            raw=want_raw)

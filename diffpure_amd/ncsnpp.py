@@ -304,7 +304,7 @@ class NCSNpp:
         # channel-changing block without resampling: Conv_2 (the 1x1 shortcut, layerspp.py:268-272) as K-segments of Conv_1
         c1 = x.shape[3]
         fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
-                 and ops.takes_segments(b, ho, wo, 3, co, co, c1, r["cin"] - c1))
+                 and ops.takes_segments(ho, wo, 3, co, co, c1, r["cin"] - c1))
         want_raw = h2s and not mode and not fused
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
                            resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw, fir=fir)

@@ -336,9 +336,10 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
 
-def takes_segments(b, h, w, ksize, c, n_out, c1, c2=0):
-    """would conv2d_h2 (fp16 x fp16) run this launch on the kernel that accepts 1x1 K-segments of c1 (+ c2) channels?"""
-    return bool(_lib.load().dp_conv2d_nhwc_h2_takes_segments(b, h, w, ksize, c, n_out, c1, c2))
+def takes_segments(h, w, ksize, c, n_out, c1, c2=0):
+    """may an fp16 x fp16 convolution of this LAYER shape carry 1x1 K-segments of c1 (+ c2) channels?  (a function of the layer, never
+    of the batch: fused or not, any sharding of a batch takes the same arithmetic)"""
+    return bool(_lib.load().dp_conv2d_nhwc_h2_takes_segments(h, w, ksize, c, n_out, c1, c2))
 
 
 def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1.0, out=None, colstats=False, out_f16=False):

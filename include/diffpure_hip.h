@@ -131,8 +131,9 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
  *             out += [seg1 | seg2] . w[:, KS*KS*C:].  This folds a ResBlock's 1x1 skip_connection (unet.py:223-230, 262-264;
  *             layerspp.py:268-272: Conv_2 / NIN shortcut) over its raw input - the channel concatenation of the two skip
  *             sources - into its second 3x3 convolution: the skip tensor is never written or re-read (`bias` then carries the sum
- *             of both biases).  Only the 8-wave 256x256 kernel takes segments: ask dp_conv2d_nhwc_h2_takes_segments() first;
- *             passing segments for a launch it refuses is an error. */
+ *             of both biases).  Every fp16 x fp16 tile variant the dispatcher can pick for such a launch has a segment loader (the
+ *             8-wave kernel, the one-wave-per-SIMD kernel, the generic tiles incl. split-K) and all give identical bits, so whether a
+ *             layer is fused is a property of the LAYER, never of the batch: dp_conv2d_nhwc_h2_takes_segments(). */
 int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       const void* w, int N,
                       const float* bias, const float* temb, int temb_stride,
@@ -140,9 +141,9 @@ int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
                       void* out, int ldo, float* colstats, int* tile_rows,
                       void* work, long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, int res_fmt,
                       const void* seg1, int segC1, const void* seg2, int segC2, void* stream);
-/* 1 when dp_conv2d_nhwc_h2 would run an fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) of this shape on the kernel that takes 1x1
- * K-segments (a function of the shape and of the process-wide tuning switches only), else 0. */
-int dp_conv2d_nhwc_h2_takes_segments(int B, int H, int W, int KS, int C, int N, int segC1, int segC2);
+/* 1 when an fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) of this layer shape may carry 1x1 K-segments of segC1 (+ segC2) channels
+ * (whole 32-channel slices everywhere), else 0.  A function of the layer shape only. */
+int dp_conv2d_nhwc_h2_takes_segments(int H, int W, int KS, int C, int N, int segC1, int segC2);
 /* Scratch the call above needs for this layer shape (0 for most): low-resolution levels (H*W <= 64) are reduced with
  * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
  * layer shape only, never on B, so that results do not depend on how a batch is sharded. */

@@ -52,7 +52,7 @@ def main():
         wf = ops.order_conv_weight_w16(ops.fuse_skip_weight(w3, ws)).half().to(DEV)
         w3p, wsp = ops.order_conv_weight_w16(w3).half().to(DEV), ops.order_conv_weight_w16(ws).half().to(DEV)
         bias = torch.randn(co, device=DEV)
-        if not ops.takes_segments(B, H, H, 3, co, co, c1, c2):
+        if not ops.takes_segments(H, H, 3, co, co, c1, c2):
             print(f"{H} {co}: segments not taken at B={B}")
             continue
         raw = torch.nn.functional.pad(torch.cat([s1, s2], dim=3), (0, 0, 1, 1, 1, 1)).contiguous()

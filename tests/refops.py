@@ -20,6 +20,11 @@ def _cat(x, x2):
     return x if x2 is None else torch.cat([x, x2], dim=3)
 
 
+def _up(t):
+    """plain fp16 tensors (the fp16 residual stream) are evaluated in fp32; fp32 / fp64 inputs keep their type"""
+    return t.float() if t.dtype == torch.float16 else t
+
+
 def h2_encode(t):
     """fp32 [..., C] -> h2 [..., 2C] fp16: per 8 channels, 8 hi then 8 lo."""
     shp = t.shape
@@ -95,10 +100,9 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     return _act(y) if colstats else y
 
 
-def takes_segments(b, h, w, ksize, c, n_out, c1, c2=0):
-    """host-logic tests: every fp16 x fp16 launch with whole 32-channel slices takes K-segments (on the GPU: only the launches of
-    the 8-wave kernel, dp_conv2d_nhwc_h2_takes_segments)"""
-    return c % 32 == 0 and c1 > 0 and c1 % 32 == 0 and c2 % 32 == 0
+def takes_segments(h, w, ksize, c, n_out, c1, c2=0):
+    """dp_conv2d_nhwc_h2_takes_segments: whole 32-channel slices everywhere; a function of the layer shape only"""
+    return c % 32 == 0 and c1 > 0 and c1 % 32 == 0 and c2 % 32 == 0 and n_out % 4 == 0
 
 
 def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
@@ -178,7 +182,7 @@ def linear(x, wp, n_out, bias=None):
 
 def group_norm_stats(x, groups, eps, x2=None):
     from diffpure_amd import ops
-    xin = _cat(ops.tensor_of(x), ops.tensor_of(x2)).float()      # (fp16 stream tensors: statistics of the rounded values here)
+    xin = _up(_cat(ops.tensor_of(x), ops.tensor_of(x2)))         # (fp16 stream tensors: statistics of the rounded values here)
     b, h, w, c = xin.shape
     v = xin.reshape(b, h * w, groups, c // groups).double()
     mean = v.mean(dim=(1, 3))
@@ -223,7 +227,7 @@ def _resample(y, mode, fir=None):
 
 def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resample=RESAMPLE_NONE, stats=None,
                split=False, raw=False, fir=None):
-    xin = _cat(x, x2).float()                                    # fp32, or plain fp16 on the fp16 residual stream
+    xin = _up(_cat(x, x2))                                       # fp32 / fp64, or plain fp16 on the fp16 residual stream
     y = F.group_norm(xin.permute(0, 3, 1, 2), groups, gamma, beta, eps).permute(0, 2, 3, 1)
     if film is not None:
         fs, fh = film
@@ -342,7 +346,7 @@ def add(a, b):
 
 
 def to_h2(x, mode=RESAMPLE_NONE, fmt="h2", fir=None):
-    return _operand_encoder(fmt)(F.pad(_resample(x.float(), mode, fir), (0, 0, 1, 1, 1, 1)))
+    return _operand_encoder(fmt)(F.pad(_resample(_up(x), mode, fir), (0, 0, 1, 1, 1, 1)))
 
 
 def silu(x):

@@ -11,7 +11,7 @@ lap() { echo "[$(( $(date +%s) - S )) s] $1" >> $O/dev_timeline.log; }
 timeout 400 python -m pytest tests/test_gpu_ops.py -m gpu -x -q > $O/dev_ops.log 2>&1; echo "rc=$?" >> $O/dev_ops.log; lap ops
 tail -4 $O/dev_ops.log | cut -c1-300
 if [ "${1:-all}" = "ops" ]; then exit 0; fi
-timeout 700 python -m pytest tests -m gpu -q --deselect tests/test_gpu_ops.py > $O/dev_tests.log 2>&1; echo "rc=$?" >> $O/dev_tests.log; lap tests
+timeout 700 python -m pytest tests -m gpu -q -s --deselect tests/test_gpu_ops.py > $O/dev_tests.log 2>&1; echo "rc=$?" >> $O/dev_tests.log; lap tests
 grep -E "passed|failed|error" $O/dev_tests.log | tail -3 | cut -c1-300
 grep -E "^FAILED|^ERROR" $O/dev_tests.log | head -20 | cut -c1-250
 grep -hE "max-abs|rel\. error|K-segment" $O/dev_tests.log $O/dev_ops.log | cut -c1-220 | head -60
