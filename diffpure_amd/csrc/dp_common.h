@@ -51,7 +51,23 @@ __device__ __forceinline__ float dp_sigmoid_f(float v) {
     r = fmaf(fmaf(-d, r, 1.0f), r, r);
     return d > 3.0e38f ? 0.f : r;          // d = inf: rcp gives 0 but the Newton step would make NaN (inf * 0)
 }
-__device__ __forceinline__ float dp_silu_f(float v) { return v * dp_sigmoid_f(v); }
+// (the product is pinned in a register: left free, the compiler contracts it into whatever consumes it - an add of the 2x2 mean
+//  resampler, the fp16 conversion - in one kernel and not in its twin, and results that must agree bit for bit differ in the last place)
+__device__ __forceinline__ float dp_silu_f(float v) {
+    float r = v * dp_sigmoid_f(v);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
+// fp32 -> fp16, round to nearest even, of the fp32 value AS ROUNDED TO fp32.  Left to itself the compiler folds a preceding multiply
+// into the conversion (v_fma_mixlo_f16: ONE rounding of the exact product) wherever the product has no other fp32 use - which
+// kernel variant, output format or resampling mode does so is an accident of code shape, and the double-rounding cases (1e-4 of
+// the elements) then differ by one fp16 ulp between variants that must give identical bits (a batch's sharding picks the
+// variant).  The empty asm pins the fp32 value in a register first.
+__device__ __forceinline__ _Float16 dp_to_half(float v) {
+    asm volatile("" : "+v"(v));
+    return (_Float16)v;
+}
 
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {

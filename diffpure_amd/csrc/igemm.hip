@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_f32(ConvArgs p) {
                 if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
                 if (resp) v += rv[i][r];
                 v *= p.scale;
-                if (p.ofmt) reinterpret_cast<_Float16*>(outp)[(size_t)row * p.ldo + col] = (_Float16)v;
+                if (p.ofmt) reinterpret_cast<_Float16*>(outp)[(size_t)row * p.ldo + col] = dp_to_half(v);
                 else outp[(size_t)row * p.ldo + col] = v;
                 cs += v;
                 cq += v * v;

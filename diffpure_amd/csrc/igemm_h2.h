@@ -51,7 +51,7 @@ typedef _Float16 dp_half4 __attribute__((ext_vector_type(4)));
 
 // one output element in the format p.ofmt names (the generic, one-element-per-lane path of the tile variants)
 __device__ __forceinline__ void dp_conv_store(const ConvH2Args& p, size_t row, int col, float v) {
-    if (p.ofmt) reinterpret_cast<_Float16*>(p.out)[row * p.ldo + col] = (_Float16)v;
+    if (p.ofmt) reinterpret_cast<_Float16*>(p.out)[row * p.ldo + col] = dp_to_half(v);
     else p.out[row * p.ldo + col] = v;
 }
 

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
                 if (tembp) v += hw32 ? tv[i] : tembp[(size_t)(row / HW) * p.temb_stride + col];
                 if (resp) v += rv[i][r];
                 v *= p.scale;
-                if constexpr (decltype(out16)::value) outh[(size_t)row * p.ldo + col] = (_Float16)v;
+                if constexpr (decltype(out16)::value) outh[(size_t)row * p.ldo + col] = dp_to_half(v);
                 else outp[(size_t)row * p.ldo + col] = v;
                 cs += v;
                 cq += v * v;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvH2Args p) {
             cq[j] += v[j] * v[j];
         }
         if (p.ofmt) {
-            const dp_half4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            const dp_half4 h = {dp_to_half(v[0]), dp_to_half(v[1]), dp_to_half(v[2]), dp_to_half(v[3])};
             *reinterpret_cast<dp_half4*>(reinterpret_cast<_Float16*>(p.out) + (size_t)row * p.ldo + col0) = h;
         } else {
             *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col0) = v;

@@ -45,6 +45,9 @@ __device__ __forceinline__ void dw_wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// (Round 4 measured a start-up de-phasing of the CUs - the first workgroup of CU slot c starting c / 32 of a tile late, so that the
+//  256 epilogues do not hit HBM together: 0 % on 256^2 256->256 at B=64, -2...-4 % on the shorter launches, -1...-2 % on the
+//  purification (profiles/r04/dephase_ab.log).  The epilogue's cost is not a lockstep burst.  Removed.)
 // MODE (timing ablations, DP_ABLATE builds only; WRONG RESULTS): 1 = no DMA in the steady state, 2 = no barrier / vmcnt wait,
 // 4 = no ds_reads, 8 = no epilogue stores, 16 = no activation DMA, 32 = no weight DMA
 template <int MODE>
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
         rotate();
     }
 
-    if constexpr (!(MODE & 8)) sw_epilogue_any<1, 1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
+    if constexpr (!(MODE & 8)) sw_epilogue_any<1, 1, 4>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
 }
 
 
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw8u(ConvH2Args p) {
     tail(dw_const<7>{});
     tail(dw_const<8>{});
 
-    sw_epilogue_any<1, 1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
+    sw_epilogue_any<1, 1, 4>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
 }
 
 }  // namespace

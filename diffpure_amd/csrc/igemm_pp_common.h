@@ -77,7 +77,7 @@ __device__ __forceinline__ void pp_epilogue_t(const ConvH2Args& p, f32x16 (&acc)
                 if (tembp) v += hw32 ? tv[j] : tembp[(size_t)(row / HW) * p.temb_stride + col0 + j * 32];
                 if (resp) v += rv[j][r];
                 v *= p.scale;
-                if constexpr (OUT16) outh[(size_t)row * p.ldo + col0 + j * 32] = (_Float16)v;
+                if constexpr (OUT16) outh[(size_t)row * p.ldo + col0 + j * 32] = dp_to_half(v);
                 else outp[(size_t)row * p.ldo + col0 + j * 32] = v;
                 cs[i][j] += v;
                 cq[i][j] += v * v;

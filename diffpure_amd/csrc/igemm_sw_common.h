@@ -31,7 +31,10 @@ __device__ __forceinline__ float sw_swap1(float v) {
 // one dword = two adjacent columns of one row per lane, then the same lane-pair exchange - 8 loads per 32 x 32 tile instead of 16.
 // A wave-uniform run-time branch inside the OUT16 instantiation (a third instantiation of the whole epilogue made the 512-register
 // kernel spill its accumulators).
-template <bool OUT16, int NQ, int JP>
+// RA: look-ahead of the fp16 residual loads, in column tiles.  1: a tile's 8 loads are issued when the tile is processed (eight dependent
+// HBM round trips per 64 x 128 wave tile).  4 (the 8-wave kernel, whose 48 fragment registers are free by now): the loads of all four
+// tiles of a 32-row block - 32 dwords per lane - fly together, two round trips per wave tile.
+template <bool OUT16, int NQ, int JP, int RA>
 __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2 * NQ][4], int row0, int colw, int rec0, int lr, int lk,
                                             int HW) {
     // Every tile variant must produce the SAME bits, column records included: products and sums stay separate instructions
@@ -71,6 +74,18 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                 cs[ii][j] = 0.f;
                 cq[ii][j] = 0.f;
             }
+            dp_half2 hraw[RA == 4 ? 4 : 1][8];
+            if constexpr (RA == 4) {
+                if (p.res && res16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gptr rb = (gptr)(reinterpret_cast<const _Float16*>(p.res) + (size_t)rowt * p.ldr + colw + j * 32);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            hraw[j][k] = *reinterpret_cast<const __attribute__((address_space(1))) dp_half2*>(rb + rows_of(2 * k) * ldr_b + vr0);
+                    }
+                }
+            }
 #pragma unroll
             for (int jh = 0; jh < 4 / JP; ++jh) {   // JP column tiles at a time
                 float rv[JP][16];
@@ -82,7 +97,8 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
 #pragma unroll
                             for (int k = 0; k < 8; ++k) {
                                 // even lane: row r = 2k, columns (lr, lr + 1); odd lane: row 2k + 1, columns (lr - 1, lr)
-                                const dp_half2 h = *reinterpret_cast<const __attribute__((address_space(1))) dp_half2*>(rb + rows_of(2 * k) * ldr_b + vr0);
+                                const dp_half2 h = RA == 4 ? hraw[RA == 4 ? jh * JP + jj : 0][k]
+                                                           : *reinterpret_cast<const __attribute__((address_space(1))) dp_half2*>(rb + rows_of(2 * k) * ldr_b + vr0);
                                 const float mine = odd ? (float)h[1] : (float)h[0];
                                 const float other = sw_swap1(odd ? (float)h[0] : (float)h[1]);
                                 rv[jj][2 * k] = odd ? other : mine;
@@ -120,7 +136,7 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                         for (int k = 0; k < 8; ++k) {
                             const float mine = odd ? vv[jj][2 * k + 1] : vv[jj][2 * k];
                             const float other = sw_swap1(odd ? vv[jj][2 * k] : vv[jj][2 * k + 1]);
-                            const dp_half2 h = {(_Float16)(odd ? other : mine), (_Float16)(odd ? mine : other)};
+                            const dp_half2 h = {dp_to_half(odd ? other : mine), dp_to_half(odd ? mine : other)};
                             // the even lane keeps row r = 2k and stores columns (lr, lr + 1); the odd lane keeps row 2k + 1, columns (lr - 1, lr)
                             *reinterpret_cast<dp_half2*>(oh + rows_of(2 * k) * ldo_b + vo0) = h;
                         }
@@ -149,11 +165,11 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
     }
 }
 
-template <int NQ, int JP>
+template <int NQ, int JP, int RA = 1>
 __device__ __forceinline__ void sw_epilogue_any(const ConvH2Args& p, f32x16 (&acc)[2 * NQ][4], int row0, int colw, int rec0, int lr, int lk,
                                                 int HW) {
-    if (p.ofmt) sw_epilogue<true, NQ, JP>(p, acc, row0, colw, rec0, lr, lk, HW);
-    else sw_epilogue<false, NQ, JP>(p, acc, row0, colw, rec0, lr, lk, HW);
+    if (p.ofmt) sw_epilogue<true, NQ, JP, RA>(p, acc, row0, colw, rec0, lr, lk, HW);
+    else sw_epilogue<false, NQ, JP, 1>(p, acc, row0, colw, rec0, lr, lk, HW);
 }
 
 // Measured on this epilogue and NOT kept (tests/probes/pp_ablate.py, B=64, bit-identical results):

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
         auto xf = [&](f32x4 v) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float u = v[j] * a[j] + d[j];
+                float u = fmaf(v[j], a[j], d[j]);       // (explicit: every GroupNorm-apply kernel evaluates the same fused multiply-add)
                 v[j] = ACT ? dp_silu_f(u) : u;
             }
             return v;
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = (j < 4) == !odd ? mine[j & 3] : other[j & 3];      // even lane: [mine | other]; odd: [other | mine]
-                const _Float16 hi = (_Float16)v;
-                out[j] = odd ? (_Float16)(v - (float)hi) : hi;
+                const _Float16 hi = dp_to_half(v);
+                out[j] = odd ? dp_to_half(v - (float)hi) : hi;
             }
             return out;
         };
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void gn_apply_h2q_kernel(ApplyArgs p, int CQT,
             } else {
                 half4 h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
+                for (int j = 0; j < 4; ++j) h[j] = dp_to_half(v[j]);
                 *reinterpret_cast<half4*>(base + (opix * CQ + cq) * 8) = h;
             }
         };
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(ApplyArgs p, int CVT, int
             f32x4 v = gn_load(p, pix, c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float u = v[j] * a[j] + d[j];
+                float u = fmaf(v[j], a[j], d[j]);       // (explicit: every GroupNorm-apply kernel evaluates the same fused multiply-add)
                 v[j] = ACT ? dp_silu_f(u) : u;
             }
             return v;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
         auto xf32 = [&](half8 v, float (&o)[8]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float u = (float)v[j] * a[j] + d[j];
+                const float u = fmaf((float)v[j], a[j], d[j]);
                 o[j] = ACT ? dp_silu_f(u) : u;
             }
         };
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
             xf32(v, o);
             half8 h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (_Float16)o[j];
+            for (int j = 0; j < 8; ++j) h[j] = dp_to_half(o[j]);
             return h;
         };
         half8* yrow = reinterpret_cast<half8*>(p.y) + orow * CO + co;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
                 xf32(src[(r0 + p.W) * so], v10);
                 xf32(src[(r0 + p.W + 1) * so], v11);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f);
+                for (int j = 0; j < 8; ++j) o[j] = dp_to_half(((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f);
             }
             yrow[(size_t)qx * CO] = o;
         }

@@ -347,17 +347,17 @@ H1_CASES = H2_CASES + PP_CASES + [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (8, 64
                                   (5, 16, 16, 160, 256, 3, 2, False, 1.0),
                                   # one / several image rows per 256-pixel tile, 1 .. 3 channel slices, two column tiles, a wide image
                                   (1, 256, 256, 96, 512, 3, 1, True, 1.0), (4, 32, 32, 32, 256, 3, 2, True, 0.5), (1, 8, 512, 64, 256, 3, 0, False, 1.0),
-                                  # > 256 tiles: the persistent form of the one-wave-per-SIMD kernel walks 2-3 tiles per workgroup, the last
-                                  # round is ragged (600 tiles of 256x256; 300 of 512x128)
+                                  # > 256 tiles, a ragged last round (600 tiles of 256x256; 300 of 512x128)
                                   (3, 160, 320, 64, 256, 3, 2, True, 0.5), (3, 160, 320, 32, 128, 3, 1, False, 1.0)]
 
 
-@pytest.mark.parametrize("passes", [2, 1])
+@pytest.mark.parametrize("passes", [2])
 @pytest.mark.parametrize("case", H1_CASES, ids=[str(c) for c in H1_CASES])
 def test_conv2d_h1_fp16_activations(dev, case, passes, tune):
-    """Plain-fp16 activation operand ("h1") x split-fp16 weights: passes=2 ("f16x2") must equal the exact convolution of
-    the fp16-ROUNDED activations with the full weights to fp32-class accuracy, passes=1 ("f16") the one with the
-    fp16-rounded weights as well; every tile variant gives the same bits (column-sum records included)."""
+    """Plain-fp16 activation operand ("h1") x split-fp16 weights, passes=2 ("f16x2"): must equal the exact convolution of
+    the fp16-ROUNDED activations with the full weights to fp32-class accuracy; every tile variant gives the same bits
+    (column-sum records included).  (One pass on hi|lo panels - round 2's "f16" - is gone since ABI 6: one pass means plain
+    fp16 panels, test_conv2d_fp16_weights_single_pass.)"""
     from diffpure_amd import ops
     B, H, W, C, N, k, temb_rows, has_res, scale = case
     x = rnd(B, H, W, C, seed=1)
@@ -666,7 +666,7 @@ def test_torch_ops_namespace_runs_the_hip_kernels(dev):
     st = ops.group_norm_stats(x, 32, 1e-5)
     assert torch.equal(T.group_norm_silu(x, gamma, beta, 32, 1e-5, True, 2, st), ops.group_norm(x, 32, 1e-5, gamma, beta, act=True, split="h1", stats=st))
     wh = ops.pack_conv_weight_h2(w, dev)
-    for split, passes in (("h2", 3), ("h1", 2), ("h1", 1)):
+    for split, passes in (("h2", 3), ("h1", 2)):
         xh = ops.group_norm(x, 32, 1e-5, gamma, beta, act=True, split=split)
         assert torch.equal(T.conv2d_h2(xh, wh, None, 96, 3, passes), ops.conv2d_h2(xh, wh, 96, 3, passes=passes))
         y2, c2 = T.conv2d_h2_stats(xh, wh, bias, 96, 3)          # passes = 0: the full arithmetic of the operand format
