@@ -13,7 +13,8 @@ reassembled with one RCCL all_gather inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (3x3 implicit-
 GEMM convolution; algorithmic FLOPs / hipEvent-timed launch durations over the timed region) and
-`cpu_baseline` (the CPU oracle of the same network timed on this box's host cores, rank 0, N=1).
+`cpu_baseline` (the CPU oracle of the same network timed on ALL of this box's host cores - cores / 16 pinned 16-thread workers at
+once - rank 0, N=1).
 """
 import argparse
 import json
@@ -165,22 +166,26 @@ def build_engine(workload, device, seed, precision):
     return ncsnpp.NCSNpp(cfg, device, precision).load_state_dict(sd), sd, cfg
 
 
-def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
-    """Oracle (CPU restatement of the reference's PyTorch path) on this box's host cores: time whole
-    UNet forwards at a reduced batch until ~budget_s of CPU work is spent, extrapolate to images/s
-    for the full n_steps-step purification (the UNet call is >99.9 % of a step)."""
+CPU_WORKER_THREADS = 16     # oneDNN convolutions at batch 1-4 peak at ~16 threads on the MI355X host (probe: 8t 0.152 s, 16t 0.112 s,
+                            # 32t 0.199 s, 64t 0.409 s, 256t > 100 s per NCSN++ forward): the host is used as cores / 16 workers of 16 threads
+
+
+def cpu_worker(workload, t_int, seed, budget_s, cores):
+    """One oracle worker (a process of its own: `bench.py --cpu-worker`): pinned to `cores`, `len(cores)` torch threads, times whole
+    UNet forwards (and forward + input-gradient passes for the adjoint workload) at a small batch for ~budget_s.  Prints one JSON line."""
+    os.sched_setaffinity(0, cores)
+    torch.set_num_threads(len(cores))
+    from diffpure_amd import guided_unet, ncsnpp, synth
     from oracle import guided_unet as og
     from oracle import ncsnpp as on
-    # usable cores = the affinity mask (os.cpu_count() over-reports inside a cgroup / container);
-    # oneDNN convolutions at batch 1-4 peak at ~16 threads on the MI355X host (probe: 8t 0.152 s, 16t 0.112 s, 32t 0.199 s, 64t 0.409 s, 256t >100 s).
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("DIFFPURE_CPU_THREADS", "16")))
-    torch.set_num_threads(cores)
     if workload == "imagenet256_guided":
+        sd = synth.synth_state_dict(guided_unet.param_shapes(guided_unet.parse_config(IMAGENET_CFG)), seed)
         cfg = og.parse_guided_config(IMAGENET_CFG)
         b = 1
         x = torch.rand(b, 3, 256, 256) * 2 - 1
         fn = lambda: og.guided_unet_forward(sd, cfg, x, torch.full((b,), float(t_int)))
     else:
+        sd = synth.synth_state_dict(ncsnpp.param_shapes(ncsnpp.parse_config(CIFAR_CFG)), seed)
         cfg = on.parse_ncsnpp_config(CIFAR_CFG)
         b = 4
         x = torch.rand(b, 3, 32, 32) * 2 - 1
@@ -196,6 +201,7 @@ def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
 
     with torch.no_grad():
         s_fwd, calls, el = timed(fn)
+    rec = dict(s_fwd=s_fwd, calls=calls, cpu_s=el, batch=b, threads=len(cores))
     if workload.endswith("_adjoint"):
         # the adjoint solve costs one forward + one input-gradient pass per step (autograd on the CPU)
         def fb():
@@ -203,13 +209,42 @@ def cpu_baseline(workload, sd, t_int, n_steps, budget_s=12.0):
             out = on.ncsnpp_forward(sd, cfg, xr, torch.full((b,), 99.9))
             torch.autograd.grad(out, xr, torch.ones_like(out))
         s_fb, calls2, el2 = timed(fb)
-        per_image = n_steps * s_fwd + n_steps * s_fb
-        return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
-                    sample=f"{calls} forward(s) + {calls2} forward+input-gradient pass(es) at batch {b} ({el + el2:.1f} s of CPU "
-                           f"work); {n_steps} ODE steps + {n_steps} adjoint steps extrapolated; torch-CPU oracle")
-    return dict(value=1.0 / (s_fwd * n_steps), unit="images/s", cores=cores, kind="port",
-                sample=f"{calls} UNet forward(s) at batch {b} ({el:.1f} s of CPU work), x{n_steps} steps extrapolated; "
-                       "oracle = torch-CPU fp32 restatement of the reference modules (pinned to them by tests/golden)")
+        rec.update(s_fb=s_fb, calls_fb=calls2, cpu_s=el + el2)
+    print("CPUWORKER " + json.dumps(rec), flush=True)
+
+
+def cpu_baseline(workload, t_int, n_steps, seed, budget_s=12.0):
+    """Oracle (CPU restatement of the reference's PyTorch path) on THIS BOX'S HOST CORES - all of them: the cores this process may
+    use (affinity mask) are split into workers of CPU_WORKER_THREADS threads (the size at which one oracle forward is fastest),
+    every worker is a process of its own pinned to its block of cores, all run at once for ~budget_s, and their rates add up
+    (independent images).  Extrapolated to images/s of the full n_steps-step purification (the UNet call is > 99.9 % of a step)."""
+    import subprocess
+    usable = sorted(os.sched_getaffinity(0))
+    per = min(CPU_WORKER_THREADS, len(usable))
+    nw = max(1, min(len(usable) // per, int(os.environ.get("DIFFPURE_CPU_WORKERS", "16"))))
+    procs = []
+    for w in range(nw):
+        cores = ",".join(str(c) for c in usable[w * per:(w + 1) * per])
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cores, "--workload", workload, "--t", str(t_int),
+                                       "--seed", str(seed), "--cpu-budget", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    recs = []
+    for p_ in procs:
+        out, _ = p_.communicate(timeout=600)
+        for line in out.splitlines():
+            if line.startswith("CPUWORKER "):
+                recs.append(json.loads(line[len("CPUWORKER "):]))
+    if not recs:
+        return dict(value=None, unit="images/s", cores=0, kind="port", sample="no oracle worker finished")
+    adjoint = workload.endswith("_adjoint")
+    rate = sum(1.0 / (n_steps * r["s_fwd"] + (n_steps * r["s_fb"] if adjoint else 0.0)) for r in recs)
+    cpu_s = sum(r["cpu_s"] for r in recs)
+    return dict(value=rate, unit="images/s", cores=len(recs) * per, kind="port",
+                host={"cpu_count": os.cpu_count(), "usable_cores": len(usable), "workers": len(recs), "threads_per_worker": per,
+                      "images_per_s_per_worker": [1.0 / (n_steps * r["s_fwd"] + (n_steps * r["s_fb"] if adjoint else 0.0)) for r in recs]},
+                sample=(f"{len(recs)} oracle workers x {per} threads, all at once (the box's {len(usable)} usable cores of {os.cpu_count()}); "
+                        f"each: {recs[0]['calls']} UNet forward(s)" + (f" + {recs[0].get('calls_fb')} forward+input-gradient pass(es)" if adjoint else "") +
+                        f" at batch {recs[0]['batch']}, {cpu_s:.0f} s of CPU work in all; x{n_steps} steps" + (f" + {n_steps} adjoint steps" if adjoint else "") +
+                        " extrapolated; oracle = torch-CPU fp32 restatement of the reference modules (pinned to them by tests/golden)"))
 
 
 def timed_region(a, world, one_call, fence, before_first=None, after_first=None, use_dist=None):
@@ -248,6 +283,8 @@ def stub_main(a, rank, world):
     gathered = torch.empty((world * B, 3, hw, hw)) if world > 1 else None
 
     def one_call(i):
+        if a.stub_slow_rank == rank and a.stub_sleep > 0:
+            time.sleep(a.stub_sleep)            # (tests: the reported time must be the MAX over ranks)
         idx = torch.arange(rank * B, rank * B + B, dtype=torch.float32).view(-1, 1, 1, 1)
         y = x * 0.5 + idx
         if world > 1:
@@ -294,11 +331,17 @@ def main():
                     help="TEST HOOK (tests/test_bench_multirank.py): run the launch / sharding / all_gather / timing harness on CPU "
                          "ranks over gloo with a stand-in for the purification engine; the line it prints is marked stub and is "
                          "not a measurement")
+    ap.add_argument("--stub-slow-rank", type=int, default=-1, help="TEST HOOK (--stub-engine): this rank sleeps --stub-sleep seconds per call")
+    ap.add_argument("--stub-sleep", type=float, default=0.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="TEST HOOK (tests/test_gpu_dist.py): take the multi-rank code path - init_process_group('nccl', device_id), "
                          "device-side all_gather_into_tensor of the purified shards, barrier, MAX all-reduce of the time - at world "
                          "size 1 as well, so that RCCL runs on the one GPU a test box has")
+    ap.add_argument("--cpu-worker", default=None, help="INTERNAL (cpu_baseline): run one oracle worker pinned to these cores (comma list)")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
     a = ap.parse_args()
+    if a.cpu_worker is not None:
+        return cpu_worker(a.workload, a.t, a.seed, a.cpu_budget, [int(c) for c in a.cpu_worker.split(",")])
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -325,8 +368,11 @@ def main():
     # per-GPU batches of BASELINE.json's configs: ImageNet 64 (configs[2], and 512 sharded 8 ways in configs[3]),
     # CIFAR 256 (configs[1]), CIFAR adjoint 128 (configs[4])
     B = a.batch or (64 if a.workload == "imagenet256_guided" else (128 if adjoint else 256))
+    t_build = time.time()
     net, sd, _ = build_engine(a.workload, dev, a.seed, a.precision)
     pur = Purifier(net, wl["kind"], dev)
+    torch.cuda.synchronize()
+    build_s = time.time() - t_build          # synthetic weights + packing + upload: outside the timed region, reported per rank
     n_steps = len(sde_schedule(wl["kind"], a.t, a.dt))
     hw = wl["hw"]
     gen = torch.Generator().manual_seed(a.seed + rank)
@@ -373,6 +419,12 @@ def main():
     el, y = timed_region(a, world, one_call, fence, before_first, after_first, use_dist)
     sclk = clock.stop()
     gather_ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], y)) if use_dist else None
+    build_all = [build_s]
+    if use_dist:                # so that the first real multi-GPU run explains its own wall time
+        tb = torch.tensor([build_s], dtype=torch.float64, device=dev)
+        allb = [torch.zeros_like(tb) for _ in range(world)]
+        dist.all_gather(allb, tb)
+        build_all = [float(v.item()) for v in allb]
     # the boundary hands over device tensors (runner.image_editing_sample(img) with img on the GPU), so `value` is timed with the
     # batch resident in HBM; the host->device copy of one batch is measured here, outside the timed region, for the record
     xh = x.cpu().pin_memory()
@@ -410,8 +462,12 @@ def main():
             if dom["ms"] > 0:
                 ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
                 launches_per_call = dom["n"]
+                held = (sclk or {}).get("median")
                 roof.update({
                     "achieved": ach, "frac": ach / peak, "executed_frac": ach * passes / peak,
+                    # the same against the peak at the clock this run HELD (the chip is power-limited under MFMA load: 2.5 PF assumes
+                    # 2.4 GHz): achieved / (peak x sclk_median / 2400).  null if the clock could not be sampled.
+                    "frac_at_held_clock": (ach / (peak * held / 2400.0)) if held else None,
                     "avg_launch_ms": dom["ms"] / dom["n"],
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
                     "algorithmic_gflop_per_launch": dom["flop"] / dom["n"] / 1e9,
@@ -423,6 +479,13 @@ def main():
                     "other_kernels_share_of_step": {"3x3 on other tile variants (stem, head, split-K levels)": prof["other3x3"]["ms"] / window_ms,
                                                     "1x1 convolutions / linear": (prof["conv1x1"]["ms"] + prof["pp1x1"]["ms"]) / window_ms},
                 })
+                gn = prof.get("gn_apply")
+                if gn and gn["ms"] > 0:     # the second kernel of the step: HBM-bound, measured with the same hipEvent pairs
+                    gbs = gn["bytes"] / (gn["ms"] * 1e-3) / 1e9
+                    roof["second_kernel"] = {"kernel": "GroupNorm-apply (gn_apply_h16 / gn_apply_h2q: normalise + FiLM + SiLU + resample, emits the convolution operand)",
+                                             "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                             "frac_of_measured_copy_rate_6290": gbs / 6290.0, "algorithmic_bytes_per_launch": gn["bytes"] / gn["n"],
+                                             "avg_launch_ms": gn["ms"] / gn["n"], "sampled_launches": gn["n"], "time_share_of_step": gn["ms"] / window_ms}
                 if a.workload == "imagenet256_guided" and a.precision in ("f16", "f16sr"):
                     busy = pmc_mfma_busy()
                     if busy is not None:
@@ -464,6 +527,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "image": f"3x{hw}x{hw}",
                        "parallelism": f"batch-sharded x{world}, one all_gather of outputs"},
             "roofline": roof,
+            "engine_build_s_per_rank": build_all,
             "input": {"resident_in_hbm_before_timing": True, "h2d_ms_per_batch_pinned": h2d_ms,
                       "value_if_h2d_were_inside_the_timed_region": images / (el + h2d_ms * 1e-3 * a.steps)},
         }
@@ -471,7 +535,7 @@ def main():
             out["collectives"] = {"backend": dist.get_backend(), "world_size": world, "forced_at_world_1": bool(a.force_dist and world == 1),
                                   "all_gather_into_tensor_on_device": True, "gathered_equals_local_shard": gather_ok}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.workload, sd, a.t, n_steps)
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.t, n_steps, a.seed)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

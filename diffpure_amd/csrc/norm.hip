@@ -675,6 +675,12 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
         for (int i = 0; i < 4; ++i) p.fir[i] = fir4[i];
     const int CQ = C / 4, CQT = CQ < 256 ? CQ : 256, qslots = 256 / CQT;     // operand formats: C % 8 == 0, so CQ and CQT are even
     const unsigned rows = (unsigned)(B * (out_fmt ? p.Ho + 2 : p.Ho));
+    void* rec = nullptr;
+    {   // algorithmic HBM bytes: every source element the output needs once (4 B) + every output element once
+        const double in_px = resample == 1 || resample == 3 ? (double)H * W : (double)p.Ho * p.Wo * (resample ? 4 : 1);
+        const double out_px = (double)(out_fmt ? (p.Ho + 2) * (p.Wo + 2) : p.Ho * p.Wo);
+        dp_prof_begin(DP_PROF_GN_APPLY, 0.0, (double)B * C * (in_px * 4 + out_px * (out_fmt == 2 ? 2 : 4) * (y_raw ? 2 : 1)), (hipStream_t)stream, &rec);
+    }
 #define GN_APPLY_LAUNCH(ACT_) \
     do {                                                                                                                              \
         if (resample >= 3) hipLaunchKernelGGL((gn_apply_kernel<ACT_, true>), dim3(rows), dim3(CQT * qslots), 0, (hipStream_t)stream, p, CQT, qslots);   \
@@ -697,6 +703,7 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
     }
 #undef GN_APPLY_LAUNCH
 #undef GN_H2Q_LAUNCH
+    dp_prof_end(rec, (hipStream_t)stream);
     DP_LAUNCH_CHECK("gn_apply");
     return 0;
 }
@@ -726,6 +733,12 @@ extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, i
     const int CO = C / 8, COT = CO < 256 ? CO : 256, slots = 256 / COT;
     const unsigned rows = (unsigned)(B * (out_fmt == 2 ? p.Ho + 2 : p.Ho));
     const dim3 g(rows), blk((unsigned)(COT * slots));
+    void* rec = nullptr;
+    {   // algorithmic HBM bytes: every source element the output needs once (2 B) + every output element once (2 B)
+        const double in_px = resample == 1 ? (double)H * W : (double)p.Ho * p.Wo * (resample ? 4 : 1);
+        const double out_px = (double)(out_fmt == 2 ? (p.Ho + 2) * (p.Wo + 2) : p.Ho * p.Wo);
+        dp_prof_begin(DP_PROF_GN_APPLY, 0.0, (double)B * C * 2.0 * (in_px + out_px * (y_raw ? 2 : 1)), (hipStream_t)stream, &rec);
+    }
     if (out_fmt == 2) {
         if (act) hipLaunchKernelGGL((gn_apply_h16_kernel<true, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
         else hipLaunchKernelGGL((gn_apply_h16_kernel<false, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
@@ -733,6 +746,7 @@ extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, i
         if (act) hipLaunchKernelGGL((gn_apply_h16_kernel<true, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
         else hipLaunchKernelGGL((gn_apply_h16_kernel<false, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
     }
+    dp_prof_end(rec, (hipStream_t)stream);
     DP_LAUNCH_CHECK("gn_apply_h16");
     return 0;
 }

@@ -886,7 +886,7 @@ def prof_enabled():
     return _PROF_ON
 
 
-PROF_KINDS = ("pp3x3", "conv1x1", "other3x3", "pp1x1")       # DP_PROF_* of include/diffpure_hip.h
+PROF_KINDS = ("pp3x3", "conv1x1", "other3x3", "pp1x1", "gn_apply")       # DP_PROF_* of include/diffpure_hip.h
 
 
 def prof_collect():

@@ -42,11 +42,13 @@ int dp_get_tuning(const char* name, int* value);
  * kept); dp_prof_collect() synchronises the recorded events and returns, per launch kind, total milliseconds, launches
  * algorithmic FLOPs (2*M*N*K) and algorithmic HBM bytes (every operand and the output once), plus the number of launches that were NOT recorded because the window exceeded the
  * record buffer (65 536 launches) - callers must report a non-zero `dropped`. */
-enum { DP_PROF_3X3_PP = 0,      /* 3x3 convolutions on the 8-wave ping-pong kernel (the dominant kernel) */
+enum { DP_PROF_3X3_PP = 0,      /* 3x3 convolutions on the 256-wide tile kernels (8-wave / one-wave-per-SIMD / ping-pong: the dominant kernel) */
        DP_PROF_1X1 = 1,         /* 1x1 convolutions / linear layers, any kernel */
        DP_PROF_3X3_OTHER = 2,   /* 3x3 convolutions on the other tile variants (stem, head, split-K levels, small shapes) */
        DP_PROF_1X1_PP = 3,      /* 1x1 convolutions that ran on the ping-pong kernel (a rocprofv3 per-kernel total covers kinds 0 + 3) */
-       DP_PROF_KINDS = 4 };
+       DP_PROF_GN_APPLY = 4,    /* GroupNorm-apply launches (dp_gn_apply / dp_gn_apply_h16): the HBM-bound second kernel of a step; flop = 0,
+                                   bytes = every input element once + every output element once */
+       DP_PROF_KINDS = 5 };
 int dp_prof_enable(int on);
 int dp_prof_collect(double* ms, long long* n, double* flop, double* bytes, long long* dropped);
 

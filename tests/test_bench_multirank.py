@@ -41,6 +41,23 @@ def test_bench_launch_gather_and_timing_harness(n):
     assert abs(d["value"] - d["config"]["global_batch"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
 
 
+def test_bench_harness_at_world_8_takes_the_max_over_ranks():
+    """The driver's 8-GPU launch line over gloo with the stub engine: eight ranks, shards in rank order, and the reported time is
+    the MAX over ranks - rank 5 is made to sleep 0.25 s per call, so every step must take at least that long although seven of
+    the eight ranks finish at once.  (No 8-GPU node is available to the builder: NO scaling curve has been measured.)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--stub-engine", "--stub-slow-rank", "5", "--stub-sleep", "0.25", "--batch", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["stub"] is True and d["n_gpus"] == 8 and d["config"]["global_batch"] == 24 and d["gather_ok"] is True
+    assert d["ms_per_step"] >= 250.0, d["ms_per_step"]
+    assert abs(d["value"] - 24 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
+
+
 def test_bench_refuses_a_world_size_that_does_not_match_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine"], capture_output=True, text=True,
                        timeout=120, cwd=ROOT)

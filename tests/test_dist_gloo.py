@@ -91,6 +91,53 @@ def test_sharded_purify_world2(n):
         assert ok and shape == (n, 3, 4, 4), (rank, ok, shape)
 
 
+def _run_world(target, world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+@pytest.mark.parametrize("n", [512 // 32, 11, 3])
+def test_sharded_purify_world8_rank_order_ragged_batch_and_gradients(n):
+    """BASELINE.json configs[3] shards 8 ways (ref:eval_sde_adv.py:220-228 runs adv_batch_size x ngpus).  Eight CPU ranks over gloo:
+    a batch that divides evenly (16 = 2 per rank), a ragged one (11: ranks 0-4 get 2, rank 5 one, ranks 6-7 none and contribute
+    padding only), and fewer images than ranks (3) - shards reassembled in rank order, gradients all-gathered back."""
+    for rank, ok, shape in _run_world(_worker, 8, n):
+        assert ok and shape == (n, 3, 4, 4), (rank, ok, shape)
+    for rank, ok_fwd, ok_grad, shape in _run_world(_grad_worker, 8, n):
+        assert ok_fwd and ok_grad and shape == (n, 3, 4, 4), (rank, ok_fwd, ok_grad, shape)
+
+
+def _dtype_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diffpure_amd import dist as ddist
+        x = torch.zeros(n, 3, 4, 4, dtype=torch.float64)
+        try:
+            ddist.sharded_purify(lambda xl, s0: xl.float(), x)
+            q.put((rank, "no error"))
+        except ValueError as e:
+            q.put((rank, "ValueError" if "float32" in str(e) else str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_purify_rejects_a_wrong_dtype_on_every_rank_together():
+    """The dtype contract is checked on the replicated INPUT before anything rank-specific runs: with 3 ranks and 2 images the
+    image-less rank used to raise alone (its result is `x * 1.0` in x's dtype) while the others entered the all-gather and hung."""
+    for rank, what in _run_world(_dtype_worker, 3, 2):
+        assert what == "ValueError", (rank, what)
+
+
 def test_shard_bounds():
     from diffpure_amd.dist import shard_bounds
     assert [shard_bounds(512, r, 8)[:2] for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]

@@ -422,6 +422,30 @@ def test_checkpoint_format_round_trip_on_the_gpu():
         assert maxabs(out, g["out"]) < tol, (precision, maxabs(out, g["out"]))
 
 
+def test_guided_checkpoint_file_round_trip_on_the_gpu():
+    """A 256x256_diffusion_uncond.pt-shaped file WRITTEN by the reference module (tests/golden/make_golden_guided_ckpt.py) through
+    factory.build_guided on the HIP engine (runners/diffpure_sde.py:163-170), every precision mode, against the reference module after
+    ITS load path - with use_fp16 False (the fp32 model) and, for scale, True (the reference's own convert_to_fp16 torso, which sits
+    6.5e-3 from its fp32 self on this forward).  The small config has a 32-channel attention head: the attention fallback (fp32 proj_out)
+    inside an fp16 residual stream."""
+    import argparse
+    import os
+    from conftest import GOLDEN
+    from diffpure_amd import factory
+    g = load_golden("guided_ckpt.pt")
+    config = argparse.Namespace(model=argparse.Namespace(**g["cfg"]))
+    for precision, tol in (("f32", 1e-4), ("f16x3", 1e-4), ("f16sr", 2e-2)):
+        net, mc = factory.build_guided(argparse.Namespace(precision=precision), config, DEV, model_dir=os.path.join(GOLDEN, "ckpt", "guided"))
+        out = nchw(net.forward(nhwc(g["x"]).to(DEV), g["t"].float().to(DEV))).cpu()
+        err, err16 = maxabs(out, g["out_fp32"]), maxabs(out, g["out_fp16"])
+        print(f"guided checkpoint round trip [{precision}]: max-abs vs the reference fp32 model {err:.3e}; vs the reference's own use_fp16 torso {err16:.3e} "
+              f"(reference fp16 vs fp32: {g['fp16_vs_fp32_maxabs']:.3e})")
+        assert err < tol, (precision, err)
+        assert precision != "f16sr" or net._lean16
+    with pytest.raises(FileNotFoundError):
+        factory.build_guided(argparse.Namespace(precision="f32"), config, DEV, model_dir=os.path.join(GOLDEN, "no_such_dir"))
+
+
 def test_ncsnpp_fir_forward_vs_reference_golden():
     """`fir: True` NCSN++ (upfirdn2d resampling in the BigGAN blocks) on the HIP engine against the
     reference module's forward (tests/golden/make_golden_fir.py)."""

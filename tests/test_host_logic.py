@@ -512,6 +512,51 @@ def test_checkpoint_format_round_trip_through_the_factory():
         factory.ncsnpp_state_from_checkpoint(bad, pn.parse_config(g["cfg"]))
 
 
+def test_guided_checkpoint_file_round_trip_through_the_factory():
+    """A 256x256_diffusion_uncond.pt-shaped state_dict file written by the REFERENCE's own module and read back by its own load path
+    (tests/golden/make_golden_guided_ckpt.py; runners/diffpure_sde.py:163-170) loads through diffpure_amd.factory.build_guided - found in
+    model_dir, no synthetic-weights flag - and gives the reference's output; `use_fp16` in the config selects nothing here (the precision
+    mode does), and the reference's own fp16 torso is further from its fp32 self than the engine is."""
+    import argparse
+    import os
+    from conftest import GOLDEN
+    from diffpure_amd import factory
+    g = load_golden("guided_ckpt.pt")
+    for use_fp16 in (False, True):
+        config = argparse.Namespace(model=argparse.Namespace(**dict(g["cfg"], use_fp16=use_fp16)))
+        net, mc = factory.build_guided(argparse.Namespace(precision="f32"), config, "cpu", model_dir=os.path.join(GOLDEN, "ckpt", "guided"))
+        assert mc["use_fp16"] is use_fp16
+        out = nchw(net.forward(nhwc(g["x"]), g["t"].float()))
+        torch.testing.assert_close(out, g["out_fp32"], rtol=2e-4, atol=2e-5)
+    assert (out - g["out_fp16"]).abs().max() > 1e-3 and g["fp16_vs_fp32_maxabs"] > 1e-3
+    with pytest.raises(FileNotFoundError):
+        factory.build_guided(argparse.Namespace(precision="f32"), config, "cpu", model_dir=os.path.join(GOLDEN, "no_such_dir"))
+    bad = dict(torch.load(os.path.join(GOLDEN, "ckpt", "guided", "256x256_diffusion_uncond.pt"), map_location="cpu"))
+    bad.pop("out.2.weight")
+    with pytest.raises(KeyError):
+        pg.GuidedUNet(pg.parse_config(g["cfg"]), "cpu").load_state_dict(bad)
+
+
+def test_replica_offsets_do_not_depend_on_the_order_engines_are_built_in():
+    """Advisor (round 3): the sample offset of a DataParallel replica was the ordinal of its GPU among the engines built SO FAR - built
+    lazily from the replica threads, so cuda:2 before cuda:1 gave both 1 << 32.  It is a function of the device now."""
+    from runners import _common
+
+    class FakePur:
+        def __init__(self, dev):
+            self.device = dev
+
+    pool = _common.EnginePool(lambda dev: FakePur(dev), "cpu")
+    want = {i: (1 + i) << 32 for i in range(4)}
+    assert pool.replica_offset(torch.device("cuda", 2)) == want[2]          # nothing built for it yet
+    assert pool.replica_offset(torch.device("cuda", 1)) == want[1]
+    pool._by_dev[("cuda", 2)] = FakePur(torch.device("cuda", 2))           # "built" in the wrong order
+    pool._by_dev[("cuda", 1)] = FakePur(torch.device("cuda", 1))
+    assert [pool.replica_offset(torch.device("cuda", i)) for i in range(4)] == [want[i] for i in range(4)]
+    assert len({pool.replica_offset(d) for d in ("cpu", torch.device("cuda", 0), torch.device("cuda", 1), torch.device("cuda", 7))}) == 4
+    assert pool.replica_offset("cpu") == 0
+
+
 def test_fir_resamplers_match_the_reference_upfirdn2d():
     """tests/refops.py's statement of the FIR modes (what the HIP kernels are held to on the GPU) against
     up_or_down_sampling.upsample_2d / downsample_2d of the reference (golden: tests/golden/make_golden_fir.py)."""
