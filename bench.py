@@ -447,16 +447,16 @@ def main():
         unet_tflops = value / world * wl["gflop"] * n_steps / 1e3
         roof = {"bound": "mfma",
                 "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
-                          (f"conv_igemm_dw8u = conv_igemm_dw<8 waves> with the nine taps of a channel slice unrolled (3x3 implicit GEMM, 256x256 tile, one 8-wave workgroup per CU: two free-running waves per "
-                           f"SIMD with 64x128 wave tiles sharing the tile in LDS, separate LDS rings for activations and weights, counted "
-                           f"vmcnt, one barrier per k-tile; launches with fewer than 256 tiles run conv_igemm_sw, the one-wave-per-SIMD "
-                           f"form; {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
+                          (f"conv_igemm_dw (3x3 implicit GEMM, 256x256 tile, one 8-wave workgroup per CU: two free-running waves per SIMD with 64x128 "
+                           f"wave tiles sharing the tile in LDS, the OLDER wave of every SIMD staging the rows of both (LDS-DMA, separate rings for "
+                           f"activations and weights, counted vmcnt, one barrier per k-tile); launches with fewer than 256 tiles run conv_igemm_sw, the "
+                           f"one-wave-per-SIMD form; {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
                            f"conv_igemm_h2_pp (3x3 implicit GEMM on the 8-wave ping-pong kernel; {passes} x v_mfma_f32_32x32x16_f16 per "
                            f"product; executed MFMA flops = {passes} x achieved)"),
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "peak_note": "dense fp16 MFMA peak at the 2.4 GHz nominal clock (MI355X_MICROARCH.md); see sclk_mhz for the clock this run held",
                 "mfma_passes": passes, "sclk_mhz": sclk, "end_to_end_unet_tflops_per_gpu": unet_tflops,
-                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DIFFPURE_LEAN16", "DP_H2_SW", "DP_H2_DW", "DP_H2_DW_UNROLL", "DP_H2_DW_PRIO", "DP_H2_PP", "DIFFPURE_STREAMS") if k in os.environ}}
+                "switches": {k: os.environ[k] for k in ("DIFFPURE_LEAN", "DIFFPURE_LEAN16", "DP_H2_SW", "DP_H2_DW", "DP_H2_PP", "DIFFPURE_STREAMS") if k in os.environ}}
         if prof is not None:
             dom = prof["pp3x3"] if prof["pp3x3"]["n"] else prof["other3x3"]      # f32 / tiny shapes never reach the ping-pong kernel
             if dom["ms"] > 0:

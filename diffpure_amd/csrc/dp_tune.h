@@ -6,7 +6,8 @@
 // them into a separate libdiffpure_hip_ablate.so.  The switches are PROCESS-WIDE (relaxed atomics: a thread that flips one
 // while another thread launches is well-defined, and the other thread's launches pick either variant - same bits either way).
 // Round 4 removed the switches of the variants that measured slower and were pruned from the library (two workgroups per CU,
-// persistent tile loop, halo tile, four-phase ping-pong schedule, start-up staggers, GroupNorm fold, non-quad GroupNorm-apply).
+// persistent tile loop, halo tile, four-phase ping-pong schedule, start-up staggers, GroupNorm fold, non-quad GroupNorm-apply) and of
+// the slice-unrolled / static-priority forms of the 8-wave kernel that its asymmetric staging superseded: 16 -> 5 switches.
 #pragma once
 
 enum DpTune {
@@ -15,8 +16,6 @@ enum DpTune {
     DP_T_H2_NN,            // DP_H2_NN: few-output-channels kernel - 0 off
     DP_T_H2_DW,            // DP_H2_DW: the 8-wave 256x256 kernel (igemm_h2_dw.hip) on launches of >= 256 tiles - 0 off
     DP_T_GN_FINALIZE_SAMPLE, // DP_GN_FINALIZE_SAMPLE: small feature maps - one finalize workgroup per sample instead of per (sample, group) - 0 off
-    DP_T_H2_DW_UNROLL,     // DP_H2_DW_UNROLL: 3x3 launches of the 8-wave kernel run the slice-unrolled loop (nine taps per body) - 0 the rolled loop
-    DP_T_H2_DW_PRIO,       // DP_H2_DW_PRIO: that loop with s_setprio 1 on waves 4-7 (the younger wave of every SIMD; timing only) - 0 off
     DP_T_COUNT
 };
 

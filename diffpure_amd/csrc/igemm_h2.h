@@ -24,7 +24,6 @@ struct ConvH2Args {
     int passes;         // MFMA passes per product: 3 = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi ("f16x3"); 2 = a_hi*w_lo + a_hi*w_hi
                         // (activations rounded to fp16, weights to 22 bits); 12 = a_lo*w_hi + a_hi*w_hi (weights rounded);
                         // 1 = a_hi*w_hi (plain fp16 operands, fp32 accumulation)
-    int stagger;        // igemm_h2_dw.hip: the DP_H2_DW_PRIO switch of the slice-unrolled kernel (timing only)
     int wfmt;           // weight panel: 0 = h2 (hi|lo), 1 = plain fp16 (afmt 1, passes 1 only)
     int afmt;           // activation operand: 0 = h2 ([..][C/8][hi 8|lo 8] fp16, passes 3 | 12), 1 = h1 (plain fp16, passes 2 | 1)
     int ofmt;           // output: 0 = fp32 [M][ldo]; 1 = plain fp16 [M][ldo] (the final fp32 value rounded to nearest; `out` then
@@ -65,7 +64,7 @@ bool dp_conv_sw_applies(const ConvH2Args& p, int bn);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn);
 
 // One 8-wave workgroup per CU on 256x256 tiles, two free-running waves per SIMD sharing the tile (igemm_h2_dw.hip): fp16 x fp16;
-// the launcher fills p.tiles / p.stagger.
+// the launcher fills p.tiles.
 bool dp_conv_dw_applies(const ConvH2Args& p);
 void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s);
 

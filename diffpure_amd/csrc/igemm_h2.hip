@@ -531,7 +531,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.afmt = a_fmt;
     p.wfmt = w_fmt;
     p.ofmt = out_fmt;
-    p.stagger = 0;
+
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&

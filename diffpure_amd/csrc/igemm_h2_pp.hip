@@ -448,7 +448,7 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn) {
         else if (M_ == 0 && p.passes == 12) PP_LAUNCH1(BM_, BN_, 0, 12, false, 0, false); \
         else PP_LAUNCH1(BM_, BN_, M_, 3, false, 0, false);                      \
     } while (0)
-    p.stagger = 0;
+
     if (bn == 128) {
         PP_LAUNCH(512, 128, 0);
         return;

@@ -31,7 +31,6 @@ def timeit(fn, iters):
 def main():
     B = 64
     ops.set_tuning("DP_H2_DW", 1)
-    ops.set_tuning("DP_H2_DW_UNROLL", 0)        # the ablation modes live in the rolled loop
     for (H, ci, co) in [(256, 256, 256), (128, 512, 512), (64, 512, 512)]:
         x = torch.randn(B, H, H, ci)
         w = torch.randn(co, ci, 3, 3) * (1.0 / (9 * ci)) ** 0.5

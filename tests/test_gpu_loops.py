@@ -233,7 +233,7 @@ def test_guided_full_stochastic_adjoint_runs_at_batch_8():
 
 # ---- round 4: the configurations BASELINE.json benchmarks, at THEIR batch; the stochastic adjoint at the product grid ----------
 def test_ncsnpp_loop_at_batch_256_reproduces_the_golden_samples_bit_for_bit():
-    """BASELINE.json configs[1] runs B=256: the 32^2 / 16^2 levels then take the 256-wide tile kernels (`conv_igemm_dw8u`, the
+    """BASELINE.json configs[1] runs B=256: the 32^2 / 16^2 levels then take the 256-wide tile kernels (`conv_igemm_dw`, the
     512x128 one-wave-per-SIMD tiles) that a B=4 batch never reaches.  The four golden images lead a batch of 256: bit-identical
     to the B=4 run, hence within 1e-3 of the reference modules' 100-step loop."""
     from diffpure_amd.sde import Purifier

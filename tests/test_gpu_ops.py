@@ -447,21 +447,16 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
         for name in ("DP_H2_SW", "DP_H2_DW"):
             tune.delenv(name)
         tune.setenv("DP_H2_PP", "0")
-    # the 8-wave kernel (igemm_h2_dw.hip: one workgroup per CU on 256x256 tiles, two free-running waves per SIMD); taken only where
-    # the launch has >= 256 tiles, elsewhere the other variants run.  The 3x3 launches run the slice-unrolled loop by default,
-    # DP_H2_DW_UNROLL=0 the rolled one; DP_H2_DW_PRIO (static priority of waves 4-7) changes timing only.
+    # the 8-wave kernel (igemm_h2_dw.hip: one workgroup per CU on 256x256 tiles, two free-running waves per SIMD, the older wave of every
+    # SIMD staging the rows of both); taken only where the launch has >= 256 tiles, elsewhere the other variants run
     if B * H * W % 256 == 0 and N % 256 == 0 and not (H * W <= 64) and C * k * k >= 128:
         tune.setenv("DP_H2_DW", "1")
         tune.setenv("DP_H2_PP", "1")
-        for unroll, prio in ((1, 0), (1, 1), (0, 0)):
-            tune.setenv("DP_H2_DW_UNROLL", unroll)
-            tune.setenv("DP_H2_DW_PRIO", prio)
-            for _ in range(3):
-                got, got_cs = run()
-                assert torch.equal(got, base), ("dw8", unroll, prio)
-                assert torch.equal(got_cs, base_cs), ("dw8", unroll, prio)
-        for name in ("DP_H2_DW", "DP_H2_DW_UNROLL", "DP_H2_DW_PRIO"):
-            tune.delenv(name)
+        for _ in range(3):
+            got, got_cs = run()
+            assert torch.equal(got, base), "dw8"
+            assert torch.equal(got_cs, base_cs), "dw8"
+        tune.delenv("DP_H2_DW")
         tune.setenv("DP_H2_PP", "0")
     if B * H * W % 256 == 0 and N % 128 == 0 and not (H * W <= 64):
         tune.setenv("DP_H2_PP", "1")

@@ -72,89 +72,105 @@ def test_swizzle_is_conflict_free_for_shifted_rows():
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-# csrc/igemm_h2_dw.hip::conv_igemm_dw8u - the slice-unrolled k-loop of the 8-wave 256x256 convolution kernel.
-# Restated: which 16-byte unit of the bordered fp16 operand / of the fp16 weight panel every LDS-DMA piece of every k-tile
-# fetches, into which ring stage, in which iteration it is issued and waited for - and that every MFMA fragment read of k-tile t
-# finds k-tile t's data (tap t % 9 of channel slice t // 9) in the stage it addresses, for every output row / column of the tile.
-def _dw8u_schedule(nsl):
-    """-> list of (iteration t, [('A'|'B', k-tile staged, ring stage)]) in issue order, incl. the prologue (t = -1)"""
-    nt = 9 * nsl
-    sched = [(-1, [("B", 0, 0), ("A", 0, 0), ("A", 1, 1), ("B", 1, 1)])]
-    for t in range(nt):
-        q = t % 9
-        last = t // 9 == nsl - 1
-        if last and q >= 7:
-            sched.append((t, []))                        # tail iterations: nothing left to stage
-        else:
-            sched.append((t, [("B", t + 2, (q + 2) % 3), ("A", t + 2, (q + 2) % 3)]))
+# csrc/igemm_h2_dw.hip::conv_igemm_dw - the k-loop of the 8-wave 256x256 convolution kernel with ASYMMETRIC staging (round 4): the
+# older wave of every SIMD (waves 0-3) stages the rows of both waves of its SIMD, the younger (4-7) issues no LDS-DMA.
+# Restated: which 16-byte unit of the bordered fp16 operand / of the fp16 weight panel every LDS-DMA piece of every k-tile fetches,
+# into which ring stage, in which iteration and at which point of it (IN segment A, or LATE = after the vmcnt wait, in front of the
+# barrier) it is issued, what the counted vmcnt wait of every iteration therefore covers - and that every MFMA fragment read of
+# k-tile t finds k-tile t's data in the stage it addresses, for every output row of the tile, incl. 1x1 K-segments.
+def _dw_schedule(nt):
+    """-> list of (iteration t, when, [(operand, piece it, k-tile staged, ring stage)]) in ISSUE ORDER of a staging wave, incl. the
+    prologue (t = -1); piece it: 0, 1 = own rows, 2, 3 = the partner's"""
+    sched = [(-1, "prologue", [("B", it, 0, 0) for it in range(4)] + [("A", it, 0, 0) for it in range(4)] +
+              [("A", it, 1, 1) for it in range(4)] + [("B", it, 1, 1) for it in range(4)])]
+    for t in range(nt - 2):                               # steady iterations: k-tile t + 2 exists
+        st = (t + 2) % 3
+        sched.append((t, "in A", [("B", 0, t + 2, st), ("B", 1, t + 2, st), ("A", 0, t + 2, st), ("A", 1, t + 2, st)]))
+        sched.append((t, "late", [("B", 2, t + 2, st), ("B", 3, t + 2, st), ("A", 2, t + 2, st), ("A", 3, t + 2, st)]))
     return sched
 
 
-@pytest.mark.parametrize("nsl", [1, 2, 3, 8])
-def test_dw8u_ring_schedule_has_no_raw_or_war_hazard(nsl):
-    """Ring of three stages, prefetch distance two, ONE barrier per k-tile (after the wave's own pieces of k-tile t+1 landed):
-    every k-tile is staged exactly once, into stage (k-tile mod 3) - the compile-time stage of position q = t mod 9 because
-    9 = 0 (mod 3) -; it is staged at least one barrier before its first read (RAW) and never while the k-tile it overwrites can
-    still be read (WAR: reads of k-tile t happen in iterations t-1 (after the barrier) and t (before the barrier))."""
-    nt = 9 * nsl
-    staged_at, stage_of = {}, {}
-    for t, pieces in _dw8u_schedule(nsl):
-        for op, kt, st in pieces:
-            assert (op, kt) not in staged_at, "staged twice"
+@pytest.mark.parametrize("nt", [4, 9, 18, 72, 75])
+def test_dw_ring_schedule_has_no_raw_or_war_hazard(nt):
+    """Rings of three stages, prefetch distance two, ONE barrier per k-tile.  In iteration t the staging wave issues its own four
+    pieces of k-tile t+2 inside segment A, then waits with vmcnt(4) - in issue order that leaves exactly those four in flight, so the
+    wait covers the LATE pieces of the previous iteration too -, then issues the partner's four pieces of k-tile t+2, then meets the
+    barrier.  Every piece of k-tile t+1 has therefore landed before barrier(t), after which its fragments are first read (RAW); a
+    stage is rewritten in iteration t only after every read of the k-tile it held (t-1: read in iterations t-2 after the barrier
+    and t-1 before it) lies behind barrier(t-1), which the issuing wave has passed (WAR)."""
+    queue, landed_by_wait = [], {}                        # issue-ordered (k-tile, operand, piece); per iteration: what its wait retires
+    staged = {}
+    for t, when, pieces in _dw_schedule(nt):
+        if when == "late":                                # the wait of iteration t sits between "in A" and "late"
+            keep = queue[-4:]                             # s_waitcnt vmcnt(4): the four youngest may still fly
+            assert all(kt == t + 2 for kt, _, _ in keep)
+            landed_by_wait[t] = {q for q in queue[:-4]}
+            queue = keep
+        for op, it, kt, st in pieces:
+            assert (op, it, kt) not in staged, "staged twice"
             assert kt < nt and st == kt % 3
-            staged_at[(op, kt)], stage_of[(op, kt)] = t, st
+            staged[(op, it, kt)] = (t, when)
+            queue.append((kt, op, it))
+        if when == "prologue":                            # vmcnt(8): k-tile 0 landed
+            assert {kt for kt, _, _ in queue[:-8]} == {0} and len(queue[:-8]) == 8
+            queue = queue[-8:]
     for op in "AB":
-        assert sorted(k for (o, k) in staged_at if o == op) == list(range(nt))
-        for kt in range(nt):
-            issue = staged_at[(op, kt)]
-            # RAW: the first read of k-tile kt comes after the barrier of iteration kt - 1; the wait before that barrier
-            # covers every piece issued up to iteration kt - 2 (pieces of iteration kt - 1 may still fly)
-            assert issue <= kt - 2 or issue == -1, (op, kt, issue)
-            # WAR: the stage held k-tile kt - 3, last read before the barrier of iteration kt - 3; the write is issued in
-            # iteration kt - 2 (or the prologue)
-            if kt >= 3:
-                assert issue >= kt - 2
+        for it in range(4):
+            assert sorted(k for (o, i, k) in staged if o == op and i == it) == list(range(nt))
+    done = set()
+    for t in range(nt - 2):
+        done |= landed_by_wait[t]
+        # RAW: before barrier(t) every piece of k-tile t + 1 has landed
+        assert all((t + 1, op, it) in done or t + 1 <= 0 for op in "AB" for it in range(4)), t
+    for (op, it, kt), (t, when) in staged.items():
+        if kt >= 3:                                       # WAR: stage kt % 3 held k-tile kt - 3, whose last reads precede barrier(kt - 3)
+            assert t == kt - 2                            # ... and this piece is issued in iteration kt - 2 > kt - 3
 
 
-@pytest.mark.parametrize("shape", [(1, 32, 32, 32), (2, 16, 16, 64), (1, 64, 64, 96), (1, 8, 512, 64)], ids=str)
-def test_dw8u_pieces_and_fragment_reads_agree(shape):
-    B, H, W, C = shape
+@pytest.mark.parametrize("shape", [(1, 32, 32, 32, 0, 0), (2, 16, 16, 64, 0, 0), (1, 4, 512, 32, 0, 0), (1, 10, 128, 32, 0, 0),
+                                   (1, 16, 16, 32, 64, 32), (1, 16, 32, 64, 32, 0)], ids=str)
+def test_dw_pieces_and_fragment_reads_agree(shape):
+    """Piece -> (rows, LDS destination, source address) of the staging waves against the fragment reads of all eight waves, for the
+    3x3 part and the 1x1 K-segments that follow it (plain fp16 NHWC tensors, no border)."""
+    B, H, W, C, C1, C2 = shape
     Wp, HW, pad = W + 2, H * W, 1
-    nsl = C // 32
-    ATILE = 256 * 64
+    nt_main = 9 * (C // 32)
+    nt = nt_main + (C1 + C2) // 32
     total = B * (H + 2) * Wp * C
-    toffx = []                                            # as the kernel builds it: byte offset of the k-tile staged at position q
-    for q in range(9):
-        tap = (q + 2) % 9
-        ky, kx = divmod(tap, 3)
-        toffx.append(((ky - pad) * Wp + (kx - pad)) * C * 2 + (64 if q + 2 >= 9 else 0))
-    t0 = ((0 - pad) * Wp + (0 - pad)) * C * 2
     for tile_m in range(B * HW // 256):
         m0 = tile_m * 256
-        lds = {}                                          # (stage, byte offset in stage) -> (k-tile, element offset fetched)
-        actr_slice = 0                                    # + 64 bytes per finished slice
+        lds = {}                                          # (stage, byte offset in stage) -> (k-tile, tensor, element offset fetched)
 
-        def piece_a(off, stage, kt):
-            for wave in range(8):
-                for it in range(2):
+        def piece_a(kt):
+            """the four activation pieces of k-tile kt as the staging waves (0-3) issue them"""
+            stage = kt % 3
+            for wave in range(4):
+                for it in range(4):
+                    rows0 = (wave + (it >> 1) * 4) * 32 + (it & 1) * 16
                     for lane in range(64):
                         lrow = lane >> 2
                         ls = (lane & 3) ^ ((lrow >> 2) & 3)
-                        m = m0 + wave * 32 + it * 16 + lrow
-                        b, rem = divmod(m, HW)
-                        oy, ox = divmod(rem, W)
-                        src = ((b * (H + 2) + oy + 1) * Wp + ox + 1) * C * 2 + ls * 16 + actr_slice + off
-                        assert src % 16 == 0 and 0 <= src // 2 and src // 2 + 8 <= total, "fetch outside the tensor"
-                        lds[(stage, wave * 2048 + it * 1024 + lane * 16)] = (kt, src // 2)
+                        m = m0 + rows0 + lrow
+                        if kt < nt_main:
+                            c, tap = divmod(kt, 9)
+                            ky, kx = divmod(tap, 3)
+                            b, rem = divmod(m, HW)
+                            oy, ox = divmod(rem, W)
+                            src = ((b * (H + 2) + oy + 1) * Wp + ox + 1) * C * 2 + ls * 16 + ((ky - pad) * Wp + (kx - pad)) * C * 2 + c * 64
+                            assert src % 16 == 0 and 0 <= src // 2 and src // 2 + 8 <= total, "fetch outside the tensor"
+                            what = ("x", src // 2)
+                        else:
+                            j = kt - nt_main
+                            seg, cs, c = (1, C1, j) if j < C1 // 32 else (2, C2, j - C1 // 32)
+                            src = m * cs * 2 + ls * 16 + c * 64
+                            assert src // 2 + 8 <= B * HW * cs
+                            what = (f"seg{seg}", src // 2)
+                        lds[(stage, rows0 * 64 + lane * 16)] = (kt,) + what
 
-        piece_a(t0, 0, 0)
-        piece_a(t0 + C * 2, 1, 1)
-        for t in range(9 * nsl):
-            s, q = divmod(t, 9)
-            # reads of k-tile t (set 1 in this iteration's first half; set 0 was read after the previous barrier): stage q % 3
-            tap = t % 9
-            ky, kx = divmod(tap, 3)
-            for wr in range(4):
+        piece_a(0)
+        piece_a(1)
+        for t in range(nt):
+            for wr in range(4):                           # fragment reads of k-tile t: stage t % 3, every wave's 64 rows
                 for i in range(2):
                     for lr in range(32):
                         row = wr * 64 + i * 32 + lr
@@ -163,11 +179,15 @@ def test_dw8u_pieces_and_fragment_reads_agree(shape):
                         oy, ox = divmod(rem, W)
                         for slot in range(4):             # k-slot s * 2 + lk: 8 channels each
                             so = (slot ^ ((lr >> 2) & 3)) << 4
-                            kt, got = lds[(q % 3, row * 64 + so)]
-                            want = ((b * (H + 2) + oy + ky) * Wp + ox + kx) * C + s * 32 + slot * 8
-                            assert kt == t and got == want, (tile_m, t, row, slot)
-            if not (s == nsl - 1 and q >= 7):
-                piece_a(toffx[q], (q + 2) % 3, t + 2)
-            if q == 8:
-                actr_slice += 64
-        assert ATILE == 8 * 2048
+                            kt, tensor, got = lds[(t % 3, row * 64 + so)]
+                            if t < nt_main:
+                                c, tap = divmod(t, 9)
+                                ky, kx = divmod(tap, 3)
+                                want = ("x", ((b * (H + 2) + oy + ky) * Wp + ox + kx) * C + c * 32 + slot * 8)
+                            else:
+                                j = t - nt_main
+                                seg, cs, c = (1, C1, j) if j < C1 // 32 else (2, C2, j - C1 // 32)
+                                want = (f"seg{seg}", m * cs + c * 32 + slot * 8)
+                            assert kt == t and (tensor, got) == want, (tile_m, t, row, slot)
+            if t + 2 < nt:
+                piece_a(t + 2)
