@@ -559,7 +559,11 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     } while (0)
     {   // fp16 x fp16: the 8-wave 256x256 kernel (igemm_h2_dw.hip) on launches of at least one tile per CU; DP_H2_DW = 0 never.
         // Bit-identical to the other variants.
-        if (dp_tune(DP_T_H2_DW) != 0 && dp_tune(DP_T_H2_PP) != 0 && dp_conv_dw_applies(p) && tiles(256, 256) >= 256) {
+        bool force_dw = false;
+#ifdef DP_ABLATE    // probes: the 8-wave kernel on launches of ANY number of tiles (an epilogue without 255 other CUs in theirs)
+        force_dw = getenv("DP_H2_DW_FORCE") != nullptr;
+#endif
+        if (dp_tune(DP_T_H2_DW) != 0 && dp_tune(DP_T_H2_PP) != 0 && dp_conv_dw_applies(p) && (tiles(256, 256) >= 256 || force_dw)) {
             dp_launch_conv_dw(p, s);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;

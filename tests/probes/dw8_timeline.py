@@ -29,7 +29,12 @@ DEV = "cuda:0"
 
 def main():
     B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 64
-    for (H, ci, co, with_res) in [(256, 256, 256, True), (128, 512, 512, True), (64, 512, 512, False)]:
+    shapes = [(B, 256, 256, 256, True), (B, 128, 512, 512, True), (B, 64, 512, 512, False)]
+    if "--few-tiles" in sys.argv:       # the epilogue of a launch with 16 / 64 tiles: few other CUs share HBM with it (DP_H2_DW_FORCE, ablate build)
+        os.environ["DP_H2_DW_FORCE"] = "1"
+        shapes = [(1, 64, 256, 256, True), (4, 64, 256, 256, True), (16, 64, 256, 256, True), (64, 64, 256, 256, True), (64, 256, 256, 256, True),
+                  (1, 64, 256, 256, False), (64, 256, 256, 256, False)]
+    for (B, H, ci, co, with_res) in shapes:
         x = torch.randn(B, H, H, ci)
         w = torch.randn(co, ci, 3, 3) * (1.0 / (9 * ci)) ** 0.5
         wh = ops.order_conv_weight_w16(w).half().to(DEV)

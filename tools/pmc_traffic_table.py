@@ -21,7 +21,7 @@ import sys
 def short(name):
     if "conv_igemm_dw" in name or "conv_igemm_sw" in name or "conv_igemm_halo" in name or "conv_igemm_h2_pp" in name:
         return "conv_igemm_h2_pp"            # the dominant kernel: the 256-wide-tile convolution in its one-wave-per-SIMD / ping-pong variants
-    m = re.search(r"(conv_igemm_h2|conv_igemm_f32|splitk_epilogue|gn_apply_f16in|gn_apply_h2q|gn_apply|round_weights|gn_finalize_cols|gn_stats|"
+    m = re.search(r"(conv_igemm_h2|conv_igemm_f32|splitk_epilogue|gn_apply_h16|gn_apply_h2q|gn_apply|round_weights|gn_finalize_cols|gn_stats|"
                   r"gn_finalize|attn_flash|attn_pack|em_step|ddpm_step|temb|softmax_rows|gemm_strided|philox|axpby|silu|pack_h2)", name)
     return m.group(1) if m else name[:60]
 
@@ -69,6 +69,9 @@ def main():
                    source="tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over bench.py --t 2")
         print(json.dumps(row))
         json.dump(row, open(os.path.join(d, "row.json"), "w"), indent=1)
+    gn = out.get("gn_apply_h16")
+    if gn:          # the second kernel of the step
+        json.dump(dict(kernel="gn_apply_h16", **gn), open(os.path.join(d, "row_gn.json"), "w"), indent=1)
     for k, v in list(out.items())[:12]:
         print(f"{k:22s} n={v['launches']:5d} fetch {v['fetch_bytes_per_launch'] or 0:.3e} write {v['write_bytes_per_launch'] or 0:.3e} "
               f"B/launch, {v['avg_ms_under_profiler']:.3f} ms, {v['hbm_tb_per_s_under_profiler'] or 0:.2f} TB/s")
