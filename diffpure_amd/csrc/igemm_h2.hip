@@ -40,6 +40,11 @@
 #include "dp_tune.h"
 #include "igemm_h2.h"
 
+// Every tile variant must produce the SAME bits, column records included (a batch's sharding picks the variant): products and sums stay
+// separate IEEE operations in this file - left to itself the compiler contracts `cq += v * v` (and `v *= scale; cs += v`) into FMAs in one
+// code shape and not in another.  Explicit fmaf() calls are unaffected.
+#pragma clang fp contract(off)
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -313,7 +318,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float cs = 0.f, cq = 0.f;
+            // column records: the lane's 16 values as TWO chains (even r, odd r), then their sum - the order of igemm_sw_common.h,
+            // whose packed fp32 arithmetic works on row pairs
+            float cs2[2] = {0.f, 0.f}, cq2[2] = {0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -324,9 +331,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_h2(ConvH2Args p) {
                 v *= p.scale;
                 if constexpr (decltype(out16)::value) outh[(size_t)row * p.ldo + col] = dp_to_half(v);
                 else outp[(size_t)row * p.ldo + col] = v;
-                cs += v;
-                cq += v * v;
+                cs2[r & 1] += v;
+                cq2[r & 1] += v * v;
             }
+            float cs = cs2[0] + cs2[1], cq = cq2[0] + cq2[1];
             if (p.colstats) {
                 cs += __shfl_xor(cs, 32, 64);
                 cq += __shfl_xor(cq, 32, 64);

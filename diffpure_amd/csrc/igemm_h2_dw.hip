@@ -65,7 +65,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     constexpr int ATILE = BMT * 64;             // activation tile of one k-tile
     constexpr int NPB = 2;                      // weight pieces per wave and k-tile
     constexpr int BBASE = ADEPTH * ATILE;
-    __shared__ __attribute__((aligned(1024))) char smem[ADEPTH * ATILE + BDEPTH * BTILE];
+    // the operand rings (96 KB); after the k-loop the same memory is the landing zone of the fp16 residual (igemm_sw_common.h, 136 KB)
+    constexpr int RINGS = ADEPTH * ATILE + BDEPTH * BTILE;
+    __shared__ __attribute__((aligned(1024))) char smem[RINGS > SW_EPI_LDS ? RINGS : SW_EPI_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
 
     unsigned tl_e0 = 0;
     if constexpr (MODE & 64) tl_e0 = stamp();
-    if constexpr (!(MODE & 8)) sw_epilogue_any<1, 1, 4>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW);
+    if constexpr (!(MODE & 8)) sw_epilogue_any<1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW, smem + wave * (16 * SW_EPI_PITCH));
     if constexpr (MODE & 64) {
         const unsigned tl_e1 = stamp();
         if (p.ws && lane == 0) {

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     constexpr int TILE_A = BM * 64, TILE_B = BN * 64;       // one operand tile of a k-tile: rows x 64 bytes (32 fp16)
     constexpr int STAGE = TILE_A + TILE_B;                  // A tile, then B tile
     constexpr int NPA = BM / 64, NPB = BN / 64;             // DMA pieces (16 rows) per wave and k-tile
-    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE];
+    // the operand ring; after the k-loop the same memory is the landing zone of the fp16 residual (igemm_sw_common.h, 136 KB)
+    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE > SW_EPI_LDS ? NB * STAGE : SW_EPI_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    sw_epilogue_any<2, 1>(p, acc, m0 + wr * 128, n0 + wc * 128, tile_m * (BM / 64) + wr * 2, lr, lk, HW);
+    sw_epilogue_any<2>(p, acc, m0 + wr * 128, n0 + wc * 128, tile_m * (BM / 64) + wr * 2, lr, lk, HW, smem + wave * (32 * SW_EPI_PITCH));
 }
 
 

@@ -3,6 +3,11 @@
 #pragma once
 #include "igemm_h2.h"
 
+// Every tile variant must produce the SAME bits, column records included (a batch's sharding picks the variant): products and sums stay
+// separate IEEE operations in this file - left to itself the compiler contracts `cq += v * v` (and `v *= scale; cs += v`) into FMAs in one
+// code shape and not in another.  Explicit fmaf() calls are unaffected.
+#pragma clang fp contract(off)
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -28,7 +33,7 @@ __device__ __forceinline__ void pp_glds(unsigned voff, const char* sbase, const 
 
 // ---- epilogue of a 128 x 64 wave tile (acc[4][2] MFMA tiles of 32 x 32) at rows m0 + wr*128, columns n0 + wc*64:
 // bias / temb / residual / scale, store, per-column (sum, sumsq) of every 64 output rows.
-// 32-row sub-sums (16 values per lane in r order, then the partner half-wave) paired even+odd: the
+// 32-row sub-sums (the lane's 16 values as two chains - even r, odd r - added, then the partner half-wave) paired even+odd: the
 // tile-shape-independent order of igemm.hip.  Both sub-sums of a record live in this wave: no LDS.
 // OUT16 (p.ofmt 1): the tensor is stored as plain fp16 (one 2-byte store per value; the packed form lives in igemm_sw_common.h).  A
 // template parameter, chosen once per kernel by pp_epilogue: tested per store it costs a branch per element.
@@ -51,6 +56,7 @@ __device__ __forceinline__ void pp_epilogue_t(const ConvH2Args& p, f32x16 (&acc)
     float cs[4][2], cq[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        float cs2[2][2], cq2[2][2];          // [r & 1][j]: two chains per column (even r, odd r), the order of igemm_sw_common.h
         const int rowb = m0 + wr * 128 + i * 32 + 4 * lk;
         float rv[2][16];
         float tv[2];
@@ -65,8 +71,8 @@ __device__ __forceinline__ void pp_epilogue_t(const ConvH2Args& p, f32x16 (&acc)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             tv[j] = (tembp && hw32) ? tembp[(size_t)(rowb / HW) * p.temb_stride + col0 + j * 32] : 0.f;
-            cs[i][j] = 0.f;
-            cq[i][j] = 0.f;
+            cs2[0][j] = cs2[1][j] = 0.f;
+            cq2[0][j] = cq2[1][j] = 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -79,9 +85,14 @@ __device__ __forceinline__ void pp_epilogue_t(const ConvH2Args& p, f32x16 (&acc)
                 v *= p.scale;
                 if constexpr (OUT16) outh[(size_t)row * p.ldo + col0 + j * 32] = dp_to_half(v);
                 else outp[(size_t)row * p.ldo + col0 + j * 32] = v;
-                cs[i][j] += v;
-                cq[i][j] += v * v;
+                cs2[r & 1][j] += v;
+                cq2[r & 1][j] += v * v;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cs[i][j] = cs2[0][j] + cs2[1][j];
+            cq[i][j] = cq2[0][j] + cq2[1][j];
         }
         if (p.colstats) {
 #pragma unroll

@@ -250,6 +250,149 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
     }
 }
 
+
+// ---- ONE-PASS form for small feature maps (round 4; CIFAR-10 sizes) ---------------------------------------------------------
+// The three launches above read x and dy twice (statistics pass, apply pass).  When all pixels of a block of whole groups of one
+// sample fit the registers of a workgroup - HW x CB <= 512 threads x ITEMS quads - ONE workgroup per (sample, channel block) reads
+// them ONCE: every thread keeps (dxh, xh) of its ITEMS <= 8 channel quads (one quad column, pixels pl, pl + PL, ...), the group sums go
+// through LDS in a fixed order (double, as reduce_partials), and dx is formed from the registers.  The same values up to the
+// summation order of the two group sums (which is again a function of the sample's shape only: results do not depend on the batch).
+// `add1` / `add2` (optional, fp32 output only): a second gradient that arrives at the same tensor - the identity / 1x1 skip branch
+// of a ResBlock - is added in the same pass instead of an `add` launch of its own.
+struct FusedArgs {
+    BwdArgs b;
+    const float* add1;
+    const float* add2;
+    float add_scale;            // dx += add_scale * add
+    int CB, QB, PL;             // channels / quads per block, pixel lanes (512 / QB)
+};
+
+template <int ITEMS>
+__global__ __launch_bounds__(512) void gn_bwd_fused_kernel(FusedArgs a) {
+    const BwdArgs& p = a.b;
+    __shared__ float red_s[512];
+    __shared__ float red_q[512];
+    __shared__ double part[2 * 512];                    // run sums of the second reduction level
+    __shared__ float gsum[2 * 64];                      // (m1, m2) of the block's groups (CB / cpg <= 64)
+    const int t = threadIdx.x;
+    const int nblk = (p.C4 * 4) / a.CB;
+    const int b = blockIdx.x / nblk, cb = blockIdx.x - b * nblk;
+    const int HW = p.H * p.W;
+    const int q = t % a.QB, pl = t / a.QB;
+    const int c = cb * a.CB + q * 4;                    // this thread's channel quad (one group: cpg % 4 == 0)
+    f32x4 dxh[ITEMS], xh[ITEMS];
+    float s = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int px = pl + k * a.PL;
+        if (px < HW) {
+            const int y = px / p.W, x = px - y * p.W;
+            quad_grad<false>(p, b, (size_t)b * HW + px, y, x, c, dxh[k], xh[k]);
+            s += (dxh[k][0] + dxh[k][1]) + (dxh[k][2] + dxh[k][3]);
+            sq += (dxh[k][0] * xh[k][0] + dxh[k][1] * xh[k][1]) + (dxh[k][2] * xh[k][2] + dxh[k][3] * xh[k][3]);
+        }
+    }
+    red_s[t] = s;
+    red_q[t] = sq;
+    __syncthreads();
+    // (sum, sum.x) per group in double, in a fixed two-level order: a group's n = 512 / gpb thread partials (entry e = lane-row l *
+    // cpg4 + k) are cut into P = min(16, n) runs, one thread per run, then one thread per group adds the P run sums.
+    const int cpg4 = p.cpg / 4, gpb = a.CB / p.cpg;     // quads per group, groups per block
+    const int n = 512 / gpb, P = n < 16 ? n : 16, run = n / P;
+    if (t < gpb * P) {
+        const int g = t / P, j = t - g * P;
+        double ds = 0.0, dq = 0.0;
+        for (int e = j * run; e < (j + 1) * run; ++e) {
+            const int l = e / cpg4, k = e - l * cpg4;
+            const int idx = l * a.QB + g * cpg4 + k;
+            ds += red_s[idx];
+            dq += red_q[idx];
+        }
+        part[2 * t] = ds;
+        part[2 * t + 1] = dq;
+    }
+    __syncthreads();
+    if (t < gpb) {
+        double ds = 0.0, dq = 0.0;
+        for (int j = 0; j < P; ++j) {
+            ds += part[2 * (t * P + j)];
+            dq += part[2 * (t * P + j) + 1];
+        }
+        const double inv = 1.0 / ((double)HW * p.cpg);
+        gsum[2 * t] = (float)(ds * inv);
+        gsum[2 * t + 1] = (float)(dq * inv);
+    }
+    __syncthreads();
+    const int gl = (q * 4) / p.cpg;                     // the quad's group inside the block
+    const float m1 = gsum[2 * gl], m2 = gsum[2 * gl + 1];
+    const float rstd = p.stats[(b * p.G + c / p.cpg) * 2 + 1];
+    const int C = p.C4 * 4;
+    const int BORDER = p.out_fmt ? 1 : 0;
+    const int Wq = p.W + 2 * BORDER, Hq = p.H + 2 * BORDER;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int px = pl + k * a.PL;
+        if (px >= HW) continue;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (dxh[k][j] - m1 - xh[k][j] * m2);
+        const size_t pix = (size_t)b * HW + px;
+        if (p.out_fmt == 0) {
+            const bool first = c < p.C1;
+            float* d = first ? p.dx1 + pix * p.C1 + c : p.dx2 + pix * p.C2 + (c - p.C1);
+            const float* ad = first ? (a.add1 ? a.add1 + pix * p.C1 + c : nullptr) : (a.add2 ? a.add2 + pix * p.C2 + (c - p.C1) : nullptr);
+            if (ad) {
+                const f32x4 e = ld4(ad);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += a.add_scale * e[j];
+            }
+            *reinterpret_cast<f32x4*>(d) = o;
+        } else {
+            const int y = px / p.W, x = px - y * p.W;
+            const size_t qpix = ((size_t)b * Hq + y + 1) * Wq + x + 1;
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+            if (p.out_fmt == 2) {                       // plain fp16 operand: this quad's 8 bytes
+                half4v h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (_Float16)o[j];
+                *reinterpret_cast<half4v*>(reinterpret_cast<char*>(p.dx1) + (qpix * C + c) * 2) = h;
+            } else {                                    // h2: octet = [8 hi | 8 lo]; this quad is half of an octet
+                half4v hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hi[j] = (_Float16)o[j];
+                    lo[j] = (_Float16)(o[j] - (float)hi[j]);
+                }
+                char* base = reinterpret_cast<char*>(p.dx1) + (qpix * C + (c & ~7)) * 4 + (c & 4) * 2;
+                *reinterpret_cast<half4v*>(base) = hi;
+                *reinterpret_cast<half4v*>(base + 16) = lo;
+            }
+        }
+    }
+    if (BORDER) {       // the zero border of the operand: this block's channels of the sample's frame pixels
+        const int nb = 2 * Wq + 2 * p.H;                // frame pixels
+        const int esz = p.out_fmt == 2 ? 2 : 4;         // bytes per channel in the operand
+        for (int i = t; i < nb * a.QB; i += 512) {
+            const int f = i / a.QB, qq = i - f * a.QB;
+            int y, x;
+            if (f < Wq) { y = 0; x = f; }
+            else if (f < 2 * Wq) { y = Hq - 1; x = f - Wq; }
+            else { const int r = f - 2 * Wq; y = 1 + (r >> 1); x = (r & 1) ? Wq - 1 : 0; }
+            const size_t qpix = ((size_t)b * Hq + y) * Wq + x;
+            const int cc = cb * a.CB + qq * 4;
+            char* base = reinterpret_cast<char*>(p.dx1);
+            if (p.out_fmt == 2) {
+                *reinterpret_cast<unsigned long long*>(base + (qpix * C + cc) * 2) = 0ull;
+            } else {
+                char* o8 = base + (qpix * C + (cc & ~7)) * 4 + (cc & 4) * 2;
+                *reinterpret_cast<unsigned long long*>(o8) = 0ull;
+                *reinterpret_cast<unsigned long long*>(o8 + 16) = 0ull;
+            }
+            (void)esz;
+        }
+    }
+}
+
 struct Fir4 { float k[4]; };
 
 // adjoint of the plain 2x resamplers (x-branch of a resampling ResBlock)
@@ -374,6 +517,56 @@ extern "C" int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2,
     if (resample >= 3) hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     DP_LAUNCH_CHECK("gn_bwd_apply");
+    return 0;
+}
+
+// Channel block of the one-pass form for this tensor shape, or 0 when the three-launch form has to serve (a function of the
+// shape only): the largest CB = whole groups, a multiple of 8 channels, dividing C, with 512 % (CB / 4) == 0 and
+// HW * CB <= 512 threads * 8 quads * 4, the registers of one workgroup (16 quads per thread spill).
+static int gn_bwd_fused_block(int HW, int C, int G, int C1) {
+    const int cpg = C / G;
+    if (cpg % 4 != 0 || HW <= 0) return 0;
+    int best = 0;
+    for (int cb = cpg; cb <= C && cb <= 256; cb += cpg) {
+        if (C % cb != 0 || cb % 8 != 0 || 512 % (cb / 4) != 0) continue;
+        if ((long long)HW * cb > 512ll * 8 * 4) continue;
+        if (C1 % cb != 0 && C1 != C) continue;          // a block never straddles the two sources
+        best = cb;
+    }
+    return best;
+}
+
+extern "C" int dp_gn_bwd_fused_ok(int H, int W, int C1, int C2, int G, int resample) {
+    if (resample < 0 || resample > 2 || G <= 0 || (C1 + C2) % G != 0) return 0;
+    return gn_bwd_fused_block(H * W, C1 + C2, G, C1) != 0 ? 1 : 0;
+}
+
+extern "C" int dp_gn_bwd_fused(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+                               const float* stats, const float* gamma, const float* beta, const float* fscale,
+                               const float* fshift, int film_stride, int act, int resample, const float* dy,
+                               int out_fmt, void* dx1, float* dx2, const float* add1, const float* add2, float add_scale, void* stream) {
+    FusedArgs a{};
+    if (int rc = fill_common(a.b, "dp_gn_bwd_fused", x1, C1, x2, C2, B, H, W, G, stats, gamma, beta, fscale, fshift,
+                             film_stride, act, resample, nullptr, dy)) return rc;
+    DP_REQUIRE(resample <= 2, "dp_gn_bwd_fused: the FIR resampling modes take the three-launch form");
+    DP_REQUIRE(dx1 && (C2 == 0 || dx2), "dp_gn_bwd_fused: output missing");
+    DP_REQUIRE(out_fmt == 0 || ((out_fmt == 1 || out_fmt == 2) && C2 == 0 && !add1 && !add2),
+               "dp_gn_bwd_fused: operand output (1 = h2, 2 = h1) needs a single source and takes no addend");
+    DP_REQUIRE((!add1 || dp_aligned16(add1)) && (!add2 || (C2 > 0 && dp_aligned16(add2))), "dp_gn_bwd_fused: addend");
+    const int C = C1 + C2;
+    a.CB = gn_bwd_fused_block(H * W, C, G, C1);
+    DP_REQUIRE(a.CB != 0, "dp_gn_bwd_fused: shape %dx%d x %d channels / %d groups does not fit one workgroup per channel block (ask dp_gn_bwd_fused_ok)", H, W, C, G);
+    a.QB = a.CB / 4;
+    a.PL = 512 / a.QB;
+    a.add1 = add1; a.add2 = add2; a.add_scale = add_scale;
+    a.b.dx1 = (float*)dx1; a.b.dx2 = dx2; a.b.out_fmt = out_fmt;
+    const int items = (H * W + a.PL - 1) / a.PL;
+    const dim3 g((unsigned)(B * (C / a.CB))), blk(512);
+    hipStream_t s = (hipStream_t)stream;
+    if (items <= 2) hipLaunchKernelGGL(gn_bwd_fused_kernel<2>, g, blk, 0, s, a);
+    else if (items <= 4) hipLaunchKernelGGL(gn_bwd_fused_kernel<4>, g, blk, 0, s, a);
+    else hipLaunchKernelGGL(gn_bwd_fused_kernel<8>, g, blk, 0, s, a);
+    DP_LAUNCH_CHECK("gn_bwd_fused");
     return 0;
 }
 

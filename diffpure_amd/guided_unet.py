@@ -526,17 +526,18 @@ class GuidedUNet:
         dh2, _ = ops.group_norm_bwd(t["hmid"], G, P[n + ".g2"], P[n + ".b2"], t["st2"], dh3, film=t["film"], act=True,
                                     split=r["dh2_1"])
         dh1 = self._dconv(dh2, n + ".dw1", r["dh2_1"], ci, 3)
-        dx, dx2 = ops.group_norm_bwd(t["x"], G, P[n + ".g1"], P[n + ".b1"], t["st1"], dh1, x2=t["x2"], act=True, resample=mode)
+        # the gradient of the skip branch joins dx inside the GroupNorm backward (ops.group_norm_bwd)
+        ad = ad2 = None
         if mode:
-            dx = ops.add(dx, ops.resample_bwd(dout, mode))
+            ad = ops.resample_bwd(dout, mode)
         elif ci != co:
             c1 = t["x"].shape[3]
-            dx = ops.add(dx, self._dconv(dout16 if gs else dout, n + ".dws1", gs, c1, 1))
-            if dx2 is not None:
-                dx2 = ops.add(dx2, self._dconv(dout16 if gs else dout, n + ".dws2", gs, ci - c1, 1))
+            ad = self._dconv(dout16 if gs else dout, n + ".dws1", gs, c1, 1)
+            if t["x2"] is not None:
+                ad2 = self._dconv(dout16 if gs else dout, n + ".dws2", gs, ci - c1, 1)
         else:
-            dx = ops.add(dx, dout)
-        return dx, dx2
+            ad = dout
+        return ops.group_norm_bwd(t["x"], G, P[n + ".g1"], P[n + ".b1"], t["st1"], dh1, x2=t["x2"], act=True, resample=mode, addend=ad, addend2=ad2)
 
     def _attn_bwd(self, t, dout):
         r, P = t["r"], self.p
@@ -548,8 +549,7 @@ class GuidedUNet:
         dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), r["heads"], t["layout"])
         del probs
         dxn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
-        dx, _ = ops.group_norm_bwd(t["x"], self.GN_GROUPS, P[n + ".g"], P[n + ".b"], t["st"], dxn)
-        return ops.add(dx, dout)
+        return ops.group_norm_bwd(t["x"], self.GN_GROUPS, P[n + ".g"], P[n + ".b"], t["st"], dxn, addend=dout)[0]
 
     def vjp(self, tape, dout):
         """(d eps / d x)^T dout for the forward that filled `tape`. dout: [B,H,W,Cd] fp32 cotangent on the

@@ -480,19 +480,21 @@ class NCSNpp:
         dh2, _ = ops.group_norm_bwd(t["hmid"], self._groups(co), P[n + ".g1"], P[n + ".b1"], t["st1"], dh3, act=True,
                                     split=r["dh2_0"])
         dh1 = self._dconv(dh2, n + ".dw0", r["dh2_0"], ci, 3)
-        dx, dx2 = ops.group_norm_bwd(t["x"], self._groups(ci), P[n + ".g0"], P[n + ".b0"], t["st0"], dh1, x2=t["x2"], act=True,
-                                     resample=mode, fir=fir)
+        # the gradient of the skip branch joins dx inside the GroupNorm backward (one pass on small feature maps; ops.group_norm_bwd)
+        ad = ad2 = None
+        asc = 1.0
         if mode:
             ds = self._dconv(dout16 if g2 else dout, n + ".dw2a", g2, ci, 1, scale=INV_SQRT2)
-            dx = ops.add(dx, ops.resample_bwd(ds, mode, fir=fir))
+            ad = ops.resample_bwd(ds, mode, fir=fir)
         elif ci != co:
             c1 = t["x"].shape[3]
-            dx = ops.add(dx, self._dconv(dout16 if g2 else dout, n + ".dw2a", g2, c1, 1, scale=INV_SQRT2))
-            if dx2 is not None:
-                dx2 = ops.add(dx2, self._dconv(dout16 if g2 else dout, n + ".dw2b", g2, ci - c1, 1, scale=INV_SQRT2))
+            ad = self._dconv(dout16 if g2 else dout, n + ".dw2a", g2, c1, 1, scale=INV_SQRT2)
+            if t["x2"] is not None:
+                ad2 = self._dconv(dout16 if g2 else dout, n + ".dw2b", g2, ci - c1, 1, scale=INV_SQRT2)
         else:
-            dx = ops.axpby(dx, 1.0, dout, INV_SQRT2)
-        return dx, dx2
+            ad, asc = dout, INV_SQRT2
+        return ops.group_norm_bwd(t["x"], self._groups(ci), P[n + ".g0"], P[n + ".b0"], t["st0"], dh1, x2=t["x2"], act=True,
+                                  resample=mode, fir=fir, addend=ad, addend2=ad2, addend_scale=asc)
 
     def _attn_bwd(self, t, dout):
         r, P = t["r"], self.p
@@ -504,8 +506,7 @@ class NCSNpp:
         dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), 1, "split")
         del probs
         dhn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
-        dx, _ = ops.group_norm_bwd(t["x"], self._groups(c), P[n + ".g"], P[n + ".b"], t["st"], dhn)
-        return ops.axpby(dx, 1.0, dout, INV_SQRT2)
+        return ops.group_norm_bwd(t["x"], self._groups(c), P[n + ".g"], P[n + ".b"], t["st"], dhn, addend=dout, addend_scale=INV_SQRT2)[0]
 
     def vjp(self, tape, dout):
         """(d out / d x)^T dout for the forward that filled `tape`; dout [B,H,W,channels] fp32."""

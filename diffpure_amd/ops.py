@@ -546,10 +546,13 @@ def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
 
 
 def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False,
-                   fir=None):
+                   fir=None, addend=None, addend2=None, addend_scale=1.0, one_pass=None):
     """Input gradient of `group_norm` (same arguments - incl. the FIR taps for resample modes 3 / 4 -, `stats` from the forward,
     dy at the forward's output resolution). -> (dx, dx2); with split=True (single source) dx is the zero-bordered h2
-    operand for the next dgrad convolution."""
+    operand for the next dgrad convolution.
+    addend / addend2 (fp32 output only): a second gradient arriving at the same tensors (the skip branch of a ResBlock): dx += addend_scale * addend,
+    dx2 += addend_scale * addend2 - inside the one-pass kernel where the shape fits one workgroup per channel block (small feature maps), else by
+    an `add` launch behind the three-launch form.  one_pass=False forces the three-launch form (tests, probes)."""
     _chk(x, "gn_bwd.x", 4)
     _chk(dy, "gn_bwd.dy", 4)
     b, h, w, c1 = x.shape
@@ -563,24 +566,42 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
         fstride = 0 if fs.shape[0] == 1 else fs.stride(0)
     ho, wo = _out_hw(h, w, resample)
     assert dy.shape == (b, ho, wo, c), (dy.shape, (b, ho, wo, c))
-    fkeep, fptr = _fir_arg(resample, fir)
-    ns = _nsplit(h * w)
-    partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
-    sums = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
-    s = _stream()
-    common = (_ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
-              fstride, 1 if act else 0, resample, fptr, _ptr(dy))
-    _lib.call("dp_gn_bwd_stats", *common, ns, _ptr(partial), _ptr(sums), s)
     ofmt = 0 if not split else (2 if split == "h1" else 1)     # split: True / "h2" -> h2 operand, "h1" -> plain fp16 operand
     if ofmt:
-        assert x2 is None
+        assert x2 is None and addend is None and addend2 is None
         dx = torch.empty((b, h + 2, w + 2, c if ofmt == 2 else 2 * c), device=x.device, dtype=torch.float16)
         dx2 = None
     else:
         dx = torch.empty_like(x)
         dx2 = None if x2 is None else torch.empty_like(x2)
+        if addend is not None:
+            _chk(addend, "gn_bwd.addend", 4)
+            assert addend.shape == x.shape
+        if addend2 is not None:
+            assert x2 is not None and _chk(addend2, "gn_bwd.addend2", 4).shape == x2.shape
+    s = _stream()
+    if one_pass is not False and resample <= RESAMPLE_DOWN and gn_bwd_fused_ok(h, w, c1, c2, groups, resample):
+        _lib.call("dp_gn_bwd_fused", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
+                  fstride, 1 if act else 0, resample, _ptr(dy), ofmt, _ptr(dx), _ptr(dx2), _ptr(addend), _ptr(addend2), float(addend_scale), s)
+        return dx, dx2
+    fkeep, fptr = _fir_arg(resample, fir)
+    ns = _nsplit(h * w)
+    partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
+    sums = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
+    common = (_ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
+              fstride, 1 if act else 0, resample, fptr, _ptr(dy))
+    _lib.call("dp_gn_bwd_stats", *common, ns, _ptr(partial), _ptr(sums), s)
     _lib.call("dp_gn_bwd_apply", *common, _ptr(sums), ofmt, _ptr(dx), _ptr(dx2), s)
+    if addend is not None:
+        dx = add(dx, addend) if addend_scale == 1.0 else axpby(dx, 1.0, addend, addend_scale)
+    if addend2 is not None:
+        dx2 = add(dx2, addend2) if addend_scale == 1.0 else axpby(dx2, 1.0, addend2, addend_scale)
     return dx, dx2
+
+
+def gn_bwd_fused_ok(h, w, c1, c2, groups, resample=RESAMPLE_NONE):
+    """does the one-pass GroupNorm backward serve this tensor shape?  (a function of the shape only)"""
+    return bool(_lib.load().dp_gn_bwd_fused_ok(h, w, c1, c2, groups, resample))
 
 
 def resample_bwd(dy, mode, fir=None):

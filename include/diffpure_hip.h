@@ -279,6 +279,16 @@ int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2, int B, int
                     const float* stats, const float* gamma, const float* beta,
                     const float* fscale, const float* fshift, int film_stride, int act, int resample,
                     const float* fir4, const float* dy, const float* sums, int out_fmt, void* dx1, float* dx2, void* stream);
+/* The same operator in ONE pass over x and dy (ABI 6), for small feature maps - CIFAR-10 sizes: one workgroup per (sample, block of
+ * whole groups) keeps its pixels in registers between the group sums and the update, so x and dy are read once instead of twice and
+ * three launches become one.  dp_gn_bwd_fused_ok(): does the tensor shape fit (a function of the shape only; resample 0 | 1 | 2 - the
+ * FIR modes keep the three-launch form)?  add1 / add2 (optional, fp32 output only): a second gradient arriving at the same tensors
+ * (the skip branch of a ResBlock, unet.py:262-264 / layerspp.py:272-274) is added in the same pass (dx += add_scale * add), replacing a dp_add / dp_axpby launch. */
+int dp_gn_bwd_fused_ok(int H, int W, int C1, int C2, int G, int resample);
+int dp_gn_bwd_fused(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+                    const float* stats, const float* gamma, const float* beta,
+                    const float* fscale, const float* fshift, int film_stride, int act, int resample,
+                    const float* dy, int out_fmt, void* dx1, float* dx2, const float* add1, const float* add2, float add_scale, void* stream);
 /* Adjoint of the plain 2x resamplers: mode 1 (forward was nearest x2): dx[Ho/2][Wo/2] = sum of the
  * 2x2 dy block; mode 2 (forward was mean 2x2): dx[2Ho][2Wo] = 0.25 * dy[y/2][x/2]; modes 3 / 4 (forward was the
  * FIR x2 up / down of dp_gn_apply with taps fir4[4]): the transposed stencils

@@ -5,8 +5,8 @@ REFERENCE'S OWN MODULE (torch.save(model.state_dict())) and read back the way th
     model, _ = create_model_and_diffusion(**model_config)
     model.load_state_dict(torch.load(f'{model_dir}/256x256_diffusion_uncond.pt', map_location='cpu'))
     if model_config['use_fp16']: model.convert_to_fp16()
-on a SMALL configuration of the same family (resblock_updown + scale-shift norm + learn_sigma, 32x32, 32/64 channels, one
-32-channel head at 16x16: 0.8 M parameters, 3.3 MB), with `use_fp16` both False and True.
+on a SMALL configuration of the same family (resblock_updown + scale-shift norm + learn_sigma, 32x32, 128/128 channels - GroupNorm32 needs >= 4 channels per group on the engine -, four
+32-channel heads at 16x16), with `use_fp16` both False and True.
 
 Run in the build container only (needs /root/reference):   python tests/golden/make_golden_guided_ckpt.py
   tests/golden/ckpt/guided/256x256_diffusion_uncond.pt   the state_dict file (fp32 tensors, as the real one)
@@ -28,7 +28,7 @@ import make_golden as mg  # noqa: E402
 def main():
     mg.import_reference()
     from guided_diffusion.script_util import create_model_and_diffusion, model_and_diffusion_defaults
-    model_cfg = dict(image_size=32, num_channels=32, num_res_blocks=1, channel_mult="1,2", attention_resolutions="16",
+    model_cfg = dict(image_size=32, num_channels=128, num_res_blocks=1, channel_mult="1,1", attention_resolutions="16",
                      num_head_channels=32, resblock_updown=True, use_scale_shift_norm=True, learn_sigma=True, class_cond=False,
                      use_fp16=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing="1000", rescale_timesteps=True)
     torch.manual_seed(0)

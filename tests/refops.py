@@ -278,9 +278,13 @@ def attention_bwd(qkv, probs, dout, n_heads, layout):
     return g
 
 
+def gn_bwd_fused_ok(h, w, c1, c2, groups, resample):
+    return False
+
+
 def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=False, resample=RESAMPLE_NONE, split=False,
-                   fir=None):
-    """autograd through the torch statement of the forward (eps folded back out of `stats`)."""
+                   fir=None, addend=None, addend2=None, addend_scale=1.0, one_pass=None):
+    """autograd through the torch statement of the forward (eps folded back out of `stats`); dx += addend_scale * addend."""
     with torch.enable_grad():
         a = x.detach().clone().requires_grad_(True)
         b2 = None if x2 is None else x2.detach().clone().requires_grad_(True)
@@ -303,6 +307,10 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
         grads = torch.autograd.grad(y, [a] + ([] if b2 is None else [b2]), dy)
     dx = grads[0]
     dx2 = grads[1] if b2 is not None else None
+    if addend is not None:
+        dx = dx + addend_scale * addend
+    if addend2 is not None:
+        dx2 = dx2 + addend_scale * addend2
     if split == "h1":
         return F.pad(dx, (0, 0, 1, 1, 1, 1)).half(), None
     if split:
@@ -460,7 +468,7 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
     return dx.permute(0, 2, 3, 1).contiguous() if in_nhwc else dx.contiguous()
 
 
-PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd",
+PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd", "gn_bwd_fused_ok",
            "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "group_norm_f16in", "resample", "attention", "attention_fused",
            "attention_fused_ok", "silu", "axpby", "takes_segments",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]

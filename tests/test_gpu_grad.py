@@ -95,6 +95,68 @@ def test_group_norm_bwd(case):
         assert torch.equal(g16.cpu(), torch.nn.functional.pad(g1.cpu(), (0, 0, 1, 1, 1, 1)).half())     # and its plain-fp16 form
 
 
+ONE_PASS_CASES = [
+    # B, H, W, C1, C2, G, act, resample, addends, scale       (the adjoint's shapes: NCSN++ 32..4, guided 8 / 16)
+    (3, 32, 32, 128, 0, 32, True, 0, 1, 0.7071067811865476),
+    (3, 32, 32, 128, 0, 32, True, 2, 1, 1.0),
+    (2, 16, 16, 256, 0, 32, True, 0, 1, 0.7071067811865476),
+    (2, 16, 16, 256, 256, 32, True, 0, 2, 1.0),
+    (2, 16, 16, 128, 128, 32, True, 1, 2, 1.0),
+    (2, 8, 8, 256, 256, 32, True, 0, 2, 1.0),
+    (2, 8, 8, 256, 0, 32, False, 0, 1, 0.7071067811865476),      # attention pre-norm
+    (5, 4, 4, 256, 0, 32, True, 1, 0, 1.0),
+    (2, 8, 8, 1024, 1024, 32, True, 0, 2, 1.0),                  # guided, 8 x 8
+    (2, 16, 16, 512, 0, 32, True, 0, 1, 1.0),
+    (2, 6, 10, 64, 64, 32, True, 0, 2, 1.0),                     # ragged pixel count
+]
+
+
+@pytest.mark.parametrize("case", ONE_PASS_CASES, ids=[str(c) for c in ONE_PASS_CASES])
+def test_group_norm_bwd_one_pass_form_with_folded_skip_gradient(case):
+    """The one-pass GroupNorm backward (csrc/norm_bwd.hip gn_bwd_fused_kernel: group sums and dx from registers, skip-branch
+    gradient added in the same pass) against the fp64 autograd reference and against the three-launch form + add."""
+    from diffpure_amd import ops
+    B, H, W, C1, C2, G, act, rs, nadd, scale = case
+    C = C1 + C2
+    assert ops.gn_bwd_fused_ok(H, W, C1, C2, G, rs)
+    x = rnd(B, H, W, C1, seed=1) * 2 + 0.5
+    x2 = (rnd(B, H, W, C2, seed=2) - 1.0) if C2 else None
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    tab = 0.3 * rnd(B, 2 * C, seed=5)
+    ho, wo = (2 * H, 2 * W) if rs == 1 else ((H // 2, W // 2) if rs == 2 else (H, W))
+    dy = rnd(B, ho, wo, C, seed=6)
+    ad = rnd(B, H, W, C1, seed=7) if nadd >= 1 else None
+    ad2 = rnd(B, H, W, C2, seed=8) if nadd >= 2 and C2 else None
+    d64 = lambda t: None if t is None else t.double()
+    st64 = refops.group_norm_stats(x.double(), G, 1e-5, d64(x2)).double()
+    ref1, ref2 = refops.group_norm_bwd(x.double(), G, gamma.double(), beta.double(), st64, dy.double(), d64(x2),
+                                       (tab[:, :C].double(), tab[:, C:].double()), act, rs, addend=d64(ad), addend2=d64(ad2),
+                                       addend_scale=scale)
+    d = lambda t: None if t is None else t.to(DEV)
+    tab_d = tab.to(DEV)
+    film_d = (tab_d[:, :C], tab_d[:, C:])
+    st = ops.group_norm_stats(d(x), G, 1e-5, d(x2))
+    kw = dict(x2=d(x2), film=film_d, act=act, resample=rs, addend=d(ad), addend2=d(ad2), addend_scale=scale)
+    g1, g2 = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), **kw)
+    t1, t2 = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), one_pass=False, **kw)
+    assert relerr(g1.cpu(), ref1.float()) < 2e-4 and relerr(g1, t1) < 2e-6
+    if C2:
+        assert relerr(g2.cpu(), ref2.float()) < 2e-4 and relerr(g2, t2) < 2e-6
+    else:
+        for split in (True, "h1"):
+            kw2 = dict(film=film_d, act=act, resample=rs, split=split)
+            gh, _ = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), **kw2)
+            g0, _ = ops.group_norm_bwd(d(x), G, d(gamma), d(beta), st, d(dy), film=film_d, act=act, resample=rs)
+            want = refops.to_h2(g0.cpu()) if split is True else torch.nn.functional.pad(g0.cpu(), (0, 0, 1, 1, 1, 1)).half()
+            assert torch.equal(gh.cpu(), want)
+    # a sample's gradient does not depend on the batch it sits in
+    s1, _ = ops.group_norm_bwd(d(x)[1:2].contiguous(), G, d(gamma), d(beta), st[1:2].contiguous(), d(dy)[1:2].contiguous(),
+                               x2=None if x2 is None else d(x2)[1:2].contiguous(), film=(tab_d[1:2, :C], tab_d[1:2, C:]), act=act, resample=rs,
+                               addend=None if ad is None else d(ad)[1:2].contiguous(), addend2=None if ad2 is None else d(ad2)[1:2].contiguous(),
+                               addend_scale=scale)
+    assert torch.equal(s1[0], g1[1])
+
+
 @pytest.mark.parametrize("case", [(2, 16, 256, 1, "split"), (2, 64, 128, 2, "legacy"), (1, 256, 256, 4, "legacy"), (2, 64, 128, 2, "split")],
                          ids=str)
 def test_attention_bwd(case):
