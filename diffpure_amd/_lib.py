@@ -34,7 +34,7 @@ SIGNATURES = {
     "dp_resample_bwd": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
     "dp_softmax_bwd_rows": [_p, _p, _ll, _i, _p],
     "dp_add": [_p, _p, _p, _ll, _p],
-    "dp_attention_fused": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
+    "dp_attention_fused": [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "dp_resize_affine": [_p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _p],
     "dp_resize_affine_bwd": [_p, _i, _i, _i, _i, _i, _f, _p, _i, _i, _i, _p],
     "dp_softmax_rows": [_p, _ll, _i, _p],

@@ -17,6 +17,12 @@
 //                 accumulator registers - no shuffle: the key order inside a register octet is
 //                 {0,1,2,3,8,9,10,11 | 4,5,6,7,12,13,14,15}, and attn_pack stores V^T in exactly that order)
 // LDS rows are 128 bytes (32 k-values as hi|lo octets) with the XOR swizzle of igemm_h2.hip.
+//
+// ONE-PASS form (H1, round 4: the fp16 x fp16 precision modes - the arithmetic of the reference's own use_fp16 attention,
+// unet.py:358-361): qkv arrives as plain fp16 (the qkv convolution stores it so), ONE MFMA pass per product.  Q and K are read
+// where the convolution left them - a K slice of a key is 64 contiguous bytes of its qkv row, which is all an LDS-DMA lane needs -
+// so attn_pack shrinks to the transposition of V (attn_pack_vt); the 1/sqrt(d) goes onto the scores.  LDS rows are 64 bytes
+// (32 k-values) with the swizzle of igemm_h2_dw.hip: half the bytes through L2 -> LDS of a kernel that re-reads K and V T/128 times.
 #include "dp_common.h"
 
 namespace {
@@ -30,6 +36,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int KB = 32;                // keys per block
 
 __device__ __forceinline__ int swz128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }       // 64-byte rows: 4 slots
 
 struct PackArgs {
     const float* qkv;
@@ -96,6 +103,35 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
     }
 }
 
+// One-pass form: V^T only.  qkv16 [B][T][3C] fp16 -> vt [z][T/32][D][32 keys] fp16 (64-byte rows), keys in the accumulator order.
+struct PackVtArgs {
+    const _Float16* qkv;
+    int T, C, NH;
+    int ov, sh;             // channel offset of v of head 0 and the head stride
+    char* vt;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_pack_vt_kernel(PackVtArgs p) {
+    const int nblk = p.T / KB;
+    const int z = blockIdx.x / nblk, blk = blockIdx.x - z * nblk;
+    const int b = z / p.NH, h = z - b * p.NH;
+    const size_t row0 = (size_t)b * p.T + (size_t)blk * KB;
+    const int c3 = 3 * p.C;
+    for (int item = threadIdx.x; item < D * 4; item += 256) {     // D d x 4 position octets; lanes run along d (coalesced reads of V rows)
+        const int dd = item % D, po = item / D;
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = po * 8 + j;
+            const int p16 = pos & 15;
+            const int kk = (pos & 16) + ((p16 >> 3) & 1) * 4 + ((p16 >> 2) & 1) * 8 + (p16 & 3);   // inverse of key_pos
+            v[j] = p.qkv[(row0 + kk) * c3 + h * p.sh + p.ov + dd];
+        }
+        *reinterpret_cast<half8*>(p.vt + (((size_t)z * nblk + blk) * D + dd) * 64 + po * 16) = v;
+    }
+}
+
 struct FlashArgs {
     const char* qh;
     const char* kh;
@@ -103,20 +139,25 @@ struct FlashArgs {
     float* out;         // [B][T][C] fp32, or (out16) the zero-bordered "h1" operand [B][T/W + 2][W + 2][C] fp16 (border pre-zeroed)
     int T, C, NH;
     int out16, W;
+    // one-pass form: qh / kh point at q / k of head 0 inside qkv16 (fp16), rows of row_bytes, heads head_bytes apart; qscale on the scores
+    int row_bytes, head_bytes;
+    float qscale;
 };
 
 #define AT_GLDS(src, dst)                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),     \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-// QW waves per workgroup, 32 queries each.  LDS per stage: K tile SL slices x 32 rows x 128 B, V^T tile D rows x 128 B.
-template <int QW, int D>
+// QW waves per workgroup, 32 queries each.  LDS per stage: K tile SL slices x 32 rows x ROWB bytes, V^T tile D rows x ROWB bytes;
+// ROWB = 128 (hi|lo octets, three passes) or 64 (H1: plain fp16, one pass).
+template <int QW, int D, bool H1>
 __global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 64 ? 1 : 8))) void attn_flash_kernel(FlashArgs p) {
     constexpr int NT = QW * 64;
     constexpr int SL = D / 32;
-    constexpr int KT = SL * KB * 128, VT = D * 128, STAGE = KT + VT;        // D = 64: 8 KB + 8 KB; D = 256: 32 KB + 32 KB
+    constexpr int ROWB = H1 ? 64 : 128, SPR = ROWB / 16;                    // bytes / 16-byte slots per LDS row
+    constexpr int KT = SL * KB * ROWB, VT = D * ROWB, STAGE = KT + VT;      // three-pass D = 64: 8 KB + 8 KB; D = 256: 32 KB + 32 KB
     constexpr int PIECES = STAGE / (NT * 16);                               // DMA instructions per thread per block
-    constexpr int ROWS_PER_PIECE = NT / 8;                                  // 128-byte rows per workgroup-wide piece
+    constexpr int ROWS_PER_PIECE = NT / SPR;                                // LDS rows per workgroup-wide piece
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -128,20 +169,22 @@ __global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 
     const int nkb = p.T / KB;
 
     // ---- staging: the stage image is STAGE/128 rows of 128 B: rows [0, SL*32) = K (slice-major), then D rows of V^T
-    const int r_in_piece = tid >> 3, ps = tid & 7;
+    const int r_in_piece = tid / SPR, ps = tid % SPR;
+    const int zb = z / p.NH, zh = z - zb * p.NH;
     static_assert((SL * KB) % ROWS_PER_PIECE == 0, "a DMA piece is all K rows or all V^T rows");
     const char* src[PIECES];
     // bytes to advance the source per key block: piece i is K rows for i < SL*KB / ROWS_PER_PIECE, V^T rows after (compile time)
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const int row = i * ROWS_PER_PIECE + r_in_piece;
-        const int ls = ps ^ ((row >> 1) & 7);
+        const int ls = H1 ? ps ^ ((row >> 2) & 3) : ps ^ ((row >> 1) & 7);
         if (row < SL * KB) {
             const int sl = row / KB, key = row - sl * KB;
-            src[i] = p.kh + (((size_t)z * p.T + key) * D) * 4 + sl * 128 + ls * 16;
+            if constexpr (H1) src[i] = p.kh + ((size_t)zb * p.T + key) * p.row_bytes + (size_t)zh * p.head_bytes + sl * 64 + ls * 16;
+            else src[i] = p.kh + (((size_t)z * p.T + key) * D) * 4 + sl * 128 + ls * 16;
         } else {
             const int dd = row - SL * KB;
-            src[i] = p.vt + (((size_t)z * nkb) * D + dd) * 128 + ls * 16;
+            src[i] = p.vt + (((size_t)z * nkb) * D + dd) * ROWB + ls * 16;
         }
     }
     const int wdst = wave * 8 * 128;        // this wave's first row inside a piece (wave-uniform)
@@ -149,14 +192,18 @@ __global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 
         char* base = smem + stage * STAGE + wdst;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            AT_GLDS(src[i], base + i * ROWS_PER_PIECE * 128);
-            src[i] += (i * ROWS_PER_PIECE < SL * KB) ? KB * D * 4 : D * 128;
+            AT_GLDS(src[i], base + i * ROWS_PER_PIECE * ROWB);
+            src[i] += (i * ROWS_PER_PIECE < SL * KB) ? (H1 ? (size_t)KB * p.row_bytes : (size_t)KB * D * 4) : (size_t)D * ROWB;
         }
     };
 
     // ---- Q fragments (B operand: column = query lr, k = 8 consecutive d of octet ks*2 + lk), kept in registers
-    half8 qh[D / 16], ql[D / 16];
-    {
+    half8 qh[D / 16], ql[H1 ? 1 : D / 16];
+    if constexpr (H1) {
+        const char* qrow = p.qh + ((size_t)zb * p.T + q0 + lr) * p.row_bytes + (size_t)zh * p.head_bytes;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) qh[ks] = *reinterpret_cast<const half8*>(qrow + (ks * 2 + lk) * 16);
+    } else {
         const char* qrow = p.qh + (((size_t)z * p.T + q0 + lr) * D) * 4;
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) {
@@ -189,12 +236,21 @@ __global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) {
             const int sl = ks >> 1, st = ks & 1;
-            const char* rowp = Ks + sl * (KB * 128);
-            const half8 kh = *reinterpret_cast<const half8*>(rowp + swz128(lr, st * 4 + lk * 2));
-            const half8 kl = *reinterpret_cast<const half8*>(rowp + swz128(lr, st * 4 + lk * 2 + 1));
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+            const char* rowp = Ks + sl * (KB * ROWB);
+            if constexpr (H1) {
+                const half8 kh = *reinterpret_cast<const half8*>(rowp + swz64(lr, st * 2 + lk));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+            } else {
+                const half8 kh = *reinterpret_cast<const half8*>(rowp + swz128(lr, st * 4 + lk * 2));
+                const half8 kl = *reinterpret_cast<const half8*>(rowp + swz128(lr, st * 4 + lk * 2 + 1));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+            }
+        }
+        if constexpr (H1) {                 // 1 / sqrt(d): the three-pass form has it on the packed Q
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= p.qscale;
         }
 
         // online softmax for query lr: this lane holds 16 of the block's 32 keys, lane ^ 32 the other 16
@@ -230,11 +286,16 @@ __global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 
             }
 #pragma unroll
             for (int t = 0; t < D / 32; ++t) {
-                const half8 vh = *reinterpret_cast<const half8*>(Vs + swz128(t * 32 + lr, g * 4 + lk * 2));
-                const half8 vl = *reinterpret_cast<const half8*>(Vs + swz128(t * 32 + lr, g * 4 + lk * 2 + 1));
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[t], 0, 0, 0);
+                if constexpr (H1) {
+                    const half8 vh = *reinterpret_cast<const half8*>(Vs + swz64(t * 32 + lr, g * 2 + lk));
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[t], 0, 0, 0);
+                } else {
+                    const half8 vh = *reinterpret_cast<const half8*>(Vs + swz128(t * 32 + lr, g * 4 + lk * 2));
+                    const half8 vl = *reinterpret_cast<const half8*>(Vs + swz128(t * 32 + lr, g * 4 + lk * 2 + 1));
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -268,9 +329,10 @@ __global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 
 
 }  // namespace
 
-extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, void* out, int out_fmt, int W,
+extern "C" int dp_attention_fused(const void* qkv, int qkv_fmt, int B, int T, int C, int n_heads, int layout, void* out, int out_fmt, int W,
                                   void* work, void* stream) {
     DP_REQUIRE(qkv && out && work && B > 0 && T > 0 && C > 0 && n_heads > 0, "dp_attention_fused: bad args");
+    DP_REQUIRE(qkv_fmt == 0 || qkv_fmt == 1, "dp_attention_fused: qkv_fmt %d (0 = fp32, three-pass arithmetic; 1 = fp16, one pass)", qkv_fmt);
     const int D = C / n_heads;
     DP_REQUIRE(C % n_heads == 0 && (D == 64 || D == 256), "dp_attention_fused: head dimension must be 64 or 256 (got %d)", D);
     DP_REQUIRE(T % 64 == 0 && (D == 64 || T % 128 == 0), "dp_attention_fused: token count must be a multiple of 64 (128 at head dimension 256), got %d", T);
@@ -278,21 +340,38 @@ extern "C" int dp_attention_fused(const float* qkv, int B, int T, int C, int n_h
     DP_REQUIRE(out_fmt == 0 || (out_fmt == 1 && W > 0 && T % W == 0), "dp_attention_fused: out_fmt 1 (bordered fp16 operand) needs the image width W | T (got %d, W=%d)", out_fmt, W);
     DP_REQUIRE(dp_aligned16(qkv) && dp_aligned16(out) && dp_aligned16(work), "dp_attention_fused: misaligned tensor");
     hipStream_t s = (hipStream_t)stream;
+    const int Z = B * n_heads;
+    int oq, ok, ov, sh;
+    if (layout == 0) { oq = 0; ok = D; ov = 2 * D; sh = 3 * D; }       // 'legacy': heads x [q | k | v]
+    else { oq = 0; ok = C; ov = 2 * C; sh = D; }                       // 'split' : [Q | K | V]
+    const float qscale = 1.0f / sqrtf((float)D);
+    if (qkv_fmt == 1) {                     // one fp16 pass: Q and K are read in place, only V^T is packed
+        const _Float16* q16 = static_cast<const _Float16*>(qkv);
+        PackVtArgs pv{q16, T, C, n_heads, ov, sh, (char*)work};
+        if (D == 64) hipLaunchKernelGGL(attn_pack_vt_kernel<64>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pv);
+        else hipLaunchKernelGGL(attn_pack_vt_kernel<256>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pv);
+        DP_LAUNCH_CHECK("attn_pack_vt");
+        FlashArgs fa{reinterpret_cast<const char*>(q16 + oq), reinterpret_cast<const char*>(q16 + ok), (const char*)work, static_cast<float*>(out),
+                     T, C, n_heads, out_fmt, out_fmt ? W : 1, 3 * C * 2, sh * 2, qscale};
+        if (D == 256) hipLaunchKernelGGL((attn_flash_kernel<4, 256, true>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
+        else if (T % 128 == 0) hipLaunchKernelGGL((attn_flash_kernel<4, 64, true>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL((attn_flash_kernel<2, 64, true>), dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
+        DP_LAUNCH_CHECK("attn_flash");
+        return 0;
+    }
     const size_t part = (size_t)B * T * C * 4;
     PackArgs pa;
-    pa.qkv = qkv; pa.B = B; pa.T = T; pa.C = C; pa.NH = n_heads;
-    if (layout == 0) { pa.oq = 0; pa.ok = D; pa.ov = 2 * D; pa.sh = 3 * D; }       // 'legacy': heads x [q | k | v]
-    else { pa.oq = 0; pa.ok = C; pa.ov = 2 * C; pa.sh = D; }                       // 'split' : [Q | K | V]
-    pa.qscale = 1.0f / sqrtf((float)D);
+    pa.qkv = static_cast<const float*>(qkv); pa.B = B; pa.T = T; pa.C = C; pa.NH = n_heads;
+    pa.oq = oq; pa.ok = ok; pa.ov = ov; pa.sh = sh;
+    pa.qscale = qscale;
     pa.qh = (char*)work; pa.kh = pa.qh + part; pa.vt = pa.kh + part;
-    const int Z = B * n_heads;
     if (D == 64) hipLaunchKernelGGL(attn_pack_kernel<64>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
     else hipLaunchKernelGGL(attn_pack_kernel<256>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
     DP_LAUNCH_CHECK("attn_pack");
-    FlashArgs fa{pa.qh, pa.kh, pa.vt, static_cast<float*>(out), T, C, n_heads, out_fmt, out_fmt ? W : 1};
-    if (D == 256) hipLaunchKernelGGL((attn_flash_kernel<4, 256>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
-    else if (T % 128 == 0) hipLaunchKernelGGL((attn_flash_kernel<4, 64>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
-    else hipLaunchKernelGGL((attn_flash_kernel<2, 64>), dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
+    FlashArgs fa{pa.qh, pa.kh, pa.vt, static_cast<float*>(out), T, C, n_heads, out_fmt, out_fmt ? W : 1, 0, 0, 1.0f};
+    if (D == 256) hipLaunchKernelGGL((attn_flash_kernel<4, 256, false>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
+    else if (T % 128 == 0) hipLaunchKernelGGL((attn_flash_kernel<4, 64, false>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
+    else hipLaunchKernelGGL((attn_flash_kernel<2, 64, false>), dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
     DP_LAUNCH_CHECK("attn_flash");
     return 0;
 }

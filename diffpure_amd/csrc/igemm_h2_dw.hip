@@ -58,6 +58,9 @@ struct dw_const { static constexpr int value = Q; };
 // k-tile (A: 8 MFMA | 6 ds_read | 4 DMA pieces; B: 4 MFMA; W: the counted vmcnt wait; S: the barrier; C: 6 ds_read | 4 MFMA), sums
 // the segment durations over its k-loop and writes [A, B, W, S, C, epilogue, k-tiles, total] (shader cycles) to p.ws per
 // (workgroup, wave): tests/probes/dw8_timeline.py.
+// 256 (correct results, full speed): TILE LIFETIME - four stamps per wave (entry, k-loop start, k-loop end, exit) and the CU the workgroup
+// ran on (HW_ID / XCC_ID): prologue, k-loop and epilogue cycles per tile and the gap between consecutive workgroups of one CU
+// (tests/probes/dw8_lifetime.py).
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     constexpr int ADEPTH = 3, DA = ADEPTH - 1;  // ring stages / prefetch distance of both operands
@@ -69,6 +72,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     constexpr int RINGS = ADEPTH * ATILE + BDEPTH * BTILE;
     __shared__ __attribute__((aligned(1024))) char smem[RINGS > SW_EPI_LDS ? RINGS : SW_EPI_LDS];
 
+    unsigned life0 = 0;
+    if constexpr (MODE & 256) life0 = (unsigned)__builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     unsigned tl[5] = {0u, 0u, 0u, 0u, 0u};      // MODE & 64: summed segment durations
     unsigned tl_n = 0, tl_s0 = 0, tl_begin = 0;
     auto stamp = []() { return (unsigned)__builtin_amdgcn_s_memtime(); };
-    if constexpr (MODE & 64) tl_begin = stamp();
+    if constexpr (MODE & (64 | 256)) tl_begin = stamp();
     int t = 0;
     // ROLE (compile time: one copy of the loop per role behind a wave-uniform branch, so that every copy is straight-line code the
     // scheduler can pin): 0 = symmetric (four pieces in segment A), 1 = older wave (four own pieces in A, the partner's four after
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     }
 
     unsigned tl_e0 = 0;
-    if constexpr (MODE & 64) tl_e0 = stamp();
+    if constexpr (MODE & (64 | 256)) tl_e0 = stamp();
     if constexpr (!(MODE & 8)) sw_epilogue_any<1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW, smem + wave * (16 * SW_EPI_PITCH));
     if constexpr (MODE & 64) {
         const unsigned tl_e1 = stamp();
@@ -341,6 +346,21 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
             o[5] = (float)(tl_e1 - tl_e0);
             o[6] = (float)tl_n;
             o[7] = (float)(tl_e1 - tl_begin);
+        }
+    }
+    if constexpr (MODE & 256) {
+        __builtin_amdgcn_s_waitcnt(0);              // the wave's stores have left: exit = the moment the CU may take the next workgroup's wave
+        const unsigned life3 = stamp();
+        if (p.ws && lane == 0) {
+            float* o = p.ws + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = (float)(life0 & 0xffffu);
+            o[1] = (float)(life0 >> 16);
+            o[2] = (float)(tl_begin - life0);
+            o[3] = (float)(tl_e0 - tl_begin);
+            o[4] = (float)(life3 - tl_e0);
+            o[5] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu);          // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
+            o[6] = (float)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu);             // XCC_ID
+            o[7] = (float)tile;
         }
     }
 }
@@ -369,7 +389,7 @@ void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s) {
         const char* e = getenv("DP_H2_DW_MODE");
         switch (e ? atoi(e) : 0) {
 #define DW_CASE(M_) case M_: hipLaunchKernelGGL((conv_igemm_dw<M_>), g, b, 0, s, p); return
-            DW_CASE(1); DW_CASE(2); DW_CASE(3); DW_CASE(6); DW_CASE(4); DW_CASE(7); DW_CASE(8); DW_CASE(16); DW_CASE(32); DW_CASE(64); DW_CASE(128); DW_CASE(192);
+            DW_CASE(1); DW_CASE(2); DW_CASE(3); DW_CASE(6); DW_CASE(4); DW_CASE(7); DW_CASE(8); DW_CASE(16); DW_CASE(32); DW_CASE(64); DW_CASE(128); DW_CASE(192); DW_CASE(256);
 #undef DW_CASE
             default: break;
         }

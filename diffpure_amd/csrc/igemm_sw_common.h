@@ -114,8 +114,11 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
         for (int b = 0; b < 16 * NQ; ++b)           // block b = rows 4b .. 4b + 3 of the wave tile; lane l lands at block + 16 l
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(4 * b) * ldr_b),
                                              (__attribute__((address_space(3))) void*)(lds_wave + b * SW_EPI_PITCH), 16, 0, 0);
-        // the wave reads only what it brought in itself: its own vmcnt, no barrier (the compiler does not order LDS reads behind LDS-DMA)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the wave reads only what it brought in itself: its own vmcnt, no barrier (the compiler does not order LDS reads behind LDS-DMA).
+        // First the blocks of the first 32-row MFMA tile row (loads return in issue order: 8 (NQ - 1) + 8 younger DMAs may still fly);
+        // the rest is waited for before the second tile row, under whose arithmetic it lands (a CU's L2 -> LDS path moves the 128 KB
+        // in ~4 000 cycles)
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(16 * NQ - 8) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
     // the lane's own column in the landing zone: row 32 i + 4 lk + 2 (k & 1) + 8 (k >> 1) + e, column 32 j + lr
@@ -127,6 +130,13 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * q + ii;
             const int rowt = row0 + i * 32;         // wave-uniform
+            if constexpr (RK == 2) {
+                if (i == 1) {                       // everything has landed (this also waits for the first tile row's stores: loads and stores share the counter)
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x2 tv = {tvv[i][j], tvv[i][j]};

@@ -150,9 +150,9 @@ Tensor attention(const Tensor& qkv, int64_t n_heads, bool legacy_layout) {
     const int64_t B = qkv.size(0), T = qkv.size(1), C = qkv.size(2) / 3, d = C / n_heads;
     void* s = cur_stream(qkv);
     Tensor out = at::empty({B, T, C}, qkv.options());
-    if (d == 64 && T % 64 == 0) {       // flash-style kernel: the T x T scores never leave the registers
+    if ((d == 64 && T % 64 == 0) || (d == 256 && T % 128 == 0)) {       // flash-style kernel: the T x T scores never leave the registers
         Tensor work = at::empty({3 * B * T * C}, qkv.options());
-        DP_CALL(dp_attention_fused(qkv.data_ptr<float>(), (int)B, (int)T, (int)C, (int)n_heads, legacy_layout ? 0 : 1,
+        DP_CALL(dp_attention_fused(qkv.data_ptr<float>(), /*qkv_fmt=*/0, (int)B, (int)T, (int)C, (int)n_heads, legacy_layout ? 0 : 1,
                                    out.data_ptr<float>(), /*out_fmt=*/0, /*W=*/0, work.data_ptr(), s));
         return out;
     }

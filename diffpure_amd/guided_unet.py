@@ -377,14 +377,19 @@ class GuidedUNet:
         b, hh, ww, _ = x.shape
         st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS)
         xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
-        qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        # fp16 x fp16 modes, no tape (the backward pass recomputes the probabilities from an fp32 qkv): qkv is stored as plain fp16 by the
+        # convolution and the flash kernel runs ONE fp16 pass on it, Q and K read in place (csrc/attention.hip; the arithmetic of the
+        # reference's use_fp16 attention, unet.py:358-361)
+        fused = bool(r.get("proj16")) and ops.attention_fused_ok(hh * ww, c // r["heads"])
+        q16 = fused and tape is None and os.environ.get("DIFFPURE_ATTN16", "1") != "0"
+        qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"], **({"out_f16": True} if q16 else {}))
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
         # The taped forward keeps only qkv: the [B*heads, T, T] probabilities (2.1 GB per 32x32 layer at B=64) are
         # RECOMPUTED per block in the backward pass, as the reference does by checkpointing exactly these blocks
         # (guided_diffusion/unet.py:305) - so the forward runs the fused flash kernel with or without a tape.
         if tape is not None:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv, layout=layout))
-        if r.get("proj16") and ops.attention_fused_ok(hh * ww, c // r["heads"]):
+        if fused:
             ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), r["heads"], layout, operand_hw=(hh, ww))
             return self._ch2(ah, P[n + ".wproj16"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True,
                              **({"out_f16": True} if self._o16(hh * ww, tape) else {}))

@@ -342,11 +342,14 @@ class NCSNpp:
         b, hh, ww, _ = x.shape
         st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS)
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
-        qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"])
+        # fp16 x fp16 modes without a tape: fp16 qkv, one fp16 pass of the flash kernel (see GuidedUNet._attn)
+        fused = bool(r.get("proj16")) and ops.attention_fused_ok(hh * ww, c)
+        q16 = fused and tape is None and os.environ.get("DIFFPURE_ATTN16", "1") != "0"
+        qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"], **({"out_f16": True} if q16 else {}))
         # the taped forward keeps only qkv; the probabilities are recomputed per block in the backward pass (see GuidedUNet._attn)
         if tape is not None:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv))
-        if r.get("proj16") and ops.attention_fused_ok(hh * ww, c):      # with or without a tape, as GuidedUNet._attn
+        if fused:                                   # with or without a tape, as GuidedUNet._attn
             ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), 1, "split", operand_hw=(hh, ww))
             return self._ch2(ah, P[n + ".w3h"], c, 1, bias=P[n + ".c3"], res=x, scale=INV_SQRT2, colstats=True,
                              **({"out_f16": True} if self._o16(hh * ww, tape) else {}))

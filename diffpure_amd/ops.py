@@ -713,19 +713,23 @@ def attention_fused_ok(t, d):
 def attention_fused(qkv, n_heads, layout, operand_hw=None):
     """softmax(q k^T / sqrt(d)) v without materialising the scores (csrc/attention.hip).  operand_hw=(H, W) (H * W tokens):
     the result is written as the zero-bordered fp16 operand [B, H+2, W+2, C] of the following 1x1 convolution
-    (conv2d_h2, "h1" format) instead of fp32 [B, T, C]."""
-    _chk(qkv, "attention_fused.qkv", 3)
+    (conv2d_h2, "h1" format) instead of fp32 [B, T, C].
+    qkv fp32: split-fp16 operands, three MFMA passes (fp32-class accuracy).  qkv fp16 (the qkv convolution's out_f16): ONE fp16 pass,
+    Q and K read in place - the fp16 x fp16 precision modes."""
+    assert qkv.is_cuda and qkv.is_contiguous() and qkv.dim() == 3 and qkv.dtype in (torch.float32, torch.float16), "attention_fused.qkv"
     b, t, c3 = qkv.shape
     c = c3 // 3
-    work = torch.empty((3 * b * t * c,), device=qkv.device, dtype=torch.float32)
+    f16 = qkv.dtype == torch.float16
+    work = torch.empty((b * t * c,), device=qkv.device, dtype=torch.float16) if f16 else torch.empty((3 * b * t * c,), device=qkv.device, dtype=torch.float32)
+    lay = 0 if layout == "legacy" else 1
     if operand_hw is not None:
         hh, ww = operand_hw
         assert hh * ww == t, (operand_hw, t)
         out = torch.zeros((b, hh + 2, ww + 2, c), device=qkv.device, dtype=torch.float16)       # the border stays zero
-        _lib.call("dp_attention_fused", _ptr(qkv), b, t, c, n_heads, 0 if layout == "legacy" else 1, _ptr(out), 1, ww, _ptr(work), _stream())
+        _lib.call("dp_attention_fused", _ptr(qkv), 1 if f16 else 0, b, t, c, n_heads, lay, _ptr(out), 1, ww, _ptr(work), _stream())
         return out
     out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
-    _lib.call("dp_attention_fused", _ptr(qkv), b, t, c, n_heads, 0 if layout == "legacy" else 1, _ptr(out), 0, 0, _ptr(work), _stream())
+    _lib.call("dp_attention_fused", _ptr(qkv), 1 if f16 else 0, b, t, c, n_heads, lay, _ptr(out), 0, 0, _ptr(work), _stream())
     return out
 
 

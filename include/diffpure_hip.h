@@ -303,15 +303,17 @@ int dp_softmax_bwd_rows(const float* p, float* dp, long long rows, int cols, voi
 int dp_add(const float* a, const float* b, float* out, long long n, void* stream);
 
 /* Fused attention for the inference path (no probabilities kept): out[b,t,h*d+:] = softmax(q k^T / sqrt(d)) v per
- * head on the fp16 matrix cores with split-fp16 operands (fp32-class accuracy), flash-style (the T x T scores stay
- * in registers).  Same operand conventions as dp_gemm_strided-based attention: qkv [B,T,3C] fp32, layout 0 =
- * 'legacy' (heads x [q|k|v], QKVAttentionLegacy unet.py:345-362), 1 = 'split' ([Q|K|V]); head dimension 64,
- * T % 64 == 0.  work: 3 * B * T * C * 4 bytes of 16-byte-aligned scratch (packed Q, K and transposed V).
+ * head on the fp16 matrix cores, flash-style (the T x T scores stay in registers).  layout 0 = 'legacy' (heads x [q|k|v],
+ * QKVAttentionLegacy unet.py:345-362), 1 = 'split' ([Q|K|V]); head dimension 64 (T % 64 == 0) or 256 (T % 128 == 0).
+ * qkv_fmt 0: qkv [B,T,3C] fp32, split-fp16 operands, three MFMA passes per product (fp32-class accuracy);
+ *            work: 3 * B * T * C * 4 bytes of 16-byte-aligned scratch (packed Q, K and transposed V).
+ * qkv_fmt 1: qkv [B,T,3C] plain fp16 (the qkv convolution's out_fmt 1), ONE fp16 MFMA pass per product - the arithmetic of the
+ *            reference's use_fp16 attention (unet.py:358-361); Q and K are read in place, work (B * T * C * 2 bytes) holds V^T.
  * out_fmt 0: out is fp32 [B][T][C].  out_fmt 1: the tokens are the pixels of an image of width W (T % W == 0) and out is the
  * zero-bordered plain-fp16 operand [B][T/W + 2][W + 2][C] of the proj_out 1x1 convolution (a_fmt 1 of dp_conv2d_nhwc_h2;
  * AttentionBlock.proj_out, unet.py:312): the kernel writes the interior pixels (rounded to nearest), the CALLER zeroes
  * the border. */
-int dp_attention_fused(const float* qkv, int B, int T, int C, int n_heads, int layout, void* out, int out_fmt, int W,
+int dp_attention_fused(const void* qkv, int qkv_fmt, int B, int T, int C, int n_heads, int layout, void* out, int out_fmt, int W,
                        void* work, void* stream);
 
 /* ---- the steps either side of the purifier ---------------------------------------

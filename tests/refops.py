@@ -124,7 +124,7 @@ def attention_fused_ok(t, d):
 
 
 def attention_fused(qkv, n_heads, layout, operand_hw=None):
-    out = attention(qkv, n_heads, layout)
+    out = attention(_up(qkv), n_heads, layout)
     if operand_hw is None:
         return out
     hh, ww = operand_hw

@@ -168,6 +168,33 @@ def test_attention_fused_flash_kernel(dev, case, monkeypatch):
     assert torch.equal(got, ops.attention_fused(qkv.to(dev), heads, layout))      # deterministic
 
 
+@pytest.mark.parametrize("case", FUSED_ATT_CASES, ids=[str(c) for c in FUSED_ATT_CASES])
+def test_attention_fused_one_pass_fp16(dev, case):
+    """The one-pass form of csrc/attention.hip (round 4; the fp16 x fp16 precision modes): qkv as the qkv convolution stores it - plain
+    fp16 -, Q and K read in place, V^T packed, ONE fp16 MFMA pass per product, 1/sqrt(d) on the scores.  Against fp64 attention of the SAME
+    fp16-rounded qkv (the error that is left is the fp16 rounding of the probabilities, 2^-11 relative, and fp32 accumulation), against
+    the three-pass kernel on the same values, and the bordered-operand output against the plain one."""
+    from diffpure_amd import ops
+    B, T, C, heads, layout, gain = case
+    q16 = (rnd(B, T, 3 * C, seed=11) * gain).half()
+    ref = refops.attention(q16.double(), heads, layout).float()
+    got = ops.attention_fused(q16.to(dev), heads, layout)
+    assert got.dtype == torch.float32
+    tol = 1.5e-3 * max(1.0, gain)           # |out| <~ max |v| ~ 4 gain; P rounded to fp16: relative 2^-11 per term, averaging over T keys
+    close(got, ref, rtol=2e-3, atol=tol)
+    three = ops.attention_fused(q16.float().to(dev), heads, layout)
+    close(got, three.cpu(), rtol=2e-3, atol=tol)
+    assert torch.equal(got, ops.attention_fused(q16.to(dev), heads, layout))      # deterministic
+    err = (got.cpu() - ref).abs().max().item()
+    print(f"one-pass fp16 attention {case}: max-abs error {err:.2e} (outputs up to {ref.abs().max().item():.2f})")
+    d = C // heads
+    ww = 16 if T % 16 == 0 else 8
+    op = ops.attention_fused(q16.to(dev), heads, layout, operand_hw=(T // ww, ww))
+    want = torch.nn.functional.pad(got.view(B, T // ww, ww, C), (0, 0, 1, 1, 1, 1)).half()
+    diff = (op.float() - want.float()).abs()
+    assert (diff <= want.float().abs() * 2.0 ** -10 + 1e-7).all() and (op != want).float().mean().item() < 1e-3
+
+
 def test_softmax_forced_large_logits(dev):
     from diffpure_amd import _lib
     x = rnd(37, 200, seed=12) * 30
