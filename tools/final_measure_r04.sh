@@ -33,6 +33,10 @@ if [ -z "$QUICK" ]; then
   find "$O" -name "*kernel_trace.csv" -delete; find "$O" -name "*agent_info.csv" -delete
   timeout 200 python bench.py --t 150 --dt 1.5e-3 --steps 1 --warmup 1 --no-cpu-baseline > "$O/bench_t150_dt1.5e-3_100step.json" 2> "$O/bench_t150a.err"; lap bench_t150_100
   timeout 200 python bench.py --t 150 --steps 1 --warmup 1 --no-cpu-baseline > "$O/bench_t150_150step.json" 2> "$O/bench_t150b.err"; lap bench_t150_150
+  timeout 100 python tests/probes/dw8_lifetime.py > "$O/dw8_lifetime.log" 2>&1; lap lifetime
+  timeout 150 python tests/probes/dw8_timeline.py > "$O/dw8_timeline.log" 2>&1; lap timeline
+  timeout 100 python tests/probes/conv_epi_probe.py > "$O/conv_epi_probe.log" 2>&1; lap epi_probe
+  timeout 100 python tests/probes/gn_bwd_one_pass_probe.py > "$O/gn_bwd_one_pass_probe.log" 2>&1; lap gn_bwd_probe
   grep -E "passed|failed" "$O/gpu_tests.log" | tail -2; grep -E "^FAILED|^ERROR" "$O/gpu_tests.log" | head; tail -2 "$O/smoke.log"
 fi
 cat "$O/timeline.log"
