@@ -586,9 +586,11 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         const int pp = dp_tune(DP_T_H2_PP);
         // one workgroup per CU: the grid runs in rounds of 256 tiles; take the variant when the last round is not
         // mostly empty (measured at B=16: 407-450 TFLOP/s vs 326-375 on full rounds, 262 vs 350 on half a round)
+        // (round 4: a single round on at least half the CUs is taken too - the 16x16 level of NCSN++ at B = 128, 128 tiles: +1.7 % on the
+        // adjoint bench against the 128x128 tiles, profiles/r04/adjoint_pp_fill_rule_ab.log)
         auto fills = [&](int bm, int bn) {
             const long long t = tiles(bm, bn), rounds = (t + 255) / 256;
-            return t >= 256 && t * 5 >= rounds * 256 * 4;
+            return (t >= 256 && t * 5 >= rounds * 256 * 4) || (t >= 128 && t < 256);
         };
         int bn = 0;
         if (p.ksplit > 1) bn = 0;            // split-K layers never take the ping-pong variants (shape-only rule)
