@@ -59,6 +59,18 @@ __device__ __forceinline__ float dp_silu_f(float v) {
     return r;
 }
 
+// SiLU for results that are rounded to fp16 right away (GroupNorm-apply over the fp16 residual stream): exp2 of v * -log2(e) straight on the
+// hardware unit (relative error ~|v| 2^-24, 1e-6 at |v| = 20) and the reciprocal unit's 1 ulp - 2^-11 is what survives the store.  The full
+// dp_silu_f costs ~30 issue slots per element (two quarter-rate transcendentals, the carried rounding error of the exponent, a Newton step,
+// range selects), which made that kernel - 4 bytes of HBM traffic per element - instruction-bound: ~12 slots here.
+// v -> -inf: exp2 = inf, rcp = 0, result -0 (the limit); v -> +inf: v.
+__device__ __forceinline__ float dp_silu_fast_f(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
+    float r = v * __builtin_amdgcn_rcpf(1.0f + e);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 // fp32 -> fp16, round to nearest even, of the fp32 value AS ROUNDED TO fp32.  Left to itself the compiler folds a preceding multiply
 // into the conversion (v_fma_mixlo_f16: ONE rounding of the exact product) wherever the product has no other fp32 use - which
 // kernel variant, output format or resampling mode does so is an accident of code shape, and the double-rounding cases (1e-4 of

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float u = fmaf((float)v[j], a[j], d[j]);
-                o[j] = ACT ? dp_silu_f(u) : u;
+                o[j] = ACT ? dp_silu_fast_f(u) : u;            // every result of this kernel is stored as fp16
             }
         };
         auto xf = [&](half8 v) {

@@ -863,6 +863,14 @@ def test_stem_convolution_fp16_output(dev):
     assert y16.t.dtype == torch.float16 and torch.equal(y16.t, y32.t.half()) and torch.equal(y16.cols.buf, y32.cols.buf)
 
 
+def ulp_close(got, ref, what, rate=0.05):
+    """fp16 tensors equal up to one fp16 ulp (2^-10 relative, one subnormal step absolute) in at most `rate` of the elements"""
+    g, r = got.float(), ref.float()
+    diff = (g - r).abs()
+    assert (diff <= r.abs() * 2.0 ** -10 + 6.0e-8).all(), (what, diff.max().item())
+    assert (got != ref).float().mean().item() < rate, (what, (got != ref).float().mean().item())
+
+
 H16_CASES = [(2, 8, 8, 256, 0, 32), (3, 6, 10, 64, 0, 16), (1, 16, 16, 1024, 0, 32), (2, 8, 8, 256, 128, 32), (2, 16, 16, 128, 128, 32),
              (1, 4, 260, 128, 0, 32), (2, 8, 8, 512, 1024, 32)]
 
@@ -872,7 +880,9 @@ def test_group_norm_fp16_input_equals_group_norm_of_the_upconverted_tensors(dev,
     """dp_gn_apply_h16 (plain fp16 NHWC in - a first convolution's fp16 output, the fp16 residual stream, the two sources of a skip
     concatenation - -> bordered fp16 operand, or a plain fp16 tensor) gives the bytes of dp_gn_apply(out_fmt 2) on the same values held
     as fp32: FiLM rows per sample / broadcast / absent, with and without SiLU, 2x nearest-up / 2x2 mean-down, the raw second output, no
-    normalisation at all (resampled identity skip, raw operand of a 1x1 convolution)."""
+    normalisation at all (resampled identity skip, raw operand of a 1x1 convolution).  With SiLU the fp16 kernel evaluates the sigmoid on the
+    hardware exp2 / reciprocal units without the fp32-accuracy corrections of the fp32 kernels (dp_silu_fast_f): the stored fp16 values
+    differ from the fp32 kernel's by at most one fp16 ulp, in a small fraction of the elements."""
     from diffpure_amd import ops
     B, H, W, C1, C2, G = case
     C = C1 + C2
@@ -889,12 +899,16 @@ def test_group_norm_fp16_input_equals_group_norm_of_the_upconverted_tensors(dev,
                 ref = ops.group_norm(xf, G, 1e-5, gamma, beta, x2=x2f, film=film, act=act, resample=rs, split="h1", stats=stats)
                 got = ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, film=film, act=act, resample=rs, split="h1", stats=stats)
                 assert got.dtype == torch.float16 and got.shape == ref.shape
-                assert torch.equal(got, ref), (case, film_rows, act, rs)
+                if act:
+                    ulp_close(got, ref, (case, film_rows, act, rs))
+                else:
+                    assert torch.equal(got, ref), (case, film_rows, act, rs)
     y, yr = ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, act=True, split="h1", stats=stats, raw=True)
     y0, yr0 = ops.group_norm(xf, G, 1e-5, gamma, beta, x2=x2f, act=True, split="h1", stats=stats, raw=True)
-    assert torch.equal(y, y0) and torch.equal(yr, yr0)
+    ulp_close(y, y0, "raw")
+    assert torch.equal(yr, yr0)
     if C2 == 0:
-        assert torch.equal(ops.group_norm_f16in(x16, G, gamma, beta, stats, act=True), y0)
+        assert torch.equal(ops.group_norm_f16in(x16, G, gamma, beta, stats, act=True), y)
         for rs in (0, 1, 2) if H % 2 == 0 and W % 2 == 0 else (0, 1):
             assert torch.equal(ops.to_h2(x16, rs, fmt="h1"), ops.to_h2(xf, rs, fmt="h1")), rs
             if rs:
