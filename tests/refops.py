@@ -120,7 +120,7 @@ def group_norm_f16in(x16, groups, gamma, beta, stats, film=None, act=False):
 
 
 def attention_fused_ok(t, d):
-    return d == 64 and t % 64 == 0
+    return (d == 64 and t % 64 == 0) or (d == 256 and t % 128 == 0)
 
 
 def attention_fused(qkv, n_heads, layout, operand_hw=None):

@@ -603,3 +603,61 @@ def test_fir_adjoint_stencils_match_autograd(taps):
         for mode, name in ((ops.RESAMPLE_FIR_UP, "up"), (ops.RESAMPLE_FIR_DOWN, "down")):
             got = nchw(refops.fir_adjoint_stencil(nhwc(g["dy_" + name]), mode, k))
             torch.testing.assert_close(got, g["dx_" + name], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
+def test_one_pass_attention_and_folded_skip_gradient_wiring(kind, monkeypatch):
+    """Round 4: (1) in the fp16 x fp16 modes the qkv convolution of an attention block the flash kernel covers hands it an fp16 qkv
+    (one fp16 pass, Q / K read in place) - but only without a tape (the backward pass recomputes the probabilities from an fp32 qkv),
+    and DIFFPURE_ATTN16=0 switches it off; (2) the backward pass hands the gradient of every ResBlock's skip branch and of an attention
+    block's residual to the GroupNorm backward as `addend` (one pass on the GPU where the shape allows) instead of separate add launches -
+    the input gradient still equals torch.autograd through the oracle's restatement of the reference network."""
+    from diffpure_amd import ops
+    if kind == "ncsnpp":
+        g = load_golden("ncsnpp_full.pt")                 # 16x16 attention with one head of 256 channels: the flash kernel's D = 256 form
+        cfg = pn.parse_config(g["cfg"])
+        sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+        build = lambda prec: pn.NCSNpp(cfg, "cpu", precision=prec).load_state_dict(sd)
+        x, tt = g["x"][:1], g["labels"][:1]
+        ocfg = on.parse_ncsnpp_config(g["cfg"])
+        ofwd = lambda xx: on.ncsnpp_forward(sd, ocfg, xx, tt)
+    else:
+        g = load_golden("guided_small.pt")
+        cfg = pg.parse_config(g["cfg"])
+        sd = synth_state_dict(pg.param_shapes(cfg), g["seed"])
+        build = lambda prec: pg.GuidedUNet(cfg, "cpu", precision=prec).load_state_dict(sd)
+        x, tt = g["x"][:1], g["t"][:1].float()
+        ocfg = og.parse_guided_config(g["cfg"])
+        ofwd = lambda xx: og.guided_unet_forward(sd, ocfg, xx, tt)
+    seen = []
+    real_att = ops.attention_fused
+    monkeypatch.setattr(ops, "attention_fused", lambda qkv, *a, **kw: (seen.append(qkv.dtype), real_att(qkv, *a, **kw))[1])
+    net = build("f16sr")
+    fusable = [r for r in (net.plan["mid"] + [r for b in net.plan.get("down", net.plan.get("inp")) for r in b]) if r["kind"] == "attn" and r.get("proj16")]
+    net.forward(nhwc(x), tt)
+    if fusable:
+        assert seen and all(d == torch.float16 for d in seen), seen
+        seen.clear()
+        net.forward(nhwc(x), tt, tape=[])
+        assert seen and all(d == torch.float32 for d in seen), seen       # taped: fp32 qkv, three passes
+        seen.clear()
+        monkeypatch.setenv("DIFFPURE_ATTN16", "0")
+        net.forward(nhwc(x), tt)
+        assert seen and all(d == torch.float32 for d in seen), seen
+        monkeypatch.delenv("DIFFPURE_ATTN16")
+    # (2) backward wiring at fp32-class arithmetic
+    adds, bwd = [], []
+    real_add, real_bwd = ops.add, ops.group_norm_bwd
+    monkeypatch.setattr(ops, "add", lambda a, b: (adds.append(1), real_add(a, b))[1])
+    monkeypatch.setattr(ops, "group_norm_bwd", lambda *a, **kw: (bwd.append(kw.get("addend") is not None), real_bwd(*a, **kw))[1])
+    net32 = build("f16x3")
+    tape = []
+    out = net32.forward(nhwc(x), tt, tape=tape)
+    cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
+    got = nchw(net32.vjp(tape, cot))
+    xr = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        (want,) = torch.autograd.grad(ofwd(xr), xr, nchw(cot))
+    assert (got - want).abs().max() < 2e-3 * want.abs().max(), ((got - want).abs().max().item(), want.abs().max().item())
+    assert sum(bwd) >= len([r for r in tape if isinstance(r, dict)]) // 2      # every ResBlock / attention block folds its skip gradient
+    assert len(adds) < sum(bwd)                                                   # and hardly any separate add is left
