@@ -61,6 +61,15 @@ struct dw_const { static constexpr int value = Q; };
 // 256 (correct results, full speed): TILE LIFETIME - four stamps per wave (entry, k-loop start, k-loop end, exit) and the CU the workgroup
 // ran on (HW_ID / XCC_ID): prologue, k-loop and epilogue cycles per tile and the gap between consecutive workgroups of one CU
 // (tests/probes/dw8_lifetime.py).
+// 512 (correct results): BUFFER-FORM STAGING - every LDS-DMA piece is a `buffer_load_dwordx4 ... lds` with the tensor base in a descriptor,
+// the per-k-tile advance (tap / slice offset, weight k-tile) in the instruction's SCALAR offset and ONE constant 32-bit lane offset per piece,
+// instead of a 64-bit per-lane pointer advanced by a vector add per piece (8 v_lshl_add_u64 per k-tile in the staging wave's issue stream,
+// which the round-4 timeline names as what bounds a SIMD's pair of waves).  A/B against mode 0 in tests/probes/dw8_timeline.py.
+// one LDS-DMA piece in buffer form (MODE 512): 16 bytes per lane from (descriptor base + scalar offset + lane offset) to lds + 16 lane
+__device__ __forceinline__ void dw_buf_lds16(sw_rsrc r, char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     constexpr int ADEPTH = 3, DA = ADEPTH - 1;  // ring stages / prefetch distance of both operands
@@ -102,6 +111,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     // -0.7 ... -1.8 %, the DMA latency is no longer covered; s_setprio 1 on either wave on top: -2.2 / +0.0 %.)
     // Piece index it: 0, 1 = own rows, 2, 3 = the partner's (wave + 4).
     constexpr bool ASYM = (MODE & 128) == 0;
+    constexpr bool BUF = (MODE & 512) != 0;
     constexpr int NPIECE = ASYM ? 4 : 2;
     const char* actr[NPIECE];                   // centre pixel of the lane's A row (segments: the lane's pixel), + slot
     const char* bptr[NPIECE];
@@ -118,6 +128,27 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
         const int n = n0 + rows_of_piece(it) + lrow;                // block layout of the fp16 panels (ops.order_conv_weight_w16)
         bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
+    // buffer-form staging (MODE 512): descriptors + constant lane offsets + scalar offsets
+    unsigned voA[NPIECE], voB[NPIECE];
+    sw_rsrc rsA, rsB;
+    int soA_bias = 0, a_so = 0, soB = 0;
+    if constexpr (BUF) {
+        auto pix = [&](int m) {                 // pixel index of output row m inside the zero-bordered operand
+            const int b = m / HW, rem = m - b * HW;
+            const int oy = rem / p.W, ox = rem - oy * p.W;
+            return (long long)(b * (p.H + 2) + oy + 1) * Wp + ox + 1;
+        };
+        const long long P0 = pix(m0);           // (wave-uniform) the tile's first pixel; pixel indices grow with m
+        soA_bias = (Wp + 1) * p.C * 2;          // the most negative tap offset: the scalar offset stays >= 0
+        rsA = sw_make_rsrc(p.x + (P0 - (Wp + 1)) * p.C * 2);
+        rsB = sw_make_rsrc(p.w + (size_t)(n0 >> 5) * p.K * 64);
+#pragma unroll
+        for (int it = 0; it < NPIECE; ++it) {
+            voA[it] = (unsigned)((pix(m0 + rows_of_piece(it) + lrow) - P0) * p.C * 2 + ls * 16);
+            const int n = n0 + rows_of_piece(it) + lrow;
+            voB[it] = (unsigned)(((n >> 5) - (n0 >> 5)) * p.K * 64 + (n & 31) * 16 + ls * 512);
+        }
+    }
     const bool older = !ASYM || wave < 4;       // (wave-uniform) the wave that stages
     // (tap, slice) of the next activation k-tile to stage, inside the current K-segment: segment 0 = the KS x KS convolution over
     // p.x (C / 32 slices of `taps` k-tiles), then the 1x1 segments over p.seg1 / p.seg2 (segC / 32 slices of one k-tile)
@@ -131,24 +162,39 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
                 const int sc = cur_seg == 1 ? p.segC1 : p.segC2;
 #pragma unroll
                 for (int j = 0; j < NPIECE; ++j) actr[j] = sb + (size_t)(m0 + rows_of_piece(j) + lrow) * sc * 2 + ls * 16;
+                if constexpr (BUF) {
+                    rsA = sw_make_rsrc(sb + (size_t)m0 * sc * 2);
+#pragma unroll
+                    for (int j = 0; j < NPIECE; ++j) voA[j] = (unsigned)((rows_of_piece(j) + lrow) * sc * 2 + ls * 16);
+                }
                 seg_slices = sc / 32;
                 cur_c = 0;
             }
             if (cur_seg == 0) {
                 const int ky = p.KS == 3 ? (cur_tap * 11) >> 5 : 0, kx = cur_tap - ky * p.KS;     // tap / 3 for tap < 9, no division
                 a_off = ((long long)(ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + (long long)cur_c * 64;
+                if constexpr (BUF) a_so = __builtin_amdgcn_readfirstlane(((ky - p.pad) * Wp + (kx - p.pad)) * p.C * 2 + cur_c * 64 + soA_bias);
             } else {
                 a_off = (long long)cur_c * 64;
+                if constexpr (BUF) a_so = __builtin_amdgcn_readfirstlane(cur_c * 64);
             }
         }
+        if constexpr (BUF)
+            dw_buf_lds16(rsA, smem + aoff + rows_of_piece(it) * 64, voA[it], a_so);
+        else
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + a_off),
                                          (__attribute__((address_space(3))) void*)(smem + aoff + rows_of_piece(it) * 64), 16, 0, 0);
         if (it == NPIECE - 1 && (cur_seg != 0 || ++cur_tap == taps)) { cur_tap = 0; ++cur_c; }
     };
     auto pieceB = [&](int boff, int it) {
+        if constexpr (BUF) {
+            dw_buf_lds16(rsB, smem + boff + rows_of_piece(it) * 64, voB[it], soB);
+            if (it == NPIECE - 1) soB += 2048;  // the pieces of a k-tile are issued in order 0 .. NPIECE - 1
+        } else {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
                                          (__attribute__((address_space(3))) void*)(smem + boff + rows_of_piece(it) * 64), 16, 0, 0);
         bptr[it] += 2048;
+        }
     };
     auto issueA = [&](int aoff) {
 #pragma unroll
@@ -389,7 +435,7 @@ void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s) {
         const char* e = getenv("DP_H2_DW_MODE");
         switch (e ? atoi(e) : 0) {
 #define DW_CASE(M_) case M_: hipLaunchKernelGGL((conv_igemm_dw<M_>), g, b, 0, s, p); return
-            DW_CASE(1); DW_CASE(2); DW_CASE(3); DW_CASE(6); DW_CASE(4); DW_CASE(7); DW_CASE(8); DW_CASE(16); DW_CASE(32); DW_CASE(64); DW_CASE(128); DW_CASE(192); DW_CASE(256);
+            DW_CASE(1); DW_CASE(2); DW_CASE(3); DW_CASE(6); DW_CASE(4); DW_CASE(7); DW_CASE(8); DW_CASE(16); DW_CASE(32); DW_CASE(64); DW_CASE(128); DW_CASE(192); DW_CASE(256); DW_CASE(512);
 #undef DW_CASE
             default: break;
         }

@@ -71,7 +71,8 @@ def main():
         timed(0, 20)                                    # warm the clocks
         ref = out.clone()
         modes = {128: "symmetric staging (round 3: every wave its own 4 pieces inside segment A)",
-                 0: "asymmetric staging (round 4, shipped: the older wave of every SIMD stages all 8 pieces of the pair - 4 in A, 4 after its vmcnt wait)"}
+                 0: "asymmetric staging (round 4, shipped: the older wave of every SIMD stages all 8 pieces of the pair - 4 in A, 4 after its vmcnt wait)",
+                 512: "shipped staging with BUFFER-form LDS-DMA (descriptor base, scalar tap / k-tile offset, one constant lane offset per piece; not shipped: measured here)"}
         rates = {m: [] for m in modes}
         same = {}
         for _ in range(4):                              # alternate: the chip is power-limited, single measurements drift by several %
