@@ -191,3 +191,113 @@ def test_dw_pieces_and_fragment_reads_agree(shape):
                             assert kt == t and (tensor, got) == want, (tile_m, t, row, slot)
             if t + 2 < nt:
                 piece_a(t + 2)
+
+
+# ---- epilogue of the 256-wide kernels (csrc/igemm_sw_common.h, round 4) -----------------------------------------------------------
+SW_EPI_PITCH = 1088         # LDS bytes per 4-row block of the residual landing zone
+
+
+def acc_row(lk, r):
+    """row (inside a 32-row MFMA tile) of accumulator register r of a lane in half-wave lk (v_mfma_f32_32x32x16_f16 C layout)"""
+    return 4 * lk + (r & 3) + 8 * (r >> 2)
+
+
+@pytest.mark.parametrize("NQ", [1, 2], ids=["dw: 64 x 128 wave tile", "sw: 128 x 128 wave tile"])
+def test_residual_landing_zone_addressing(NQ):
+    """The fp16 residual of a wave tile (64 NQ rows x 128 columns) lands in LDS by 16 NQ LDS-DMA instructions - block b = rows 4b .. 4b+3,
+    lane l fetches 16 bytes (row l >> 4 of the block, columns 8 (l & 15) ..) and lands at b * SW_EPI_PITCH + 16 l - and every lane then
+    reads, for MFMA tile (i, j) and register pair k, its own column's rows (2k, 2k+1) at CONSTANT offsets from one base register.
+    Restated element by element: every read picks up exactly the element the accumulator register holds the output of; the two
+    half-waves of a read instruction touch disjoint LDS banks (the 64-byte skew of the pitch)."""
+    rows, cols = 64 * NQ, 128
+    lds = {}                                    # LDS byte address (even) -> (row, col) of the fp16 element stored there
+    for b in range(16 * NQ):
+        for lane in range(64):
+            row, c0 = 4 * b + (lane >> 4), (lane & 15) * 8
+            for h in range(8):
+                addr = b * SW_EPI_PITCH + lane * 16 + 2 * h
+                assert addr not in lds
+                lds[addr] = (row, c0 + h)
+    assert len(lds) == rows * cols and max(lds) < 16 * NQ * SW_EPI_PITCH
+    for i in range(2 * NQ):
+        for j in range(4):
+            for k in range(8):
+                for e in range(2):
+                    off = (8 * i + 2 * (k >> 1)) * SW_EPI_PITCH + 2 * (k & 1) * 256 + j * 64 + e * 256      # the kernel's `o` and `o + 128` halves
+                    banks = {0: set(), 1: set()}
+                    for lk in range(2):
+                        for lr in range(32):
+                            addr = lk * SW_EPI_PITCH + lr * 2 + off
+                            want = (32 * i + acc_row(lk, 2 * k + e), 32 * j + lr)
+                            assert lds[addr] == want, (i, j, k, e, lk, lr)
+                            banks[lk].add((addr // 4) % 64)
+                    assert len(banks[0]) == 16 and len(banks[1]) == 16 and not (banks[0] & banks[1])
+                    assert not ({x % 32 for x in banks[0]} & {x % 32 for x in banks[1]})           # also disjoint on a 32-bank LDS
+
+
+def test_fp16_pair_store_selectors():
+    """OUT16: a lane converts its pair (rows 2k, 2k+1 of ITS column) with one v_cvt_pk_f16_f32 (low half = row 2k), takes the packed pair
+    of the lane of the neighbouring column through DPP quad_perm [1,0,3,2] and picks two halves with ONE v_perm_b32 whose selector
+    depends on the lane's parity: the even lane stores row 2k, columns (lr, lr+1), the odd lane row 2k+1, columns (lr-1, lr) - at the byte
+    offset ((4 lk + odd) * ld + lr - odd) * 2 from the pair's row base.  v_perm_b32 D = bytes of {S0 (partner), S1 (own)}: selector byte
+    values 0-3 pick S1's bytes, 4-7 pick S0's."""
+    def perm(s0, s1, sel):
+        src = [(s1 >> (8 * n)) & 0xFF for n in range(4)] + [(s0 >> (8 * n)) & 0xFF for n in range(4)]
+        return sum(src[(sel >> (8 * n)) & 0xFF] << (8 * n) for n in range(4))
+
+    SEL = {0: 0x05040100, 1: 0x03020706}
+    ld = 256
+    tile = {}                                    # (row, col) -> 16-bit pattern standing for the fp16 value
+    val = lambda row, col: (row * 251 + col * 7 + 1) & 0xFFFF
+    packed = lambda lk, lr, k: val(acc_row(lk, 2 * k), lr) | (val(acc_row(lk, 2 * k + 1), lr) << 16)
+    stored = {}
+    for k in range(8):
+        rowb = 2 * (k & 1) + 8 * (k >> 1)        # the pair's row inside the tile for lk = 0 (wave-uniform part of the address)
+        for lk in range(2):
+            for lr in range(32):
+                odd = lr & 1
+                own, partner = packed(lk, lr, k), packed(lk, lr ^ 1, k)
+                d = perm(partner, own, SEL[odd])
+                byte = (rowb * ld) * 2 + ((4 * lk + odd) * ld + lr - odd) * 2
+                row, col = byte // 2 // ld, byte // 2 % ld
+                for h in range(2):
+                    assert (row, col + h) not in stored
+                    stored[(row, col + h)] = (d >> (16 * h)) & 0xFFFF
+    assert len(stored) == 32 * 32
+    assert all(v == val(r, c) for (r, c), v in stored.items())
+
+
+def test_column_record_order_is_two_chains_per_lane():
+    """The GroupNorm column records of every tile kernel sum a lane's 16 values of a 32-row MFMA tile as TWO chains - even and odd
+    accumulator registers, i.e. the first and second row of every register pair - then add the chains, then the partner half-wave, then
+    the two MFMA tiles of a 64-row record.  The packed fp32 epilogue (two rows per instruction) and the scalar epilogues of the other
+    kernels must spell the same order: restated in float32 and compared bit for bit against a per-chain evaluation."""
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((64, 1)).astype(np.float32) * 3          # one column of a 64-row record
+    def scalar_form(vals):                       # igemm.hip / igemm_h2.hip / igemm_pp_common.h: cs2[r & 1] += v
+        tot = np.float32(0)
+        parts = []
+        for i in range(2):                       # the two 32-row MFMA tiles
+            half = []
+            for lk in range(2):
+                cs2 = [np.float32(0), np.float32(0)]
+                for r in range(16):
+                    cs2[r & 1] = np.float32(cs2[r & 1] + vals[32 * i + acc_row(lk, r), 0])
+                half.append(np.float32(cs2[0] + cs2[1]))
+            parts.append(np.float32(half[0] + half[1]))
+        return np.float32(parts[0] + parts[1])
+    def packed_form(vals):                       # igemm_sw_common.h: s2 += {v[2k], v[2k+1]} (v_pk_add_f32), then s2.x + s2.y
+        parts = []
+        for i in range(2):
+            half = []
+            for lk in range(2):
+                s2 = np.zeros(2, dtype=np.float32)
+                for k in range(8):
+                    pair = np.array([vals[32 * i + acc_row(lk, 2 * k), 0], vals[32 * i + acc_row(lk, 2 * k + 1), 0]], dtype=np.float32)
+                    s2 = (s2 + pair).astype(np.float32)
+                half.append(np.float32(s2[0] + s2[1]))
+            parts.append(np.float32(half[0] + half[1]))
+        return np.float32(parts[0] + parts[1])
+    assert scalar_form(v).tobytes() == packed_form(v).tobytes()
+    assert scalar_form(v * v).tobytes() == packed_form(v * v).tobytes()
+    assert abs(float(scalar_form(v)) - float(v.astype(np.float64).sum())) < 1e-4
