@@ -301,3 +301,60 @@ def test_column_record_order_is_two_chains_per_lane():
     assert scalar_form(v).tobytes() == packed_form(v).tobytes()
     assert scalar_form(v * v).tobytes() == packed_form(v * v).tobytes()
     assert abs(float(scalar_form(v)) - float(v.astype(np.float64).sum())) < 1e-4
+
+
+# ---- one-pass fp16 attention (csrc/attention.hip, H1 form, round 4) --------------------------------------------------------------
+def swz64(row, slot):
+    return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4)
+
+
+@pytest.mark.parametrize("cfg", [(64, 4), (64, 2), (256, 4)], ids=["D=64 QW=4", "D=64 QW=2", "D=256 QW=4"])
+def test_one_pass_attention_staging_and_fragments(cfg):
+    """attn_flash_kernel<QW, D, H1 = true>: a stage is SL * 32 rows of K (slice-major: row = sl * 32 + key, 64 bytes = 32 d-values of that key,
+    read IN PLACE from the fp16 qkv tensor) followed by D rows of V^T (32 key positions each, written by attn_pack_vt).  Restated: which
+    16-byte unit every LDS-DMA lane fetches and where it lands; which unit every MFMA fragment read of S^T = K Q^T and O^T += V^T P^T picks
+    up; that the d-range of a K fragment equals the d-range of the Q fragment it is multiplied with; and that the key ORDER inside a V^T row
+    (attn_pack_vt) is the order in which the S^T accumulator registers hand the probabilities back as the B operand."""
+    D, QW = cfg
+    NT, SL, KB = QW * 64, D // 32, 32
+    KT, VT = SL * KB * 64, D * 64
+    STAGE = KT + VT
+    PIECES = STAGE // (NT * 16)
+    RPP = NT // 4
+    assert (SL * KB) % RPP == 0 and PIECES * NT * 16 == STAGE
+    lds = {}                                     # byte offset of a 16-byte unit in the stage -> ("K", key, d0) | ("V", dd, pos0)
+    for tid in range(NT):
+        wave, lane = tid // 64, tid % 64
+        r_in_piece, ps = tid // 4, tid % 4
+        for i in range(PIECES):
+            row = i * RPP + r_in_piece
+            ls = ps ^ ((row >> 2) & 3)
+            dst = wave * 1024 + i * RPP * 64 + lane * 16             # M0 = stage + wave's first row of the piece; lane l lands at + 16 l
+            assert dst == row * 64 + ps * 16                         # i.e. physical slot ps of LDS row `row`
+            if row < SL * KB:
+                sl, key = divmod(row, KB)
+                lds[dst] = ("K", key, sl * 32 + ls * 8)              # source: qkv row of the key, k channels sl * 32 + 8 ls ..
+            else:
+                lds[dst] = ("V", row - SL * KB, ls * 8)              # source: V^T row dd, key positions 8 ls ..
+    assert len(lds) == STAGE // 16
+    for lk in range(2):
+        for lr in range(32):
+            for ks in range(D // 16):                                # S^T = K_blk Q^T: A = K rows (key lr), B = Q (query lr), k = 8 d-values
+                sl, st = ks >> 1, ks & 1
+                unit = lds[sl * (KB * 64) + swz64(lr, st * 2 + lk)]
+                q_d0 = (ks * 2 + lk) * 8                             # the Q fragment: bytes (ks * 2 + lk) * 16 of the query's row
+                assert unit == ("K", lr, q_d0), (lk, lr, ks, unit)
+            for g in range(2):                                       # O^T += V^T_blk P^T: A = V^T rows (d), B = P registers 8 g .. 8 g + 7
+                for t in range(D // 32):
+                    unit = lds[KT + swz64(t * 32 + lr, g * 2 + lk)]
+                    assert unit == ("V", t * 32 + lr, (g * 2 + lk) * 8)
+    # key order of a V^T row: position pos holds key kk(pos) (attn_pack_vt); the B operand of key group g supplied by half-wave lk is the
+    # accumulator registers r = 8 g + j, whose keys are acc_row(lk, r) - position (2 g + lk) * 8 + j of the row must hold exactly that key
+    def kk(pos):
+        p16 = pos & 15
+        return (pos & 16) + ((p16 >> 3) & 1) * 4 + ((p16 >> 2) & 1) * 8 + (p16 & 3)
+    assert sorted(kk(p) for p in range(32)) == list(range(32))
+    for g in range(2):
+        for lk in range(2):
+            for j in range(8):
+                assert kk((2 * g + lk) * 8 + j) == acc_row(lk, 8 * g + j)
