@@ -43,10 +43,12 @@ DTYPE_NOTES = {
              "GroupNorm / residuals / SDE state; purified pixels 1.3e-4 max-abs from the reference modules over the 100-step "
              "256^2 loop (north_star bar 1e-3; tests/test_gpu_loops.py) - wider than the reference's own use_fp16 torso "
              "(configs/imagenet.yml:18)",
-    "f16sr": "fp16 activations x fp16 weights, 1 MFMA pass per product, fp32 accumulation, fp32 GroupNorm / residuals / SDE state; the "
+    "f16sr": "fp16 activations x fp16 weights, 1 MFMA pass per product, fp32 accumulation, fp32 GroupNorm statistics / SDE state, fp16 residual "
+             "stream and one-pass fp16 attention (the reference's own use_fp16 torso arithmetic, configs/imagenet.yml:18; DIFFPURE_LEAN16=0 / "
+             "DIFFPURE_ATTN16=0 keep them fp32 / three-pass); the "
              "fp16 weight panels are re-rounded STOCHASTICALLY (unbiased, Philox-keyed by the step) from the fp32 masters before "
              "every UNet call, so the weight-rounding error averages out over the solver steps instead of accumulating as a fixed "
-             "model perturbation: purified pixels 2.2e-4 max-abs from the reference modules over the 100-step 256^2 loop (north_star "
+             "model perturbation: purified pixels 2.3e-4 max-abs from the reference modules over the 100-step 256^2 loop (north_star "
              "bar 1e-3; round-to-nearest fp16 weights - the reference's own use_fp16 arithmetic - give 1.0e-3)",
     "f16": "fp16 activations x fp16 weights, 1 MFMA pass, fp32 accumulation = the arithmetic of the reference's use_fp16 "
            "torso; purified pixels 1.0e-3 from fp32 (at the north_star bar, not under it: not the default)",
