@@ -63,7 +63,8 @@ __device__ __forceinline__ float dp_silu_f(float v) {
 // hardware unit (relative error ~|v| 2^-24, 1e-6 at |v| = 20) and the reciprocal unit's 1 ulp - 2^-11 is what survives the store.  The full
 // dp_silu_f costs ~30 issue slots per element (two quarter-rate transcendentals, the carried rounding error of the exponent, a Newton step,
 // range selects), which made that kernel - 4 bytes of HBM traffic per element - instruction-bound: ~12 slots here.
-// v -> -inf: exp2 = inf, rcp = 0, result -0 (the limit); v -> +inf: v.
+// v -> +inf: v.  Very negative FINITE v (below about -89): exp2 overflows to inf, rcp = 0, result -0 (the limit of SiLU).  v = -inf itself gives
+// -inf * 0 = NaN (dp_silu_f returns -0 there): a normalised activation is never infinite unless the tensor already carried an inf / NaN.
 __device__ __forceinline__ float dp_silu_fast_f(float v) {
     const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
     float r = v * __builtin_amdgcn_rcpf(1.0f + e);

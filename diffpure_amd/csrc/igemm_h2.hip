@@ -543,9 +543,9 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
-                                 ldo % 4 == 0 && (!res || ldr % 4 == 0)),
-               "dp_conv2d_nhwc_h2: this layer is reduced with split-K and needs dp_conv2d_nhwc_h2_workspace() bytes of scratch "
-               "(and row strides that are multiples of 4)");
+                                 ldo % 4 == 0 && (!res || (ldr % 4 == 0 && ((size_t)res & (res_fmt ? 7 : 15)) == 0))),
+               "dp_conv2d_nhwc_h2: this layer is reduced with split-K and needs dp_conv2d_nhwc_h2_workspace() bytes of scratch, row "
+               "strides that are multiples of 4 and a residual aligned to four of its elements (the split-K epilogue reads quads)");
     DP_REQUIRE(!colstats || tile_rows, "dp_conv2d_nhwc_h2: colstats needs tile_rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     void* rec = nullptr;

@@ -422,7 +422,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
 bool dp_conv_dw_applies(const ConvH2Args& p) {
     const bool seg_ok = (!p.seg1 || (p.segC1 > 0 && p.segC1 % 32 == 0)) && (!p.seg2 || (p.seg1 && p.segC2 > 0 && p.segC2 % 32 == 0));
     return p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % 256 == 0 && p.N % 256 == 0 && p.C % 32 == 0 &&
-           p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0) && seg_ok && (p.rfmt == 0 || p.ofmt == 1);
+           p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0) && seg_ok && (p.rfmt == 0 || p.ofmt == 1) &&
+           // the fp16 residual lands through 16-byte LDS-DMA pieces: rows and base 16-byte aligned, or the generic tiles take the launch
+           (p.rfmt == 0 || (dp_aligned16(p.res) && p.ldr % 8 == 0));
 }
 
 void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s) {
@@ -435,7 +437,7 @@ void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s) {
         const char* e = getenv("DP_H2_DW_MODE");
         switch (e ? atoi(e) : 0) {
 #define DW_CASE(M_) case M_: hipLaunchKernelGGL((conv_igemm_dw<M_>), g, b, 0, s, p); return
-            DW_CASE(1); DW_CASE(2); DW_CASE(3); DW_CASE(6); DW_CASE(4); DW_CASE(7); DW_CASE(8); DW_CASE(16); DW_CASE(32); DW_CASE(64); DW_CASE(128); DW_CASE(192); DW_CASE(256); DW_CASE(512);
+            DW_CASE(1); DW_CASE(2); DW_CASE(3); DW_CASE(6); DW_CASE(4); DW_CASE(5); DW_CASE(7); DW_CASE(8); DW_CASE(16); DW_CASE(32); DW_CASE(64); DW_CASE(128); DW_CASE(192); DW_CASE(256); DW_CASE(512);
 #undef DW_CASE
             default: break;
         }

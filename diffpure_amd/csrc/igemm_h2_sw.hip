@@ -312,7 +312,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 bool dp_conv_sw_applies(const ConvH2Args& p, int bn) {
     return (bn == 256 || bn == 128) && p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % (bn == 256 ? 256 : 512) == 0 &&
-           p.N % bn == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0) && (p.rfmt == 0 || p.ofmt == 1);
+           p.N % bn == 0 && p.C % 32 == 0 && (!p.temb || (p.H * p.W) % 32 == 0) && (p.rfmt == 0 || p.ofmt == 1) &&
+           (p.rfmt == 0 || (dp_aligned16(p.res) && p.ldr % 8 == 0));   // 16-byte LDS-DMA pieces of the fp16 residual (igemm_sw_common.h)
 }
 
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn) {

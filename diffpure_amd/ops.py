@@ -176,7 +176,7 @@ class WeightPool:
         off = 0
         for name, p in self._pending:
             n = p.numel()
-            self.master[off:off + n].copy_(p.reshape(-1).to(self.device))
+            self.master[off:off + n].copy_(p.reshape(-1))       # host -> its slice of the flat buffer directly (no staging tensor + device copy)
             self._views[name] = self.work[off:off + n].view(p.shape)
             off += n
         self._pending = []
@@ -710,6 +710,25 @@ def attention_fused_ok(t, d):
     return ((d == 64 and t % 64 == 0) or (d == 256 and t % 128 == 0)) and os.environ.get("DIFFPURE_ATTN_FUSED", "1") != "0"
 
 
+_BORDERED = {}
+
+
+def _bordered_f16(shape, device):
+    """A zero-bordered fp16 operand buffer [B, H+2, W+2, C] whose border was zeroed ONCE, reused by every launch of the same shape on
+    the same (device, stream, host thread): the attention kernel writes only the interior, the 1x1 convolution behind it is the only
+    reader and is queued on the same stream before the next writer (round 4 re-zeroed a fresh tensor per attention block: 16 ATen fill
+    launches per guided UNet call).  Keyed by the host thread as well, so that two engines driven from two threads on one stream never
+    share a buffer."""
+    import threading
+    key = (device.index, _stream(), threading.get_ident(), tuple(shape))
+    buf = _BORDERED.get(key)
+    if buf is None:
+        if len(_BORDERED) > 64:      # shapes of a few networks / batch sizes; never grows without bound
+            _BORDERED.clear()
+        buf = _BORDERED[key] = torch.zeros(shape, device=device, dtype=torch.float16)
+    return buf
+
+
 def attention_fused(qkv, n_heads, layout, operand_hw=None):
     """softmax(q k^T / sqrt(d)) v without materialising the scores (csrc/attention.hip).  operand_hw=(H, W) (H * W tokens):
     the result is written as the zero-bordered fp16 operand [B, H+2, W+2, C] of the following 1x1 convolution
@@ -725,7 +744,7 @@ def attention_fused(qkv, n_heads, layout, operand_hw=None):
     if operand_hw is not None:
         hh, ww = operand_hw
         assert hh * ww == t, (operand_hw, t)
-        out = torch.zeros((b, hh + 2, ww + 2, c), device=qkv.device, dtype=torch.float16)       # the border stays zero
+        out = _bordered_f16((b, hh + 2, ww + 2, c), qkv.device)       # the border is zero and stays zero: the kernel writes the interior only
         _lib.call("dp_attention_fused", _ptr(qkv), 1 if f16 else 0, b, t, c, n_heads, lay, _ptr(out), 1, ww, _ptr(work), _stream())
         return out
     out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)

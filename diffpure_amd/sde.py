@@ -25,6 +25,7 @@ import torch
 from . import ops
 
 BETA_MIN, BETA_MAX, N_DISC = 0.1, 20.0, 1000
+_CHECK_FINITE = os.environ.get("DIFFPURE_CHECK_FINITE", "0") == "1"
 
 
 def discrete_alphas_cumprod():
@@ -250,7 +251,19 @@ class Purifier:
 
     def _eps(self, x, table, k, key=None):
         self._reround(k if key is None else key)
-        return self.net.forward(x, table_row=table[k:k + 1])
+        eps = self.net.forward(x, table_row=table[k:k + 1])
+        self._check_finite(eps, k)
+        return eps
+
+    def _check_finite(self, eps, k):
+        """DIFFPURE_CHECK_FINITE=1 (validation switch, off by default: it synchronises with the host every step): the fp16 residual
+        stream of the fp16 x fp16 modes stores activations with a plain fp32 -> fp16 conversion (no saturation), so a block output
+        beyond 65504 becomes inf and the next GroupNorm turns the whole sample into NaN - silently.  The synthetic and the
+        published checkpoints stay far below that range, a fine-tuned one need not: with the switch on, the first UNet call whose
+        output is not finite raises and names the step, instead of the loop returning NaN images."""
+        if _CHECK_FINITE and not bool(torch.isfinite(eps).all()):
+            raise FloatingPointError(f"score network output is not finite at solver step {k} (precision {getattr(self.net, 'precision', '?')}): "
+                                     "an activation overflowed the fp16 residual stream; run with DIFFPURE_LEAN16=0 (fp32 stream) or precision f16x3")
 
     # -- the UNet call of a step as ONE HIP graph launch --------------------------------------------
     def _graph_wanted(self, shape):
@@ -380,7 +393,11 @@ class Purifier:
             tape = []
             # reverse step k re-crosses the INTERVAL of forward step N-1-k (from its far end: it evaluates eps at
             # s = 1e-5 + k*step, the forward step evaluated it at the interval's other end) and takes that step's stochastic
-            # weight rounding (f16sr): per interval, forward and adjoint see the same rounded network
+            # weight-rounding KEY (f16sr).  Same key does not mean the same network bit for bit: the taped forward is the fp32-stream
+            # variant (fp32 residual stream, three-pass attention, separate w2 / skip panels - which draw their own roundings where
+            # the no-tape forward reads one fused [w2 | skip] panel), so forward solve and adjoint agree per interval only up to the
+            # rounding noise itself (bounded by tests/test_gpu_grad.py::test_taped_and_untaped_forward_agree_under_f16sr; the
+            # directional derivative of the f16sr forward solve is checked against finite differences next to it)
             self._reround(len(sched) - 1 - k)
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             g = self.net.vjp(tape, a)                       # (d eps / d y)^T a

@@ -38,6 +38,11 @@ Round 4:
                            `--diffusion_type sde` attacks, runners/diffpure_sde.py:236-238), every vector-Jacobian product by
                            torch.autograd THROUGH THE REFERENCE'S RevVPSDE.f (score network included), seeded cotangent
   guided_sde_adjoint10.pt  the same on the full 256x256 guided UNet, B=1, t=10 (10 EM steps of dt=1e-3 + 10 adjoint steps)
+Round 5:
+  guided_loop150_dt0.0015.pt  BASELINE.json configs[2] AS WRITTEN: t*=0.15 in 100 EM steps, i.e. dt=1.5e-3 (B=1; every rounding enters the
+                           state 1.5x larger than on the dt=1e-3 grid of guided_loop150.pt)          [target: guided_loop150_dt]
+  guided_sde_adjoint100.pt the stochastic adjoint on the full guided UNet at the PRODUCT grid: t=100, 100 EM steps + 100 adjoint
+                           steps, B=1 (what run_scripts/imagenet/run_in_rand_inf.sh differentiates, at t=100)   [target: guided_sde_adjoint100; ~35 min]
 """
 import os
 import sys
@@ -207,17 +212,17 @@ def ncsnpp_sde_adjoint():
     print("ncsnpp_sde_adjoint100", n, float(x_final.abs().mean()), float(grad.abs().mean()), float(grad.abs().max()))
 
 
-def guided_sde_adjoint():
+def guided_sde_adjoint(t_int=10):
     RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
     mod, kw = build_guided()
     rv = RevVPSDE(model=mod, score_type="guided_diffusion", img_shape=(3, 256, 256), model_kwargs=None)
-    b, t_int, dt = 1, 10, 1e-3
+    b, dt = 1, 1e-3
     x0 = torch.rand(b, 3, 256, 256, generator=torch.Generator().manual_seed(91)) * 2 - 1
     cot = torch.randn(b, 3, 256, 256, generator=torch.Generator().manual_seed(90))
     x_final, grad, y_back, n, _ = sde_adjoint_loop(rv, x0, cot, t_int, dt, SEED)
     torch.save(dict(cfg=kw, seed=SEED, noise_seed=SEED, t=t_int, dt=dt, steps=n, x0=x0, cot=cot, x_final=x_final,
-                    grad=grad), os.path.join(HERE, "guided_sde_adjoint10.pt"))
-    print("guided_sde_adjoint10", n, float(x_final.abs().mean()), float(grad.abs().mean()), float(grad.abs().max()))
+                    grad=grad), os.path.join(HERE, f"guided_sde_adjoint{t_int}.pt"))
+    print(f"guided_sde_adjoint{t_int}", n, float(x_final.abs().mean()), float(grad.abs().mean()), float(grad.abs().max()))
 
 
 def guided_ddpm_loop():
@@ -260,16 +265,17 @@ def guided_ddpm_loop():
     print("guided_ddpm_loop100", float(x.abs().mean()))
 
 
-def guided_loop150():
+def guided_loop150(dt=1e-3):
     RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
     mod, kw = build_guided()
     rv = RevVPSDE(model=mod, score_type="guided_diffusion", img_shape=(3, 256, 256), model_kwargs=None)
     x0 = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(94)) * 2 - 1
     with torch.no_grad():
-        x, keep, n = em_loop(rv, x0, 150, 1e-3, SEED, snaps=(100,))
-    torch.save(dict(cfg=kw, seed=SEED, noise_seed=SEED, t=150, dt=1e-3, steps=n, x0=x0, out=x, snaps=keep),
-               os.path.join(HERE, "guided_loop150.pt"))
-    print("guided_loop150", n, float(x.abs().mean()))
+        x, keep, n = em_loop(rv, x0, 150, dt, SEED, snaps=(100,) if dt == 1e-3 else (50,))
+    name = "guided_loop150" if dt == 1e-3 else f"guided_loop150_dt{dt:g}"
+    torch.save(dict(cfg=kw, seed=SEED, noise_seed=SEED, t=150, dt=dt, steps=n, x0=x0, out=x, snaps=keep),
+               os.path.join(HERE, name + ".pt"))
+    print(name, n, float(x.abs().mean()))
 
 
 def guided_loop_seeds():
@@ -333,6 +339,10 @@ def main():
             ncsnpp_sde_adjoint()
         elif w == "guided_sde_adjoint":
             guided_sde_adjoint()
+        elif w == "guided_sde_adjoint100":
+            guided_sde_adjoint(100)
+        elif w == "guided_loop150_dt":
+            guided_loop150(1.5e-3)
         else:
             raise SystemExit(f"unknown target {w}")
         print(f"{w}: {time.time() - t0:.0f} s", flush=True)

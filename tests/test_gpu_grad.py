@@ -516,3 +516,65 @@ def test_ldsde_runner_autograd_on_gpu_vs_oracle_adjoint(tmp_path, precision):
     print(f"ldsde runner + adjoint, small NCSN++ [{precision}]: x max-abs {err_x:.3e}, dL/dx rel. error {relerr(gx.cpu(), ref):.3e}")
     assert err_x < PIX_TOL[precision], err_x
     assert relerr(gx.cpu(), ref) < GRAD_TOL[precision], relerr(gx.cpu(), ref)
+
+
+# ---- round 5: the adjoint under the SHIPPED arithmetic against the forward solve it differentiates ------------------------------
+def _ncsnpp_full_f16sr():
+    from diffpure_amd import ncsnpp as pn
+    g = load_golden("ncsnpp_full.pt")
+    cfg = pn.parse_config(g["cfg"])
+    sd = synth_state_dict(pn.param_shapes(cfg), g["seed"])
+    return pn.NCSNpp(cfg, DEV, "f16sr").load_state_dict(sd), g
+
+
+def test_taped_and_untaped_forward_agree_under_f16sr():
+    """The adjoint solves re-run the network TAPED: fp32 residual stream, three-pass attention, separate w2 / skip panels (their own
+    stochastic-rounding draws) - the forward solve ran it UNTAPED on the fp16 stream with fused [w2 | skip] panels (advisor, round 4).
+    Same re-rounding key, same input: the two evaluations of eps may differ by rounding noise only.  Bounded here (and printed):
+    max-abs below 1 % of the largest entry, mean-abs below 0.2 % - the size of either one's distance to the fp32 reference."""
+    net, g = _ncsnpp_full_f16sr()
+    x, lab = nhwc(g["x"]).to(DEV), g["labels"].to(DEV)
+    net.reround(7)
+    a = net.forward(x, lab).float().cpu()
+    net.reround(7)
+    tape = []
+    b = net.forward(x, lab, tape=tape).float().cpu()
+    del tape
+    ref = nhwc(g["out"])
+    scale = ref.abs().max().item()
+    d_ab, d_a, d_b = (a - b).abs().max().item(), (a - ref).abs().max().item(), (b - ref).abs().max().item()
+    print(f"f16sr eps: untaped vs taped max-abs {d_ab:.3e} (mean {(a - b).abs().mean():.3e}); vs the reference module: untaped {d_a:.3e}, "
+          f"taped {d_b:.3e}; largest entry {scale:.3f}")
+    assert d_ab < 1e-2 * scale and (a - b).abs().mean().item() < 2e-3 * scale, (d_ab, scale)
+
+
+def test_ode_vjp_f16sr_directional_derivative_vs_finite_differences_of_the_f16sr_forward_solve():
+    """`ode_vjp` re-rounds the weights of adjoint step k with the key of forward step N-1-k (sde.py: the interval it re-crosses).  What
+    that must deliver is the derivative of the forward solve AS SHIPPED (f16sr: fp16 stream, stochastic weight rounding keyed by the
+    step).  Checked directly: L(x0) = <cot, ode(x0)> with the forward noise fixed; the central difference of L along the unit
+    direction d = grad / |grad| (|eps d|_2 = 0.5: ~6e-3 per pixel, far above the fp16 rounding noise of L, far below the curvature
+    scale) against <grad, d> = |grad| from the adjoint.  20 Euler steps of the product's dt = 1e-3 on the full NCSN++, B=2.  The
+    continuous adjoint (optimise-then-discretise, as torchdiffeq's) differs from the exact gradient of the discrete solve by
+    O(dt): the bar is 2 %."""
+    from diffpure_amd.sde import Purifier
+    net, g = _ncsnpp_full_f16sr()
+    pur = Purifier(net, "ncsnpp", DEV)
+    gen = torch.Generator().manual_seed(11)
+    x0 = g["x"]
+    e = torch.randn(x0.shape, generator=gen)
+    cot = torch.randn(x0.shape, generator=gen)
+    t, step = 20, 1e-3
+    solve = lambda xx: pur.ode(xx, t, step, noise=dict(e=e, z=[])).cpu()
+    xf = pur.ode(x0, t, step, noise=dict(e=e, z=[]))
+    grad = (pur.ode_vjp(xf, cot, t, step) * pur.diffuse_scale(t)).cpu().double()
+    gn = grad.norm().item()
+    d = (grad / gn).float()
+    h = 0.5
+    lp = (cot.double() * solve(x0 + h * d).double()).sum().item()
+    lm = (cot.double() * solve(x0 - h * d).double()).sum().item()
+    fd = (lp - lm) / (2 * h)
+    h2 = 0.25
+    fd2 = ((cot.double() * solve(x0 + h2 * d).double()).sum().item() - (cot.double() * solve(x0 - h2 * d).double()).sum().item()) / (2 * h2)
+    print(f"f16sr ode_vjp: <grad, d> = |grad| = {gn:.5f}; central difference of the f16sr forward solve: {fd:.5f} (h=0.5), {fd2:.5f} (h=0.25); "
+          f"relative gaps {abs(fd - gn) / gn:.3e} / {abs(fd2 - gn) / gn:.3e}")
+    assert abs(fd - gn) < 2e-2 * gn and abs(fd2 - gn) < 2e-2 * gn, (fd, fd2, gn)

@@ -127,6 +127,23 @@ def test_guided_loop_150_steps_vs_reference_golden(precision):
     assert err < 1e-3, err
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
+def test_config3_as_written_t150_dt1p5e3_100_steps_vs_reference_golden(precision):
+    """BASELINE.json configs[2] AS WRITTEN: t* = 0.15 in 100 Euler-Maruyama steps, i.e. dt = 1.5e-3 (the 150-step test above walks
+    the dt = 1e-3 grid of the reference's scripts - a different grid: here every per-step rounding enters the state 1.5x larger, the
+    float32 clock takes 100 strides of 1.5e-3 and the last stride is the short one onto 1 - 1e-5).  B=1, whole tensor, against the
+    reference's UNetModel driven through RevVPSDE.f / .g on that clock (make_golden_loops.py guided_loop150_dt).  Round 5."""
+    from diffpure_amd.sde import Purifier, sde_schedule
+    g = load_golden("guided_loop150_dt0.0015.pt")
+    assert g["t"] == 150 and g["dt"] == 1.5e-3 and g["steps"] == 100 == len(sde_schedule("guided", g["t"], g["dt"]))
+    pur = Purifier(guided_full(precision), "guided", DEV)
+    out = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    err = maxabs(out, g["out"])
+    print(f"guided t*=0.15 dt=1.5e-3 100-step loop [{precision}]: purified max-abs vs reference modules {err:.3e}, "
+          f"mean-abs {(out - g['out']).abs().mean():.3e}")
+    assert err < 1e-3, err
+
+
 def test_guided_loop_more_noise_seeds_vs_reference_golden():
     """The headline loop (100 steps) at the shipped precision for two more Brownian paths (noise seeds 7 and 20240926; the
     first is in test_guided_loop_100_steps_vs_reference_golden): the max over 196 608 pixels of a stochastic scheme is not
@@ -229,6 +246,55 @@ def test_guided_full_stochastic_adjoint_runs_at_batch_8():
     # deterministic: the Brownian path is regenerated from the Philox key, nothing stored
     g2 = (pur.sde_vjp(xf, cot, 100, 1e-2, seed=3, sample0=0) * pur.diffuse_scale(100)).cpu()
     assert torch.equal(g, g2)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
+def test_guided_sde_stochastic_adjoint_100_plus_100_steps_vs_reference_golden(precision):
+    """Round 5 - the ImageNet adaptive-attack gradient at the PRODUCT grid (run_scripts/imagenet/run_in_rand_inf.sh ->
+    runners/diffpure_sde.py:236-238): the FULL 256x256 guided UNet, B=1, t*=0.1, dt=1e-3: 100 EM steps, then 100 steps of the
+    stochastic adjoint along the regenerated Brownian path - against the reference's own RevVPSDE.f / .g with torch.autograd
+    through the reference UNetModel for every vector-Jacobian product (make_golden_loops.py guided_sde_adjoint100, ~35 min of CPU)."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("guided_sde_adjoint100.pt")
+    assert g["steps"] == 100 and g["t"] == 100
+    pur = Purifier(guided_full(precision), "guided", DEV)
+    xf = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0)
+    err_x = maxabs(xf.cpu(), g["x_final"])
+    grad = (pur.sde_vjp(xf, g["cot"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0) * pur.diffuse_scale(g["t"])).cpu()
+    torch.cuda.empty_cache()
+    scale = g["grad"].abs().max().item()
+    err_g = maxabs(grad, g["grad"])
+    print(f"guided stochastic adjoint 100+100 [{precision}]: x max-abs {err_x:.3e}; dL/dx max-abs {err_g:.3e} (largest entry {scale:.3f})")
+    assert err_x < 1e-3, err_x
+    assert err_g < 5e-3 * scale, (err_g, scale)
+
+
+def test_guided_full_stochastic_adjoint_at_batch_8_reproduces_the_golden_sample_bit_for_bit():
+    """The same golden sample leading a batch of EIGHT (twice the reference's own per-GPU batch of 4): x(t'_end) and dL/dx of sample
+    0 equal the B=1 run bit for bit (taped forward, dgrad tile variants and the one-pass GroupNorm backward are batch-invariant),
+    hence sit within the bars of the reference-generated golden; the tape stays under 80 GiB."""
+    from diffpure_amd.sde import Purifier
+    g = load_golden("guided_sde_adjoint100.pt")
+    pur = Purifier(guided_full("f16sr"), "guided", DEV)
+    x1 = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0)
+    g1 = (pur.sde_vjp(x1, g["cot"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0) * pur.diffuse_scale(g["t"])).cpu()
+    gen = torch.Generator().manual_seed(6)
+    x0 = torch.cat([g["x0"], torch.rand(7, 3, 256, 256, generator=gen) * 2 - 1])
+    cot = torch.cat([g["cot"], torch.randn(7, 3, 256, 256, generator=gen)])
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    xb = pur.sde(x0, g["t"], g["dt"], seed=g["noise_seed"], sample0=0)
+    gb = (pur.sde_vjp(xb, cot, g["t"], g["dt"], seed=g["noise_seed"], sample0=0) * pur.diffuse_scale(g["t"]))[:1].cpu()
+    peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
+    torch.cuda.empty_cache()
+    scale = g["grad"].abs().max().item()
+    err_x, err_g = maxabs(xb[:1].cpu(), g["x_final"]), maxabs(gb, g["grad"])
+    print(f"guided stochastic adjoint 100+100 [f16sr] at B=8: x {err_x:.3e}, dL/dx {err_g:.3e} of {scale:.3f}; equal to the B=1 run: "
+          f"{torch.equal(xb[:1].cpu(), x1.cpu())} / {torch.equal(gb, g1)}; peak working set {peak:.1f} GiB above the resident engines")
+    assert torch.equal(xb[:1].cpu(), x1.cpu()) and torch.equal(gb, g1)
+    assert err_x < 1e-3 and err_g < 5e-3 * scale, (err_x, err_g, scale)
+    assert peak < 80, peak
 
 
 # ---- round 4: the configurations BASELINE.json benchmarks, at THEIR batch; the stochastic adjoint at the product grid ----------

@@ -707,6 +707,88 @@ def test_torch_ops_namespace_runs_the_hip_kernels(dev):
         T.conv2d_nhwc(x, wp[:, :8].contiguous(), bias, 96, 3)     # TORCH_CHECK -> RuntimeError with the library's message
 
 
+def test_torch_ops_abi6_operators_and_autograd_formulas(dev):
+    """Round 5: torch.ops.diffpure_hip at ABI 6 - the fp16-stream operators run the same kernels as diffpure_amd.ops bit for bit, and
+    torch.autograd works THROUGH conv2d_nhwc / group_norm_silu / attention / resize_affine (dL/dx against torch's own autograd of the
+    equivalent torch expressions)."""
+    import torch.nn.functional as F
+    from diffpure_amd import ops, torch_ops  # noqa: F401
+    T = torch.ops.diffpure_hip
+    B, H, W, C, N = 2, 16, 16, 64, 64
+    x = rnd(B, H, W, C, seed=1)
+    xh = _h1_bordered(x, dev)
+    w3 = rnd(N, C, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * C))
+    ws = rnd(N, 32, 1, 1, seed=3, scale=1.0 / math.sqrt(32))
+    bias = rnd(N, seed=4).to(dev)
+    table = rnd(B, N + 8, seed=5).to(dev)
+    res16 = rnd(B, H, W, N, seed=6).half().to(dev)
+    seg = rnd(B, H, W, 32, seed=7).half().to(dev)
+    w16 = ops.order_conv_weight_w16(w3).half().to(dev)
+    wf = ops.order_conv_weight_w16(ops.fuse_skip_weight(w3, ws)).half().to(dev)
+    # conv2d_h2_ex: temb rows + fp16 residual + fp16 output + records; then with a 1x1 K-segment
+    y, cols = T.conv2d_h2_ex(xh, w16, bias, table[:, 4:4 + N], res16, None, None, N, 3, 0, 1, 0.5, True, True)
+    r = ops.conv2d_h2(xh, w16, N, 3, bias=bias, temb=table[:, 4:4 + N], res=res16, scale=0.5, colstats=True, w_fmt=1, out_f16=True)
+    assert y.dtype == torch.float16 and torch.equal(y, r.t) and torch.equal(cols, r.cols.buf)
+    y, cols = T.conv2d_h2_ex(xh, wf, bias, None, None, seg, None, N, 3, 0, 1, 1.0, True, True)
+    r = ops.conv2d_h2(xh, wf, N, 3, bias=bias, colstats=True, w_fmt=1, out_f16=True, segs=(seg,))
+    assert torch.equal(y, r.t) and torch.equal(cols, r.cols.buf)
+    # gn_apply_h16 on that fp16 tensor with its records' statistics: operand form, FiLM + SiLU; the resampled plain tensor
+    st = ops.group_norm_stats(r, 32, 1e-5)
+    gamma, beta = (1 + 0.1 * rnd(N, seed=8)).to(dev), (0.1 * rnd(N, seed=9)).to(dev)
+    film = rnd(B, 2 * N, seed=10, scale=0.3).to(dev)
+    a, _ = T.gn_apply_h16(r.t, None, st, gamma, beta, film[:, :N], film[:, N:], 32, True, 0, 2, False)
+    assert torch.equal(a, ops.group_norm(r.t, 32, 1e-5, gamma, beta, film=(film[:, :N], film[:, N:]), act=True, split="h1", stats=st))
+    a, _ = T.gn_apply_h16(r.t, None, None, None, None, None, None, 1, False, 2, 3, False)
+    assert torch.equal(a, ops.resample(r.t, ops.RESAMPLE_DOWN))
+    # attention_fused: fp16 qkv, one pass, bordered operand out; fp32 qkv
+    qkv = rnd(2, 256, 3 * 128, seed=11).to(dev)
+    assert torch.equal(T.attention_fused(qkv, 2, True, 0), ops.attention_fused(qkv, 2, "legacy"))
+    q16 = qkv.half()
+    assert torch.equal(T.attention_fused(q16, 2, True, 16), ops.attention_fused(q16, 2, "legacy", operand_hw=(16, 16)))
+    # round_weights == WeightPool.round (stochastic, keyed)
+    pool = ops.WeightPool(torch.device(dev), stochastic=True)
+    pool.add("w", w3)
+    pool.finalize()
+    pool.round(5)
+    work = torch.empty_like(pool.work)
+    T.round_weights(pool.master, work, True, pool.seed, 5)
+    assert torch.equal(work, pool.work)
+    # ---- autograd through the operators --------------------------------------------------------------------------------------
+    wp = ops.pack_conv_weight(w3).to(dev)
+    xr = x.to(dev).requires_grad_(True)
+    cot = rnd(B, H, W, N, seed=12).to(dev)
+    (g,) = torch.autograd.grad(T.conv2d_nhwc(xr, wp, bias, N, 3), xr, cot)
+    xt = x.to(dev).requires_grad_(True)
+    (gt,) = torch.autograd.grad(F.conv2d(xt.permute(0, 3, 1, 2), w3.to(dev), bias, padding=1).permute(0, 2, 3, 1), xt, cot)
+    assert (g - gt).abs().max() < 1e-4 * gt.abs().max(), (g - gt).abs().max()
+    gam, bet = (1 + 0.1 * rnd(C, seed=13)).to(dev), (0.1 * rnd(C, seed=14)).to(dev)
+    xr = (x * 2 + 0.5).to(dev).requires_grad_(True)
+    cot = rnd(B, H, W, C, seed=15).to(dev)
+    (g,) = torch.autograd.grad(T.group_norm_silu(xr, gam, bet, 32, 1e-5, True, 0), xr, cot)
+    xt = (x * 2 + 0.5).to(dev).requires_grad_(True)
+    (gt,) = torch.autograd.grad(F.silu(F.group_norm(xt.permute(0, 3, 1, 2), 32, gam, bet, 1e-5)).permute(0, 2, 3, 1), xt, cot)
+    assert (g - gt).abs().max() < 1e-4 * gt.abs().max(), (g - gt).abs().max()
+    for heads, c, legacy in ((2, 128, True), (3, 96, False)):       # flash forward (d = 64) / GEMM + softmax forward (d = 32); both backward by GEMMs
+        qr = rnd(2, 64, 3 * c, seed=16).to(dev).requires_grad_(True)
+        cot = rnd(2, 64, c, seed=17).to(dev)
+        (g,) = torch.autograd.grad(T.attention(qr, heads, legacy), qr, cot)
+        qt = qr.detach().clone().requires_grad_(True)
+        d = c // heads
+        if legacy:
+            q_, k_, v_ = qt.view(2, 64, heads, 3, d).unbind(3)
+        else:
+            q_, k_, v_ = qt.view(2, 64, 3, heads, d).unbind(2)
+        att = torch.softmax(torch.einsum("bthd,bshd->bhts", q_, k_) / math.sqrt(d), dim=-1)
+        (gt,) = torch.autograd.grad(torch.einsum("bhts,bshd->bthd", att, v_).reshape(2, 64, c), qt, cot)
+        assert (g - gt).abs().max() < 2e-4 * gt.abs().max(), (heads, (g - gt).abs().max())
+    img = torch.rand(2, 3, 28, 28).to(dev).requires_grad_(True)
+    cot = rnd(2, 32, 32, 3, seed=18).to(dev)
+    (g,) = torch.autograd.grad(T.resize_affine(img, 32, 32, -0.5, 2.0, False, True), img, cot)
+    it = img.detach().clone().requires_grad_(True)
+    (gt,) = torch.autograd.grad(((F.interpolate(it, size=(32, 32), mode="bilinear", align_corners=False) - 0.5) * 2.0).permute(0, 2, 3, 1), it, cot)
+    assert (g - gt).abs().max() < 1e-5 * max(1.0, gt.abs().max().item())
+
+
 FP16_OUT_CASES = [(2, 32, 32, 256, 256, 3, 2, True, 1.0), (1, 128, 128, 64, 256, 3, 1, False, 0.5), (4, 16, 16, 128, 128, 3, 0, False, 1.0),
                   (8, 8, 8, 256, 256, 3, 1, True, 1.0), (3, 16, 16, 96, 72, 3, 0, False, 1.0), (2, 64, 64, 64, 512, 1, 0, True, 1.0)]
 
@@ -968,3 +1050,29 @@ def test_conv2d_few_output_channels_kernel(dev, case, tune):
     y = ops.conv2d_h2(xh, w16, N, 3, bias=bias, scale=0.5, w_fmt=1, colstats=True)
     assert torch.equal(y.t, base)
 
+
+
+def test_conv2d_fp16_residual_through_the_c_abi_with_an_offset_strided_residual(dev):
+    """Round 5 (advisor): the C ABI accepts any 4-byte-aligned fp16 residual with an even row stride; the 256-wide tile kernels fetch
+    the residual in 16-byte LDS-DMA pieces and therefore take only 16-byte-aligned residuals whose row stride is a multiple of 8
+    elements - any other goes to the generic tiles.  A launch that fills the chip (256 tiles: the 8-wave kernel's case) with the
+    residual at a 4-byte offset and a row stride of N + 2 elements must give the bits of the same launch on a contiguous copy."""
+    import ctypes
+    from diffpure_amd import _lib, ops
+    B, H, W, C, N = 64, 32, 32, 64, 256
+    x = _h1_bordered(rnd(B, H, W, C, seed=1), dev)
+    wf = ops.order_conv_weight_w16(rnd(N, C, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * C))).half().to(dev)
+    bias = rnd(N, seed=3).to(dev)
+    M = B * H * W
+    res = rnd(M, N, seed=4).half().to(dev)
+    want = ops.conv2d_h2(x, wf, N, 3, bias=bias, res=res.view(B, H, W, N), scale=0.5, colstats=True, w_fmt=1, out_f16=True)
+    ldr = N + 2
+    store = torch.zeros(M * ldr + 2, dtype=torch.float16, device=dev)
+    store[2:].view(M, ldr)[:, :N] = res                     # residual rows start 4 bytes into the allocation, stride N + 2
+    out = torch.empty((B, H, W, N), device=dev, dtype=torch.float16)
+    cs, tr = ops._colstats_alloc(M, N, x.device)
+    _lib.call("dp_conv2d_nhwc_h2", x.data_ptr(), C, B, H, W, 3, wf.data_ptr(), N, bias.data_ptr(), None, 0, store.data_ptr() + 4, ldr, 0.5,
+              out.data_ptr(), N, cs.data_ptr(), ctypes.addressof(tr), None, 0, 1, 1, 1, 1, 1, None, 0, None, 0, ops._stream())
+    torch.cuda.synchronize()
+    assert tr.value == want.cols.tile_rows
+    assert torch.equal(out, want.t) and torch.equal(cs, want.cols.buf)

@@ -109,6 +109,12 @@ def test_solver_clocks():
         assert len(grid) - 1 == t_int
         assert abs(float(grid[-1] - grid[-2]) - 9.9e-4) < 2e-5
     assert len(osol.sde_time_grid(100, 5e-3)) - 1 == 20
+    # BASELINE.json configs[2] as written (t* = 0.15 in 100 steps, dt = 1.5e-3): 100 strides, the last one short; the engine's clock
+    # (diffpure_amd/sde.py::sde_clock) is the same float32 sequence, value for value
+    from diffpure_amd.sde import sde_clock
+    g15 = osol.sde_time_grid(150, 1.5e-3)
+    assert len(g15) - 1 == 100 and float(g15[-1] - g15[-2]) < 1.5e-3
+    assert [float(v) for v in g15] == [float(v) for v in sde_clock(150, 1.5e-3)]
     ts = torch.linspace(0.1, 1e-5, 2)
     tau = osol.ode_grid(-ts, 1e-3)
     assert len(tau) == 101 and tau[0] == -ts[0] and tau[-1] == -ts[1]

@@ -1,0 +1,82 @@
+#!/bin/bash
+# Round-5 measurement calls on the GPU box (gpurun).  Everything lands under gpurun_out/r05/<stage>/ (copied into profiles/r05/ afterwards).
+#   bash tools/r05_measure.sh explore     per-shape CIFAR table, rocprofv3 kernel stats of the CIFAR forward / adjoint at HEAD, power / clock
+#                                         experiment of the dominant kernel, batch-sensitivity table, the ImageNet SDE-adjoint bench lines
+#   bash tools/r05_measure.sh tests       the whole -m gpu suite + smoke
+#   bash tools/r05_measure.sh bench       default bench line (runner boundary) + rocprofv3 kernel stats of the same command
+#   bash tools/r05_measure.sh closing     tests + bench + every other bench line + PMC passes (the round's closing state)
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+cd "$R"
+STAGE=${1:-explore}
+O="$R/gpurun_out/r05/$STAGE"
+rm -rf "$O"; mkdir -p "$O"
+export TMPDIR=/tmp
+S=$(date +%s)
+lap() { echo "[$(( $(date +%s) - S )) s] $1" >> "$O/timeline.log"; }
+: > "$O/timeline.log"
+rocstats() {   # rocstats <name> <timeout> <bench args...>: rocprofv3 kernel stats of one bench command
+  local name=$1 to=$2; shift 2
+  ( cd /tmp && timeout "$to" rocprofv3 --kernel-trace --stats -d "$O/prof_$name" -o run --output-format csv -- python "$R/bench.py" "$@" --no-cpu-baseline --no-resident-call > "$O/bench_${name}_under_rocprof.json" 2> "$O/rocprof_$name.err" )
+  find "$O/prof_$name" -name "*kernel_trace.csv" -delete; find "$O/prof_$name" -name "*agent_info.csv" -delete
+  f=$(find "$O/prof_$name" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/${name}_kernel_stats.csv"
+  lap "rocprof_$name"
+}
+gputests() {
+  timeout 1500 python -m pytest tests -m gpu -q -s > "$O/gpu_tests.log" 2>&1; echo "rc=$?" >> "$O/gpu_tests.log"; lap gpu_tests
+  timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; echo "rc=$?" >> "$O/smoke.log"; lap smoke
+  grep -E "passed|failed" "$O/gpu_tests.log" | tail -2; grep -E "^FAILED|^ERROR" "$O/gpu_tests.log" | head; tail -2 "$O/smoke.log"
+}
+benchdefault() {
+  timeout 600 python bench.py --steps 2 --warmup 1 > "$O/bench_default_f16sr_b64.json" 2> "$O/bench_default.err"; lap bench_default
+  rocstats default 300 --steps 1 --warmup 0
+}
+case "$STAGE" in
+explore)
+  timeout 120 python tests/probes/cifar_conv_shapes.py > "$O/cifar_conv_shapes.log" 2>&1; lap cifar_conv_shapes
+  rocstats cifar_t10 200 --workload cifar32_ncsnpp --t 10 --steps 1 --warmup 0
+  rocstats cifar_adjoint_t10 200 --workload cifar32_ncsnpp_adjoint --t 10 --steps 1 --warmup 0
+  timeout 150 python tests/probes/dw8_power.py --seconds 4 > "$O/dw8_power.log" 2>&1; lap dw8_power
+  timeout 400 python tools/batch_table.py > "$O/batch_table.json" 2> "$O/batch_table.md"; lap batch_table
+  for B in 4 32; do
+    timeout 400 python bench.py --workload imagenet256_guided_sde_adjoint --batch $B --steps 1 --warmup 0 --no-cpu-baseline --no-resident-call > "$O/bench_guided_sde_adjoint_b$B.json" 2> "$O/bench_guided_sde_adjoint_b$B.err"; lap bench_guided_sde_adjoint_b$B
+  done
+  rocstats guided_sde_adjoint_b4_t10 300 --workload imagenet256_guided_sde_adjoint --batch 4 --t 10 --steps 1 --warmup 0
+  ;;
+tests) gputests ;;
+bench) benchdefault ;;
+closing)
+  gputests
+  benchdefault
+  timeout 400 bash tools/pmc_traffic.sh --precision f16sr > "$O/pmc.log" 2>&1; lap pmc_traffic
+  find "$R/gpurun_out/pmc_traffic" -name "*counter_collection.csv" -delete
+  PMC_GROUPS="sq1 sq2 sq3 tcc1 grbm" timeout 500 bash tools/pmc_conv.sh dw_r05 --dw 1 --res16 --f16out > "$O/pmc_conv.log" 2>&1; lap pmc_conv
+  timeout 300 python bench.py --workload cifar32_ncsnpp --steps 3 --warmup 1 > "$O/bench_cifar_b256_f16sr.json" 2> "$O/bench_cifar.err"; lap bench_cifar
+  timeout 400 python bench.py --workload cifar32_ncsnpp_adjoint --steps 2 --warmup 1 > "$O/bench_cifar_adjoint_b128_f16sr.json" 2> "$O/bench_adjoint.err"; lap bench_adjoint
+  rocstats cifar_t10 200 --workload cifar32_ncsnpp --t 10 --steps 1 --warmup 0
+  rocstats cifar_adjoint_t10 200 --workload cifar32_ncsnpp_adjoint --t 10 --steps 1 --warmup 0
+  timeout 300 python bench.py --t 150 --dt 1.5e-3 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_t150_dt1.5e-3_100step.json" 2> "$O/bench_t150a.err"; lap bench_t150_100
+  timeout 300 python bench.py --t 150 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_t150_150step.json" 2> "$O/bench_t150b.err"; lap bench_t150_150
+  for B in 4 32; do
+    timeout 400 python bench.py --workload imagenet256_guided_sde_adjoint --batch $B --steps 1 --warmup 0 $([ $B = 4 ] && echo --no-cpu-baseline) --no-resident-call > "$O/bench_guided_sde_adjoint_b$B.json" 2> "$O/bench_guided_sde_adjoint_b$B.err"; lap bench_guided_sde_adjoint_b$B
+  done
+  ;;
+esac
+cat "$O/timeline.log"
+python - "$O" <<'P'
+import json, glob, os, sys
+for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        r = d["roofline"]
+        g = r.get("second_kernel") or {}
+        print(os.path.basename(f), "images/s", round(d["value"], 3), "resident", (d.get("input") or {}).get("value_resident_batch_engine_call"), "conv TF", r.get("achieved") and round(r["achieved"], 1),
+              "frac", r.get("frac") and round(r["frac"], 3), "held", r.get("frac_at_held_clock") and round(r["frac_at_held_clock"], 3), "share", r.get("time_share_of_step") and round(r["time_share_of_step"], 3),
+              "sclk", (r.get("sclk_mhz") or {}).get("median"), "GN GB/s", g.get("achieved") and round(g["achieved"]), "peak GiB", d.get("peak_device_memory_gib") and round(d["peak_device_memory_gib"], 1),
+              "cpu", (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline") or {}).get("kind"), "cores", (d.get("cpu_baseline") or {}).get("cores"))
+    except Exception as e:
+        print(f, "unreadable", e)
+P
+for f in "$O"/*_kernel_stats.csv; do [ -f "$f" ] && { echo "== $f"; head -14 "$f" | cut -c1-160; }; done
+[ -f "$O/cifar_conv_shapes.log" ] && cat "$O/cifar_conv_shapes.log"
+[ -f "$O/dw8_power.log" ] && cat "$O/dw8_power.log"
+[ -f "$O/batch_table.md" ] && cat "$O/batch_table.md"
