@@ -7,7 +7,7 @@
 // while another thread launches is well-defined, and the other thread's launches pick either variant - same bits either way).
 // Round 4 removed the switches of the variants that measured slower and were pruned from the library (two workgroups per CU,
 // persistent tile loop, halo tile, four-phase ping-pong schedule, start-up staggers, GroupNorm fold, non-quad GroupNorm-apply) and of
-// the slice-unrolled / static-priority forms of the 8-wave kernel that its asymmetric staging superseded: 16 -> 5 switches.
+// the slice-unrolled / static-priority forms of the 8-wave kernel that its asymmetric staging superseded: 16 -> 5 switches (round 5 adds DP_H2_DH for the new half-height tile kernel: 6).
 #pragma once
 
 enum DpTune {
@@ -15,6 +15,7 @@ enum DpTune {
     DP_T_H2_SW,            // DP_H2_SW: one-wave-per-SIMD kernel (igemm_h2_sw.hip) - 0 off, 1 its 256x256 tiles only, 2 also 512x128 tiles (N % 256 != 0)
     DP_T_H2_NN,            // DP_H2_NN: few-output-channels kernel - 0 off
     DP_T_H2_DW,            // DP_H2_DW: the 8-wave 256x256 kernel (igemm_h2_dw.hip) on launches of >= 256 tiles - 0 off
+    DP_T_H2_DH,            // DP_H2_DH: the 4-wave 128x256 kernel (igemm_h2_dh.hip) on launches of fewer than 256 tiles of 256x256 - 0 off, 1 un-split layers only, 2 also the split-K levels
     DP_T_GN_FINALIZE_SAMPLE, // DP_GN_FINALIZE_SAMPLE: small feature maps - one finalize workgroup per sample instead of per (sample, group) - 0 off
     DP_T_COUNT
 };

@@ -580,6 +580,30 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             return 0;
         }
     }
+    {   // fp16 x fp16 launches that leave CUs idle on 256x256 tiles (fewer than 256 of them): the 4-wave kernel on 128x256 tiles
+        // (igemm_h2_dh.hip) - twice the workgroups, up to two per CU.  From 64 tiles of 256x256 up (128 half tiles: at least half the CUs);
+        // smaller launches stay on the generic tiles.  DP_H2_DH = 0 never.  Bit-identical to the other variants.
+        const long long t256 = tiles(256, 256);
+        if (dp_tune(DP_T_H2_DH) != 0 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && tiles(128, 256) >= 128 && t256 < 256 && dp_conv_dh_applies(p)) {
+            dp_launch_conv_dh(p, s);
+            dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
+            if (tile_rows) *tile_rows = 64;
+            dp_prof_end(rec, s);
+            DP_LAUNCH_CHECK("conv_igemm_dh");
+            return 0;
+        }
+        // split-K levels (<= 64 pixels per sample): the same kernel, one part per grid.y, from 128 workgroups up (DP_H2_DH = 1: never;
+        // 2, the default: yes); the reduction + epilogue kernel below is shared with the generic tiles
+        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit > 1 && tiles(128, 256) * p.ksplit >= 128 && dp_conv_dh_applies(p)) {
+            dp_launch_conv_dh(p, s);
+            DP_LAUNCH_CHECK("conv_igemm_dh (split-K)");
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, s, p);
+            if (tile_rows) *tile_rows = 64;
+            dp_prof_end(rec, s);
+            DP_LAUNCH_CHECK("splitk_epilogue");
+            return 0;
+        }
+    }
     // 256x256 ping-pong variant (igemm_h2_pp.hip): DP_H2_PP = 0 never, 1 whenever the shape allows, 2 when it
     // also fills the chip (>= one tile per CU); default 2 (dp_tune.h: read once; probes flip it with dp_set_tuning).
     {

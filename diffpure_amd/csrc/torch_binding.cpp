@@ -274,11 +274,18 @@ std::tuple<Tensor, Tensor> gn_apply_h16(const Tensor& x, const c10::optional<Ten
         C2 = x2->size(3);
     }
     const int64_t C = C1 + C2, Ho = resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H), Wo = resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W);
-    const float* fs = opt_ptr(fscale, "film scale");
-    const float* fh = opt_ptr(fshift, "film shift");
+    // FiLM rows [1 | B, C]: the two may be column views of one [R, 2C] table (unit column stride, a common row stride)
+    const float* fs = nullptr;
+    const float* fh = nullptr;
     int fstride = 0;
-    if (fs) {
-        TORCH_CHECK(fh && fscale->size(-1) == C && (fscale->size(0) == 1 || fscale->size(0) == B), "diffpure_hip: FiLM rows are [1 | B, C]");
+    if (fscale.has_value() && fscale->defined()) {
+        TORCH_CHECK(fshift.has_value() && fshift->defined(), "diffpure_hip: FiLM scale without shift");
+        for (const Tensor* t : {&*fscale, &*fshift})
+            TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->dim() == 2 && t->stride(1) == 1 && t->size(1) == C &&
+                            (t->size(0) == 1 || t->size(0) == B), "diffpure_hip: FiLM rows are fp32 [1 | B, C] with unit column stride");
+        TORCH_CHECK(fscale->stride(0) == fshift->stride(0) && fscale->size(0) == fshift->size(0), "diffpure_hip: FiLM scale and shift share a row stride");
+        fs = fscale->data_ptr<float>();
+        fh = fshift->data_ptr<float>();
         fstride = fscale->size(0) == 1 ? 0 : (int)fscale->stride(0);
     }
     c10::DeviceGuard guard(x.device());

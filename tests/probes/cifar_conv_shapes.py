@@ -29,8 +29,8 @@ def timeit(fn, iters):
 
 
 def main():
-    for B in (256, 128):
-        tot16 = tot32 = totf = 0.0
+    for B in (256, 128, 64):
+        tot16 = tot32 = totf = old16 = old32 = 0.0
         print(f"== B={B}: H Cin->Cout (x count) | tiles of 256x256 | stream form (fp16 out + fp16 res): us, TFLOP/s | taped form (fp32 out + fp32 res): us, TFLOP/s")
         for (H, ci, co, cnt) in SHAPES:
             x = torch.randn(B, H, H, ci)
@@ -48,8 +48,13 @@ def main():
             tot16 += t16 * cnt
             tot32 += t32 * cnt
             totf += flop * cnt
-            print(f"{H:3d} {ci:4d}->{co:3d} (x{cnt:2d}) | {B * H * H // 256 * (co // 128) // 2:5d} | {t16 * 1e3:7.1f} {flop / t16 / 1e9:6.0f} | {t32 * 1e3:7.1f} {flop / t32 / 1e9:6.0f}", flush=True)
-        print(f"-- B={B} weighted over one forward: stream form {tot16:.2f} ms ({totf / tot16 / 1e9:.0f} TFLOP/s), taped form {tot32:.2f} ms ({totf / tot32 / 1e9:.0f} TFLOP/s)")
+            with ops.tuning(DP_H2_DH=0):        # round 5: the same launches without the half-height tile kernel (what took them in round 4)
+                o16, o32 = timeit(f16, 30), timeit(f32, 30)
+            old16 += o16 * cnt
+            old32 += o32 * cnt
+            print(f"{H:3d} {ci:4d}->{co:3d} (x{cnt:2d}) | {B * H * H // 256 * (co // 128) // 2:5d} | {t16 * 1e3:7.1f} {flop / t16 / 1e9:6.0f} | {t32 * 1e3:7.1f} {flop / t32 / 1e9:6.0f}"
+                  f" | DP_H2_DH=0: {o16 * 1e3:7.1f} {flop / o16 / 1e9:6.0f} | {o32 * 1e3:7.1f} {flop / o32 / 1e9:6.0f}", flush=True)
+        print(f"-- B={B} weighted over one forward: stream form {tot16:.2f} ms ({totf / tot16 / 1e9:.0f} TFLOP/s), taped form {tot32:.2f} ms ({totf / tot32 / 1e9:.0f} TFLOP/s); with DP_H2_DH=0: {old16:.2f} / {old32:.2f} ms")
 
 
 if __name__ == "__main__":

@@ -37,19 +37,33 @@ DEV = "cuda:0"
 
 class Sampler:
     def __init__(self):
-        self.sclk_path = next(iter(sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))), None)
-        cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) + \
-            sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        # the sysfs node of THE GPU torch runs on (the box exposes several cards; the first attempt of this probe read card0's sensors while
+        # the kernels ran on card56): matched by PCI bus id, as bench.py's SclkSampler does
+        dev = None
+        try:
+            bus = torch.cuda.get_device_properties(0).pci_bus_id
+            for c in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if f":{bus:02x}:" in os.path.realpath(c):
+                    dev = c
+        except Exception:
+            pass
+        if dev is None:
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            dev = os.path.dirname(cands[0]) if len(cands) == 1 else None
+        self.dev = dev
+        self.sclk_path = os.path.join(dev, "pp_dpm_sclk") if dev else None
+        cands = (sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_average"))) + sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_input")))) if dev else []
         self.pow_path = cands[0] if cands else None
+        self.all_power = cands
         self.sclk, self.power, self._stop = [], [], threading.Event()
         self._th = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
         while not self._stop.is_set():
-            try:
-                for line in open(self.sclk_path):
-                    if "*" in line:
-                        self.sclk.append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+            try:    # several lines may carry a '*' (a sleep level next to the active one): the active clock is the largest starred level
+                vals = [float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()) for line in open(self.sclk_path) if "*" in line]
+                if vals:
+                    self.sclk.append(max(vals))
             except Exception:
                 pass
             try:
@@ -97,7 +111,12 @@ def main():
     variants = [("dw", {}, "0"), ("sw", {"DP_H2_DW": 0}, "0"), ("generic", {"DP_H2_PP": 0}, "0"), ("dw -reads", {}, "4"), ("dw -actDMA", {}, "16"),
                 ("dw -wDMA", {}, "32"), ("dw -DMA", {}, "1"), ("dw -DMA-reads", {}, "5"), ("dw -stores", {}, "8"), ("dw (again)", {}, "0")]
     print(f"3x3 {ci}->{co} at {H}^2, B={B}, fp16 residual + fp16 output; {seconds:.0f} s per variant; power from "
-          f"{Sampler().pow_path}, clock from {Sampler().sclk_path}")
+          f"{Sampler().pow_path} (all power sensors: {Sampler().all_power}), clock from {Sampler().sclk_path}")
+    try:        # what the vendor tool says at idle, for the units of the sysfs sensor
+        import subprocess
+        print(subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=30).stdout[-1500:])
+    except Exception as e:
+        print("rocm-smi unavailable:", e)
     print(f"{'variant':16s} {'ms':>8s} {'TFLOP/s':>8s} {'sclk MHz':>9s} {'power W':>8s} {'TF/W':>6s} {'Mcycles/launch':>15s} {'launches':>8s}")
     for name, tune, mode in variants:
         os.environ["DP_H2_DW_MODE"] = mode

@@ -156,6 +156,7 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
                       ("igemm_h2.hip", ("conv_igemm_h2ILi128ELi128ELi32ELi0E", "conv_igemm_h2ILi64ELi64ELi32ELi0E")),
                       ("igemm_h2_sw.hip", ("conv_igemm_swILi0ELi256E", "conv_igemm_swILi0ELi128E")),
                       ("igemm_h2_dw.hip", ("conv_igemm_dwILi0E",)),
+                      ("igemm_h2_dh.hip", ("conv_igemm_dh",)),
                       ("attention.hip", ("attn_flash_kernelILi4E", "attn_flash_kernelILi2E"))):
         out = tmp_path / (src + ".s")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",

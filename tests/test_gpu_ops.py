@@ -733,11 +733,11 @@ def test_torch_ops_abi6_operators_and_autograd_formulas(dev):
     r = ops.conv2d_h2(xh, wf, N, 3, bias=bias, colstats=True, w_fmt=1, out_f16=True, segs=(seg,))
     assert torch.equal(y, r.t) and torch.equal(cols, r.cols.buf)
     # gn_apply_h16 on that fp16 tensor with its records' statistics: operand form, FiLM + SiLU; the resampled plain tensor
-    st = ops.group_norm_stats(r, 32, 1e-5)
+    st = ops.group_norm_stats(r, 16, 1e-5)           # 64 channels: 16 groups of 4
     gamma, beta = (1 + 0.1 * rnd(N, seed=8)).to(dev), (0.1 * rnd(N, seed=9)).to(dev)
     film = rnd(B, 2 * N, seed=10, scale=0.3).to(dev)
-    a, _ = T.gn_apply_h16(r.t, None, st, gamma, beta, film[:, :N], film[:, N:], 32, True, 0, 2, False)
-    assert torch.equal(a, ops.group_norm(r.t, 32, 1e-5, gamma, beta, film=(film[:, :N], film[:, N:]), act=True, split="h1", stats=st))
+    a, _ = T.gn_apply_h16(r.t, None, st, gamma, beta, film[:, :N], film[:, N:], 16, True, 0, 2, False)
+    assert torch.equal(a, ops.group_norm(r.t, 16, 1e-5, gamma, beta, film=(film[:, :N], film[:, N:]), act=True, split="h1", stats=st))
     a, _ = T.gn_apply_h16(r.t, None, None, None, None, None, None, 1, False, 2, 3, False)
     assert torch.equal(a, ops.resample(r.t, ops.RESAMPLE_DOWN))
     # attention_fused: fp16 qkv, one pass, bordered operand out; fp32 qkv
@@ -1076,3 +1076,77 @@ def test_conv2d_fp16_residual_through_the_c_abi_with_an_offset_strided_residual(
     torch.cuda.synchronize()
     assert tr.value == want.cols.tile_rows
     assert torch.equal(out, want.t) and torch.equal(cs, want.cols.buf)
+
+
+DH_CASES = [
+    # B, H, W, C, N, temb rows (0 none / 1 broadcast / 2 per sample), residual (0 none / 16 / 32), fp16 output, K-segment channels (C1, C2), scale
+    (128, 16, 16, 256, 256, 2, 16, True, (0, 0), 0.70710678),     # NCSN++ 16x16 level at the adjoint benchmark's batch: 128 tiles of 256x256
+    (128, 16, 16, 256, 256, 0, 32, False, (0, 0), 0.70710678),    # the same launch in the taped forward (fp32 stream)
+    (128, 16, 16, 256, 256, 0, 0, False, (0, 0), 1.0),            # ... and as an input-gradient convolution
+    (128, 16, 16, 256, 256, 0, 0, True, (256, 128), 0.70710678),  # up path 384 -> 256: the 1x1 skip as two K-segments
+    (4, 64, 64, 512, 512, 1, 16, True, (0, 0), 1.0),              # guided UNet 64x64 level at the reference's per-GPU batch of 4
+    (3, 64, 64, 256, 512, 2, 0, True, (256, 0), 1.0),             # 96 tiles of 256x256 -> 192 half tiles (two per CU on some), one segment
+    (65, 16, 16, 64, 256, 2, 16, True, (0, 0), 1.0),              # M = 16 640 = 130 x 128: an odd number of half tiles (M % 256 != 0)
+    # split-K levels (<= 64 pixels per sample; the split factor is fixed by the layer shape): one part per grid.y, raw partial sums
+    (256, 8, 8, 256, 256, 2, 16, True, (0, 0), 0.70710678),       # NCSN++ 8x8 level at B = 256: 128 half tiles x 2 parts of 36 k-tiles
+    (256, 4, 4, 256, 256, 2, 32, False, (0, 0), 0.70710678),      # 4x4 level: 32 half tiles x 4 parts of 18 k-tiles, fp32 stream
+    (128, 8, 8, 256, 256, 0, 0, True, (256, 128), 0.70710678),    # 8x8 up path with two K-segments: 2 parts of 42 k-tiles, the cut inside segment 1
+    (64, 8, 8, 1024, 1024, 1, 16, True, (0, 0), 1.0),             # guided UNet 8x8 level at B = 64: 32 x 4 half tiles x 2 parts of 144
+]
+
+
+@pytest.mark.parametrize("case", DH_CASES, ids=[str(c) for c in DH_CASES])
+def test_conv2d_half_height_tile_kernel_is_bit_identical(dev, case, tune):
+    """Round 5: conv_igemm_dh (128x256 tiles, four waves, two workgroups per CU) takes the fp16 x fp16 launches that leave CUs idle on
+    256x256 tiles.  Identical bits to the generic tiles and to the one-wave-per-SIMD kernel it replaces there - output (fp16 or fp32),
+    column records - with time-embedding rows, fp16 / fp32 residual and 1x1 K-segments; and the dispatcher's own choice is this kernel."""
+    from diffpure_amd import ops
+    B, H, W, C, N, temb_rows, res_kind, out16, (C1, C2), scale = case
+    h = rnd(B, H, W, C, seed=1)
+    w3 = rnd(N, C, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * C))
+    hh = _h1_bordered(h, dev)
+    bias = rnd(N, seed=3).to(dev)
+    table = rnd(B if temb_rows == 2 else 1, N + 8, seed=4).to(dev) if temb_rows else None
+    res = None
+    if res_kind:
+        res = rnd(B, H, W, N, seed=5).to(dev)
+        res = res.half() if res_kind == 16 else res
+    segs = None
+    if C1:
+        ws = rnd(N, C1 + C2, 1, 1, seed=6, scale=1.0 / math.sqrt(C1 + C2))
+        wf = ops.order_conv_weight_w16(ops.fuse_skip_weight(w3, ws)).half().to(dev)
+        segs = (rnd(B, H, W, C1, seed=7).half().to(dev),) + ((rnd(B, H, W, C2, seed=8).half().to(dev),) if C2 else ())
+    else:
+        wf = ops.order_conv_weight_w16(w3).half().to(dev)
+
+    def run():
+        y = ops.conv2d_h2(hh, wf, N, 3, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale, colstats=True,
+                          w_fmt=1, out_f16=out16, segs=segs)
+        return y.t, y.cols.buf.clone()
+
+    tune.setenv("DP_H2_PP", "0")                    # generic tiles
+    base, base_cs = run()
+    tune.delenv("DP_H2_PP")
+    tune.setenv("DP_H2_DH", "0")                    # what took these launches before: the one-wave-per-SIMD kernel / generic tiles
+    old, old_cs = run()
+    assert torch.equal(old, base) and torch.equal(old_cs, base_cs)
+    tune.delenv("DP_H2_DH")
+    ops.prof_enable(True)
+    for _ in range(2):
+        got, got_cs = run()                         # default dispatch: conv_igemm_dh
+        assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
+    ops.prof_enable(False)
+    prof = ops.prof_collect()
+    if H * W > 64:      # (un-split launches are booked with the 256-wide tile kernels, i.e. they did not run on the generic tiles)
+        assert prof["pp3x3"]["n"] == 2 and prof["other3x3"]["n"] == 0, prof
+    sub = slice(0, 2)                               # fp64 reference on two samples
+    ref = torch.nn.functional.conv2d(h[sub].half().double().permute(0, 3, 1, 2), w3.half().double(), None, padding=1).permute(0, 2, 3, 1) + bias.cpu().double()
+    if segs:
+        ref = ref + torch.cat([s_[sub].cpu() for s_ in segs], dim=3).double() @ ws[:, :, 0, 0].half().double().t()
+    if table is not None:
+        ref = ref + table[:, 4:4 + N].cpu().double()[:2 if temb_rows == 2 else 1].view(-1, 1, 1, N)
+    if res is not None:
+        ref = ref + res[sub].cpu().double()
+    ref = (ref * scale).float()
+    err = (got[sub].float().cpu() - ref).abs().max().item()
+    assert err < (2e-3 if out16 else 3e-5) * max(1.0, ref.abs().max().item()), err

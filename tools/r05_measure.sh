@@ -42,6 +42,20 @@ explore)
   done
   rocstats guided_sde_adjoint_b4_t10 300 --workload imagenet256_guided_sde_adjoint --batch 4 --t 10 --steps 1 --warmup 0
   ;;
+dh)     # the half-height tile kernel: its tests, the per-shape A/B, the adjoint / small-batch bench lines with and without it
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "half_height or k_segments or fp16_output or offset_strided or torch_ops" > "$O/dh_tests.log" 2>&1; echo "rc=$?" >> "$O/dh_tests.log"; lap dh_tests
+  tail -5 "$O/dh_tests.log"
+  timeout 200 python tests/probes/cifar_conv_shapes.py > "$O/cifar_conv_shapes.log" 2>&1; lap cifar_conv_shapes
+  for DH in 0 1 0 1; do
+    DP_H2_DH=$DH timeout 300 python bench.py --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_cifar_adjoint_t20_dh$DH.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_cifar_adjoint_t20_dh$DH.json').read().strip().splitlines()[-1]); print('adjoint t20 DH=$DH', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz'])" | tee -a "$O/dh_ab.log"
+  done; lap adjoint_ab
+  for DH in 0 1; do
+    DP_H2_DH=$DH timeout 300 python bench.py --batch 4 --t 20 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_guided_b4_t20_dh$DH.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_guided_b4_t20_dh$DH.json').read().strip().splitlines()[-1]); print('guided B=4 t20 DH=$DH', round(d['value'],3), 'images/s', d['roofline']['sclk_mhz'])" | tee -a "$O/dh_ab.log"
+  done; lap guided_b4_ab
+  timeout 150 python tests/probes/dw8_power.py --seconds 4 > "$O/dw8_power.log" 2>&1; lap dw8_power
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
