@@ -20,6 +20,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 struct BwdArgs {
     const float* x1;
     const float* x2;
+    int x_fmt;                   // 0: x1 / x2 are fp32; 1: plain fp16 (the taped forward of the fp16 x fp16 modes keeps the fp16 residual stream)
     int C1, C2, B, H, W, G;      // H, W: INPUT resolution of the forward operator
     const float* stats;          // [B][G][2] mean, rstd of the forward
     const float* gamma;
@@ -38,9 +39,23 @@ struct BwdArgs {
     float* dx2;
     int out_fmt;
     float fir[4];                // resample 3 / 4: the forward's 1-D taps k[0..3]
+    // apply pass, fp32 output only (round 5; the one-pass kernel had it since round 4): a second gradient arriving at the same tensors -
+    // the skip branch of a ResBlock - is added in the same pass, dx += add_scale * add, instead of by a dp_add / dp_axpby launch
+    const float* add1;
+    const float* add2;
+    float add_scale;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+typedef _Float16 half4q __attribute__((ext_vector_type(4)));
+// a channel quad of the forward's INPUT tensor in its stored format (element index e from the tensor's base)
+__device__ __forceinline__ f32x4 ld4x(const float* base, size_t e, int x_fmt) {
+    if (x_fmt) {
+        const half4q h = *reinterpret_cast<const half4q*>(reinterpret_cast<const _Float16*>(base) + e);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    return ld4(base + e);
+}
 
 // Transposes of the FIR x2 resamplers (forward per axis, zero outside the image - csrc/norm.hip):
 //   up   : out[2i] = 2 (k3 x[i-1] + k1 x[i]),  out[2i+1] = 2 (k2 x[i] + k0 x[i+1])
@@ -111,7 +126,7 @@ __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, 
 // returns dxh and xh for one channel quad of one input pixel
 template <bool FIR>
 __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, int y, int x, int c, f32x4& dxh, f32x4& xh) {
-    const f32x4 xv = (c < p.C1) ? ld4(p.x1 + pix * p.C1 + c) : ld4(p.x2 + pix * p.C2 + (c - p.C1));
+    const f32x4 xv = (c < p.C1) ? ld4x(p.x1, pix * p.C1 + c, p.x_fmt) : ld4x(p.x2, pix * p.C2 + (c - p.C1), p.x_fmt);
     const int g = c / p.cpg;
     const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
     const f32x4 ga = ld4(p.gamma + c), be = ld4(p.beta + c);
@@ -243,7 +258,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
             dst[1] = lo;
         } else {
             const int c = c8 * 8;
-            float* d = (c < p.C1) ? p.dx1 + pix * p.C1 + c : p.dx2 + pix * p.C2 + (c - p.C1);
+            const bool first = c < p.C1;
+            const size_t e = first ? pix * p.C1 + c : pix * p.C2 + (c - p.C1);
+            const float* ad = first ? p.add1 : p.add2;
+            if (ad) {
+                const f32x4 a0 = ld4(ad + e), a1 = ld4(ad + e + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[0][j] += p.add_scale * a0[j];
+                    o[1][j] += p.add_scale * a1[j];
+                }
+            }
+            float* d = (first ? p.dx1 : p.dx2) + e;
             *reinterpret_cast<f32x4*>(d) = o[0];
             *reinterpret_cast<f32x4*>(d + 4) = o[1];
         }
@@ -454,12 +480,13 @@ inline unsigned grid_cap(long long items, int block, int cap) {
     return (unsigned)g;
 }
 
-int fill_common(BwdArgs& p, const char* fn, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+int fill_common(BwdArgs& p, const char* fn, const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta, const float* fscale, const float* fshift,
                 int film_stride, int act, int resample, const float* fir4, const float* dy) {
     const int C = C1 + C2;
     DP_REQUIRE(x1 && stats && gamma && beta && dy && B > 0 && H > 0 && W > 0 && G > 0, "%s: bad args", fn);
     DP_REQUIRE(C2 == 0 || x2, "%s: x2 missing", fn);
+    DP_REQUIRE(x_fmt == 0 || x_fmt == 1, "%s: x_fmt 0 (fp32) or 1 (plain fp16)", fn);
     DP_REQUIRE(C % (4 * G) == 0 && C1 % 8 == 0 && C % 8 == 0, "%s: need C %% (4*G) == 0 and C1, C %% 8 == 0 (C=%d+%d, G=%d)", fn, C1, C2, G);
     DP_REQUIRE((fscale == nullptr) == (fshift == nullptr), "%s: FiLM scale and shift come together", fn);
     DP_REQUIRE(resample >= 0 && resample <= 4, "%s: resample mode %d", fn, resample);
@@ -467,7 +494,7 @@ int fill_common(BwdArgs& p, const char* fn, const float* x1, int C1, const float
     DP_REQUIRE(resample < 3 || fir4, "%s: the FIR resampling modes (3, 4) need the 4 filter taps", fn);
     DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(dy), "%s: misaligned tensor", fn);
     p = BwdArgs{};
-    p.x1 = x1; p.x2 = x2; p.C1 = C1; p.C2 = C2; p.B = B; p.H = H; p.W = W; p.G = G;
+    p.x1 = static_cast<const float*>(x1); p.x2 = static_cast<const float*>(x2); p.x_fmt = x_fmt; p.C1 = C1; p.C2 = C2; p.B = B; p.H = H; p.W = W; p.G = G;
     p.stats = stats; p.gamma = gamma; p.beta = beta; p.fscale = fscale; p.fshift = fshift;
     p.film_stride = film_stride; p.act = act; p.resample = resample; p.dy = dy;
     p.C4 = C / 4; p.cpg = C / G;
@@ -481,12 +508,12 @@ int fill_common(BwdArgs& p, const char* fn, const float* x1, int C1, const float
 
 }  // namespace
 
-extern "C" int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+extern "C" int dp_gn_bwd_stats(const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                                const float* stats, const float* gamma, const float* beta, const float* fscale,
                                const float* fshift, int film_stride, int act, int resample, const float* fir4, const float* dy,
                                int nsplit, float* partial, float* sums, void* stream) {
     BwdArgs p;
-    if (int rc = fill_common(p, "dp_gn_bwd_stats", x1, C1, x2, C2, B, H, W, G, stats, gamma, beta, fscale, fshift,
+    if (int rc = fill_common(p, "dp_gn_bwd_stats", x1, C1, x2, C2, x_fmt, B, H, W, G, stats, gamma, beta, fscale, fshift,
                              film_stride, act, resample, fir4, dy)) return rc;
     DP_REQUIRE(partial && sums && nsplit > 0, "dp_gn_bwd_stats: scratch missing");
     DP_REQUIRE(p.C4 <= 1024 && G <= p.C4, "dp_gn_bwd_stats: C too wide");
@@ -502,16 +529,20 @@ extern "C" int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2,
     return 0;
 }
 
-extern "C" int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+extern "C" int dp_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                                const float* stats, const float* gamma, const float* beta, const float* fscale,
                                const float* fshift, int film_stride, int act, int resample, const float* fir4, const float* dy,
-                               const float* sums, int out_fmt, void* dx1, float* dx2, void* stream) {
+                               const float* sums, int out_fmt, void* dx1, float* dx2, const float* add1, const float* add2, float add_scale,
+                               void* stream) {
     BwdArgs p;
-    if (int rc = fill_common(p, "dp_gn_bwd_apply", x1, C1, x2, C2, B, H, W, G, stats, gamma, beta, fscale, fshift,
+    if (int rc = fill_common(p, "dp_gn_bwd_apply", x1, C1, x2, C2, x_fmt, B, H, W, G, stats, gamma, beta, fscale, fshift,
                              film_stride, act, resample, fir4, dy)) return rc;
     DP_REQUIRE(sums && dx1 && (C2 == 0 || dx2), "dp_gn_bwd_apply: output missing");
     DP_REQUIRE(out_fmt == 0 || ((out_fmt == 1 || out_fmt == 2) && C2 == 0), "dp_gn_bwd_apply: operand output (1 = h2, 2 = h1) needs a single source");
+    DP_REQUIRE((!add1 && !add2) || out_fmt == 0, "dp_gn_bwd_apply: an addend needs the fp32 output form");
+    DP_REQUIRE((!add1 || dp_aligned16(add1)) && (!add2 || (C2 > 0 && dp_aligned16(add2))), "dp_gn_bwd_apply: addend");
     p.sums = sums; p.dx1 = (float*)dx1; p.dx2 = dx2; p.out_fmt = out_fmt;
+    p.add1 = add1; p.add2 = add2; p.add_scale = add_scale;
     const int border = out_fmt ? 1 : 0;
     const long long total = (long long)B * (H + 2 * border) * (W + 2 * border) * (p.C4 / 2);
     if (resample >= 3) hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
@@ -541,12 +572,12 @@ extern "C" int dp_gn_bwd_fused_ok(int H, int W, int C1, int C2, int G, int resam
     return gn_bwd_fused_block(H * W, C1 + C2, G, C1) != 0 ? 1 : 0;
 }
 
-extern "C" int dp_gn_bwd_fused(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+extern "C" int dp_gn_bwd_fused(const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                                const float* stats, const float* gamma, const float* beta, const float* fscale,
                                const float* fshift, int film_stride, int act, int resample, const float* dy,
                                int out_fmt, void* dx1, float* dx2, const float* add1, const float* add2, float add_scale, void* stream) {
     FusedArgs a{};
-    if (int rc = fill_common(a.b, "dp_gn_bwd_fused", x1, C1, x2, C2, B, H, W, G, stats, gamma, beta, fscale, fshift,
+    if (int rc = fill_common(a.b, "dp_gn_bwd_fused", x1, C1, x2, C2, x_fmt, B, H, W, G, stats, gamma, beta, fscale, fshift,
                              film_stride, act, resample, nullptr, dy)) return rc;
     DP_REQUIRE(resample <= 2, "dp_gn_bwd_fused: the FIR resampling modes take the three-launch form");
     DP_REQUIRE(dx1 && (C2 == 0 || dx2), "dp_gn_bwd_fused: output missing");

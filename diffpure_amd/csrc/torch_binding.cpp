@@ -348,16 +348,16 @@ Tensor group_norm_silu_bwd(const Tensor& x, const Tensor& stats, const Tensor& g
     void* s = cur_stream(x);
     Tensor dx = at::empty_like(x);
     if (dp_gn_bwd_fused_ok(H, W, C, 0, G, 0)) {
-        DP_CALL(dp_gn_bwd_fused(x.data_ptr<float>(), C, nullptr, 0, B, H, W, G, stats.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(),
+        DP_CALL(dp_gn_bwd_fused(x.data_ptr<float>(), C, nullptr, 0, /*x_fmt=*/0, B, H, W, G, stats.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(),
                                 nullptr, nullptr, 0, act ? 1 : 0, 0, dy.data_ptr<float>(), 0, dx.data_ptr(), nullptr, nullptr, nullptr, 1.f, s));
         return dx;
     }
     const int ns = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)H * W / 256, 128));
     Tensor partial = at::empty({B, ns, G, 2}, x.options()), sums = at::empty({B, G, 2}, x.options());
-    DP_CALL(dp_gn_bwd_stats(x.data_ptr<float>(), C, nullptr, 0, B, H, W, G, stats.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr,
+    DP_CALL(dp_gn_bwd_stats(x.data_ptr<float>(), C, nullptr, 0, /*x_fmt=*/0, B, H, W, G, stats.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr,
                             nullptr, 0, act ? 1 : 0, 0, nullptr, dy.data_ptr<float>(), ns, partial.data_ptr<float>(), sums.data_ptr<float>(), s));
-    DP_CALL(dp_gn_bwd_apply(x.data_ptr<float>(), C, nullptr, 0, B, H, W, G, stats.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr,
-                            nullptr, 0, act ? 1 : 0, 0, nullptr, dy.data_ptr<float>(), sums.data_ptr<float>(), 0, dx.data_ptr(), nullptr, s));
+    DP_CALL(dp_gn_bwd_apply(x.data_ptr<float>(), C, nullptr, 0, /*x_fmt=*/0, B, H, W, G, stats.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(), nullptr,
+                            nullptr, 0, act ? 1 : 0, 0, nullptr, dy.data_ptr<float>(), sums.data_ptr<float>(), 0, dx.data_ptr(), nullptr, nullptr, nullptr, 1.f, s));
     return dx;
 }
 Tensor group_norm_stats(const Tensor& x, int64_t groups, double eps) {

@@ -195,9 +195,10 @@ class GuidedUNet:
         # ... and (round 4, DIFFPURE_LEAN16=0 switches it off) the RESIDUAL STREAM itself travels as plain fp16 between the blocks -
         # the reference's own arithmetic for this network (`use_fp16: True`, configs/imagenet.yml:18: convert_to_fp16 casts the
         # whole torso, unet.py:626-632, so h IS fp16 there) with fp32 accumulation / epilogues / GroupNorm statistics on top.
-        # Decided in load_state_dict (every convolution on the stream must be on the fp16 matrix path); forward passes that keep a
-        # tape (the adjoints) stay fp32.
+        # Decided in load_state_dict (every convolution on the stream must be on the fp16 matrix path).  Round 5: forward passes that
+        # keep a tape (the adjoints) run on the same stream (`_tape16`; see _o16).
         self._lean16 = False
+        self._tape16 = os.environ.get("DIFFPURE_TAPE16", "1") != "0"
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -321,9 +322,12 @@ class GuidedUNet:
             self._gpool.round(key)
 
     def _o16(self, hw, tape):
-        """is a residual-stream tensor of `hw` pixels per sample stored as plain fp16?  (fp16 x fp16 modes, no tape, and whole
-        column records per sample - an fp16 tensor's GroupNorm statistics exist only as its producer's records)"""
-        return self._lean16 and tape is None and hw % 64 == 0
+        """is a residual-stream tensor of `hw` pixels per sample stored as plain fp16?  (fp16 x fp16 modes and whole column records per
+        sample - an fp16 tensor's GroupNorm statistics exist only as its producer's records.)  Round 5: WITH a tape as well
+        (`_tape16`, DIFFPURE_TAPE16=0 restores the fp32-stream tape of round 4): the adjoint solves re-run and differentiate exactly
+        the network the forward solve evaluated - same stream format, same fused [w2 | skip] panels, same one-pass attention, bit
+        for bit - the tape holds fp16 tensors (half the memory) and the GroupNorm backward reads them as stored (x_fmt 1)."""
+        return self._lean16 and (tape is None or self._tape16) and hw % 64 == 0
 
     def _res(self, r, xa, x2a, film_table, tape=None):
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors; fp32, or plain
@@ -347,9 +351,9 @@ class GuidedUNet:
                            raw=want_raw)
         if want_raw:
             h, xraw = h
-        # (the taped forward keeps fp32 for the backward pass; below 64 pixels per sample the column records straddle samples and
+        # (below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
-        mid16 = self._lean and tape is None and r["h2_1"] and r["h2_2"] and (ho * wo) % 64 == 0
+        mid16 = self._lean and (tape is None or self._tape16) and r["h2_1"] and r["h2_2"] and (ho * wo) % 64 == 0
         h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True, **({"out_f16": True} if mid16 else {}))
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
@@ -377,11 +381,11 @@ class GuidedUNet:
         b, hh, ww, _ = x.shape
         st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS)
         xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
-        # fp16 x fp16 modes, no tape (the backward pass recomputes the probabilities from an fp32 qkv): qkv is stored as plain fp16 by the
+        # fp16 x fp16 modes (with or without a tape: the backward pass recomputes the probabilities from the taped qkv): qkv is stored as plain fp16 by the
         # convolution and the flash kernel runs ONE fp16 pass on it, Q and K read in place (csrc/attention.hip; the arithmetic of the
         # reference's use_fp16 attention, unet.py:358-361)
         fused = bool(r.get("proj16")) and ops.attention_fused_ok(hh * ww, c // r["heads"])
-        q16 = fused and tape is None and os.environ.get("DIFFPURE_ATTN16", "1") != "0"
+        q16 = fused and (tape is None or self._tape16) and os.environ.get("DIFFPURE_ATTN16", "1") != "0"
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(xn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"], **({"out_f16": True} if q16 else {}))
         layout = "split" if self.cfg["use_new_attention_order"] else "legacy"
         # The taped forward keeps only qkv: the [B*heads, T, T] probabilities (2.1 GB per 32x32 layer at B=64) are
@@ -549,9 +553,15 @@ class GuidedUNet:
         n, c = r["name"], r["ch"]
         b, hh, ww, _ = dout.shape
         da = self._dconv(dout, n + ".dwproj", r.get("dh2_p", False) == "h1" and "h1", c, 1)
-        qkv = t["qkv"].view(b, hh * ww, 3 * c)
-        _, probs = ops.attention(qkv, r["heads"], t["layout"], return_probs=True)      # recomputed, freed after this block
-        dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), r["heads"], t["layout"])
+        qkv = t["qkv"]
+        if qkv.dtype == torch.float16:          # taped on the fp16 stream: the GEMMs of the backward take fp32 operands (the same values)
+            qkv = qkv.float()
+        qkv = qkv.view(b, hh * ww, 3 * c)
+        # probabilities recomputed (freed after this block), without the P V product nobody reads; in the fp16 x fp16 modes the
+        # products whose shapes dp_gemm_strided_h16 serves (q k^T and dP at head dimension 64) run on the fp16 matrix cores
+        h16 = getattr(self, "_gpool", None) is not None and os.environ.get("DIFFPURE_ATTN_BWD16", "1") != "0"
+        _, probs = ops.attention(qkv, r["heads"], t["layout"], probs_only=True, h16=h16)
+        dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), r["heads"], t["layout"], h16=h16)
         del probs
         dxn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
         return ops.group_norm_bwd(t["x"], self.GN_GROUPS, P[n + ".g"], P[n + ".b"], t["st"], dxn, addend=dout)[0]

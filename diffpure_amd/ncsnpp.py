@@ -154,6 +154,7 @@ class NCSNpp:
         # fp16 x fp16 modes: the first convolution of a ResBlock stores its output as fp16 (see GuidedUNet)
         self._lean = self._pool is not None and os.environ.get("DIFFPURE_LEAN", "1") != "0"
         self._lean16 = False         # fp16 residual stream: decided in load_state_dict
+        self._tape16 = os.environ.get("DIFFPURE_TAPE16", "1") != "0"     # round 5: the taped forward runs on it too (GuidedUNet._o16)
         self.device = torch.device(device)
         self.plan = _plan(cfg)
         self.p = {}
@@ -284,7 +285,7 @@ class NCSNpp:
 
     def _o16(self, hw, tape):
         """is a residual-stream tensor of `hw` pixels per sample stored as plain fp16?  (see GuidedUNet._o16)"""
-        return self._lean16 and tape is None and hw % 64 == 0
+        return self._lean16 and (tape is None or self._tape16) and hw % 64 == 0
 
     def _res(self, r, xa, x2a, dense, tape=None):
         """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors; fp32, or plain
@@ -311,9 +312,9 @@ class NCSNpp:
         if want_raw:
             h, xraw = h
         off = r["dense_off"]
-        # (the taped forward keeps fp32 for the backward pass; below 64 pixels per sample the column records straddle samples and
+        # (below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
-        mid16 = (self._lean and tape is None and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0 and (ho * wo) % 64 == 0)
+        mid16 = (self._lean and (tape is None or self._tape16) and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0 and (ho * wo) % 64 == 0)
         h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True, **({"out_f16": True} if mid16 else {}))
         st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
         h = h.t
@@ -344,7 +345,7 @@ class NCSNpp:
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         # fp16 x fp16 modes without a tape: fp16 qkv, one fp16 pass of the flash kernel (see GuidedUNet._attn)
         fused = bool(r.get("proj16")) and ops.attention_fused_ok(hh * ww, c)
-        q16 = fused and tape is None and os.environ.get("DIFFPURE_ATTN16", "1") != "0"
+        q16 = fused and (tape is None or self._tape16) and os.environ.get("DIFFPURE_ATTN16", "1") != "0"
         qkv = (self._ch2 if r["h2"] else ops.conv2d)(hn, P[n + ".wqkv"], 3 * c, 1, bias=P[n + ".cqkv"], **({"out_f16": True} if q16 else {}))
         # the taped forward keeps only qkv; the probabilities are recomputed per block in the backward pass (see GuidedUNet._attn)
         if tape is not None:
@@ -504,9 +505,15 @@ class NCSNpp:
         n, c = str(r["idx"]), r["ch"]
         b, hh, ww, _ = dout.shape
         da = self._dconv(dout, n + ".dw3", r.get("dh2_3", False) == "h1" and "h1", c, 1, scale=INV_SQRT2)
-        qkv = t["qkv"].view(b, hh * ww, 3 * c)
-        _, probs = ops.attention(qkv, 1, "split", return_probs=True)                   # recomputed, freed after this block
-        dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), 1, "split")
+        qkv = t["qkv"]
+        if qkv.dtype == torch.float16:          # taped on the fp16 stream: the GEMMs of the backward take fp32 operands (the same values)
+            qkv = qkv.float()
+        qkv = qkv.view(b, hh * ww, 3 * c)
+        # probabilities recomputed (freed after this block); in the fp16 x fp16 modes the five products run on the fp16 matrix cores,
+        # as the dgrad convolutions around them do (DIFFPURE_GRAD16=0 keeps fp32-input MFMA)
+        h16 = getattr(self, "_gpool", None) is not None and os.environ.get("DIFFPURE_ATTN_BWD16", "1") != "0"
+        _, probs = ops.attention(qkv, 1, "split", probs_only=True, h16=h16)
+        dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), 1, "split", h16=h16)
         del probs
         dhn = self._dconv(dqkv.view(b, hh, ww, 3 * c), n + ".dwqkv", r["dh2"], c, 1)
         return ops.group_norm_bwd(t["x"], self._groups(c), P[n + ".g"], P[n + ".b"], t["st"], dhn, addend=dout, addend_scale=INV_SQRT2)[0]

@@ -551,12 +551,22 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
     dy at the forward's output resolution). -> (dx, dx2); with split=True (single source) dx is the zero-bordered h2
     operand for the next dgrad convolution.
     addend / addend2 (fp32 output only): a second gradient arriving at the same tensors (the skip branch of a ResBlock): dx += addend_scale * addend,
-    dx2 += addend_scale * addend2 - inside the one-pass kernel where the shape fits one workgroup per channel block (small feature maps), else by
-    an `add` launch behind the three-launch form.  one_pass=False forces the three-launch form (tests, probes)."""
-    _chk(x, "gn_bwd.x", 4)
+    dx2 += addend_scale * addend2 - inside the one-pass kernel where the shape fits one workgroup per channel block (small feature maps), else
+    inside the apply pass of the three-launch form.  one_pass=False forces the three-launch form (tests, probes)."""
+    # x / x2 (the forward's input as the tape holds it): fp32, or plain fp16 where the taped forward ran on the fp16 residual stream
+    x16 = isinstance(x, torch.Tensor) and x.dtype == torch.float16
+    if x16:
+        _chk_f16(x, "gn_bwd.x16")
+        if x2 is not None:
+            _chk_f16(x2, "gn_bwd.x2_16")
+    else:
+        _chk(x, "gn_bwd.x", 4)
+        if x2 is not None:
+            _chk(x2, "gn_bwd.x2", 4)
     _chk(dy, "gn_bwd.dy", 4)
     b, h, w, c1 = x.shape
-    c2 = 0 if x2 is None else _chk(x2, "gn_bwd.x2", 4).shape[3]
+    c2 = 0 if x2 is None else x2.shape[3]
+    xfmt = 1 if x16 else 0
     c = c1 + c2
     fs = fh = None
     fstride = 0
@@ -572,8 +582,8 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
         dx = torch.empty((b, h + 2, w + 2, c if ofmt == 2 else 2 * c), device=x.device, dtype=torch.float16)
         dx2 = None
     else:
-        dx = torch.empty_like(x)
-        dx2 = None if x2 is None else torch.empty_like(x2)
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        dx2 = None if x2 is None else torch.empty(x2.shape, device=x.device, dtype=torch.float32)
         if addend is not None:
             _chk(addend, "gn_bwd.addend", 4)
             assert addend.shape == x.shape
@@ -581,21 +591,19 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
             assert x2 is not None and _chk(addend2, "gn_bwd.addend2", 4).shape == x2.shape
     s = _stream()
     if one_pass is not False and resample <= RESAMPLE_DOWN and gn_bwd_fused_ok(h, w, c1, c2, groups, resample):
-        _lib.call("dp_gn_bwd_fused", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
+        _lib.call("dp_gn_bwd_fused", _ptr(x), c1, _ptr(x2), c2, xfmt, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
                   fstride, 1 if act else 0, resample, _ptr(dy), ofmt, _ptr(dx), _ptr(dx2), _ptr(addend), _ptr(addend2), float(addend_scale), s)
         return dx, dx2
     fkeep, fptr = _fir_arg(resample, fir)
     ns = _nsplit(h * w)
     partial = torch.empty((b, ns, groups, 2), device=x.device, dtype=torch.float32)
     sums = torch.empty((b, groups, 2), device=x.device, dtype=torch.float32)
-    common = (_ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
+    common = (_ptr(x), c1, _ptr(x2), c2, xfmt, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
               fstride, 1 if act else 0, resample, fptr, _ptr(dy))
     _lib.call("dp_gn_bwd_stats", *common, ns, _ptr(partial), _ptr(sums), s)
-    _lib.call("dp_gn_bwd_apply", *common, _ptr(sums), ofmt, _ptr(dx), _ptr(dx2), s)
-    if addend is not None:
-        dx = add(dx, addend) if addend_scale == 1.0 else axpby(dx, 1.0, addend, addend_scale)
-    if addend2 is not None:
-        dx2 = add(dx2, addend2) if addend_scale == 1.0 else axpby(dx2, 1.0, addend2, addend_scale)
+    # the skip branch's gradient joins dx inside the apply pass (round 5; rounds 3-4 ran an `add` launch behind it: 6.6 % of the ImageNet
+    # adjoint step)
+    _lib.call("dp_gn_bwd_apply", *common, _ptr(sums), ofmt, _ptr(dx), _ptr(dx2), _ptr(addend), _ptr(addend2), float(addend_scale), s)
     return dx, dx2
 
 
@@ -752,35 +760,47 @@ def attention_fused(qkv, n_heads, layout, operand_hw=None):
     return out
 
 
-def attention(qkv, n_heads, layout, return_probs=False):
+def _gemm(h16, m, n, k):
+    """the strided GEMM entry point: on the fp16 matrix cores (operands rounded to fp16, fp32 accumulation) where `h16` asks for it and
+    the shape is one dp_gemm_strided_h16 serves, else the fp32-input MFMA kernel"""
+    return "dp_gemm_strided_h16" if h16 and _lib.load().dp_gemm_strided_h16_ok(m, n, k) else "dp_gemm_strided"
+
+
+def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=False):
     """softmax(q k^T / sqrt(d)) v for qkv [B, T, 3C] -> [B, T, C]  (, probs [B*heads, T, T]).
     layout 'legacy': channels = heads x [q(d) | k(d) | v(d)]   (QKVAttentionLegacy, unet.py:345-362)
-    layout 'split' : channels = [Q(all heads) | K | V]         (QKVAttention unet.py:377-397; NCSN++ q,k,v NINs)"""
+    layout 'split' : channels = [Q(all heads) | K | V]         (QKVAttention unet.py:377-397; NCSN++ q,k,v NINs)
+    probs_only=True: only the probabilities are wanted (the backward pass recomputes them from the taped qkv): the P V product is
+    skipped and (None, probs) returned.  h16=True (the fp16 x fp16 precision modes' gradient path): the products run on the fp16
+    matrix cores where dp_gemm_strided_h16 serves the shape."""
     _chk(qkv, "attention.qkv", 3)
     b, t, c3 = qkv.shape
     c = c3 // 3
     d = c // n_heads
-    if not return_probs and attention_fused_ok(t, d):
+    if not return_probs and not probs_only and attention_fused_ok(t, d):
         return attention_fused(qkv, n_heads, layout)
     oq, ok, ov, sh = _attn_offsets(c, d, layout)
     s = _stream()
     scores = torch.empty((b * n_heads, t, t), device=qkv.device, dtype=torch.float32)
-    out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
     base = qkv.data_ptr()
     el = 4
     # scores[z] = (1/sqrt(d)) * Q K^T
-    _lib.call("dp_gemm_strided", base + oq * el, c3, t * c3, sh, 0, base + ok * el, c3, t * c3, sh, 1,
+    _lib.call(_gemm(h16, t, t, d), base + oq * el, c3, t * c3, sh, 0, base + ok * el, c3, t * c3, sh, 1,
               _ptr(scores), t, n_heads * t * t, t * t, t, t, d, b, n_heads, 1.0 / math.sqrt(d), s)
     _lib.call("dp_softmax_rows", _ptr(scores), b * n_heads * t, t, s)
+    if probs_only:
+        return None, scores
+    out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
     # out[z] = P V
-    _lib.call("dp_gemm_strided", _ptr(scores), t, n_heads * t * t, t * t, 0, base + ov * el, c3, t * c3, sh, 0,
+    _lib.call(_gemm(h16, t, d, t), _ptr(scores), t, n_heads * t * t, t * t, 0, base + ov * el, c3, t * c3, sh, 0,
               _ptr(out), c, t * c, d, t, d, t, b, n_heads, 1.0, s)
     return (out, scores) if return_probs else out
 
 
-def attention_bwd(qkv, probs, dout, n_heads, layout):
+def attention_bwd(qkv, probs, dout, n_heads, layout, h16=False):
     """Gradient of `attention` w.r.t. qkv: dV = P^T dO, dP = dO V^T, dS = softmax'(P, dP),
-    dQ = dS K / sqrt(d), dK = dS^T Q / sqrt(d), written into dqkv [B, T, 3C] in the same layout."""
+    dQ = dS K / sqrt(d), dK = dS^T Q / sqrt(d), written into dqkv [B, T, 3C] in the same layout.
+    h16=True: the four products on the fp16 matrix cores (see `attention`); softmax' stays fp32."""
     _chk(qkv, "attention_bwd.qkv", 3)
     _chk(probs, "attention_bwd.probs", 3)
     _chk(dout, "attention_bwd.dout", 3)
@@ -796,17 +816,17 @@ def attention_bwd(qkv, probs, dout, n_heads, layout):
     sc = 1.0 / math.sqrt(d)
     zb, zh = n_heads * t * t, t * t
     # dV[s][c] = sum_t P[t][s] dO[t][c]                 (A = P stored [K=t][M=s] -> transA)
-    _lib.call("dp_gemm_strided", _ptr(probs), t, zb, zh, 1, do0, c, t * c, d, 0, g0 + ov * el, c3, t * c3, sh,
+    _lib.call(_gemm(h16, t, d, t), _ptr(probs), t, zb, zh, 1, do0, c, t * c, d, 0, g0 + ov * el, c3, t * c3, sh,
               t, d, t, b, n_heads, 1.0, s)
     # dP[t][s] = sum_c dO[t][c] V[s][c]                 (B = V stored [N=s][K=c] -> transB)
-    _lib.call("dp_gemm_strided", do0, c, t * c, d, 0, q0 + ov * el, c3, t * c3, sh, 1, _ptr(dp), t, zb, zh,
+    _lib.call(_gemm(h16, t, t, d), do0, c, t * c, d, 0, q0 + ov * el, c3, t * c3, sh, 1, _ptr(dp), t, zb, zh,
               t, t, d, b, n_heads, 1.0, s)
     _lib.call("dp_softmax_bwd_rows", _ptr(probs), _ptr(dp), b * n_heads * t, t, s)
     # dQ[t][c] = sc * sum_s dS[t][s] K[s][c]
-    _lib.call("dp_gemm_strided", _ptr(dp), t, zb, zh, 0, q0 + ok * el, c3, t * c3, sh, 0, g0 + oq * el, c3, t * c3, sh,
+    _lib.call(_gemm(h16, t, d, t), _ptr(dp), t, zb, zh, 0, q0 + ok * el, c3, t * c3, sh, 0, g0 + oq * el, c3, t * c3, sh,
               t, d, t, b, n_heads, sc, s)
     # dK[s][c] = sc * sum_t dS[t][s] Q[t][c]            (A = dS stored [K=t][M=s] -> transA)
-    _lib.call("dp_gemm_strided", _ptr(dp), t, zb, zh, 1, q0 + oq * el, c3, t * c3, sh, 0, g0 + ok * el, c3, t * c3, sh,
+    _lib.call(_gemm(h16, t, d, t), _ptr(dp), t, zb, zh, 1, q0 + oq * el, c3, t * c3, sh, 0, g0 + ok * el, c3, t * c3, sh,
               t, d, t, b, n_heads, sc, s)
     return dqkv
 

@@ -393,11 +393,11 @@ class Purifier:
             tape = []
             # reverse step k re-crosses the INTERVAL of forward step N-1-k (from its far end: it evaluates eps at
             # s = 1e-5 + k*step, the forward step evaluated it at the interval's other end) and takes that step's stochastic
-            # weight-rounding KEY (f16sr).  Same key does not mean the same network bit for bit: the taped forward is the fp32-stream
-            # variant (fp32 residual stream, three-pass attention, separate w2 / skip panels - which draw their own roundings where
-            # the no-tape forward reads one fused [w2 | skip] panel), so forward solve and adjoint agree per interval only up to the
-            # rounding noise itself (bounded by tests/test_gpu_grad.py::test_taped_and_untaped_forward_agree_under_f16sr; the
-            # directional derivative of the f16sr forward solve is checked against finite differences next to it)
+            # weight-rounding KEY (f16sr).  Since round 5 the taped forward runs on the same fp16 residual stream as the untaped one
+            # (same fused [w2 | skip] panels, same one-pass attention): per interval, forward solve and adjoint evaluate the SAME
+            # rounded network bit for bit (tests/test_gpu_grad.py::test_taped_and_untaped_forward_agree_under_f16sr asserts equality;
+            # the directional derivative of the f16sr forward solve is checked against finite differences next to it).
+            # DIFFPURE_TAPE16=0 restores round 4's fp32-stream tape (equal only up to rounding noise).
             self._reround(len(sched) - 1 - k)
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             g = self.net.vjp(tape, a)                       # (d eps / d y)^T a

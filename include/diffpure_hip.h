@@ -172,6 +172,17 @@ int dp_gemm_strided(const float* A, int lda, long long sAb, long long sAh, int t
                     float* C, int ldc, long long sCb, long long sCh,
                     int M, int N, int K, int ZB, int ZH, float alpha, void* stream);
 
+/* The same contract on the fp16 matrix cores (round 5): the fp32 operands are rounded to fp16 (nearest) on their way into LDS, one
+ * fp16 MFMA pass per product, fp32 accumulation, fp32 result - the arithmetic the input-gradient convolutions of the fp16 x fp16
+ * precision modes already use.  Serves the attention BACKWARD of those modes (the recomputed scores and dV, dP, dQ, dK: torch autograd
+ * through unet.py:345-362 / layerspp.py:75-91 under the reference's use_fp16 torso runs them in fp16 as well).  Shapes:
+ * dp_gemm_strided_h16_ok(M, N, K) (M % 128 == 0, N % 128 == 0, K % 32 == 0); anything else stays on dp_gemm_strided. */
+int dp_gemm_strided_h16_ok(int M, int N, int K);
+int dp_gemm_strided_h16(const float* A, int lda, long long sAb, long long sAh, int transA,
+                        const float* B, int ldb, long long sBb, long long sBh, int transB,
+                        float* C, int ldc, long long sCb, long long sCh,
+                        int M, int N, int K, int ZB, int ZH, float alpha, void* stream);
+
 /* Row softmax in place, rows x cols fp32 (unet.py:358 `th.softmax(weight.float(), -1)`,
  * layerspp.py:84). */
 int dp_softmax_rows(float* x, long long rows, int cols, void* stream);
@@ -267,25 +278,31 @@ int dp_ddpm_step(const float* x, const float* out6, int B, int HW, int C,
  *   da = resample^T(dy); du = da*act'(u); dxh = du*(1+fscale)*gamma;
  *   dx = rstd*(dxh - mean_g(dxh) - xh*mean_g(dxh*xh)).
  * H, W = INPUT resolution of the forward; dy: [B][Ho][Wo][C] fp32 (Ho, Wo per `resample`).
+ * x_fmt (ABI 7): 0 = x1 / x2 are fp32 [B][H][W][C1 | C2]; 1 = PLAIN fp16 - the taped forward of the fp16 x fp16 modes keeps the fp16
+ * residual stream (round 5: the adjoint re-runs exactly the network the forward solve evaluated), so the tape holds fp16 tensors and
+ * the backward reads them as stored; dy, the sums and dx stay fp32.
  * dp_gn_bwd_stats: slab partials [B][nsplit][G][2] -> sums [B][G][2] = the two group means.
  * dp_gn_bwd_apply: dx1 [B][H][W][C1] (+ dx2 [B][H][W][C2]) fp32, or with out_fmt=1 (C2 == 0) dx1 in
  * the zero-bordered h2 operand format, out_fmt=2 in the zero-bordered plain-fp16 ("h1") operand format, ready for the
- * next dgrad convolution (three-pass / one-pass fp16 matrix path). */
-int dp_gn_bwd_stats(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+ * next dgrad convolution (three-pass / one-pass fp16 matrix path).  add1 / add2 (ABI 7; optional, fp32 output only): a second
+ * gradient arriving at the same tensors - the skip branch of a ResBlock (unet.py:262-264 / layerspp.py:272-274) - is added in the same
+ * pass, dx += add_scale * add, as dp_gn_bwd_fused does for the small feature maps. */
+int dp_gn_bwd_stats(const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                     const float* stats, const float* gamma, const float* beta,
                     const float* fscale, const float* fshift, int film_stride, int act, int resample,
                     const float* fir4, const float* dy, int nsplit, float* partial, float* sums, void* stream);
-int dp_gn_bwd_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+int dp_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                     const float* stats, const float* gamma, const float* beta,
                     const float* fscale, const float* fshift, int film_stride, int act, int resample,
-                    const float* fir4, const float* dy, const float* sums, int out_fmt, void* dx1, float* dx2, void* stream);
+                    const float* fir4, const float* dy, const float* sums, int out_fmt, void* dx1, float* dx2,
+                    const float* add1, const float* add2, float add_scale, void* stream);
 /* The same operator in ONE pass over x and dy (ABI 6), for small feature maps - CIFAR-10 sizes: one workgroup per (sample, block of
  * whole groups) keeps its pixels in registers between the group sums and the update, so x and dy are read once instead of twice and
  * three launches become one.  dp_gn_bwd_fused_ok(): does the tensor shape fit (a function of the shape only; resample 0 | 1 | 2 - the
  * FIR modes keep the three-launch form)?  add1 / add2 (optional, fp32 output only): a second gradient arriving at the same tensors
  * (the skip branch of a ResBlock, unet.py:262-264 / layerspp.py:272-274) is added in the same pass (dx += add_scale * add), replacing a dp_add / dp_axpby launch. */
 int dp_gn_bwd_fused_ok(int H, int W, int C1, int C2, int G, int resample);
-int dp_gn_bwd_fused(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int G,
+int dp_gn_bwd_fused(const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                     const float* stats, const float* gamma, const float* beta,
                     const float* fscale, const float* fshift, int film_stride, int act, int resample,
                     const float* dy, int out_fmt, void* dx1, float* dx2, const float* add1, const float* add2, float add_scale, void* stream);

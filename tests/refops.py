@@ -254,7 +254,10 @@ def resample(x, mode, fir=None):
     return _resample(x, mode, fir).contiguous()
 
 
-def attention(qkv, n_heads, layout, return_probs=False):
+def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=False):
+    """(h16 - fp16 matrix cores for the gradient path - has no CPU counterpart: the stand-in computes in fp32 either way)"""
+    if probs_only:
+        return None, attention(qkv, n_heads, layout, return_probs=True)[1]
     b, t, c3 = qkv.shape
     c = c3 // 3
     d = c // n_heads
@@ -270,7 +273,7 @@ def attention(qkv, n_heads, layout, return_probs=False):
     return (out, w.reshape(b * n_heads, t, t).contiguous()) if return_probs else out
 
 
-def attention_bwd(qkv, probs, dout, n_heads, layout):
+def attention_bwd(qkv, probs, dout, n_heads, layout, h16=False):
     with torch.enable_grad():
         q = qkv.detach().clone().requires_grad_(True)
         out = attention(q, n_heads, layout)
@@ -286,8 +289,9 @@ def group_norm_bwd(x, groups, gamma, beta, stats, dy, x2=None, film=None, act=Fa
                    fir=None, addend=None, addend2=None, addend_scale=1.0, one_pass=None):
     """autograd through the torch statement of the forward (eps folded back out of `stats`); dx += addend_scale * addend."""
     with torch.enable_grad():
-        a = x.detach().clone().requires_grad_(True)
-        b2 = None if x2 is None else x2.detach().clone().requires_grad_(True)
+        # (x / x2 may be the fp16 tensors of a tape that ran on the fp16 residual stream: same values, gradients are fp32)
+        a = x.detach().float().clone().requires_grad_(True)
+        b2 = None if x2 is None else x2.detach().float().clone().requires_grad_(True)
         xin = _cat(a, b2)
         bb, h, w, c = xin.shape
         v = xin.reshape(bb, h * w, groups, c // groups)

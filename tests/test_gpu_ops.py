@@ -764,9 +764,9 @@ def test_torch_ops_abi6_operators_and_autograd_formulas(dev):
     gam, bet = (1 + 0.1 * rnd(C, seed=13)).to(dev), (0.1 * rnd(C, seed=14)).to(dev)
     xr = (x * 2 + 0.5).to(dev).requires_grad_(True)
     cot = rnd(B, H, W, C, seed=15).to(dev)
-    (g,) = torch.autograd.grad(T.group_norm_silu(xr, gam, bet, 32, 1e-5, True, 0), xr, cot)
+    (g,) = torch.autograd.grad(T.group_norm_silu(xr, gam, bet, 16, 1e-5, True, 0), xr, cot)
     xt = (x * 2 + 0.5).to(dev).requires_grad_(True)
-    (gt,) = torch.autograd.grad(F.silu(F.group_norm(xt.permute(0, 3, 1, 2), 32, gam, bet, 1e-5)).permute(0, 2, 3, 1), xt, cot)
+    (gt,) = torch.autograd.grad(F.silu(F.group_norm(xt.permute(0, 3, 1, 2), 16, gam, bet, 1e-5)).permute(0, 2, 3, 1), xt, cot)
     assert (g - gt).abs().max() < 1e-4 * gt.abs().max(), (g - gt).abs().max()
     for heads, c, legacy in ((2, 128, True), (3, 96, False)):       # flash forward (d = 64) / GEMM + softmax forward (d = 32); both backward by GEMMs
         qr = rnd(2, 64, 3 * c, seed=16).to(dev).requires_grad_(True)
@@ -1150,3 +1150,49 @@ def test_conv2d_half_height_tile_kernel_is_bit_identical(dev, case, tune):
     ref = (ref * scale).float()
     err = (got[sub].float().cpu() - ref).abs().max().item()
     assert err < (2e-3 if out16 else 3e-5) * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("trans", [(0, 0), (0, 1), (1, 0), (1, 1)], ids=str)
+def test_gemm_strided_on_the_fp16_matrix_cores(dev, trans):
+    """Round 5: dp_gemm_strided_h16 - the strided batched GEMM with operands rounded to fp16 on their way into LDS, one fp16 MFMA pass,
+    fp32 accumulation - against the exact fp64 product of the fp16-rounded operands, in all four storage forms, with batch and head
+    strides that differ from the dense ones (the attention backward reads q, k, v in place inside qkv)."""
+    from diffpure_amd import _lib
+    ta, tb = trans
+    ZB, ZH, M, N, K = 2, 3, 256, 128, 96
+    lda, ldb, ldc = (M if ta else K) + 8, (K if tb else N) + 4, N + 12
+    ra, rb = (K if ta else M), (N if tb else K)            # stored rows
+    A = rnd(ZB, ZH, ra, lda, seed=1).to(dev)
+    B = rnd(ZB, ZH, rb, ldb, seed=2).to(dev)
+    Cm = torch.zeros(ZB, ZH, M, ldc, device=dev)
+    assert _lib.load().dp_gemm_strided_h16_ok(M, N, K) == 1 and _lib.load().dp_gemm_strided_h16_ok(M, 64, K) == 0
+    _lib.call("dp_gemm_strided_h16", A.data_ptr(), lda, ZH * ra * lda, ra * lda, ta, B.data_ptr(), ldb, ZH * rb * ldb, rb * ldb, tb,
+              Cm.data_ptr(), ldc, ZH * M * ldc, M * ldc, M, N, K, ZB, ZH, 0.25, torch.cuda.current_stream().cuda_stream)
+    a = A.cpu().half().double()
+    b = B.cpu().half().double()
+    a = (a[..., :M].transpose(-1, -2) if ta else a[..., :K])          # [.., M, K]
+    b = (b[..., :K].transpose(-1, -2) if tb else b[..., :N])          # [.., K, N]
+    ref = (0.25 * (a @ b)).float()
+    got = Cm.cpu()[..., :N]
+    assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (got - ref).abs().max()
+    assert (Cm.cpu()[..., N:] == 0).all()                             # nothing written beyond the N columns
+
+
+@pytest.mark.parametrize("case", [(2, 256, 256, 1, "split"), (2, 256, 128, 2, "legacy")], ids=str)
+def test_attention_backward_on_the_fp16_matrix_cores(dev, case):
+    """The attention backward of the fp16 x fp16 precision modes (h16=True): recomputed probabilities (no P V product) and the four
+    gradient products on dp_gemm_strided_h16 where the shape allows (NCSN++: T = 256, d = 256 - all of them; guided heads of d = 64:
+    q k^T and dP), against fp64 autograd: within 3e-3 of the largest entry (the operands carry 11 bits)."""
+    from diffpure_amd import ops
+    B, T, C, heads, layout = case
+    qkv, dout = rnd(B, T, 3 * C, seed=11), rnd(B, T, C, seed=12)
+    ref = refops.attention_bwd(qkv.double(), None, dout.double(), heads, layout).float()
+    none, probs = ops.attention(qkv.to(dev), heads, layout, probs_only=True, h16=True)
+    assert none is None
+    got = ops.attention_bwd(qkv.to(dev), probs, dout.to(dev), heads, layout, h16=True)
+    err = ((got.cpu() - ref).abs().max() / ref.abs().max()).item()
+    _, p32 = ops.attention(qkv.to(dev), heads, layout, return_probs=True)
+    g32 = ops.attention_bwd(qkv.to(dev), p32, dout.to(dev), heads, layout)
+    err32 = ((g32.cpu() - ref).abs().max() / ref.abs().max()).item()
+    print(f"attention backward {case}: fp16 matrix cores {err:.2e} of the largest entry, fp32-input MFMA {err32:.2e}")
+    assert err < 3e-3 and err32 < 1e-4, (err, err32)

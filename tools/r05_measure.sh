@@ -56,6 +56,29 @@ dh)     # the half-height tile kernel: its tests, the per-shape A/B, the adjoint
   done; lap guided_b4_ab
   timeout 150 python tests/probes/dw8_power.py --seconds 4 > "$O/dw8_power.log" 2>&1; lap dw8_power
   ;;
+attn16)   # fp16 attention backward: tests + adjoint A/B
+  timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_grad.py -m gpu -q -k "fp16_matrix_cores or torch_ops or attention_bwd or taped_and_untaped or finite_differences" > "$O/attn16_tests.log" 2>&1; echo "rc=$?" >> "$O/attn16_tests.log"; lap attn16_tests
+  grep -E "passed|failed|^FAILED|^E  |attention backward|f16sr" "$O/attn16_tests.log" | head -30
+  for V in 0 1 0 1; do
+    DIFFPURE_ATTN_BWD16=$V timeout 300 python bench.py --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_cifar_adjoint_t20_attn16_$V.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_cifar_adjoint_t20_attn16_$V.json').read().strip().splitlines()[-1]); print('adjoint t20 ATTN_BWD16=$V', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz'])" | tee -a "$O/attn16_ab.log"
+  done; lap adjoint_ab
+  ;;
+tape16)   # the taped forward on the fp16 residual stream: gradient tests + A/B
+  timeout 900 python -m pytest tests/test_gpu_grad.py tests/test_gpu_ops.py -m gpu -q -x -s -k "not conv2d" > "$O/grad_tests.log" 2>&1; echo "rc=$?" >> "$O/grad_tests.log"; lap grad_tests
+  grep -E "passed|failed|^FAILED|^E  |f16sr|adjoint|VJP" "$O/grad_tests.log" | head -40
+  timeout 900 python -m pytest tests/test_gpu_loops.py -m gpu -q -s -k "adjoint and not guided_sde_stochastic_adjoint_100 and not at_batch_8_reproduces or vjp" > "$O/loop_tests.log" 2>&1; echo "rc=$?" >> "$O/loop_tests.log"; lap loop_tests
+  grep -E "passed|failed|^FAILED|^E  |adjoint|VJP" "$O/loop_tests.log" | head -40
+  for V in 0 1 0 1; do
+    DIFFPURE_TAPE16=$V timeout 300 python bench.py --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_cifar_adjoint_t20_tape16_$V.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_cifar_adjoint_t20_tape16_$V.json').read().strip().splitlines()[-1]); print('cifar adjoint t20 TAPE16=$V', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz']['median'], 'peak GiB', round(d['peak_device_memory_gib'],1))" | tee -a "$O/tape16_ab.log"
+  done; lap cifar_adjoint_ab
+  for V in 0 1; do
+    DIFFPURE_TAPE16=$V timeout 300 python bench.py --workload imagenet256_guided_sde_adjoint --batch 32 --t 10 --steps 1 --warmup 0 --no-cpu-baseline --no-resident-call > "$O/bench_guided_adjoint_b32_t10_tape16_$V.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_guided_adjoint_b32_t10_tape16_$V.json').read().strip().splitlines()[-1]); print('guided sde adjoint B=32 t10 TAPE16=$V', round(d['value'],3), 'images/s', d['roofline']['sclk_mhz'], 'peak GiB', round(d['peak_device_memory_gib'],1))" | tee -a "$O/tape16_ab.log"
+  done; lap guided_adjoint_ab
+  rocstats guided_sde_adjoint_b32_t5 300 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
