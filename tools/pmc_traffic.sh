@@ -13,7 +13,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf "$OUT/$C"
   rocprofv3 --kernel-trace --pmc $C -d "$OUT/$C" -o run --output-format csv -- \
-      python "$REPO/bench.py" --t 2 --steps 1 --warmup 0 --no-cpu-baseline --no-conv-profile "$@" > "$OUT/$C.log" 2>&1
+      python "$REPO/bench.py" --t 2 --steps 1 --warmup 0 --no-cpu-baseline --no-conv-profile --no-resident-call "$@" > "$OUT/$C.log" 2>&1
   echo "$C rc=$?"
   find "$OUT/$C" -name "*agent_info.csv" -delete
 done

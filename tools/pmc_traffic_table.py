@@ -19,7 +19,7 @@ import sys
 
 
 def short(name):
-    if "conv_igemm_dw" in name or "conv_igemm_sw" in name or "conv_igemm_halo" in name or "conv_igemm_h2_pp" in name:
+    if "conv_igemm_dw" in name or "conv_igemm_dh" in name or "conv_igemm_sw" in name or "conv_igemm_halo" in name or "conv_igemm_h2_pp" in name:
         return "conv_igemm_h2_pp"            # the dominant kernel: the 256-wide-tile convolution in its one-wave-per-SIMD / ping-pong variants
     m = re.search(r"(conv_igemm_h2|conv_igemm_f32|splitk_epilogue|gn_apply_h16|gn_apply_h2q|gn_apply|round_weights|gn_finalize_cols|gn_stats|"
                   r"gn_finalize|attn_flash|attn_pack|em_step|ddpm_step|temb|softmax_rows|gemm_strided|philox|axpby|silu|pack_h2)", name)
