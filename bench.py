@@ -162,15 +162,16 @@ def pmc_mfma_busy():
     """MFMA utilisation of the dominant kernel by rocprofv3's own counter, from the committed PMC pass over its most common
     shape (3x3 256->256 at 256^2, B=64; tools/pmc_conv.sh): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
     Collected offline (counters cannot be read from inside the timed process), at the profiler's clock.  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r04", "pmc_conv_igemm_dw_256x256_256to256_b64_res16_out16.json")
-    try:
-        row = json.load(open(path))["conv_igemm_dw"]
-        return dict(value=row["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * row["GRBM_GUI_ACTIVE"] / 8.0),
-                    source="profiles/r04/pmc_conv_igemm_dw_256x256_256to256_b64_res16_out16.json (SQ_VALU_MFMA_BUSY_CYCLES over the SIMD "
-                           "cycles of the launch, 3x3 256->256 at 256^2, B=64, fp16 residual + fp16 output, under rocprofv3 --pmc: "
-                           "collected at HEAD by tools/final_measure_r04.sh)")
-    except Exception:
-        return None
+    for rnd in ("r05", "r04"):      # the newest committed pass (the kernel itself did not change in round 5)
+        rel = os.path.join("profiles", rnd, "pmc_conv_igemm_dw_256x256_256to256_b64_res16_out16.json")
+        try:
+            row = json.load(open(os.path.join(ROOT, rel)))["conv_igemm_dw"]
+            return dict(value=row["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * row["GRBM_GUI_ACTIVE"] / 8.0),
+                        source=rel + " (SQ_VALU_MFMA_BUSY_CYCLES over the SIMD cycles of the launch, 3x3 256->256 at 256^2, B=64, fp16 residual + "
+                                     "fp16 output, under rocprofv3 --pmc: a committed offline pass, not a measurement of this run)")
+        except Exception:
+            continue
+    return None
 
 
 def build_engine(workload, device, seed, precision):

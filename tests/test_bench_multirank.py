@@ -55,6 +55,16 @@ def test_bench_harness_at_world_8_takes_the_max_over_ranks():
     d = json.loads(lines[0])
     assert d["stub"] is True and d["n_gpus"] == 8 and d["config"]["global_batch"] == 24 and d["gather_ok"] is True
     assert d["ms_per_step"] >= 250.0, d["ms_per_step"]
+    # round 5: the line explains itself - every rank's own ms per step (the headline is their MAX), its held clock (None on CPU ranks),
+    # the time it spent inside the all-gather and its engine build time
+    r = d["ranks"]
+    assert all(len(r[k]) == 8 for k in ("ms_per_step_per_rank", "sclk_mhz_median_per_rank", "all_gather_ms_per_step_per_rank", "engine_build_s_per_rank"))
+    assert abs(max(r["ms_per_step_per_rank"]) - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+    assert all(v is not None and v >= 0.0 for v in r["all_gather_ms_per_step_per_rank"])
+    # the slow rank arrives last: it waits least inside the collective, the others wait for it there
+    ag = r["all_gather_ms_per_step_per_rank"]
+    assert ag[5] == min(ag) and max(ag) >= 200.0, ag
+    assert d["collectives"]["all_gather_ms"] == max(ag)
     assert abs(d["value"] - 24 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
 
 

@@ -180,7 +180,7 @@ def test_f16x3_mode_engine_wiring(kind, precision):
 def test_fp16_residual_stream_and_fused_skip_wiring(kind, monkeypatch):
     """Round 4, fp16 x fp16 modes: the residual stream travels as plain fp16 wherever a level has whole column records per sample
     (H*W % 64 == 0), every channel-changing ResBlock without resampling folds its 1x1 skip into its second convolution as
-    K-segments over the raw fp16 input(s), and the taped forward (adjoints) keeps fp32.  Traced on the torch statements of the ops:
+    K-segments over the raw fp16 input(s); the taped forward (adjoints) runs the same launches (round 5).  Traced on the torch statements of the ops:
     dtypes of every convolution's residual / output, the K-segment calls, and the result against the reference golden with the
     fp16 stream on and off (DIFFPURE_LEAN16=0)."""
     from diffpure_amd import ops
@@ -219,12 +219,25 @@ def test_fp16_residual_stream_and_fused_skip_wiring(kind, monkeypatch):
                                 [r for b in net.plan["inp"] for r in b] + net.plan["mid"] + [r for b in net.plan["out"] for r in b])
                     if r["kind"] == "res" and r["cin"] != r["cout"] and not r["mode"])
     assert len(fused) <= n_fusable and len(fused) >= 1
-    # the taped forward keeps the fp32 stream (the backward kernels read fp32) and never fuses
+    # round 5: the taped forward (adjoints) issues EXACTLY the launches of the untaped one - same stream format, same fused skips - and
+    # gives the same bits; the tape then holds fp16 tensors (round 4 kept an fp32-stream variant under a tape)
+    first = list(calls)
     calls.clear()
     tape = []
-    run(net, tape=tape)
+    out_t = nchw(run(net, tape=tape))
+    assert calls == first and torch.equal(out_t, out)
+    res_t = [t_ for t_ in tape if "hmid" in t_]
+    assert res_t and any(t_["x"].dtype == torch.float16 for t_ in res_t) and any(t_["hmid"].dtype == torch.float16 for t_ in res_t)
+    # ... and DIFFPURE_TAPE16=0 restores the fp32-stream tape: fp32 outputs on the stream, no fused skips
+    monkeypatch.setenv("DIFFPURE_TAPE16", "0")
+    net32 = build()
+    calls.clear()
+    tape = []
+    run(net32, tape=tape)
     assert all(c["out"] == torch.float32 or c["res"] is None for c in calls if c["k"] == 3 and c["res"] is not None)
     assert not any(c["segs"] for c in calls)
+    assert all(t_["x"].dtype == torch.float32 for t_ in tape if "hmid" in t_)
+    monkeypatch.delenv("DIFFPURE_TAPE16")
     # switch: DIFFPURE_LEAN16=0 -> round 3's fp32 stream, same function to the same tolerance
     monkeypatch.setenv("DIFFPURE_LEAN16", "0")
     net0 = build()
@@ -608,8 +621,8 @@ def test_fir_adjoint_stencils_match_autograd(taps):
 @pytest.mark.parametrize("kind", ["ncsnpp", "guided"])
 def test_one_pass_attention_and_folded_skip_gradient_wiring(kind, monkeypatch):
     """Round 4: (1) in the fp16 x fp16 modes the qkv convolution of an attention block the flash kernel covers hands it an fp16 qkv
-    (one fp16 pass, Q / K read in place) - but only without a tape (the backward pass recomputes the probabilities from an fp32 qkv),
-    and DIFFPURE_ATTN16=0 switches it off; (2) the backward pass hands the gradient of every ResBlock's skip branch and of an attention
+    (one fp16 pass, Q / K read in place) - since round 5 with a tape as well (the backward pass recomputes the probabilities from the taped
+    fp16 qkv) - and DIFFPURE_ATTN16=0 switches it off; (2) the backward pass hands the gradient of every ResBlock's skip branch and of an attention
     block's residual to the GroupNorm backward as `addend` (one pass on the GPU where the shape allows) instead of separate add launches -
     the input gradient still equals torch.autograd through the oracle's restatement of the reference network."""
     from diffpure_amd import ops
@@ -639,7 +652,7 @@ def test_one_pass_attention_and_folded_skip_gradient_wiring(kind, monkeypatch):
         assert seen and all(d == torch.float16 for d in seen), seen
         seen.clear()
         net.forward(nhwc(x), tt, tape=[])
-        assert seen and all(d == torch.float32 for d in seen), seen       # taped: fp32 qkv, three passes
+        assert seen and all(d == torch.float16 for d in seen), seen       # round 5: taped = untaped (fp16 qkv, one pass); round 4 kept fp32 here
         seen.clear()
         monkeypatch.setenv("DIFFPURE_ATTN16", "0")
         net.forward(nhwc(x), tt)

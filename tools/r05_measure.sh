@@ -79,6 +79,21 @@ tape16)   # the taped forward on the fp16 residual stream: gradient tests + A/B
   done; lap guided_adjoint_ab
   rocstats guided_sde_adjoint_b32_t5 300 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0
   ;;
+streams)
+  timeout 200 python tests/probes/two_stream_cifar.py 128 20 2 > "$O/two_stream_cifar.log" 2>&1; lap two_stream_2x128
+  timeout 200 python tests/probes/two_stream_cifar.py 64 20 4 >> "$O/two_stream_cifar.log" 2>&1; lap two_stream_4x64
+  cat "$O/two_stream_cifar.log"
+  ;;
+graph)
+  for G in 0 1 0 1; do
+    DIFFPURE_GRAPH=$G timeout 300 python bench.py --workload cifar32_ncsnpp --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile --engine-call > "$O/bench_cifar_t20_graph$G.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_cifar_t20_graph$G.json').read().strip().splitlines()[-1]); print('cifar t20 engine-call GRAPH=$G', round(d['value'],1), 'images/s', round(d['ms_per_step']/20,2), 'ms/UNet step', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/graph_ab.log"
+  done; lap graph_ab
+  for G in 0 1; do
+    DIFFPURE_GRAPH=$G timeout 300 python bench.py --batch 4 --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile --engine-call > "$O/bench_guided_b4_t20_graph$G.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_guided_b4_t20_graph$G.json').read().strip().splitlines()[-1]); print('guided B=4 t20 engine-call GRAPH=$G', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/graph_ab.log"
+  done; lap graph_b4
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
