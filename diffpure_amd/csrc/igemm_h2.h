@@ -70,8 +70,8 @@ void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s);
 
 // The same wave tiles on 128x256 tiles, four waves per workgroup, two workgroups per CU (igemm_h2_dh.hip): launches that do not fill
 // the chip with 256x256 tiles; the launcher fills p.tiles.
-bool dp_conv_dh_applies(const ConvH2Args& p);
-void dp_launch_conv_dh(ConvH2Args& p, hipStream_t s);
+bool dp_conv_dh_applies(const ConvH2Args& p, int bn);     // bn = 256: 128 x 256 tiles; bn = 128: 256 x 128 tiles (N % 256 != 0 layers)
+void dp_launch_conv_dh(ConvH2Args& p, hipStream_t s, int bn);
 
 // Few output channels (N <= 32: the 6-channel head), 3x3, fp16 x fp16: 256 x 32 tiles over x-halo activation runs (igemm_h2_nn.hip).
 bool dp_conv_nn_applies(const ConvH2Args& p);

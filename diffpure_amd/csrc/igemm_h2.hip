@@ -581,11 +581,13 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         }
     }
     {   // fp16 x fp16 launches that leave CUs idle on 256x256 tiles (fewer than 256 of them): the 4-wave kernel on 128x256 tiles
-        // (igemm_h2_dh.hip) - twice the workgroups, up to two per CU.  From 64 tiles of 256x256 up (128 half tiles: at least half the CUs);
+        // (igemm_h2_dh.hip) - twice the workgroups, up to two per CU.  From DP_H2_DH_MIN half tiles up (default 32: measured on the guided
+        // UNet's low levels at B = 4 / 16 - 128: 9.62 / 17.29, 64: 9.72, 32: 9.91 / 17.37 images/s at t = 20, profiles/r05/dhmin_ab.log -
+        // these launches are short of parallelism whatever the tile, but 32 workgroups of this kernel beat 512 of the 64x64 tiles);
         // smaller launches stay on the generic tiles.  DP_H2_DH = 0 never.  Bit-identical to the other variants.
         const long long t256 = tiles(256, 256);
-        if (dp_tune(DP_T_H2_DH) != 0 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && tiles(128, 256) >= 128 && t256 < 256 && dp_conv_dh_applies(p)) {
-            dp_launch_conv_dh(p, s);
+        if (dp_tune(DP_T_H2_DH) != 0 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && tiles(128, 256) >= dp_tune(DP_T_H2_DH_MIN) && t256 < 256 && dp_conv_dh_applies(p, 256)) {
+            dp_launch_conv_dh(p, s, 256);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
@@ -594,8 +596,21 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         }
         // split-K levels (<= 64 pixels per sample): the same kernel, one part per grid.y, from 128 workgroups up (DP_H2_DH = 1: never;
         // 2, the default: yes); the reduction + epilogue kernel below is shared with the generic tiles
-        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit > 1 && tiles(128, 256) * p.ksplit >= 128 && dp_conv_dh_applies(p)) {
-            dp_launch_conv_dh(p, s);
+        // layers with 128 output channels (NCSN++ 32x32 level) on the kernel's 256x128 form where the 512x128 one-wave-per-SIMD tiles do
+        // not fill the chip (fewer than 256 of them: B < 128 at 32x32; measured at B = 64: 429 -> 625 TFLOP/s).  On launches that do fill
+        // it the two forms are within +8 / -3 % of each other per shape and indistinguishable on the purification (720.6 vs 720.0
+        // images/s at t = 20, profiles/r05/dh128_ab.log), so the one-wave-per-SIMD tiles keep those; DP_H2_DH = 3 forces this form (probes)
+        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && N % 256 != 0 && KS == 3 && tiles(256, 128) >= dp_tune(DP_T_H2_DH_MIN) &&
+            (tiles(512, 128) < 256 || dp_tune(DP_T_H2_DH) >= 3) && dp_conv_dh_applies(p, 128)) {
+            dp_launch_conv_dh(p, s, 128);
+            dp_prof_set_kind(rec, DP_PROF_3X3_PP);
+            if (tile_rows) *tile_rows = 64;
+            dp_prof_end(rec, s);
+            DP_LAUNCH_CHECK("conv_igemm_dh<256>");
+            return 0;
+        }
+        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit > 1 && tiles(128, 256) * p.ksplit >= dp_tune(DP_T_H2_DH_MIN) && dp_conv_dh_applies(p, 256)) {
+            dp_launch_conv_dh(p, s, 256);
             DP_LAUNCH_CHECK("conv_igemm_dh (split-K)");
             hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, s, p);
             if (tile_rows) *tile_rows = 64;

@@ -39,10 +39,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int NXCD = 8;
 constexpr int ADEPTH = 3, BDEPTH = 3, DA = ADEPTH - 1;
-constexpr int ATILE = 128 * 64;                 // activation tile of one k-tile: 128 rows x 64 bytes (32 fp16)
-constexpr int BTILE = 256 * 64;                 // weight tile
-constexpr int BBASE = ADEPTH * ATILE;
-constexpr int RINGS = ADEPTH * ATILE + BDEPTH * BTILE;          // 72 KB
+constexpr int RINGS = (ADEPTH + BDEPTH) * 0 + 3 * (128 + 256) * 64;     // 72 KB: three stages of (128 + 256) operand rows x 64 bytes (32 fp16), either tile shape
 constexpr int EPI_LDS = 4 * 16 * SW_EPI_PITCH;                  // residual landing zone of four wave tiles: 68 KB (inside the dead rings)
 
 template <int N>
@@ -52,19 +49,27 @@ __device__ __forceinline__ void dh_wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// BMT x BNT = 128 x 256 (waves 2 (M) x 2 (N)) or - layers with 128 output channels - 256 x 128 (waves 4 (M) x 1): the same 64 x 128 wave
+// tile, the same 384 operand rows per k-tile and 6 DMA pieces per wave (NPA activation + NPB weight pieces of 16 rows), the same LDS.
+template <int BMT>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_dh(ConvH2Args p) {
+    static_assert(BMT == 128 || BMT == 256, "tile shapes");
+    constexpr int BNT = 384 - BMT;
+    constexpr int ATILE = BMT * 64, BTILE = BNT * 64;           // operand tiles of one k-tile
+    constexpr int BBASE = ADEPTH * ATILE;
+    constexpr int NPA = BMT / 64, NPB = BNT / 64;               // 16-row DMA pieces per wave and k-tile: 2 + 4 or 4 + 2
     __shared__ __attribute__((aligned(1024))) char smem[RINGS > EPI_LDS ? RINGS : EPI_LDS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = BMT == 128 ? wave >> 1 : wave, wc = BMT == 128 ? wave & 1 : 0;
     int tile;
     {   // XCD-aware bijective remap (speed only)
         const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
     }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 256;
+    const int m0 = tile_m * BMT, n0 = tile_n * BNT;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     // split-K (the <= 64-pixel levels, igemm_h2.hip::h2_ksplit - a function of the layer shape only): this workgroup reduces k-tiles
     // [t0, t0 + nt) of the layer's K / 32 - the same floor partition as the generic tiles, so the partial sums are the same bits -
@@ -77,18 +82,18 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dh(ConvH2Args p) {
     // the row key (the fragment reads below undo it)
     const int lrow = lane >> 2;
     const int ls = (lane & 3) ^ ((lrow >> 2) & 3);
-    const char* actr[2];                        // centre pixel of the lane's A row (segments: the lane's pixel), + slot
-    const char* bptr[4];
+    const char* actr[NPA];                      // centre pixel of the lane's A row (segments: the lane's pixel), + slot
+    const char* bptr[NPB];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int m = m0 + wave * 32 + it * 16 + lrow;
+    for (int it = 0; it < NPA; ++it) {
+        const int m = m0 + wave * (BMT / 4) + it * 16 + lrow;
         const int b = m / HW, rem = m - b * HW;
         const int oy = rem / p.W, ox = rem - oy * p.W;
         actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int n = n0 + wave * 64 + it * 16 + lrow;              // block layout of the fp16 panels (ops.order_conv_weight_w16)
+    for (int it = 0; it < NPB; ++it) {
+        const int n = n0 + wave * (BNT / 4) + it * 16 + lrow;       // block layout of the fp16 panels (ops.order_conv_weight_w16)
         bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
     // (tap, slice) of the next activation k-tile to stage, inside the current K-segment: segment 0 = the KS x KS convolution over
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dh(ConvH2Args p) {
         const char* sb = seg == 1 ? p.seg1 : p.seg2;
         const int sc = seg == 1 ? p.segC1 : p.segC2;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) actr[j] = sb + (size_t)(m0 + wave * 32 + j * 16 + lrow) * sc * 2 + ls * 16;
+        for (int j = 0; j < NPA; ++j) actr[j] = sb + (size_t)(m0 + wave * (BMT / 4) + j * 16 + lrow) * sc * 2 + ls * 16;
         seg_slices = sc / 32;
         cur_c = slice;
         cur_tap = 0;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dh(ConvH2Args p) {
             else enter_segment(2, rem - p.segC1 / 32);
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) bptr[it] += (size_t)t0 * 2048;
+        for (int it = 0; it < NPB; ++it) bptr[it] += (size_t)t0 * 2048;
     }
     long long a_off = 0;
     auto pieceA = [&](int aoff, int it) {       // aoff: byte offset of the ring stage
@@ -129,18 +134,26 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dh(ConvH2Args p) {
             }
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(actr[it] + a_off),
-                                         (__attribute__((address_space(3))) void*)(smem + aoff + (wave * 32 + it * 16) * 64), 16, 0, 0);
-        if (it == 1 && (cur_seg != 0 || ++cur_tap == taps)) { cur_tap = 0; ++cur_c; }
+                                         (__attribute__((address_space(3))) void*)(smem + aoff + (wave * (BMT / 4) + it * 16) * 64), 16, 0, 0);
+        if (it == NPA - 1 && (cur_seg != 0 || ++cur_tap == taps)) { cur_tap = 0; ++cur_c; }
     };
     auto pieceB = [&](int boff, int it) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
-                                         (__attribute__((address_space(3))) void*)(smem + boff + (wave * 64 + it * 16) * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + boff + (wave * (BNT / 4) + it * 16) * 64), 16, 0, 0);
         bptr[it] += 2048;
     };
-    auto issueA = [&](int aoff) { pieceA(aoff, 0); pieceA(aoff, 1); };
+    auto issueA = [&](int aoff) {
+#pragma unroll
+        for (int it = 0; it < NPA; ++it) pieceA(aoff, it);
+    };
     auto issueB = [&](int boff) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) pieceB(boff, it);
+        for (int it = 0; it < NPB; ++it) pieceB(boff, it);
+    };
+    // DMA piece d = 0 .. 5 of a k-tile in issue order: the NPB weight pieces, then the NPA activation pieces
+    auto piece = [&](int aoff, int boff, int d) {
+        if (d < NPB) pieceB(boff, d);
+        else pieceA(aoff, d - NPB);
     };
 
     // ---- fragments: lane -> row lr of a 32-row MFMA tile, k-half lk; 64-byte rows, slot (s*2 + lk) ^ key, key = (row >> 2) & 3
@@ -205,17 +218,17 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dh(ConvH2Args p) {
     for (; t + DA < nt; ++t) {
         // first half: 8 MFMAs on fragment set 0 | the 6 reads of set 1 and the 6 DMA pieces, one (read, piece) pair per MFMA shadow
         readA(1, ar[0], 0);
-        pieceB(br[2], 0);
+        piece(ar[DA], br[2], 0);
         readA(1, ar[0], 1);
-        pieceB(br[2], 1);
+        piece(ar[DA], br[2], 1);
         readB(1, br[0], 0);
-        pieceB(br[2], 2);
+        piece(ar[DA], br[2], 2);
         readB(1, br[0], 1);
-        pieceB(br[2], 3);
+        piece(ar[DA], br[2], 3);
         readB(1, br[0], 2);
-        pieceA(ar[DA], 0);
+        piece(ar[DA], br[2], 4);
         readB(1, br[0], 3);
-        pieceA(ar[DA], 1);
+        piece(ar[DA], br[2], 5);
         mfma_rows(0, 0, 2);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
@@ -275,22 +288,27 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_dh(ConvH2Args p) {
         return;
     }
     // after the last barrier nothing reads the rings any more: each wave lands its fp16 residual tile in its own 17 KB of them
-    sw_epilogue_any<1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * 2 + wr, lr, lk, HW, smem + wave * (16 * SW_EPI_PITCH));
+    sw_epilogue_any<1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW, smem + wave * (16 * SW_EPI_PITCH));
 }
 
 }  // namespace
 
-bool dp_conv_dh_applies(const ConvH2Args& p) {
+// bn = 256: 128 x 256 tiles (M % 128 == 0, N % 256 == 0); bn = 128: 256 x 128 tiles (M % 256 == 0, N % 128 == 0)
+bool dp_conv_dh_applies(const ConvH2Args& p, int bn) {
+    const int bm = 384 - bn;
+    if (bn != 256 && bn != 128) return false;
     const bool seg_ok = (!p.seg1 || (p.segC1 > 0 && p.segC1 % 32 == 0)) && (!p.seg2 || (p.seg1 && p.segC2 > 0 && p.segC2 % 32 == 0));
-    if (!(p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.M % 128 == 0 && p.N % 256 == 0 && p.C % 32 == 0 && seg_ok)) return false;
+    if (!(p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.M % bm == 0 && p.N % bn == 0 && p.C % 32 == 0 && seg_ok)) return false;
     if (p.ksplit > 1)       // a split-K part needs its prologue's two k-tiles and two more; the epilogue is splitk_epilogue_kernel's
         return (p.K / 32) / p.ksplit >= 4 && p.ws != nullptr;
     return p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0) && (p.rfmt == 0 || p.ofmt == 1) &&
            (p.rfmt == 0 || (dp_aligned16(p.res) && p.ldr % 8 == 0));      // 16-byte LDS-DMA pieces of the fp16 residual
 }
 
-void dp_launch_conv_dh(ConvH2Args& p, hipStream_t s) {
-    p.tiles_n = p.N / 256;
-    p.tiles = (p.M / 128) * p.tiles_n;
-    hipLaunchKernelGGL(conv_igemm_dh, dim3((unsigned)p.tiles, (unsigned)p.ksplit), dim3(NT), 0, s, p);
+void dp_launch_conv_dh(ConvH2Args& p, hipStream_t s, int bn) {
+    p.tiles_n = p.N / bn;
+    p.tiles = (p.M / (384 - bn)) * p.tiles_n;
+    const dim3 g((unsigned)p.tiles, (unsigned)p.ksplit), b(NT);
+    if (bn == 256) hipLaunchKernelGGL((conv_igemm_dh<128>), g, b, 0, s, p);
+    else hipLaunchKernelGGL((conv_igemm_dh<256>), g, b, 0, s, p);
 }

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from diffpure_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
+ALT = int(os.environ.get("PROBE_ALT_DH", "0"))     # the DP_H2_DH value of the comparison column (3: the 256x128 form on the 128-channel layers)
 # (H, Cin, Cout, count per forward)
 SHAPES = [(32, 128, 128, 34), (32, 256, 128, 9), (32, 384, 128, 1), (16, 256, 256, 33), (16, 128, 256, 1), (16, 512, 256, 8), (16, 384, 256, 1),
           (8, 256, 256, 34), (8, 512, 256, 9), (4, 256, 256, 38), (4, 512, 256, 9)]
@@ -48,13 +49,13 @@ def main():
             tot16 += t16 * cnt
             tot32 += t32 * cnt
             totf += flop * cnt
-            with ops.tuning(DP_H2_DH=0):        # round 5: the same launches without the half-height tile kernel (what took them in round 4)
+            with ops.tuning(DP_H2_DH=ALT):      # round 5: the same launches without the half-height tile kernel (ALT = 0: what took them in round 4)
                 o16, o32 = timeit(f16, 30), timeit(f32, 30)
             old16 += o16 * cnt
             old32 += o32 * cnt
             print(f"{H:3d} {ci:4d}->{co:3d} (x{cnt:2d}) | {B * H * H // 256 * (co // 128) // 2:5d} | {t16 * 1e3:7.1f} {flop / t16 / 1e9:6.0f} | {t32 * 1e3:7.1f} {flop / t32 / 1e9:6.0f}"
-                  f" | DP_H2_DH=0: {o16 * 1e3:7.1f} {flop / o16 / 1e9:6.0f} | {o32 * 1e3:7.1f} {flop / o32 / 1e9:6.0f}", flush=True)
-        print(f"-- B={B} weighted over one forward: stream form {tot16:.2f} ms ({totf / tot16 / 1e9:.0f} TFLOP/s), taped form {tot32:.2f} ms ({totf / tot32 / 1e9:.0f} TFLOP/s); with DP_H2_DH=0: {old16:.2f} / {old32:.2f} ms")
+                  f" | DP_H2_DH={ALT}: {o16 * 1e3:7.1f} {flop / o16 / 1e9:6.0f} | {o32 * 1e3:7.1f} {flop / o32 / 1e9:6.0f}", flush=True)
+        print(f"-- B={B} weighted over one forward: stream form {tot16:.2f} ms ({totf / tot16 / 1e9:.0f} TFLOP/s), taped form {tot32:.2f} ms ({totf / tot32 / 1e9:.0f} TFLOP/s); with DP_H2_DH={ALT}: {old16:.2f} / {old32:.2f} ms")
 
 
 if __name__ == "__main__":

@@ -1092,6 +1092,9 @@ DH_CASES = [
     (256, 4, 4, 256, 256, 2, 32, False, (0, 0), 0.70710678),      # 4x4 level: 32 half tiles x 4 parts of 18 k-tiles, fp32 stream
     (128, 8, 8, 256, 256, 0, 0, True, (256, 128), 0.70710678),    # 8x8 up path with two K-segments: 2 parts of 42 k-tiles, the cut inside segment 1
     (64, 8, 8, 1024, 1024, 1, 16, True, (0, 0), 1.0),             # guided UNet 8x8 level at B = 64: 32 x 4 half tiles x 2 parts of 144
+    # 128 output channels (NCSN++ 32x32 level): the 256x128 form of the kernel, taken with DP_H2_DH = 3
+    (64, 32, 32, 128, 128, 2, 16, True, (0, 0), 0.70710678),
+    (64, 32, 32, 128, 128, 0, 32, False, (128, 128), 0.70710678),
 ]
 
 
@@ -1139,6 +1142,11 @@ def test_conv2d_half_height_tile_kernel_is_bit_identical(dev, case, tune):
     prof = ops.prof_collect()
     if H * W > 64:      # (un-split launches are booked with the 256-wide tile kernels, i.e. they did not run on the generic tiles)
         assert prof["pp3x3"]["n"] == 2 and prof["other3x3"]["n"] == 0, prof
+    if N % 256 != 0:    # the 256x128 form (DP_H2_DH = 3): same bits as the 512x128 one-wave-per-SIMD tiles the default takes
+        tune.setenv("DP_H2_DH", "3")
+        got3, got3_cs = run()
+        assert torch.equal(got3, base) and torch.equal(got3_cs, base_cs)
+        tune.delenv("DP_H2_DH")
     sub = slice(0, 2)                               # fp64 reference on two samples
     ref = torch.nn.functional.conv2d(h[sub].half().double().permute(0, 3, 1, 2), w3.half().double(), None, padding=1).permute(0, 2, 3, 1) + bias.cpu().double()
     if segs:

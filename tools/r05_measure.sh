@@ -94,6 +94,28 @@ graph)
     python -c "import json,sys; d=json.loads(open('$O/bench_guided_b4_t20_graph$G.json').read().strip().splitlines()[-1]); print('guided B=4 t20 engine-call GRAPH=$G', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/graph_ab.log"
   done; lap graph_b4
   ;;
+dh128)
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "half_height" > "$O/dh_tests.log" 2>&1; echo "rc=$?" >> "$O/dh_tests.log"; lap dh_tests
+  tail -4 "$O/dh_tests.log"
+  PROBE_ALT_DH=3 timeout 200 python tests/probes/cifar_conv_shapes.py > "$O/cifar_conv_shapes_dh3.log" 2>&1; lap cifar_conv_shapes
+  grep -E "^ 32|^==|^--" "$O/cifar_conv_shapes_dh3.log"
+  for DH in 2 3 2 3; do
+    DP_H2_DH=$DH timeout 300 python bench.py --workload cifar32_ncsnpp --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile > "$O/bench_cifar_t20_dh$DH.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_cifar_t20_dh$DH.json').read().strip().splitlines()[-1]); print('cifar t20 DH=$DH', round(d['value'],1), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/dh128_ab.log"
+  done; lap cifar_ab
+  ;;
+smallb)
+  timeout 300 python tests/probes/smallbatch_conv_shapes.py > "$O/smallbatch_conv_shapes.log" 2>&1; lap smallbatch_shapes
+  cat "$O/smallbatch_conv_shapes.log"
+  for M in 128 64 32; do
+    DP_H2_DH_MIN=$M timeout 300 python bench.py --batch 4 --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile > "$O/bench_guided_b4_t20_min$M.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_guided_b4_t20_min$M.json').read().strip().splitlines()[-1]); print('guided B=4 t20 DH_MIN=$M', round(d['value'],3), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/dhmin_ab.log"
+  done; lap guided_b4
+  for M in 128 32; do
+    DP_H2_DH_MIN=$M timeout 300 python bench.py --batch 16 --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile > "$O/bench_guided_b16_t20_min$M.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_guided_b16_t20_min$M.json').read().strip().splitlines()[-1]); print('guided B=16 t20 DH_MIN=$M', round(d['value'],3), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/dhmin_ab.log"
+  done; lap guided_b16
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
@@ -108,9 +130,11 @@ closing)
   rocstats cifar_adjoint_t10 200 --workload cifar32_ncsnpp_adjoint --t 10 --steps 1 --warmup 0
   timeout 300 python bench.py --t 150 --dt 1.5e-3 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_t150_dt1.5e-3_100step.json" 2> "$O/bench_t150a.err"; lap bench_t150_100
   timeout 300 python bench.py --t 150 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_t150_150step.json" 2> "$O/bench_t150b.err"; lap bench_t150_150
-  for B in 4 32; do
-    timeout 400 python bench.py --workload imagenet256_guided_sde_adjoint --batch $B --steps 1 --warmup 0 $([ $B = 4 ] && echo --no-cpu-baseline) --no-resident-call > "$O/bench_guided_sde_adjoint_b$B.json" 2> "$O/bench_guided_sde_adjoint_b$B.err"; lap bench_guided_sde_adjoint_b$B
+  for B in 4 32 64; do
+    timeout 500 python bench.py --workload imagenet256_guided_sde_adjoint --batch $B --steps 1 --warmup 0 $([ $B != 32 ] && echo --no-cpu-baseline) --no-resident-call > "$O/bench_guided_sde_adjoint_b$B.json" 2> "$O/bench_guided_sde_adjoint_b$B.err"; lap bench_guided_sde_adjoint_b$B
   done
+  rocstats guided_sde_adjoint_b32_t5 300 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0
+  timeout 400 python tools/batch_table.py > "$O/batch_table.json" 2> "$O/batch_table.md"; lap batch_table
   ;;
 esac
 cat "$O/timeline.log"
