@@ -586,7 +586,11 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         // these launches are short of parallelism whatever the tile, but 32 workgroups of this kernel beat 512 of the 64x64 tiles);
         // smaller launches stay on the generic tiles.  DP_H2_DH = 0 never.  Bit-identical to the other variants.
         const long long t256 = tiles(256, 256);
-        if (dp_tune(DP_T_H2_DH) != 0 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && tiles(128, 256) >= dp_tune(DP_T_H2_DH_MIN) && t256 < 256 && dp_conv_dh_applies(p, 256)) {
+        // below 128 workgroups the kernel is taken only for long reductions (>= 72 k-tiles per workgroup: the guided UNet's low levels at
+        // small batches, 144 - 432): with 18 - 36 k-tiles per part (NCSN++ 4x4 / 8x8 levels at B <= 128) a few dozen of its workgroups lose
+        // to a few hundred of the 64x64 tiles (28.6 vs 26.6 us at 4x4 B = 128; adjoint bench 142.4 vs 143.0: profiles/r05/abfinal.log)
+        auto dh_enough = [&](long long wg) { return wg >= 128 || (wg >= dp_tune(DP_T_H2_DH_MIN) && (p.K / 32) / p.ksplit >= 72); };
+        if (dp_tune(DP_T_H2_DH) != 0 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && dh_enough(tiles(128, 256)) && t256 < 256 && dp_conv_dh_applies(p, 256)) {
             dp_launch_conv_dh(p, s, 256);
             dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
             if (tile_rows) *tile_rows = 64;
@@ -600,7 +604,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         // not fill the chip (fewer than 256 of them: B < 128 at 32x32; measured at B = 64: 429 -> 625 TFLOP/s).  On launches that do fill
         // it the two forms are within +8 / -3 % of each other per shape and indistinguishable on the purification (720.6 vs 720.0
         // images/s at t = 20, profiles/r05/dh128_ab.log), so the one-wave-per-SIMD tiles keep those; DP_H2_DH = 3 forces this form (probes)
-        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && N % 256 != 0 && KS == 3 && tiles(256, 128) >= dp_tune(DP_T_H2_DH_MIN) &&
+        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && N % 256 != 0 && KS == 3 && dh_enough(tiles(256, 128)) &&
             (tiles(512, 128) < 256 || dp_tune(DP_T_H2_DH) >= 3) && dp_conv_dh_applies(p, 128)) {
             dp_launch_conv_dh(p, s, 128);
             dp_prof_set_kind(rec, DP_PROF_3X3_PP);
@@ -609,7 +613,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             DP_LAUNCH_CHECK("conv_igemm_dh<256>");
             return 0;
         }
-        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit > 1 && tiles(128, 256) * p.ksplit >= dp_tune(DP_T_H2_DH_MIN) && dp_conv_dh_applies(p, 256)) {
+        if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit > 1 && dh_enough(tiles(128, 256) * p.ksplit) && dp_conv_dh_applies(p, 256)) {
             dp_launch_conv_dh(p, s, 256);
             DP_LAUNCH_CHECK("conv_igemm_dh (split-K)");
             hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, s, p);

@@ -116,6 +116,26 @@ smallb)
     python -c "import json,sys; d=json.loads(open('$O/bench_guided_b16_t20_min$M.json').read().strip().splitlines()[-1]); print('guided B=16 t20 DH_MIN=$M', round(d['value'],3), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/dhmin_ab.log"
   done; lap guided_b16
   ;;
+final)    # the state the round closes on: whole suite + smoke + the builder-run bench lines (more timed steps: the first one carries the per-launch profile)
+  gputests
+  timeout 600 python bench.py --steps 3 --warmup 1 > "$O/bench_default_f16sr_b64.json" 2> "$O/bench_default.err"; lap bench_default
+  timeout 400 python bench.py --workload cifar32_ncsnpp --steps 10 --warmup 1 > "$O/bench_cifar_b256_f16sr.json" 2> "$O/bench_cifar.err"; lap bench_cifar
+  timeout 500 python bench.py --workload cifar32_ncsnpp_adjoint --steps 5 --warmup 1 > "$O/bench_cifar_adjoint_b128_f16sr.json" 2> "$O/bench_adjoint.err"; lap bench_adjoint
+  timeout 300 python bench.py --workload imagenet256_guided_sde_adjoint --batch 4 --steps 2 --warmup 0 --no-cpu-baseline --no-resident-call > "$O/bench_guided_sde_adjoint_b4.json" 2> "$O/bench_guided_sde_adjoint_b4.err"; lap bench_guided_sde_adjoint_b4
+  timeout 300 python tools/batch_table.py --batches 4,8,16 > "$O/batch_table.json" 2> "$O/batch_table.md"; lap batch_table
+  ;;
+abfinal)
+  for M in 128 32 128 32; do
+    DP_H2_DH_MIN=$M timeout 300 python bench.py --workload cifar32_ncsnpp_adjoint --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile --engine-call > "$O/bench_cifar_adjoint_t20_min$M.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_cifar_adjoint_t20_min$M.json').read().strip().splitlines()[-1]); print('cifar adjoint t20 engine-call DH_MIN=$M', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/abfinal.log"
+  done; lap adjoint_ab
+  for M in 128 32; do
+    DP_H2_DH_MIN=$M timeout 300 python bench.py --workload cifar32_ncsnpp --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile --engine-call > "$O/bench_cifar_t20_min$M.json" 2>> "$O/bench_ab.err"
+    python -c "import json,sys; d=json.loads(open('$O/bench_cifar_t20_min$M.json').read().strip().splitlines()[-1]); print('cifar t20 engine-call DH_MIN=$M', round(d['value'],1), 'images/s', d['roofline']['sclk_mhz']['median'])" | tee -a "$O/abfinal.log"
+  done; lap cifar_ab
+  timeout 200 python tests/probes/cifar_conv_shapes.py > "$O/cifar_conv_shapes.log" 2>&1; lap shapes
+  grep -E "^ 16|^  4|^  8|^==" "$O/cifar_conv_shapes.log"
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
