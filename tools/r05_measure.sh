@@ -136,6 +136,12 @@ abfinal)
   timeout 200 python tests/probes/cifar_conv_shapes.py > "$O/cifar_conv_shapes.log" 2>&1; lap shapes
   grep -E "^ 16|^  4|^  8|^==" "$O/cifar_conv_shapes.log"
   ;;
+last)
+  gputests
+  timeout 600 python bench.py --steps 3 --warmup 1 > "$O/bench_default_f16sr_b64.json" 2> "$O/bench_default.err"; lap bench_default
+  timeout 500 python bench.py --workload cifar32_ncsnpp_adjoint --steps 3 --warmup 1 --no-cpu-baseline > "$O/bench_cifar_adjoint_b128_f16sr.json" 2> "$O/bench_adjoint.err"; lap bench_adjoint
+  timeout 300 python bench.py --workload cifar32_ncsnpp --steps 5 --warmup 1 --no-cpu-baseline > "$O/bench_cifar_b256_f16sr.json" 2> "$O/bench_cifar.err"; lap bench_cifar
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
