@@ -27,7 +27,7 @@ SIGNATURES = {
     "dp_conv2d_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _p, _p, _p],
     "dp_gn_finalize_cols": [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p],
     "dp_gemm_strided": [_p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _p],
-    "dp_gemm_strided_h16": [_p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _p],
+    "dp_gemm_strided_h16": [_p, _i, _i, _ll, _ll, _i, _p, _i, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _p],
     "dp_gemm_strided_h16_ok": [_i, _i, _i],
     "dp_gn_bwd_stats": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p],
     "dp_gn_bwd_apply": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p],

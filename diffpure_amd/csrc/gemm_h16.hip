@@ -7,6 +7,9 @@
 // (score_sde/models/layerspp.py:75-91, guided_diffusion/unet.py:345-362 under autograd) - still ran on the fp32-input matrix pipe
 // (157 TFLOP/s peak): 5.4 % of the CIFAR-10 adjoint benchmark (profiles/r05/cifar_adjoint_b128_10step_kernel_stats_start_of_round.csv).
 // Same contract as dp_gemm_strided (igemm.hip) for the shapes this kernel serves: M % 128 == 0, N % 128 == 0, K % 32 == 0.
+// Either operand may also be stored as PLAIN fp16 already (a_fmt / b_fmt 1: q, k, v read in place inside the fp16 qkv tensor the taped
+// forward keeps since round 5 - no up-conversion pass, half the operand bytes); leading dimensions and batch strides count ELEMENTS of
+// the operand's own type.
 //
 // Tile 128 x 128, four waves of 64 x 64 (2 x 2 MFMA tiles), k-tile 32.  Both operand tiles live in LDS as rows of 64 bytes (32 fp16 of
 // one row of op(A) / one column of op(B)) with the 16-byte slot XOR-swizzled by the row key (row >> 2) & 3 - the operand image of the
@@ -24,6 +27,7 @@ constexpr int NT = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 struct GemmHArgs {
     const float* A;
@@ -34,41 +38,59 @@ struct GemmHArgs {
     int M, N, K, ZH;
     float alpha;
     int tiles_n, tiles_mn;
+    int afmt, bfmt;             // 0: the operand is fp32 in memory, 1: plain fp16
 };
 
 // KCONTIG: the operand is stored [row][k] (k contiguous); else [k][row] (row contiguous).  `row` = m for A, n for B.
 template <bool KCONTIG>
 struct Stager {
-    f32x4 r[4];
-    __device__ __forceinline__ void gload(const float* base, int ld, int row0, int k0, int tid) {
+    f32x4 r[4];                 // fp32 source: the values; fp16 source: raw bits (KCONTIG: r[it] = eight halves; else r[it][0..1] = four halves)
+    // `base` points at the operand's first element (float or _Float16 according to f16), ld in elements of that type
+    __device__ __forceinline__ void gload(const void* base, bool f16, int ld, int row0, int k0, int tid) {
         if constexpr (KCONTIG) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {            // unit = (row, 8 consecutive k): 128 rows x 4 slots, two units per thread
                 const int row = (tid >> 2) + it * 64, q = tid & 3;
-                const float* s = base + (size_t)(row0 + row) * ld + k0 + q * 8;
-                r[2 * it] = *reinterpret_cast<const f32x4*>(s);
-                r[2 * it + 1] = *reinterpret_cast<const f32x4*>(s + 4);
+                const size_t e = (size_t)(row0 + row) * ld + k0 + q * 8;
+                if (f16) {
+                    r[2 * it] = *reinterpret_cast<const f32x4*>(static_cast<const _Float16*>(base) + e);       // 16 bytes = 8 halves
+                } else {
+                    const float* s = static_cast<const float*>(base) + e;
+                    r[2 * it] = *reinterpret_cast<const f32x4*>(s);
+                    r[2 * it + 1] = *reinterpret_cast<const f32x4*>(s + 4);
+                }
             }
         } else {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {            // float4 along the rows at one k: 32 k x 32 row quads, four per thread
+            for (int it = 0; it < 4; ++it) {            // four values along the rows at one k: 32 k x 32 row quads, four per thread
                 const int idx = tid + it * NT, kr = idx >> 5, rq = idx & 31;
-                r[it] = *reinterpret_cast<const f32x4*>(base + (size_t)(k0 + kr) * ld + row0 + rq * 4);
+                const size_t e = (size_t)(k0 + kr) * ld + row0 + rq * 4;
+                if (f16) {
+                    const half4 h = *reinterpret_cast<const half4*>(static_cast<const _Float16*>(base) + e);   // 8 bytes
+                    r[it] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};                          // exact: re-rounded to the same halves below
+                } else {
+                    r[it] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + e);
+                }
             }
         }
     }
-    __device__ __forceinline__ void sstore(char* tile, int tid) const {
+    __device__ __forceinline__ void sstore(char* tile, bool f16, int tid) const {
         if constexpr (KCONTIG) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int row = (tid >> 2) + it * 64, q = tid & 3;
-                half8 h;
+                char* d = tile + row * 64 + ((q ^ ((row >> 2) & 3)) << 4);
+                if (f16) {
+                    *reinterpret_cast<f32x4*>(d) = r[2 * it];       // already eight halves
+                } else {
+                    half8 h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h[j] = (_Float16)r[2 * it][j];
-                    h[4 + j] = (_Float16)r[2 * it + 1][j];
+                    for (int j = 0; j < 4; ++j) {
+                        h[j] = (_Float16)r[2 * it][j];
+                        h[4 + j] = (_Float16)r[2 * it + 1][j];
+                    }
+                    *reinterpret_cast<half8*>(d) = h;
                 }
-                *reinterpret_cast<half8*>(tile + row * 64 + ((q ^ ((row >> 2) & 3)) << 4)) = h;
             }
         } else {
 #pragma unroll
@@ -93,8 +115,9 @@ __global__ __launch_bounds__(NT) void gemm_strided_h16(GemmHArgs p) {
     const int tile_n = tz % p.tiles_n, tile_m = tz / p.tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const int zb = z / p.ZH, zh = z - zb * p.ZH;
-    const float* A = p.A + zb * p.sAb + zh * p.sAh;
-    const float* Bm = p.B + zb * p.sBb + zh * p.sBh;
+    const bool af = p.afmt != 0, bf = p.bfmt != 0;           // (workgroup-uniform) operand formats
+    const void* A = af ? (const void*)(reinterpret_cast<const _Float16*>(p.A) + zb * p.sAb + zh * p.sAh) : (const void*)(p.A + zb * p.sAb + zh * p.sAh);
+    const void* Bm = bf ? (const void*)(reinterpret_cast<const _Float16*>(p.B) + zb * p.sBb + zh * p.sBh) : (const void*)(p.B + zb * p.sBb + zh * p.sBh);
     float* C = p.C + zb * p.sCb + zh * p.sCh;
 
     // op(A)[m][k]: stored [M][lda] (k contiguous) unless TRANSA ([K][lda]);  op(B)[k][n]: stored [K][ldb] (n contiguous: NOT
@@ -114,17 +137,17 @@ __global__ __launch_bounds__(NT) void gemm_strided_h16(GemmHArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nt = p.K / 32;
-    sa.gload(A, p.lda, m0, 0, tid);
-    sb.gload(Bm, p.ldb, n0, 0, tid);
-    sa.sstore(smem, tid);
-    sb.sstore(smem + 128 * 64, tid);
+    sa.gload(A, af, p.lda, m0, 0, tid);
+    sb.gload(Bm, bf, p.ldb, n0, 0, tid);
+    sa.sstore(smem, af, tid);
+    sb.sstore(smem + 128 * 64, bf, tid);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const char* at = smem + (t & 1) * (2 * 128 * 64);
         const char* bt = at + 128 * 64;
         if (t + 1 < nt) {
-            sa.gload(A, p.lda, m0, (t + 1) * 32, tid);
-            sb.gload(Bm, p.ldb, n0, (t + 1) * 32, tid);
+            sa.gload(A, af, p.lda, m0, (t + 1) * 32, tid);
+            sb.gload(Bm, bf, p.ldb, n0, (t + 1) * 32, tid);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -140,8 +163,8 @@ __global__ __launch_bounds__(NT) void gemm_strided_h16(GemmHArgs p) {
         }
         if (t + 1 < nt) {
             char* nx = smem + ((t + 1) & 1) * (2 * 128 * 64);
-            sa.sstore(nx, tid);
-            sb.sstore(nx + 128 * 64, tid);
+            sa.sstore(nx, af, tid);
+            sb.sstore(nx + 128 * 64, bf, tid);
         }
         __syncthreads();
     }
@@ -160,16 +183,21 @@ __global__ __launch_bounds__(NT) void gemm_strided_h16(GemmHArgs p) {
 
 extern "C" int dp_gemm_strided_h16_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0 && K % 32 == 0; }
 
-extern "C" int dp_gemm_strided_h16(const float* A, int lda, long long sAb, long long sAh, int transA, const float* B, int ldb, long long sBb,
-                                   long long sBh, int transB, float* C, int ldc, long long sCb, long long sCh, int M, int N, int K, int ZB, int ZH,
-                                   float alpha, void* stream) {
+extern "C" int dp_gemm_strided_h16(const void* A, int a_fmt, int lda, long long sAb, long long sAh, int transA, const void* B, int b_fmt, int ldb,
+                                   long long sBb, long long sBh, int transB, float* C, int ldc, long long sCb, long long sCh, int M, int N, int K, int ZB,
+                                   int ZH, float alpha, void* stream) {
     DP_REQUIRE(A && B && C, "dp_gemm_strided_h16: null pointer");
+    DP_REQUIRE((a_fmt == 0 || a_fmt == 1) && (b_fmt == 0 || b_fmt == 1), "dp_gemm_strided_h16: operand formats are 0 (fp32) or 1 (plain fp16)");
+    // 16-byte loads of eight halves / four floats (8-byte loads of four halves in the transposed fp16 form): strides in multiples of 8 fp16 elements
+    DP_REQUIRE((!a_fmt || (lda % 8 == 0 && sAb % 8 == 0 && sAh % 8 == 0)) && (!b_fmt || (ldb % 8 == 0 && sBb % 8 == 0 && sBh % 8 == 0)),
+               "dp_gemm_strided_h16: an fp16 operand needs row and batch strides that are multiples of 8 elements");
     DP_REQUIRE(dp_gemm_strided_h16_ok(M, N, K), "dp_gemm_strided_h16: needs M %% 128 == 0, N %% 128 == 0, K %% 32 == 0 (got %d, %d, %d); other shapes: dp_gemm_strided", M, N, K);
     DP_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && sAb % 4 == 0 && sAh % 4 == 0 && sBb % 4 == 0 && sBh % 4 == 0 && dp_aligned16(A) && dp_aligned16(B),
                "dp_gemm_strided_h16: operands 16-byte aligned, row and batch strides multiples of 4");
     DP_REQUIRE(ZB > 0 && ZH > 0, "dp_gemm_strided_h16: empty batch");
     GemmHArgs p;
-    p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.A = static_cast<const float*>(A); p.B = static_cast<const float*>(B); p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.afmt = a_fmt; p.bfmt = b_fmt;
     p.sAb = sAb; p.sAh = sAh; p.sBb = sBb; p.sBh = sBh; p.sCb = sCb; p.sCh = sCh;
     p.M = M; p.N = N; p.K = K; p.ZH = ZH; p.alpha = alpha;
     p.tiles_n = N / 128;

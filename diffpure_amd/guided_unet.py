@@ -553,13 +553,16 @@ class GuidedUNet:
         n, c = r["name"], r["ch"]
         b, hh, ww, _ = dout.shape
         da = self._dconv(dout, n + ".dwproj", r.get("dh2_p", False) == "h1" and "h1", c, 1)
+        h16_ok = getattr(self, "_gpool", None) is not None and os.environ.get("DIFFPURE_ATTN_BWD16", "1") != "0"
         qkv = t["qkv"]
-        if qkv.dtype == torch.float16:          # taped on the fp16 stream: the GEMMs of the backward take fp32 operands (the same values)
+        # taped on the fp16 stream: the backward reads q, k, v IN PLACE where all five of its products run on dp_gemm_strided_h16 (NCSN++:
+        # T = d = 256); where some shape stays on the fp32-input kernel (64-wide heads: N = 64) the tensor is up-converted once (same values)
+        if qkv.dtype == torch.float16 and not (h16_ok and ops.attention_h16_serves(hh * ww, c // r["heads"])):
             qkv = qkv.float()
         qkv = qkv.view(b, hh * ww, 3 * c)
         # probabilities recomputed (freed after this block), without the P V product nobody reads; in the fp16 x fp16 modes the
         # products whose shapes dp_gemm_strided_h16 serves (q k^T and dP at head dimension 64) run on the fp16 matrix cores
-        h16 = getattr(self, "_gpool", None) is not None and os.environ.get("DIFFPURE_ATTN_BWD16", "1") != "0"
+        h16 = h16_ok
         _, probs = ops.attention(qkv, r["heads"], t["layout"], probs_only=True, h16=h16)
         dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), r["heads"], t["layout"], h16=h16)
         del probs

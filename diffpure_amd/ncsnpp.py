@@ -505,13 +505,16 @@ class NCSNpp:
         n, c = str(r["idx"]), r["ch"]
         b, hh, ww, _ = dout.shape
         da = self._dconv(dout, n + ".dw3", r.get("dh2_3", False) == "h1" and "h1", c, 1, scale=INV_SQRT2)
+        h16_ok = getattr(self, "_gpool", None) is not None and os.environ.get("DIFFPURE_ATTN_BWD16", "1") != "0"
         qkv = t["qkv"]
-        if qkv.dtype == torch.float16:          # taped on the fp16 stream: the GEMMs of the backward take fp32 operands (the same values)
+        # taped on the fp16 stream: the backward reads q, k, v IN PLACE where all five of its products run on dp_gemm_strided_h16 (NCSN++:
+        # T = d = 256); where some shape stays on the fp32-input kernel (64-wide heads: N = 64) the tensor is up-converted once (same values)
+        if qkv.dtype == torch.float16 and not (h16_ok and ops.attention_h16_serves(hh * ww, c // 1)):
             qkv = qkv.float()
         qkv = qkv.view(b, hh * ww, 3 * c)
         # probabilities recomputed (freed after this block); in the fp16 x fp16 modes the five products run on the fp16 matrix cores,
         # as the dgrad convolutions around them do (DIFFPURE_GRAD16=0 keeps fp32-input MFMA)
-        h16 = getattr(self, "_gpool", None) is not None and os.environ.get("DIFFPURE_ATTN_BWD16", "1") != "0"
+        h16 = h16_ok
         _, probs = ops.attention(qkv, 1, "split", probs_only=True, h16=h16)
         dqkv = ops.attention_bwd(qkv, probs, da.view(b, hh * ww, c), 1, "split", h16=h16)
         del probs

@@ -760,10 +760,23 @@ def attention_fused(qkv, n_heads, layout, operand_hw=None):
     return out
 
 
-def _gemm(h16, m, n, k):
-    """the strided GEMM entry point: on the fp16 matrix cores (operands rounded to fp16, fp32 accumulation) where `h16` asks for it and
-    the shape is one dp_gemm_strided_h16 serves, else the fp32-input MFMA kernel"""
-    return "dp_gemm_strided_h16" if h16 and _lib.load().dp_gemm_strided_h16_ok(m, n, k) else "dp_gemm_strided"
+def _gemm(h16, a, a16, a_args, bm, b16, b_args, c_args, m, n, k, zb, zh, alpha, s):
+    """one strided batched GEMM: on the fp16 matrix cores (dp_gemm_strided_h16: operands rounded to fp16 on their way into LDS - or read in
+    place where they ARE fp16 (a16 / b16) -, fp32 accumulation) where `h16` asks for it and the shape is one that kernel serves, else
+    the fp32-input MFMA kernel (fp32 operands only).  a_args / b_args = (ld, batch stride, head stride, trans) in elements."""
+    if h16 and _lib.load().dp_gemm_strided_h16_ok(m, n, k):
+        _lib.call("dp_gemm_strided_h16", a, 1 if a16 else 0, *a_args, bm, 1 if b16 else 0, *b_args, *c_args, m, n, k, zb, zh, float(alpha), s)
+        return
+    if a16 or b16:
+        raise _lib.DiffpureHipError("attention: an fp16 qkv needs every product on dp_gemm_strided_h16 (attention_h16_serves); up-convert it")
+    _lib.call("dp_gemm_strided", a, *a_args, bm, *b_args, *c_args, m, n, k, zb, zh, float(alpha), s)
+
+
+def attention_h16_serves(t, d):
+    """do all five products of the attention backward (q k^T, dV, dP, dQ, dK) have shapes dp_gemm_strided_h16 serves?  Then the taped
+    fp16 qkv is read in place; else (head dimension 64: N = 64 in dV / dQ / dK) the caller hands in an fp32 qkv."""
+    ok = _lib.load().dp_gemm_strided_h16_ok
+    return bool(ok(t, t, d) and ok(t, d, t))
 
 
 def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=False):
@@ -772,8 +785,12 @@ def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=Fa
     layout 'split' : channels = [Q(all heads) | K | V]         (QKVAttention unet.py:377-397; NCSN++ q,k,v NINs)
     probs_only=True: only the probabilities are wanted (the backward pass recomputes them from the taped qkv): the P V product is
     skipped and (None, probs) returned.  h16=True (the fp16 x fp16 precision modes' gradient path): the products run on the fp16
-    matrix cores where dp_gemm_strided_h16 serves the shape."""
-    _chk(qkv, "attention.qkv", 3)
+    matrix cores where dp_gemm_strided_h16 serves the shape; qkv may then be the plain fp16 tensor the tape holds (attention_h16_serves)."""
+    q16 = isinstance(qkv, torch.Tensor) and qkv.dtype == torch.float16
+    if q16:
+        assert h16 and qkv.is_cuda and qkv.is_contiguous() and qkv.dim() == 3, "attention: an fp16 qkv takes the h16 path"
+    else:
+        _chk(qkv, "attention.qkv", 3)
     b, t, c3 = qkv.shape
     c = c3 // 3
     d = c // n_heads
@@ -783,25 +800,29 @@ def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=Fa
     s = _stream()
     scores = torch.empty((b * n_heads, t, t), device=qkv.device, dtype=torch.float32)
     base = qkv.data_ptr()
-    el = 4
+    el = 2 if q16 else 4
     # scores[z] = (1/sqrt(d)) * Q K^T
-    _lib.call(_gemm(h16, t, t, d), base + oq * el, c3, t * c3, sh, 0, base + ok * el, c3, t * c3, sh, 1,
-              _ptr(scores), t, n_heads * t * t, t * t, t, t, d, b, n_heads, 1.0 / math.sqrt(d), s)
+    _gemm(h16, base + oq * el, q16, (c3, t * c3, sh, 0), base + ok * el, q16, (c3, t * c3, sh, 1),
+          (_ptr(scores), t, n_heads * t * t, t * t), t, t, d, b, n_heads, 1.0 / math.sqrt(d), s)
     _lib.call("dp_softmax_rows", _ptr(scores), b * n_heads * t, t, s)
     if probs_only:
         return None, scores
     out = torch.empty((b, t, c), device=qkv.device, dtype=torch.float32)
     # out[z] = P V
-    _lib.call(_gemm(h16, t, d, t), _ptr(scores), t, n_heads * t * t, t * t, 0, base + ov * el, c3, t * c3, sh, 0,
-              _ptr(out), c, t * c, d, t, d, t, b, n_heads, 1.0, s)
+    _gemm(h16, _ptr(scores), False, (t, n_heads * t * t, t * t, 0), base + ov * el, q16, (c3, t * c3, sh, 0),
+          (_ptr(out), c, t * c, d), t, d, t, b, n_heads, 1.0, s)
     return (out, scores) if return_probs else out
 
 
 def attention_bwd(qkv, probs, dout, n_heads, layout, h16=False):
     """Gradient of `attention` w.r.t. qkv: dV = P^T dO, dP = dO V^T, dS = softmax'(P, dP),
-    dQ = dS K / sqrt(d), dK = dS^T Q / sqrt(d), written into dqkv [B, T, 3C] in the same layout.
-    h16=True: the four products on the fp16 matrix cores (see `attention`); softmax' stays fp32."""
-    _chk(qkv, "attention_bwd.qkv", 3)
+    dQ = dS K / sqrt(d), dK = dS^T Q / sqrt(d), written into dqkv [B, T, 3C] (fp32) in the same layout.
+    h16=True: the four products on the fp16 matrix cores (see `attention`; qkv may be the taped fp16 tensor); softmax' stays fp32."""
+    q16 = isinstance(qkv, torch.Tensor) and qkv.dtype == torch.float16
+    if q16:
+        assert h16 and qkv.is_cuda and qkv.is_contiguous() and qkv.dim() == 3, "attention_bwd: an fp16 qkv takes the h16 path"
+    else:
+        _chk(qkv, "attention_bwd.qkv", 3)
     _chk(probs, "attention_bwd.probs", 3)
     _chk(dout, "attention_bwd.dout", 3)
     b, t, c3 = qkv.shape
@@ -809,25 +830,21 @@ def attention_bwd(qkv, probs, dout, n_heads, layout, h16=False):
     d = c // n_heads
     oq, ok, ov, sh = _attn_offsets(c, d, layout)
     s = _stream()
-    el = 4
-    dqkv = torch.empty_like(qkv)
+    el = 2 if q16 else 4
+    dqkv = torch.empty(qkv.shape, device=qkv.device, dtype=torch.float32)
     dp = torch.empty_like(probs)
     q0, g0, do0 = qkv.data_ptr(), dqkv.data_ptr(), dout.data_ptr()
     sc = 1.0 / math.sqrt(d)
     zb, zh = n_heads * t * t, t * t
     # dV[s][c] = sum_t P[t][s] dO[t][c]                 (A = P stored [K=t][M=s] -> transA)
-    _lib.call(_gemm(h16, t, d, t), _ptr(probs), t, zb, zh, 1, do0, c, t * c, d, 0, g0 + ov * el, c3, t * c3, sh,
-              t, d, t, b, n_heads, 1.0, s)
+    _gemm(h16, _ptr(probs), False, (t, zb, zh, 1), do0, False, (c, t * c, d, 0), (g0 + ov * 4, c3, t * c3, sh), t, d, t, b, n_heads, 1.0, s)
     # dP[t][s] = sum_c dO[t][c] V[s][c]                 (B = V stored [N=s][K=c] -> transB)
-    _lib.call(_gemm(h16, t, t, d), do0, c, t * c, d, 0, q0 + ov * el, c3, t * c3, sh, 1, _ptr(dp), t, zb, zh,
-              t, t, d, b, n_heads, 1.0, s)
+    _gemm(h16, do0, False, (c, t * c, d, 0), q0 + ov * el, q16, (c3, t * c3, sh, 1), (_ptr(dp), t, zb, zh), t, t, d, b, n_heads, 1.0, s)
     _lib.call("dp_softmax_bwd_rows", _ptr(probs), _ptr(dp), b * n_heads * t, t, s)
     # dQ[t][c] = sc * sum_s dS[t][s] K[s][c]
-    _lib.call(_gemm(h16, t, d, t), _ptr(dp), t, zb, zh, 0, q0 + ok * el, c3, t * c3, sh, 0, g0 + oq * el, c3, t * c3, sh,
-              t, d, t, b, n_heads, sc, s)
+    _gemm(h16, _ptr(dp), False, (t, zb, zh, 0), q0 + ok * el, q16, (c3, t * c3, sh, 0), (g0 + oq * 4, c3, t * c3, sh), t, d, t, b, n_heads, sc, s)
     # dK[s][c] = sc * sum_t dS[t][s] Q[t][c]            (A = dS stored [K=t][M=s] -> transA)
-    _lib.call(_gemm(h16, t, d, t), _ptr(dp), t, zb, zh, 1, q0 + oq * el, c3, t * c3, sh, 0, g0 + ok * el, c3, t * c3, sh,
-              t, d, t, b, n_heads, sc, s)
+    _gemm(h16, _ptr(dp), False, (t, zb, zh, 1), q0 + oq * el, q16, (c3, t * c3, sh, 0), (g0 + ok * 4, c3, t * c3, sh), t, d, t, b, n_heads, sc, s)
     return dqkv
 
 

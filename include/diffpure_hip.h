@@ -176,10 +176,12 @@ int dp_gemm_strided(const float* A, int lda, long long sAb, long long sAh, int t
  * fp16 MFMA pass per product, fp32 accumulation, fp32 result - the arithmetic the input-gradient convolutions of the fp16 x fp16
  * precision modes already use.  Serves the attention BACKWARD of those modes (the recomputed scores and dV, dP, dQ, dK: torch autograd
  * through unet.py:345-362 / layerspp.py:75-91 under the reference's use_fp16 torso runs them in fp16 as well).  Shapes:
- * dp_gemm_strided_h16_ok(M, N, K) (M % 128 == 0, N % 128 == 0, K % 32 == 0); anything else stays on dp_gemm_strided. */
+ * dp_gemm_strided_h16_ok(M, N, K) (M % 128 == 0, N % 128 == 0, K % 32 == 0); anything else stays on dp_gemm_strided.
+ * a_fmt / b_fmt: 0 = the operand is fp32 in memory, 1 = it is plain fp16 already (q, k, v inside the fp16 qkv tensor of the taped forward:
+ * read in place, no up-conversion pass); lda / ldb and the batch strides count elements of the operand's own type (fp16: multiples of 8). */
 int dp_gemm_strided_h16_ok(int M, int N, int K);
-int dp_gemm_strided_h16(const float* A, int lda, long long sAb, long long sAh, int transA,
-                        const float* B, int ldb, long long sBb, long long sBh, int transB,
+int dp_gemm_strided_h16(const void* A, int a_fmt, int lda, long long sAb, long long sAh, int transA,
+                        const void* B, int b_fmt, int ldb, long long sBb, long long sBh, int transB,
                         float* C, int ldc, long long sCb, long long sCh,
                         int M, int N, int K, int ZB, int ZH, float alpha, void* stream);
 

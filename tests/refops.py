@@ -258,6 +258,7 @@ def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=Fa
     """(h16 - fp16 matrix cores for the gradient path - has no CPU counterpart: the stand-in computes in fp32 either way)"""
     if probs_only:
         return None, attention(qkv, n_heads, layout, return_probs=True)[1]
+    qkv = qkv.float()            # (the taped fp16 qkv is read in place by the GPU kernels: same values)
     b, t, c3 = qkv.shape
     c = c3 // 3
     d = c // n_heads
@@ -273,9 +274,13 @@ def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=Fa
     return (out, w.reshape(b * n_heads, t, t).contiguous()) if return_probs else out
 
 
+def attention_h16_serves(t, d):
+    return t % 128 == 0 and d % 128 == 0
+
+
 def attention_bwd(qkv, probs, dout, n_heads, layout, h16=False):
     with torch.enable_grad():
-        q = qkv.detach().clone().requires_grad_(True)
+        q = qkv.detach().float().clone().requires_grad_(True)
         out = attention(q, n_heads, layout)
         (g,) = torch.autograd.grad(out, q, dout)
     return g
@@ -474,7 +479,7 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
 
 PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd", "gn_bwd_fused_ok",
            "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "group_norm_f16in", "resample", "attention", "attention_fused",
-           "attention_fused_ok", "silu", "axpby", "takes_segments",
+           "attention_fused_ok", "attention_h16_serves", "silu", "axpby", "takes_segments",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
 
 

@@ -1168,14 +1168,15 @@ def test_gemm_strided_on_the_fp16_matrix_cores(dev, trans):
     from diffpure_amd import _lib
     ta, tb = trans
     ZB, ZH, M, N, K = 2, 3, 256, 128, 96
-    lda, ldb, ldc = (M if ta else K) + 8, (K if tb else N) + 4, N + 12
+    lda, ldb, ldc = (M if ta else K) + 8, (K if tb else N) + 16, N + 12
     ra, rb = (K if ta else M), (N if tb else K)            # stored rows
     A = rnd(ZB, ZH, ra, lda, seed=1).to(dev)
     B = rnd(ZB, ZH, rb, ldb, seed=2).to(dev)
     Cm = torch.zeros(ZB, ZH, M, ldc, device=dev)
     assert _lib.load().dp_gemm_strided_h16_ok(M, N, K) == 1 and _lib.load().dp_gemm_strided_h16_ok(M, 64, K) == 0
-    _lib.call("dp_gemm_strided_h16", A.data_ptr(), lda, ZH * ra * lda, ra * lda, ta, B.data_ptr(), ldb, ZH * rb * ldb, rb * ldb, tb,
-              Cm.data_ptr(), ldc, ZH * M * ldc, M * ldc, M, N, K, ZB, ZH, 0.25, torch.cuda.current_stream().cuda_stream)
+    s_ = torch.cuda.current_stream().cuda_stream
+    _lib.call("dp_gemm_strided_h16", A.data_ptr(), 0, lda, ZH * ra * lda, ra * lda, ta, B.data_ptr(), 0, ldb, ZH * rb * ldb, rb * ldb, tb,
+              Cm.data_ptr(), ldc, ZH * M * ldc, M * ldc, M, N, K, ZB, ZH, 0.25, s_)
     a = A.cpu().half().double()
     b = B.cpu().half().double()
     a = (a[..., :M].transpose(-1, -2) if ta else a[..., :K])          # [.., M, K]
@@ -1184,6 +1185,13 @@ def test_gemm_strided_on_the_fp16_matrix_cores(dev, trans):
     got = Cm.cpu()[..., :N]
     assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (got - ref).abs().max()
     assert (Cm.cpu()[..., N:] == 0).all()                             # nothing written beyond the N columns
+    # operands that ARE fp16 in memory (a_fmt / b_fmt 1: q, k, v of the taped fp16 qkv, read in place): the same bits, in every mix
+    A16, B16 = A.half(), B.half()
+    for af, bf in ((1, 0), (0, 1), (1, 1)):
+        C2 = torch.zeros_like(Cm)
+        _lib.call("dp_gemm_strided_h16", (A16 if af else A).data_ptr(), af, lda, ZH * ra * lda, ra * lda, ta, (B16 if bf else B).data_ptr(), bf, ldb,
+                  ZH * rb * ldb, rb * ldb, tb, C2.data_ptr(), ldc, ZH * M * ldc, M * ldc, M, N, K, ZB, ZH, 0.25, s_)
+        assert torch.equal(C2, Cm), (af, bf)
 
 
 @pytest.mark.parametrize("case", [(2, 256, 256, 1, "split"), (2, 256, 128, 2, "legacy")], ids=str)
@@ -1204,3 +1212,12 @@ def test_attention_backward_on_the_fp16_matrix_cores(dev, case):
     err32 = ((g32.cpu() - ref).abs().max() / ref.abs().max()).item()
     print(f"attention backward {case}: fp16 matrix cores {err:.2e} of the largest entry, fp32-input MFMA {err32:.2e}")
     assert err < 3e-3 and err32 < 1e-4, (err, err32)
+    if ops.attention_h16_serves(T, C // heads):     # the taped fp16 qkv read in place: the bits of the same values handed over as fp32
+        q16 = qkv.half().to(dev)
+        _, p_a = ops.attention(q16, heads, layout, probs_only=True, h16=True)
+        g_a = ops.attention_bwd(q16, p_a, dout.to(dev), heads, layout, h16=True)
+        _, p_b = ops.attention(q16.float(), heads, layout, probs_only=True, h16=True)
+        g_b = ops.attention_bwd(q16.float(), p_b, dout.to(dev), heads, layout, h16=True)
+        assert g_a.dtype == torch.float32 and torch.equal(p_a, p_b) and torch.equal(g_a, g_b)
+    else:
+        assert heads == 2

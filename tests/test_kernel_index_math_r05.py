@@ -1,0 +1,196 @@
+"""CPU restatement of the index arithmetic of round 5's kernels, element by element - an edit of the address arithmetic in the kernels has to keep
+this file true.  No GPU.
+
+  csrc/igemm_h2_dh.hip   (conv_igemm_dh<BMT>: 128x256 / 256x128 tiles, four waves): which 16-byte unit of the zero-bordered fp16 operand and of the
+                         weight panel every LDS-DMA lane fetches and where it lands; which unit every MFMA fragment read picks up; that the
+                         pieces of four waves cover both operand tiles exactly once; the counted vmcnt (RAW) and the ring reuse (WAR) of the
+                         k-loop; the split-K cursor of a part that starts mid-way (tap fastest, then the slice, then the 1x1 segments)
+  csrc/gemm_h16.hip      (gemm_strided_h16): the LDS image of both staging forms (eight values per 16-byte store / two-byte scatter), the
+                         fragment reads, and bank-conflict freedom of a ds_read_b128 under the guide's lane groups
+"""
+import numpy as np
+import pytest
+
+KEY = lambda r: (r >> 2) & 3          # XOR key of an LDS row: 16-byte slot q of row r sits at physical slot q ^ KEY(r)
+
+
+# ---- conv_igemm_dh -------------------------------------------------------------------------------------------------------------------------------
+def dh_stage_tile(BMT, rows_src):
+    """One operand tile of a k-tile as the kernel's four waves stage it.  rows_src(row) -> element offset of that row's 32 halves (the k-tile's
+    slice) in its source tensor.  -> lds[row * 4 + physical slot] = element offset of the 8 halves the unit holds."""
+    rows = BMT
+    np_ = rows // 64                      # 16-row pieces per wave
+    lds = -np.ones(rows * 4, dtype=np.int64)
+    for wave in range(4):
+        for it in range(np_):
+            base_row = wave * (rows // 4) + it * 16
+            for lane in range(64):
+                lrow = lane >> 2
+                ls = (lane & 3) ^ KEY(lrow)                     # logical slot this lane FETCHES
+                src = rows_src(base_row + lrow) + ls * 8
+                dst_byte = base_row * 64 + lane * 16            # an LDS-DMA instruction writes lane l's 16 bytes at base + 16 l
+                assert lds[dst_byte // 16] == -1, "two lanes land on one unit"
+                lds[dst_byte // 16] = src
+    assert (lds >= 0).all(), "a unit of the tile is never staged"
+    return lds
+
+
+@pytest.mark.parametrize("BMT", [128, 256])
+def test_dh_staging_and_fragment_reads(BMT):
+    BNT = 384 - BMT
+    B, H, W, C, N = 2, 16, 16, 64, BNT
+    Wp, HW, K = W + 2, H * W, 9 * 64
+    m0, n0 = BMT, 0                        # the second row tile
+    for c in range(C // 32):
+        for tap in range(9):
+            ky, kx = divmod(tap, 3)
+            assert ky == (tap * 11) >> 5   # the kernel's division-free tap / 3
+
+            def act_row(r):                # centre pixel of output row m0 + r, shifted by the tap, slice c (fp16 elements of the bordered tensor)
+                m = m0 + r
+                b, rem = divmod(m, HW)
+                oy, ox = divmod(rem, W)
+                return ((b * (H + 2) + oy + 1 + ky - 1) * Wp + ox + 1 + kx - 1) * C + c * 32
+
+            kt = c * 9 + tap
+            la = dh_stage_tile(BMT, act_row)
+            # weights: block layout of the fp16 panels (ops.order_conv_weight_w16): [n / 32][k / 8][32 rows][8] - the staging pointer of a lane is
+            # (n >> 5) K 64 + (n & 31) 16 + ls 512 bytes, advanced by 2048 bytes per k-tile (a slot is 512 bytes away, not 16)
+            lb = -np.ones(BNT * 4, dtype=np.int64)
+            for wave in range(4):
+                for it in range(BNT // 64):
+                    for lane in range(64):
+                        lrow = lane >> 2
+                        ls = (lane & 3) ^ KEY(lrow)
+                        n = n0 + wave * (BNT // 4) + it * 16 + lrow
+                        src_bytes = (n >> 5) * K * 64 + (n & 31) * 16 + ls * 512 + kt * 2048
+                        lb[((wave * (BNT // 4) + it * 16) * 64 + lane * 16) // 16] = src_bytes // 2
+            assert (lb >= 0).all()
+            # fragment reads: wave (wr, wc), MFMA tile i / j, lane (lr, lk), k16 step s -> 8 halves = channels (s * 2 + lk) * 8 .. + 7 of the k-tile
+            for wave in range(4):
+                wr, wc = (wave >> 1, wave & 1) if BMT == 128 else (wave, 0)
+                for lr in range(32):
+                    for lk in range(2):
+                        for s_ in range(2):
+                            soff = ((s_ * 2 + lk) ^ KEY(lr)) << 4
+                            for i in range(2):
+                                row = wr * 64 + i * 32 + lr
+                                got = la[(row * 64 + soff) // 16]
+                                assert got == act_row(row) + (s_ * 2 + lk) * 8, (wave, lr, lk, s_, i)
+                            for j in range(4):
+                                row = wc * 128 + j * 32 + lr
+                                n = n0 + row
+                                got = lb[(row * 64 + soff) // 16]
+                                # element (n, k) of the panel [N32][K] in block order: block n >> 5, octet k >> 3, row n & 31
+                                k = kt * 32 + (s_ * 2 + lk) * 8
+                                want = (n >> 5) * K * 32 + (k >> 3) * 256 + (n & 31) * 8
+                                assert got == want, (wave, lr, lk, s_, j)
+
+
+def test_dh_vmcnt_and_ring_reuse():
+    """Issue order of one wave: prologue B(0) A(0) A(1) B(1), then per iteration t the six pieces of k-tile t + 2; `s_waitcnt vmcnt(6)` retires, in
+    issue order, everything but the six youngest pieces.  RAW: at the barrier of iteration t (and at the prologue's) every piece of k-tile t + 1 (0)
+    has landed.  WAR: the stage written in iteration t, (t + 2) % 3, held k-tile t - 1, whose last reads precede the barrier of iteration t - 1."""
+    for NPA, NPB in ((2, 4), (4, 2)):
+        for nt in (4, 5, 9, 72):
+            issued = []                                     # k-tile of every piece in issue order
+            issued += [0] * NPB + [0] * NPA + [1] * NPA + [1] * NPB
+            landed = lambda: set(issued[:max(0, len(issued) - 6)])          # after vmcnt(6)
+            assert 0 in landed() and issued[-6:].count(0) == 0
+            for t in range(nt - 2):
+                stage_written = (t + 2) % 3
+                assert stage_written == (t - 1) % 3         # the ring stage of k-tile t - 1: read before the barrier of iteration t - 1
+                issued += [t + 2] * (NPA + NPB)
+                done = issued[:len(issued) - 6]
+                assert done.count(t + 1) == NPA + NPB, (NPA, nt, t)         # all of k-tile t + 1 retired before its fragments are read
+            # tail: vmcnt(0)
+
+
+@pytest.mark.parametrize("segs", [(0, 0), (64, 0), (64, 32)])
+def test_dh_split_k_cursor(segs):
+    """A split-K part starts at k-tile t0 = floor(y * ntot / S): the cursor (segment, slice, tap) the kernel computes there equals the cursor a
+    part that walked from k-tile 0 has after t0 steps."""
+    C, taps = 96, 9
+    c1, c2 = segs
+    conv_tiles = taps * (C // 32)
+    ntot = conv_tiles + c1 // 32 + c2 // 32
+
+    def walk(n):
+        seg, slc, tap, seg_slices = 0, 0, 0, C // 32
+        for _ in range(n):
+            if slc == seg_slices:                            # pieceA(it == 0): this segment is staged, on to the next tensor
+                seg += 1
+                seg_slices = (c1 if seg == 1 else c2) // 32
+                slc, tap = 0, 0
+            # stage one k-tile
+            if seg != 0:
+                slc += 1
+            else:
+                tap += 1
+                if tap == taps:
+                    tap, slc = 0, slc + 1
+        if slc == seg_slices and n < ntot:                   # normalise: the switch happens lazily, at the next staging
+            seg += 1
+            seg_slices = (c1 if seg == 1 else c2) // 32
+            slc, tap = 0, 0
+        return seg, slc, tap
+
+    for S in (2, 4):
+        for y in range(S):
+            t0 = (y * ntot) // S
+            if t0 < conv_tiles:
+                cur = (0, t0 // taps, t0 % taps)
+            else:
+                rem = t0 - conv_tiles
+                cur = (1, rem, 0) if rem < c1 // 32 else (2, rem - c1 // 32, 0)
+            if t0 < ntot:
+                assert cur == walk(t0), (S, y, t0, cur, walk(t0))
+
+
+# ---- gemm_strided_h16 ----------------------------------------------------------------------------------------------------------------------------
+def test_gemm_h16_lds_image_and_fragment_reads():
+    NT = 256
+    # KCONTIG form: unit = (row, 8 consecutive k)
+    img = -np.ones((128 * 64 // 2,), dtype=np.int64)        # per fp16 element of the tile: row * 32 + k
+    for tid in range(NT):
+        for it in range(2):
+            row, q = (tid >> 2) + it * 64, tid & 3
+            d = row * 64 + ((q ^ KEY(row)) << 4)
+            for j in range(8):
+                assert img[d // 2 + j] == -1
+                img[d // 2 + j] = row * 32 + q * 8 + j
+    assert (img >= 0).all()
+    # transposed form: four rows at one k per thread and iteration, two-byte scatter: the SAME image
+    img2 = -np.ones_like(img)
+    for tid in range(NT):
+        for it in range(4):
+            idx = tid + it * NT
+            kr, rq = idx >> 5, idx & 31
+            for j in range(4):
+                row = rq * 4 + j
+                d = row * 64 + (((kr >> 3) ^ KEY(row)) << 4) + (kr & 7) * 2
+                assert img2[d // 2] == -1
+                img2[d // 2] = row * 32 + kr
+    assert np.array_equal(img, img2)
+    # fragment reads of the 32x32x16 MFMA: lane (lr, lk), k16 step s -> k = (s * 2 + lk) * 8 .. + 7 of row base + lr
+    for wr in range(2):
+        for i in range(2):
+            for lr in range(32):
+                for lk in range(2):
+                    for s_ in range(2):
+                        row = wr * 64 + i * 32 + lr
+                        off = row * 64 + (((s_ * 2 + lk) ^ KEY(lr)) << 4)
+                        got = img[off // 2:off // 2 + 8]
+                        assert list(got) == [row * 32 + (s_ * 2 + lk) * 8 + j for j in range(8)]
+    # ds_read_b128 lane groups of the guide (MI355X_MICROARCH.md, LDS): {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: 16 lanes x 4 dwords must hit
+    # 64 distinct banks (bank = (byte address / 4) mod 64)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for s_ in range(2):
+        for g in groups:
+            banks = []
+            for lane in g:
+                lr, lk = lane & 31, lane >> 5
+                off = lr * 64 + (((s_ * 2 + lk) ^ KEY(lr)) << 4)
+                banks += [((off // 4) + w) % 64 for w in range(4)]
+            assert len(set(banks)) == 64, (s_, g)

@@ -142,6 +142,14 @@ last)
   timeout 500 python bench.py --workload cifar32_ncsnpp_adjoint --steps 3 --warmup 1 --no-cpu-baseline > "$O/bench_cifar_adjoint_b128_f16sr.json" 2> "$O/bench_adjoint.err"; lap bench_adjoint
   timeout 300 python bench.py --workload cifar32_ncsnpp --steps 5 --warmup 1 --no-cpu-baseline > "$O/bench_cifar_b256_f16sr.json" 2> "$O/bench_cifar.err"; lap bench_cifar
   ;;
+q16)
+  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_grad.py -m gpu -q -k "fp16_matrix_cores or attention_bwd or adjoint or vjp or taped or finite" > "$O/q16_tests.log" 2>&1; echo "rc=$?" >> "$O/q16_tests.log"; lap q16_tests
+  tail -4 "$O/q16_tests.log"
+  timeout 600 python -m pytest tests/test_gpu_loops.py -m gpu -q -s -k "config5 or sde_stochastic_adjoint_100_plus" > "$O/q16_loops.log" 2>&1; echo "rc=$?" >> "$O/q16_loops.log"; lap q16_loops
+  grep -E "passed|failed|adjoint" "$O/q16_loops.log" | head
+  timeout 300 python bench.py --workload cifar32_ncsnpp_adjoint --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile --engine-call > "$O/bench_cifar_adjoint_t20.json" 2>> "$O/bench.err"
+  python -c "import json,sys; d=json.loads(open('$O/bench_cifar_adjoint_t20.json').read().strip().splitlines()[-1]); print('cifar adjoint t20 engine-call', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz']['median'])"; lap bench
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
