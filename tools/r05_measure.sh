@@ -150,6 +150,10 @@ q16)
   timeout 300 python bench.py --workload cifar32_ncsnpp_adjoint --t 20 --steps 2 --warmup 1 --no-cpu-baseline --no-resident-call --no-conv-profile --engine-call > "$O/bench_cifar_adjoint_t20.json" 2>> "$O/bench.err"
   python -c "import json,sys; d=json.loads(open('$O/bench_cifar_adjoint_t20.json').read().strip().splitlines()[-1]); print('cifar adjoint t20 engine-call', round(d['value'],2), 'images/s', d['roofline']['sclk_mhz']['median'])"; lap bench
   ;;
+head)
+  gputests
+  rocstats cifar_adjoint_t10 200 --workload cifar32_ncsnpp_adjoint --t 10 --steps 1 --warmup 0
+  ;;
 tests) gputests ;;
 bench) benchdefault ;;
 closing)
