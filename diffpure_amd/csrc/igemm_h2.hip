@@ -598,8 +598,6 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             DP_LAUNCH_CHECK("conv_igemm_dh");
             return 0;
         }
-        // split-K levels (<= 64 pixels per sample): the same kernel, one part per grid.y, from 128 workgroups up (DP_H2_DH = 1: never;
-        // 2, the default: yes); the reduction + epilogue kernel below is shared with the generic tiles
         // layers with 128 output channels (NCSN++ 32x32 level) on the kernel's 256x128 form where the 512x128 one-wave-per-SIMD tiles do
         // not fill the chip (fewer than 256 of them: B < 128 at 32x32; measured at B = 64: 429 -> 625 TFLOP/s).  On launches that do fill
         // it the two forms are within +8 / -3 % of each other per shape and indistinguishable on the purification (720.6 vs 720.0
@@ -613,6 +611,8 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
             DP_LAUNCH_CHECK("conv_igemm_dh<256>");
             return 0;
         }
+        // split-K levels (<= 64 pixels per sample): the same kernel, one part per grid.y (DP_H2_DH = 1: never; 2, the default: yes); the
+        // reduction + epilogue kernel is the one the generic tiles use
         if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit > 1 && dh_enough(tiles(128, 256) * p.ksplit) && dp_conv_dh_applies(p, 256)) {
             dp_launch_conv_dh(p, s, 256);
             DP_LAUNCH_CHECK("conv_igemm_dh (split-K)");

@@ -726,7 +726,9 @@ def _bordered_f16(shape, device):
     the same (device, stream, host thread): the attention kernel writes only the interior, the 1x1 convolution behind it is the only
     reader and is queued on the same stream before the next writer (round 4 re-zeroed a fresh tensor per attention block: 16 ATen fill
     launches per guided UNet call).  Keyed by the host thread as well, so that two engines driven from two threads on one stream never
-    share a buffer."""
+    share a buffer.  The tensor is therefore valid only until the next attention_fused(operand_hw=...) call of the same shape on this
+    stream and thread: the engines consume it at once (the proj_out / NIN_3 convolution); a caller that wants to keep it clones it
+    (torch.ops.diffpure_hip.attention_fused allocates a fresh one per call)."""
     import threading
     key = (device.index, _stream(), threading.get_ident(), tuple(shape))
     buf = _BORDERED.get(key)

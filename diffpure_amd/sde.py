@@ -258,9 +258,10 @@ class Purifier:
     def _check_finite(self, eps, k):
         """DIFFPURE_CHECK_FINITE=1 (validation switch, off by default: it synchronises with the host every step): the fp16 residual
         stream of the fp16 x fp16 modes stores activations with a plain fp32 -> fp16 conversion (no saturation), so a block output
-        beyond 65504 becomes inf and the next GroupNorm turns the whole sample into NaN - silently.  The synthetic and the
-        published checkpoints stay far below that range, a fine-tuned one need not: with the switch on, the first UNet call whose
-        output is not finite raises and names the step, instead of the loop returning NaN images."""
+        beyond 65504 becomes inf and the next GroupNorm turns the whole sample into NaN - silently.  The seeded synthetic weights
+        stay far below that range; the published checkpoints could not be checked here (they are not available - the reference's own
+        `use_fp16` torso, configs/imagenet.yml:18, makes the same assumption about them).  With the switch on, the first UNet call of a
+        forward solve whose output is not finite raises and names the step, instead of the loop returning NaN images."""
         if _CHECK_FINITE and not bool(torch.isfinite(eps).all()):
             raise FloatingPointError(f"score network output is not finite at solver step {k} (precision {getattr(self.net, 'precision', '?')}): "
                                      "an activation overflowed the fp16 residual stream; run with DIFFPURE_LEAN16=0 (fp32 stream) or precision f16x3")
