@@ -192,3 +192,38 @@ def test_oracle_stochastic_adjoint_at_the_product_grid_vs_reference_golden():
     a, y = osol.sde_adjoint_grad(score, g["x_final"], g["cot"], zs, t_int, dt, k_stop=snap["k_stop"], return_state=True)
     assert (y - snap["y"]).abs().max() < 2e-5, (y - snap["y"]).abs().max()
     assert (a - snap["a"]).abs().max() < 1e-4 * snap["a"].abs().max(), ((a - snap["a"]).abs().max(), snap["a"].abs().max())
+
+
+# ---- round 5: the oracle against the reference's OWN modules, live (oracle/_ref travels to the GPU box; skipped where it is absent) -------------
+@pytest.mark.parametrize("kind", ["guided", "ncsnpp"])
+def test_oracle_equals_the_reference_modules_of_oracle_ref_on_fresh_inputs(kind):
+    """oracle/_ref is a byte-exact, sha256-tracked copy of the reference's guided_diffusion/ + score_sde/models/ (oracle/make_ref.py; git-ignored,
+    travels with the snapshot).  The golden files pin the oracle at the inputs they were generated on; this test pins it on FRESH seeded inputs,
+    forward and input gradient, against the reference's nn.Module itself - wherever the copy is present and verified (build container AND GPU box)."""
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip("oracle/_ref absent or not matching oracle/ref_modules.sha256 (python oracle/make_ref.py needs /root/reference)")
+    gen = torch.Generator().manual_seed(20260926)
+    if kind == "guided":
+        g, cfg, sd = _guided("guided_small.pt")
+        mod = ref_loader.guided_unet(g["cfg"], sd)
+        x = torch.rand(g["x"].shape, generator=gen) * 2 - 1
+        t = torch.tensor([3.0, 977.0])[: x.shape[0]]
+        ref_fn, ora_fn = (lambda xx: mod(xx, t)), (lambda xx: og.guided_unet_forward(sd, cfg, xx, t))
+    else:
+        g, cfg, sd = _ncsnpp("ncsnpp_small.pt")
+        mod = ref_loader.ncsnpp(g["cfg"], sd)
+        x = torch.rand(g["x"].shape, generator=gen) * 2 - 1
+        lab = torch.tensor([0.91 * 999, 0.002 * 999])[: x.shape[0]]
+        ref_fn, ora_fn = (lambda xx: mod(xx, lab)), (lambda xx: on.ncsnpp_forward(sd, cfg, xx, lab))
+    cot = None
+    outs = []
+    for fn in (ref_fn, ora_fn):
+        xr = x.clone().requires_grad_(True)
+        y = fn(xr)
+        cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)) if cot is None else cot
+        (gx,) = torch.autograd.grad(y, xr, cot)
+        outs.append((y.detach(), gx))
+    assert outs[0][0].abs().mean() > 0.05
+    torch.testing.assert_close(outs[1][0], outs[0][0], **TOL)
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-3, atol=1e-4 * outs[0][1].abs().max().item())
