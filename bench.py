@@ -655,8 +655,8 @@ def main():
                 "kernel": "conv_igemm_f32 (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)" if a.precision == "f32" else
                           (f"conv_igemm_dw (3x3 implicit GEMM, 256x256 tile, one 8-wave workgroup per CU: two free-running waves per SIMD with 64x128 "
                            f"wave tiles sharing the tile in LDS, the OLDER wave of every SIMD staging the rows of both (LDS-DMA, separate rings for "
-                           f"activations and weights, counted vmcnt, one barrier per k-tile); launches with fewer than 256 tiles run conv_igemm_sw, the "
-                           f"one-wave-per-SIMD form; {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
+                           f"activations and weights, counted vmcnt, one barrier per k-tile); launches with fewer than 256 tiles run conv_igemm_dh, the "
+                           f"same wave tiles on 128x256 tiles with four waves per workgroup (booked here too); {passes} x v_mfma_f32_32x32x16_f16 per product)" if a.precision in ("f16", "f16sr") else
                            f"conv_igemm_h2_pp (3x3 implicit GEMM on the 8-wave ping-pong kernel; {passes} x v_mfma_f32_32x32x16_f16 per "
                            f"product; executed MFMA flops = {passes} x achieved)"),
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
