@@ -278,7 +278,8 @@ def _host_mem_available_gb():
 def cpu_baseline(workload, t_int, n_steps, seed, budget_s=6.0, start_timeout=420.0):
     """The reference's PyTorch score network (oracle/_ref; else the oracle restatement) on THIS BOX'S HOST CORES.  Workers of
     CPU_WORKER_THREADS threads (the size at which one forward is fastest), each a process pinned to its own block of cores, are
-    started ONCE; then k = 1, 2, 4, 8, 16 of them run at once for ~budget_s each and their rates add up (independent images).  The
+    started ONCE; then k = 1, 2, 4, 8, 16 of them run at once for ~budget_s each and their rates add up (independent images; the sweep
+    stops after two points in a row below the best so far).  The
     reported value is the BEST aggregate over k (`host.sweep` holds every point), extrapolated to images/s of the full purification
     (the UNet call is > 99.9 % of a step).  Never raises: a worker that fails or hangs is killed and the failure is recorded in
     `sample` - the GPU measurement this line belongs to is already done."""
@@ -287,7 +288,7 @@ def cpu_baseline(workload, t_int, n_steps, seed, budget_s=6.0, start_timeout=420
     unit, procs = "images/s", []
     try:
         usable = sorted(os.sched_getaffinity(0))
-        per = min(CPU_WORKER_THREADS, len(usable))
+        per = max(1, min(int(os.environ.get("DIFFPURE_CPU_WORKER_THREADS", str(CPU_WORKER_THREADS))), len(usable)))
         guided = workload.startswith("imagenet256_guided")
         nw = max(1, min(len(usable) // per, int(os.environ.get("DIFFPURE_CPU_WORKERS", str(CPU_SWEEP[-1])))))
         mem = _host_mem_available_gb()
@@ -322,7 +323,7 @@ def cpu_baseline(workload, t_int, n_steps, seed, budget_s=6.0, start_timeout=420
             raise RuntimeError("no CPU worker came up")
         kind = next(r for r in ready if r is not None)["kind"]
         rate_of = lambda r: 1.0 / (n_steps * r["s_fwd"] + (n_steps * r["s_fb"] if adjoint else 0.0))
-        sweep, best = [], None
+        sweep, best, stopped = [], None, False
         for k in [k for k in CPU_SWEEP if k <= len(live)] or [len(live)]:
             for p_ in live[:k]:
                 p_.stdin.write(f"GO {budget_s}\n")
@@ -337,6 +338,9 @@ def cpu_baseline(workload, t_int, n_steps, seed, budget_s=6.0, start_timeout=420
             sweep.append(pt)
             if best is None or pt["value"] > best["value"]:
                 best = pt
+            if len(sweep) >= 3 and max(sweep[-1]["value"], sweep[-2]["value"]) < best["value"]:
+                stopped = True      # two points in a row below the best: more workers only contend harder (the 16-worker point of the
+                break               # guided UNet is 13 minutes of CPU work for the lowest rate of the sweep)
         if best is None:
             raise RuntimeError("no sweep point finished")
         what = ("the reference's own nn.Module (oracle/_ref: a byte-exact copy of guided_diffusion/ + score_sde/models/, digests in "
@@ -344,7 +348,7 @@ def cpu_baseline(workload, t_int, n_steps, seed, budget_s=6.0, start_timeout=420
                 "oracle = torch-CPU fp32 restatement of the reference modules (pinned to them by tests/golden); oracle/_ref absent")
         return dict(value=best["value"], unit=unit, cores=best["workers"] * per, kind=kind,
                     host={"cpu_count": os.cpu_count(), "usable_cores": len(usable), "workers_started": len(live), "threads_per_worker": per,
-                          "mem_available_gb": mem, "sweep": sweep},
+                          "mem_available_gb": mem, "sweep": sweep, "sweep_stopped_after_two_declining_points": stopped},
                     sample=(f"best of {[p_['workers'] for p_ in sweep]} concurrent workers x {per} threads: {best['workers']} worker(s); each: "
                             f"{best['calls']} UNet forward(s)" + (f" + {best['calls_fb']} forward+input-gradient pass(es)" if adjoint else "") +
                             f" at batch {best['batch']}, {sum(p_.get('cpu_s', 0.0) for p_ in sweep):.0f} s of CPU work over the sweep; x{n_steps} steps" +
