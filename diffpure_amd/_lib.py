@@ -25,6 +25,8 @@ SIGNATURES = {
     "dp_prof_enable": [_i],
     "dp_prof_collect": [_p, _p, _p, _p, _p],
     "dp_conv2d_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _f, _p, _i, _i, _p, _p, _p],
+    "dp_conv2d_stem_ok": [_i, _i, _i, _i, _i],
+    "dp_conv2d_stem": [_p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p],
     "dp_gn_finalize_cols": [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p],
     "dp_gemm_strided": [_p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _p],
     "dp_gemm_strided_h16": [_p, _i, _i, _ll, _ll, _i, _p, _i, _i, _ll, _ll, _i, _p, _i, _ll, _ll, _i, _i, _i, _i, _i, _f, _p],

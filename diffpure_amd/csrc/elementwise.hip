@@ -20,7 +20,7 @@ void dp_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dp_last_error(void) { return g_dp_err; }
-extern "C" int dp_abi_version(void) { return 7; }
+extern "C" int dp_abi_version(void) { return 8; }
 
 // ---- tuning switches (dp_tune.h): environment read once, then only dp_set_tuning() changes a value -----------------
 namespace {

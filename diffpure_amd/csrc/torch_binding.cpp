@@ -105,6 +105,24 @@ std::tuple<Tensor, Tensor> conv2d_h2_stats(const Tensor& xh, const Tensor& wh, c
     return conv2d_h2_impl(xh, wh, bias, n_out, ksize, passes, w_fmt, true);
 }
 
+// ABI 8 (round 6): the write-bound stem kernel (csrc/stem.hip): x [B, H, W, 3] fp32, w16 = ops.pack_stem_weight -> (out, column records)
+std::tuple<Tensor, Tensor> conv2d_stem(const Tensor& x, const Tensor& w16, const c10::optional<Tensor>& bias, bool out_f16, bool want_stats) {
+    chk_f32(x, "x", 4);
+    chk_h(w16, "w16");
+    TORCH_CHECK(w16.dim() == 3 && w16.size(0) == 2 && w16.size(2) == 32, "diffpure_hip: conv2d_stem wants the [2, N, 32] fp16 (hi | lo) panel");
+    const int64_t B = x.size(0), H = x.size(1), W = x.size(2), N = w16.size(1);
+    TORCH_CHECK(dp_conv2d_stem_ok((int)x.size(3), (int)B, (int)H, (int)W, (int)N), "diffpure_hip: conv2d_stem does not serve this shape");
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty({B, H, W, N}, x.options().dtype(out_f16 ? at::kHalf : at::kFloat));
+    Tensor cols;
+    int tile_rows = 0;
+    if (want_stats) cols = at::zeros({(B * H * W + 511) / 512 * 8, 2, N}, x.options());
+    DP_CALL(dp_conv2d_stem(x.data_ptr<float>(), (int)x.size(3), (int)B, (int)H, (int)W, w16.data_ptr(), (int)N, opt_ptr(bias, "bias"),
+                           out.data_ptr(), out_f16 ? 1 : 0, want_stats ? cols.data_ptr<float>() : nullptr, want_stats ? &tile_rows : nullptr,
+                           cur_stream(x)));
+    return {out, cols};
+}
+
 // ---- GroupNorm ---------------------------------------------------------------------------------------------------
 Tensor group_norm_stats_from_cols(const Tensor& cols, int64_t batch, int64_t hw, int64_t groups, double eps) {
     chk_f32(cols, "cols", 3);
@@ -195,7 +213,7 @@ Tensor resize_affine(const Tensor& x, int64_t ho, int64_t wo, double shift, doub
 }
 
 
-// ==== ABI 6 (round 5): the operators of the fp16 residual stream, and the backward entry points ============================
+// ==== ABI 6 / 7 (rounds 4-5): the operators of the fp16 residual stream, and the backward entry points ============================
 const void* opt_h_ptr(const c10::optional<Tensor>& t, const char* name) {
     if (!t.has_value() || !t->defined()) return nullptr;
     chk_h(*t, name);
@@ -525,13 +543,15 @@ TORCH_LIBRARY(diffpure_hip, m) {
     m.def("em_step(Tensor x, Tensor eps, float nhb, float gg, float sc, bool div, float h, float g, float sqrt_h, int seed, "
           "int sample0, int step) -> Tensor");
     m.def("resize_affine(Tensor x, int ho, int wo, float shift, float scale, bool in_nhwc, bool out_nhwc) -> Tensor");
-    // ABI 6 (round 5): the fp16 residual stream
+    // ABI 6 / 7 (rounds 4-5): the fp16 residual stream
     m.def("conv2d_h2_ex(Tensor xh, Tensor wh, Tensor? bias, Tensor? temb, Tensor? res, Tensor? seg1, Tensor? seg2, int n_out, int ksize, int passes=0, "
           "int w_fmt=0, float scale=1.0, bool out_f16=False, bool want_stats=False) -> (Tensor, Tensor)");
     m.def("gn_apply_h16(Tensor x, Tensor? x2, Tensor? stats, Tensor? gamma, Tensor? beta, Tensor? film_scale, Tensor? film_shift, int groups, bool act, "
           "int resample=0, int out_fmt=2, bool raw=False) -> (Tensor, Tensor)");
     m.def("attention_fused(Tensor qkv, int n_heads, bool legacy_layout, int operand_w=0) -> Tensor");
     m.def("round_weights(Tensor master, Tensor(a!) work, bool stochastic, int seed, int key) -> ()");
+    // ABI 8 (round 6)
+    m.def("conv2d_stem(Tensor x, Tensor w16, Tensor? bias, bool out_f16=False, bool want_stats=False) -> (Tensor, Tensor)");
     // backward entry points (dL/dx; weights are constants on this path)
     m.def("group_norm_stats(Tensor x, int groups, float eps) -> Tensor");
     m.def("group_norm_silu_bwd(Tensor x, Tensor stats, Tensor gamma, Tensor beta, Tensor dy, int groups, bool act) -> Tensor");
@@ -554,6 +574,7 @@ TORCH_LIBRARY_IMPL(diffpure_hip, CUDA, m) {      // CUDA dispatch key = HIP devi
     m.impl("gn_apply_h16", gn_apply_h16);
     m.impl("attention_fused", attention_fused);
     m.impl("round_weights", round_weights);
+    m.impl("conv2d_stem", conv2d_stem);
     m.impl("group_norm_stats", group_norm_stats);
     m.impl("group_norm_silu_bwd", group_norm_silu_bwd);
     m.impl("attention_bwd", attention_bwd);

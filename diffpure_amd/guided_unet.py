@@ -241,6 +241,8 @@ class GuidedUNet:
             n = r["name"]
             if r["kind"] == "stem":
                 P[n + ".w"] = ops.pack_conv_weight(sd[n + ".weight"].detach()).to(dev)
+                if self.h2mode and r["cin"] == 3:       # the write-bound stem kernel (csrc/stem.hip) where its shape test passes
+                    P[n + ".w16"] = ops.pack_stem_weight(sd[n + ".weight"]).to(dev)
                 P[n + ".b"] = vec(n + ".bias")
             elif r["kind"] == "res":
                 P[n + ".g1"], P[n + ".b1"] = vec(n + ".in_layers.0.weight"), vec(n + ".in_layers.0.bias")
@@ -432,8 +434,11 @@ class GuidedUNet:
         P = self.p
         hs = []
         stem = self.plan["inp"][0][0]
-        h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"], colstats=True,
-                       out_f16=self._o16(x.shape[1] * x.shape[2], tape))
+        o16 = self._o16(x.shape[1] * x.shape[2], tape)
+        if (stem["name"] + ".w16") in P and ops.conv2d_stem_ok(x.shape[3], x.shape[0], x.shape[1], x.shape[2], stem["cout"]):
+            h = ops.conv2d_stem(x, P[stem["name"] + ".w16"], stem["cout"], bias=P[stem["name"] + ".b"], colstats=True, out_f16=o16)
+        else:
+            h = ops.conv2d(x, P[stem["name"] + ".w"], stem["cout"], 3, bias=P[stem["name"] + ".b"], colstats=True, out_f16=o16)
         hs.append(h)
         for blk in self.plan["inp"][1:]:
             h = self._run(blk, h, None, film, tape)

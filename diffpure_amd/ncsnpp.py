@@ -195,6 +195,8 @@ class NCSNpp:
         P["t1.w"], P["t1.b"] = ops.pack_linear_weight(sd[M + "1.weight"].detach()).to(dev), vec(M + "1.bias")
         si = self.plan["stem"]["idx"]
         P["stem.w"], P["stem.b"] = ops.pack_conv_weight(sd[M + f"{si}.weight"].detach()).to(dev), vec(M + f"{si}.bias")
+        if self.h2mode and self.plan["stem"]["cin"] == 3:       # the write-bound stem kernel (csrc/stem.hip) where its shape test passes
+            P["stem.w16"] = ops.pack_stem_weight(sd[M + f"{si}.weight"]).to(dev)
         dw, db, off = [], [], 0
         recs = [r for b in self.plan["down"] for r in b] + self.plan["mid"] + self.plan["up"]
         for r in recs:
@@ -373,7 +375,11 @@ class NCSNpp:
         P = self.p
         dense = table_row if table_row is not None else self.time_table(labels)
         st = self.plan["stem"]
-        hs = [ops.conv2d(x, P["stem.w"], st["cout"], 3, bias=P["stem.b"], colstats=True, out_f16=self._o16(x.shape[1] * x.shape[2], tape))]
+        o16 = self._o16(x.shape[1] * x.shape[2], tape)
+        if "stem.w16" in P and ops.conv2d_stem_ok(x.shape[3], x.shape[0], x.shape[1], x.shape[2], st["cout"]):
+            hs = [ops.conv2d_stem(x, P["stem.w16"], st["cout"], bias=P["stem.b"], colstats=True, out_f16=o16)]
+        else:
+            hs = [ops.conv2d(x, P["stem.w"], st["cout"], 3, bias=P["stem.b"], colstats=True, out_f16=o16)]
         for blk in self.plan["down"]:
             h = hs[-1]
             for r in blk:

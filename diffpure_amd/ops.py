@@ -380,6 +380,41 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
     return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
 
 
+def pack_stem_weight(w):
+    """OIHW [N, 3, 3, 3] stem weight -> the (hi | lo) panel of dp_conv2d_stem: [2, N, 32] fp16, k = (ky*3 + kx)*Cin + ci, columns beyond
+    9*Cin zero; hi = fp16(w), lo = fp16(w - hi) (host side, once at load)."""
+    n, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and 9 * cin <= 32, w.shape
+    wk = torch.zeros(n, 32, dtype=torch.float32)
+    wk[:, :9 * cin] = w.detach().float().permute(0, 2, 3, 1).reshape(n, 9 * cin)
+    hi = wk.half()
+    lo = (wk - hi.float()).half()
+    return torch.stack([hi, lo], dim=0).contiguous()
+
+
+def conv2d_stem_ok(cin, b, h, w, n_out):
+    """does csrc/stem.hip serve this stem shape?  (a function of the layer; the batch enters only through B*H*W % 64, which every
+    power-of-two image size satisfies at any B)"""
+    return bool(_lib.load().dp_conv2d_stem_ok(cin, b, h, w, n_out)) and os.environ.get("DIFFPURE_STEM16", "1") != "0"
+
+
+def conv2d_stem(x, wpanel, n_out, bias=None, colstats=False, out_f16=False):
+    """3x3 'same' convolution of the fp32 NHWC state x [B, H, W, 3] with the (hi | lo) panel of pack_stem_weight -> [B, H, W, n_out]
+    fp32 / plain fp16 (+ the column records), on the write-bound stem kernel (22-bit operands, three fp16 MFMA passes, fp32 accumulation)."""
+    _chk(x, "conv2d_stem.x", 4)
+    b, h, w, cin = x.shape
+    if not (isinstance(wpanel, torch.Tensor) and wpanel.is_cuda and wpanel.dtype == torch.float16 and wpanel.is_contiguous()
+            and tuple(wpanel.shape) == (2, n_out, 32)):
+        raise _lib.DiffpureHipError("conv2d_stem.w: expected the [2, N, 32] fp16 panel of pack_stem_weight on the GPU")
+    if bias is not None:
+        _chk(bias, "conv2d_stem.bias", 1)
+    out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
+    cs, tr = _colstats_alloc(b * h * w, n_out, x.device) if colstats else (None, None)
+    _lib.call("dp_conv2d_stem", _ptr(x), cin, b, h, w, _ptr(wpanel), n_out, _ptr(bias), _ptr(out), 1 if out_f16 else 0, _ptr(cs),
+              None if tr is None else ctypes.addressof(tr), _stream())
+    return Act(out, ColStats(cs, tr.value, n_out)) if colstats else out
+
+
 def linear(x, wp, n_out, bias=None):
     """[M, K] @ [K, N] + bias."""
     _chk(x, "linear.x", 2)

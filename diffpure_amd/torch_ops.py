@@ -21,7 +21,7 @@ Operators (NHWC fp32 unless stated; contracts in include/diffpure_hip.h, schemas
     attention                            softmax(q k^T / sqrt(d)) v, flash-style when d == 64
     em_step                              fused Euler-Maruyama update, in-kernel Philox noise
     resize_affine                        bilinear resize + affine + layout change
-ABI 6 (round 5) - the fp16 residual stream and the backward entry points:
+ABI 6 / 7 (rounds 4-5) - the fp16 residual stream and the backward entry points:
     conv2d_h2_ex                         the WHOLE epilogue contract: bias, time-embedding rows, fp32 / fp16 residual, scale, fp16 output,
                                          column records, 1x1 K-segments (a ResBlock's skip convolution folded into its second 3x3)
     gn_apply_h16                         GroupNorm-apply (+FiLM) (+SiLU) (+2x resample) over plain fp16 tensors -> "h1" operand / fp16 tensor
@@ -29,6 +29,8 @@ ABI 6 (round 5) - the fp16 residual stream and the backward entry points:
                                          writing the zero-bordered fp16 operand of proj_out
     round_weights                        fp32 masters -> fp16 panels in place (nearest / stochastic, Philox-keyed): precision "f16sr"
     group_norm_stats, group_norm_silu_bwd, attention_bwd, resize_affine_bwd, conv2d_nhwc_dgrad      backward entry points (dL/dx)
+ABI 8 (round 6):
+    conv2d_stem                          the 3 -> N stem convolution as a write-bound kernel (22-bit operands, three fp16 MFMA passes)
 torch.autograd: conv2d_nhwc, group_norm_silu (fp32 output form), attention and resize_affine are registered for the Autograd key with
 dL/dx formulas built from those entry points (weights are constants on this path): `y.backward()` / `torch.autograd.grad` work through them.
 """
@@ -42,7 +44,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 OPERATORS = ("conv2d_nhwc", "conv2d_nhwc_stats", "conv2d_h2", "conv2d_h2_stats", "group_norm_stats_from_cols", "group_norm_silu",
              "attention", "em_step", "resize_affine",
              "conv2d_h2_ex", "gn_apply_h16", "attention_fused", "round_weights", "group_norm_stats", "group_norm_silu_bwd", "attention_bwd",
-             "resize_affine_bwd", "conv2d_nhwc_dgrad")
+             "resize_affine_bwd", "conv2d_nhwc_dgrad", "conv2d_stem")
 
 if not os.path.exists(LIB_PATH):
     raise _lib.DiffpureHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")

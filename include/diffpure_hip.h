@@ -84,6 +84,21 @@ int dp_conv2d_nhwc(const float* x1, int C1, const float* x2, int C2,
                    void* out, int ldo, int out_fmt,
                    float* colstats, int* tile_rows, void* stream);
 
+/* The STEM of a score network (ABI 8): 3x3, stride 1, "same" zero padding, Cin = 3 -> N channels - guided_diffusion/unet.py:478-484
+ * (3 -> 256 at 256^2), score_sde/models/ncsnpp.py:232-236 (3 -> 128 at 32^2) - as a WRITE-BOUND kernel: K = 27 is one 32-wide k-tile
+ * of the fp16 matrix cores and the layer moves 2.15 GB of fp16 output against 50 MB of input at B = 64 (csrc/stem.hip).
+ *   x [B][H][W][3] fp32 (the SDE state; no border - padding is resolved in the gather);
+ *   w: [2][N][32] fp16 - the (hi, lo) split of the fp32 weights, hi = fp16(w), lo = fp16(w - hi), row n, k = (ky*3+kx)*3 + ci,
+ *      columns 27..31 zero (diffpure_amd/ops.py:pack_stem_weight);  bias [N] fp32 or NULL;
+ *   out [B*H*W][N] fp32 (out_fmt 0) or plain fp16 (out_fmt 1; rounded to nearest, the column records are those of the unrounded values).
+ * Arithmetic: x and w as 22-bit (hi, lo) pairs, x_lo*w_hi + x_hi*w_lo + x_hi*w_hi in three v_mfma_f32_32x32x16_f16 passes, fp32
+ * accumulation ("f16x3").  colstats / tile_rows as in dp_conv2d_nhwc (64-row records; M % 64 == 0 here, so no padding records are
+ * written).  dp_conv2d_stem_ok: does the kernel serve this shape (Cin == 3, N in {128, 256}, B*H*W % 64 == 0)? - a function of the
+ * layer and of nothing else a sharding of the batch could change. */
+int dp_conv2d_stem_ok(int Cin, int B, int H, int W, int N);
+int dp_conv2d_stem(const float* x, int Cin, int B, int H, int W, const void* w, int N, const float* bias,
+                   void* out, int out_fmt, float* colstats, int* tile_rows, void* stream);
+
 /* Same contract on the fp16 matrix cores with fp32-class accuracy ("f16x3"): every operand is a
  * (hi, lo) pair of fp16 numbers and every product is three v_mfma_f32_32x32x16_f16 passes
  * (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi) into one fp32 accumulator.

@@ -175,6 +175,20 @@ def conv2d(x, wp, n_out, ksize, bias=None, x2=None, temb=None, res=None, scale=1
     return _act(y) if colstats else y
 
 
+def conv2d_stem_ok(cin, b, h, w, n_out):
+    return cin == 3 and n_out in (128, 256) and (b * h * w) % 64 == 0
+
+
+def conv2d_stem(x, wpanel, n_out, bias=None, colstats=False, out_f16=False):
+    """the (hi | lo) panel of ops.pack_stem_weight back to OIHW, then the plain convolution"""
+    cin = x.shape[3]
+    wk = (wpanel[0].float() + wpanel[1].float())[:, :9 * cin].reshape(n_out, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+    y = F.conv2d(x.permute(0, 3, 1, 2), wk, bias, padding=1).permute(0, 2, 3, 1).contiguous()
+    if out_f16:
+        y = y.half()
+    return _act(y) if colstats else y
+
+
 def linear(x, wp, n_out, bias=None):
     m, k = x.shape
     return conv2d(x.view(m, 1, 1, k), wp, n_out, 1, bias=bias).view(m, n_out)
@@ -477,7 +491,7 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
     return dx.permute(0, 2, 3, 1).contiguous() if in_nhwc else dx.contiguous()
 
 
-PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd", "gn_bwd_fused_ok",
+PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_stem", "conv2d_stem_ok", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd", "gn_bwd_fused_ok",
            "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "group_norm_f16in", "resample", "attention", "attention_fused",
            "attention_fused_ok", "attention_h16_serves", "silu", "axpby", "takes_segments",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/diffpure_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.dp_abi_version() == 7
+    assert lib.dp_abi_version() == 8
 
 
 def test_ctypes_table_matches_the_header_prototypes():

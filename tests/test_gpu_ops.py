@@ -1221,3 +1221,46 @@ def test_attention_backward_on_the_fp16_matrix_cores(dev, case):
         assert g_a.dtype == torch.float32 and torch.equal(p_a, p_b) and torch.equal(g_a, g_b)
     else:
         assert heads == 2
+
+
+STEM_CASES = [(2, 32, 32, 128), (1, 256, 256, 256), (3, 16, 24, 256), (5, 8, 8, 128)]
+
+
+@pytest.mark.parametrize("case", STEM_CASES, ids=str)
+def test_stem_kernel_against_fp64_and_its_column_records(dev, case):
+    """Round 6: dp_conv2d_stem (csrc/stem.hip) - the 3 -> N stem as a write-bound kernel on 22-bit (hi, lo) operands - against the fp64
+    convolution (fp32-class: 1e-5), zero padding at all four image edges included; fp16 output = the fp32 output rounded, same records;
+    the records give the GroupNorm statistics of the unrounded tensor; a batch's leading samples are bit-identical to the small batch."""
+    from diffpure_amd import ops
+    B, H, W, N = case
+    assert ops.conv2d_stem_ok(3, B, H, W, N)
+    x = rnd(B, H, W, 3, seed=1) * 1.5
+    w = rnd(N, 3, 3, 3, seed=2, scale=0.2)
+    bias = rnd(N, seed=3)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1).float()
+    w16 = ops.pack_stem_weight(w).to(dev)
+    y32 = ops.conv2d_stem(x.to(dev), w16, N, bias=bias.to(dev), colstats=True)
+    y16 = ops.conv2d_stem(x.to(dev), w16, N, bias=bias.to(dev), colstats=True, out_f16=True)
+    close(y32.t, ref, rtol=1e-5, atol=1e-5)
+    assert y16.t.dtype == torch.float16 and torch.equal(y16.t, y32.t.half())
+    rec = (B * H * W) // 64
+    assert torch.equal(y16.cols.buf[:rec], y32.cols.buf[:rec]) and y32.cols.tile_rows == 64
+    st = ops.group_norm_stats(y16, 32, 1e-5).cpu()
+    v = ref.double().reshape(B, H * W, 32, N // 32)
+    mean, var = v.mean(dim=(1, 3)), v.var(dim=(1, 3), unbiased=False)
+    close(st[:, :, 0], mean.float(), rtol=1e-4, atol=1e-5)
+    close(st[:, :, 1], (var + 1e-5).rsqrt().float(), rtol=1e-4, atol=1e-5)
+    if B > 1:       # shard invariance: the first sample alone
+        one = ops.conv2d_stem(x[:1].contiguous().to(dev), w16, N, bias=bias.to(dev), colstats=True, out_f16=True)
+        assert torch.equal(one.t, y16.t[:1]) and torch.equal(one.cols.buf[:(H * W) // 64], y16.cols.buf[:(H * W) // 64])
+    # the dispatcher binding runs the same kernel
+    import diffpure_amd.torch_ops  # noqa: F401
+    o2, c2 = torch.ops.diffpure_hip.conv2d_stem(x.to(dev), w16, bias.to(dev), True, True)
+    assert torch.equal(o2, y16.t) and torch.equal(c2[:rec], y16.cols.buf[:rec])
+
+
+def test_stem_kernel_rejects_shapes_it_does_not_serve(dev):
+    from diffpure_amd import ops, _lib
+    assert not ops.conv2d_stem_ok(4, 2, 32, 32, 128) and not ops.conv2d_stem_ok(3, 1, 5, 5, 128) and not ops.conv2d_stem_ok(3, 2, 32, 32, 96)
+    with pytest.raises(_lib.DiffpureHipError):
+        ops.conv2d_stem(torch.zeros(1, 5, 5, 3, device=dev), ops.pack_stem_weight(torch.zeros(128, 3, 3, 3)).to(dev), 128)

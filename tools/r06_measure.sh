@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round-6 measurement calls on the GPU box (gpurun).  Everything lands under gpurun_out/r06/<stage>/ (copied into profiles/r06/ afterwards).
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+cd "$R"
+STAGE=${1:-stem}
+O="$R/gpurun_out/r06/$STAGE"
+rm -rf "$O"; mkdir -p "$O"
+export TMPDIR=/tmp
+S=$(date +%s)
+lap() { echo "[$(( $(date +%s) - S )) s] $1" >> "$O/timeline.log"; }
+: > "$O/timeline.log"
+val() { python -c "import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print('$2', round(d['value'],3), 'images/s', d.get('sclk_mhz_median', d['roofline'].get('sclk_mhz')))"; }
+rocstats() {   # rocstats <name> <timeout> <bench args...>: rocprofv3 kernel stats of one bench command
+  local name=$1 to=$2; shift 2
+  ( cd /tmp && timeout "$to" rocprofv3 --kernel-trace --stats -d "$O/prof_$name" -o run --output-format csv -- python "$R/bench.py" "$@" --no-cpu-baseline --no-resident-call > "$O/bench_${name}_under_rocprof.json" 2> "$O/rocprof_$name.err" )
+  find "$O/prof_$name" -name "*kernel_trace.csv" -delete; find "$O/prof_$name" -name "*agent_info.csv" -delete
+  f=$(find "$O/prof_$name" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/${name}_kernel_stats.csv"
+  lap "rocprof_$name"
+}
+gputests() {
+  timeout 1700 python -m pytest tests -m gpu -q -s > "$O/gpu_tests.log" 2>&1; echo "rc=$?" >> "$O/gpu_tests.log"; lap gpu_tests
+  timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; echo "rc=$?" >> "$O/smoke.log"; lap smoke
+  grep -E "passed|failed" "$O/gpu_tests.log" | tail -2; grep -E "^FAILED|^ERROR" "$O/gpu_tests.log" | head; tail -2 "$O/smoke.log"
+}
+ab() {   # ab <env var> <label> <bench args...>: same-box A/B of one switch, 0 1 0 1
+  local var=$1 label=$2; shift 2
+  for V in 0 1 0 1; do
+    env $var=$V timeout 400 python bench.py "$@" --no-cpu-baseline --no-resident-call > "$O/bench_${label}_$V.json" 2>> "$O/bench_ab.err"
+    val "$O/bench_${label}_$V.json" "$label $var=$V" | tee -a "$O/${label}_ab.log"
+  done; lap "ab_$label"
+}
+case "$STAGE" in
+stem)
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "stem" > "$O/stem_tests.log" 2>&1; echo "rc=$?" >> "$O/stem_tests.log"; lap stem_tests
+  tail -15 "$O/stem_tests.log"
+  timeout 200 python tests/probes/stem_bench.py > "$O/stem_bench.log" 2>&1; lap stem_bench
+  cat "$O/stem_bench.log"
+  ab DIFFPURE_STEM16 guided_t20 --t 20 --steps 1 --warmup 1
+  ;;
+tests)
+  gputests
+  ;;
+*)
+  echo "unknown stage $STAGE"; exit 1;;
+esac
+lap done
+cat "$O/timeline.log"
