@@ -110,7 +110,13 @@ class SclkSampler:
                 self.path = c
         if self.path is None and len(cands) == 1:
             self.path = cands[0]
+        # socket power of the SAME card (hwmon power1_average / power1_input, microwatts): the chip sits at its 1 400 W cap under the
+        # dominant kernel, so the clock it holds - and with it the roofline fraction - is a power figure
+        self.power, self.pow_path = [], None
         if self.path:
+            d = os.path.dirname(self.path)
+            pc = sorted(glob.glob(os.path.join(d, "hwmon/hwmon*/power1_average"))) + sorted(glob.glob(os.path.join(d, "hwmon/hwmon*/power1_input")))
+            self.pow_path = pc[0] if pc else None
             self._th = threading.Thread(target=self._run, daemon=True)
 
     def _read(self):
@@ -127,6 +133,11 @@ class SclkSampler:
             v = self._read()
             if v:
                 self.samples.append(v)
+            if self.pow_path:
+                try:
+                    self.power.append(float(open(self.pow_path).read().strip()) * 1e-6)
+                except Exception:
+                    pass
             self._stop.wait(0.5)
 
     def start(self):
@@ -140,7 +151,11 @@ class SclkSampler:
         if not self.samples:
             return None
         s_ = sorted(self.samples)
-        return dict(median=s_[len(s_) // 2], min=s_[0], max=s_[-1], samples=len(s_), source=self.path)
+        out = dict(median=s_[len(s_) // 2], min=s_[0], max=s_[-1], samples=len(s_), source=self.path)
+        if self.power:
+            p_ = sorted(self.power)
+            out.update(power_w_median=p_[len(p_) // 2], power_w_max=p_[-1], power_source=self.pow_path)
+        return out
 
 
 def pmc_traffic(workload, batch, precision):
@@ -156,6 +171,25 @@ def pmc_traffic(workload, batch, precision):
         if row["workload"] == workload and row["per_gpu_batch"] == batch and row["precision"] == precision:
             return row
     return None
+
+
+def traffic_keys(row, prof):
+    """roofline.traffic and the algorithmic bytes it is compared with, over the SAME launch set (round 6; round 5 printed a counter
+    average over 232 launches of three kernels next to the algorithmic bytes of the 3x3 launches of one).  rocprofv3 aggregates per
+    kernel NAME, the in-process profile per launch kind, and since ABI 8 a kind belongs to one kernel: the row's `per_kernel` entry of
+    conv_igemm_dw covers exactly kinds pp3x3 + pp1x1 (every launch of that kernel in a UNet call, 3x3 and 1x1)."""
+    pk = (row.get("per_kernel") or {}).get("conv_igemm_dw")
+    n = prof["pp3x3"]["n"] + prof["pp1x1"]["n"]
+    if not pk or not n:
+        return {"traffic": row.get("hbm_bytes_per_launch"), "traffic_note": "committed PMC pass has no per-kernel rows: the average is over every "
+                "256-wide-tile kernel's launches and is NOT comparable with algorithmic_bytes_per_launch (3x3 launches of conv_igemm_dw only)"}
+    alg = (prof["pp3x3"]["bytes"] + prof["pp1x1"]["bytes"]) / n
+    return {"traffic": pk["hbm_bytes_per_launch"], "traffic_launch_set": "every conv_igemm_dw launch of a UNet call (3x3 and 1x1), per launch",
+            "traffic_launches_per_unet_call_pmc": pk["launches"] / max(1, row.get("unet_calls_profiled", 2)),
+            "traffic_launches_per_unet_call_this_run": n / max(1, prof.get("unet_calls", 1)),
+            "algorithmic_bytes_per_launch_same_set": alg, "traffic_over_algorithmic": pk["hbm_bytes_per_launch"] / alg,
+            "traffic_fetch_bytes_per_launch": pk["fetch_bytes_per_launch"], "traffic_write_bytes_per_launch": pk["write_bytes_per_launch"],
+            "traffic_source": row.get("source", "") + " (a committed offline pass over this workload, not a measurement of this run)"}
 
 
 def pmc_mfma_busy():
@@ -246,10 +280,12 @@ def cpu_worker(workload, t_int, seed, cores):
             calls += 1
         return (time.time() - t0) / (calls * b), calls, time.time() - t0
 
+    out_ = sys.stdout       # the tagged lines' pipe; every other print of this process (libraries, the reference modules) goes to stderr
+    sys.stdout = sys.stderr
     fwd()           # warm-up (oneDNN primitive creation)
     if adjoint:
         fb()
-    print("CPUWORKER READY " + json.dumps(dict(kind=kind, batch=b, threads=len(cores))), flush=True)
+    print("CPUWORKER READY " + json.dumps(dict(kind=kind, batch=b, threads=len(cores))), file=out_, flush=True)
     for line in sys.stdin:
         parts = line.split()
         if not parts or parts[0] == "QUIT":
@@ -262,7 +298,7 @@ def cpu_worker(workload, t_int, seed, cores):
         if adjoint:
             s_fb, calls2, el2 = timed(fb, budget * 0.6)
             rec.update(s_fb=s_fb, calls_fb=calls2, cpu_s=el + el2)
-        print("CPUWORKER RES " + json.dumps(rec), flush=True)
+        print("CPUWORKER RES " + json.dumps(rec), file=out_, flush=True)
 
 
 def _host_mem_available_gb():
@@ -300,21 +336,34 @@ def cpu_baseline(workload, t_int, n_steps, seed, budget_s=6.0, start_timeout=420
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cores, "--workload", workload, "--t", str(t_int),
                                            "--seed", str(seed)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, bufsize=1))
 
+        pending = {}        # worker -> bytes read from its pipe that are not a complete line yet
+
         def read_tagged(p_, tag, timeout):
-            """next `CPUWORKER <tag> {...}` line of worker p_ within `timeout` seconds, else None"""
+            """next `CPUWORKER <tag> {...}` line of worker p_ within `timeout` seconds, else None.  The pipe is read with os.read on its
+            file descriptor into a buffer of our own (round 6, advisor): select() on the descriptor followed by the TextIO wrapper's
+            readline() could leave a tagged line inside Python's buffer - flushed together with a stray print of the worker - where
+            select() never reports it again."""
+            fd, want = p_.stdout.fileno(), "CPUWORKER " + tag + " "
             end = time.time() + timeout
-            while time.time() < end:
-                r, _, _ = select.select([p_.stdout], [], [], max(0.0, min(1.0, end - time.time())))
+            while True:
+                buf = pending.get(p_, b"")
+                while b"\n" in buf:
+                    line, buf = buf.split(b"\n", 1)
+                    pending[p_] = buf
+                    text = line.decode("utf-8", "replace")
+                    if text.startswith(want):
+                        return json.loads(text[len(want):])
+                if time.time() >= end:
+                    return None
+                r, _, _ = select.select([fd], [], [], max(0.0, min(1.0, end - time.time())))
                 if not r:
                     if p_.poll() is not None:
                         return None
                     continue
-                line = p_.stdout.readline()
-                if not line:
+                chunk = os.read(fd, 1 << 16)
+                if not chunk:
                     return None
-                if line.startswith("CPUWORKER " + tag + " "):
-                    return json.loads(line[len("CPUWORKER " + tag + " "):])
-            return None
+                pending[p_] = pending.get(p_, b"") + chunk
 
         t_start = time.time()
         ready = [read_tagged(p_, "READY", max(1.0, start_timeout - (time.time() - t_start))) for p_ in procs]
@@ -346,10 +395,16 @@ def cpu_baseline(workload, t_int, n_steps, seed, budget_s=6.0, start_timeout=420
         what = ("the reference's own nn.Module (oracle/_ref: a byte-exact copy of guided_diffusion/ + score_sde/models/, digests in "
                 "oracle/ref_modules.sha256)" if kind == "reference" else
                 "oracle = torch-CPU fp32 restatement of the reference modules (pinned to them by tests/golden); oracle/_ref absent")
+        tried = [p_["workers"] for p_ in sweep]
+        rates = ", ".join(f"{p_['workers']}: {p_['value']:.4g}" if "value" in p_ else f"{p_['workers']}: failed" for p_ in sweep)
         return dict(value=best["value"], unit=unit, cores=best["workers"] * per, kind=kind,
+                    # scalars for the driver's parser: how many concurrent workers were tried, and the host's core count - `cores` above is the
+                    # cores of the BEST point, more workers were tried and lost (they contend for memory bandwidth)
+                    cpu_workers_tried=",".join(str(k) for k in tried), cpu_workers_best=best["workers"], host_cpu_count=os.cpu_count(),
                     host={"cpu_count": os.cpu_count(), "usable_cores": len(usable), "workers_started": len(live), "threads_per_worker": per,
                           "mem_available_gb": mem, "sweep": sweep, "sweep_stopped_after_two_declining_points": stopped},
-                    sample=(f"best of {[p_['workers'] for p_ in sweep]} concurrent workers x {per} threads: {best['workers']} worker(s); each: "
+                    sample=(f"best of {tried} concurrent workers x {per} threads on a {os.cpu_count()}-core host ({unit} per point - {rates}; more "
+                            f"workers were tried and lost{', the sweep stopped after two declining points' if stopped else ''}): {best['workers']} worker(s); each: "
                             f"{best['calls']} UNet forward(s)" + (f" + {best['calls_fb']} forward+input-gradient pass(es)" if adjoint else "") +
                             f" at batch {best['batch']}, {sum(p_.get('cpu_s', 0.0) for p_ in sweep):.0f} s of CPU work over the sweep; x{n_steps} steps" +
                             (f" + {n_steps} adjoint steps" if adjoint else "") + " extrapolated; " + what))
@@ -686,9 +741,17 @@ def main():
                     "launches_in_timed_region": launches_per_call * a.steps, "dropped_records": prof["dropped"],
                     "time_share_of_step": dom["ms"] / window_ms,
                     "sampled_step_ms": window_ms,
+                    # scalars (the driver's parser keeps scalars of this object, not nested ones): the clock and socket power this run held
+                    "sclk_mhz_median": held, "power_w_median": (sclk or {}).get("power_w_median"),
+                    "algorithmic_bytes_per_launch_note": "3x3 launches of the dominant kernel only (the set `achieved` is computed over); the set "
+                                                         "`traffic` is measured over has its own key, algorithmic_bytes_per_launch_same_set",
                     "other_kernels_share_of_step": {"3x3 on other tile variants (stem, head, split-K levels)": prof["other3x3"]["ms"] / window_ms,
                                                     "1x1 convolutions / linear": (prof["conv1x1"]["ms"] + prof["pp1x1"]["ms"]) / window_ms},
                 })
+                dh = prof.get("dh3x3")
+                if dh and dh["ms"] > 0:     # launches that leave CUs idle on 256x256 tiles (fewer than 256 of them): the 4-wave 128x256-tile kernel
+                    roof["conv_igemm_dh_tflops"] = dh["flop"] / (dh["ms"] * 1e-3) / 1e12
+                    roof["conv_igemm_dh_time_share_of_step"] = (dh["ms"] + prof["dh1x1"]["ms"]) / window_ms
                 gn = prof.get("gn_apply")
                 if gn and gn["ms"] > 0:     # the second kernel of the step: HBM-bound, measured with the same hipEvent pairs
                     gbs = gn["bytes"] / (gn["ms"] * 1e-3) / 1e9
@@ -696,16 +759,15 @@ def main():
                                              "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                              "frac_of_measured_copy_rate_6290": gbs / 6290.0, "algorithmic_bytes_per_launch": gn["bytes"] / gn["n"],
                                              "avg_launch_ms": gn["ms"] / gn["n"], "sampled_launches": gn["n"], "time_share_of_step": gn["ms"] / window_ms}
+                    roof["gn_apply_tb_per_s"] = gbs / 1e3
+                    roof["gn_apply_time_share_of_step"] = gn["ms"] / window_ms
                 if a.workload == "imagenet256_guided" and a.precision in ("f16", "f16sr"):
                     busy = pmc_mfma_busy()
                     if busy is not None:
                         roof["mfma_busy_by_pmc"] = busy
                 row = pmc_traffic(a.workload, B, a.precision)
                 if row is not None:
-                    # rocprofv3 aggregates per kernel NAME: the ping-pong kernel's 3x3 and 1x1 launches together
-                    allpp_n = prof["pp3x3"]["n"] + prof["pp1x1"]["n"]
-                    roof["algorithmic_bytes_per_launch_all_pingpong_launches"] = (prof["pp3x3"]["bytes"] + prof["pp1x1"]["bytes"]) / max(1, allpp_n)
-                    roof["traffic"] = row["hbm_bytes_per_launch"]
+                    roof.update(traffic_keys(row, prof))
                     roof["traffic_detail"] = {k: row[k] for k in row if k not in ("workload", "per_gpu_batch", "precision")}
                 else:
                     roof["traffic_note"] = ("no rocprofv3 --pmc pass committed for this (workload, batch, precision): "

@@ -592,7 +592,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         auto dh_enough = [&](long long wg) { return wg >= 128 || (wg >= dp_tune(DP_T_H2_DH_MIN) && (p.K / 32) / p.ksplit >= 72); };
         if (dp_tune(DP_T_H2_DH) != 0 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && dh_enough(tiles(128, 256)) && t256 < 256 && dp_conv_dh_applies(p, 256)) {
             dp_launch_conv_dh(p, s, 256);
-            dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_PP : DP_PROF_1X1_PP);
+            dp_prof_set_kind(rec, KS == 3 ? DP_PROF_3X3_DH : DP_PROF_1X1_DH);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("conv_igemm_dh");
@@ -605,7 +605,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit == 1 && N % 256 != 0 && KS == 3 && dh_enough(tiles(256, 128)) &&
             (tiles(512, 128) < 256 || dp_tune(DP_T_H2_DH) >= 3) && dp_conv_dh_applies(p, 128)) {
             dp_launch_conv_dh(p, s, 128);
-            dp_prof_set_kind(rec, DP_PROF_3X3_PP);
+            dp_prof_set_kind(rec, DP_PROF_3X3_DH);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("conv_igemm_dh<256>");

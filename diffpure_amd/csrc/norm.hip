@@ -480,7 +480,9 @@ struct Apply16Args {
     int cpg, Ho, Wo;
 };
 
-template <bool ACT, int BORDER>
+// RS: the resampling mode as a template parameter (round 6) - the resampling loops keep eight loads in flight and must not cost the
+// un-resampled instantiation (92 registers: five resident waves per SIMD) its occupancy
+template <bool ACT, int BORDER, int RS>
 __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int COT, int slots) {
     const int C = p.C1 + p.C2, CO = C / 8;
     const int Hq = p.Ho + 2 * BORDER, Wq = p.Wo + 2 * BORDER;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
             continue;
         }
         int qx = slot;
-        if (p.resample == 0) {
+        if constexpr (RS == 0) {
             const half8* xrow = src + ((size_t)b * p.H + oy) * p.W * so;
             for (; qx + 3 * slots < Wq; qx += 4 * slots) {       // four pixels at a time: all loads issued before the first use
                 half8 rv[4];
@@ -573,31 +575,84 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
                 }
             }
         }
-        for (; qx < Wq; qx += slots) {
-            const int ox = qx - BORDER;
-            if ((unsigned)ox >= (unsigned)p.Wo) {
-                yrow[(size_t)qx * CO] = zero8;
-                if (rrow) rrow[(size_t)qx * CO] = zero8;
-                continue;
-            }
-            half8 o;
-            if (p.resample == 0) {
+        if constexpr (RS == 0) {
+            for (; qx < Wq; qx += slots) {
+                const int ox = qx - BORDER;
+                if ((unsigned)ox >= (unsigned)p.Wo) {
+                    yrow[(size_t)qx * CO] = zero8;
+                    if (rrow) rrow[(size_t)qx * CO] = zero8;
+                    continue;
+                }
                 const half8 v = src[(((size_t)b * p.H + oy) * p.W + ox) * so];
-                o = xf(v);
+                yrow[(size_t)qx * CO] = xf(v);
                 if (rrow) rrow[(size_t)qx * CO] = v;
-            } else if (p.resample == 1) {
-                o = xf(src[(((size_t)b * p.H + (oy >> 1)) * p.W + (ox >> 1)) * so]);
-            } else {
-                const size_t r0 = ((size_t)b * p.H + 2 * oy) * p.W + 2 * ox;
-                float v00[8], v01[8], v10[8], v11[8];
-                xf32(src[r0 * so], v00);
-                xf32(src[(r0 + 1) * so], v01);
-                xf32(src[(r0 + p.W) * so], v10);
-                xf32(src[(r0 + p.W + 1) * so], v11);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = dp_to_half(((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f);
             }
-            yrow[(size_t)qx * CO] = o;
+            continue;
+        }
+        // ---- 2x resampling.  y_raw here (round 6) is the RESAMPLED RAW input as a plain tensor [B][Ho][Wo][C] - the identity skip of an
+        // up / down ResBlock (unet.py:245-250), the residual of its second convolution - written from the values this pass has in
+        // registers anyway (rounds 4-5 ran a second launch over x for it: 1.2 % of the headline step)
+        if (BORDER && slot == 0) {
+            yrow[0] = zero8;
+            yrow[(size_t)(Wq - 1) * CO] = zero8;
+        }
+        half8* srow = p.y_raw ? reinterpret_cast<half8*>(p.y_raw) + ((size_t)b * p.Ho + oy) * p.Wo * CO + co : nullptr;
+        if constexpr (RS == 1) {
+            // nearest x2: a source pixel is normalised ONCE for its two outputs of this row; four source pixels in flight
+            const half8* xrow = src + ((size_t)b * p.H + (oy >> 1)) * p.W * so;
+            for (int sx = slot; sx < p.W; sx += 4 * slots) {
+                half8 rv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rv[k] = sx + k * slots < p.W ? xrow[(size_t)(sx + k * slots) * so] : zero8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int s1 = sx + k * slots;
+                    if (s1 >= p.W) break;
+                    const half8 o = xf(rv[k]);
+                    yrow[(size_t)(2 * s1 + BORDER) * CO] = o;
+                    yrow[(size_t)(2 * s1 + 1 + BORDER) * CO] = o;
+                    if (srow) {
+                        srow[(size_t)(2 * s1) * CO] = rv[k];
+                        srow[(size_t)(2 * s1 + 1) * CO] = rv[k];
+                    }
+                }
+            }
+        } else if constexpr (RS == 2) {
+            // 2x2 mean: two outputs (eight source loads) in flight
+            const half8* xr0 = src + ((size_t)b * p.H + 2 * oy) * p.W * so;
+            const half8* xr1 = xr0 + (size_t)p.W * so;
+            for (int ox = slot; ox < p.Wo; ox += 2 * slots) {
+                half8 rv[2][4];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int o1 = ox + k * slots;
+                    const bool in = o1 < p.Wo;
+                    rv[k][0] = in ? xr0[(size_t)(2 * o1) * so] : zero8;
+                    rv[k][1] = in ? xr0[(size_t)(2 * o1 + 1) * so] : zero8;
+                    rv[k][2] = in ? xr1[(size_t)(2 * o1) * so] : zero8;
+                    rv[k][3] = in ? xr1[(size_t)(2 * o1 + 1) * so] : zero8;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int o1 = ox + k * slots;
+                    if (o1 >= p.Wo) break;
+                    float v00[8], v01[8], v10[8], v11[8];
+                    xf32(rv[k][0], v00);
+                    xf32(rv[k][1], v01);
+                    xf32(rv[k][2], v10);
+                    xf32(rv[k][3], v11);
+                    half8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = dp_to_half(((v00[j] + v01[j]) + (v10[j] + v11[j])) * 0.25f);
+                    yrow[(size_t)(o1 + BORDER) * CO] = o;
+                    if (srow) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            o[j] = dp_to_half((((float)rv[k][0][j] + (float)rv[k][1][j]) + ((float)rv[k][2][j] + (float)rv[k][3][j])) * 0.25f);
+                        srow[(size_t)o1 * CO] = o;
+                    }
+                }
+            }
         }
     }
 }
@@ -710,7 +765,8 @@ extern "C" int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int
 
 // GroupNorm-apply over PLAIN fp16 tensors (the fp16 residual stream / a first convolution's fp16 output): see gn_apply_h16_kernel.
 // out_fmt 2 = the zero-bordered "h1" operand [B][Ho+2][Wo+2][C]; 3 = a plain fp16 tensor [B][Ho][Wo][C].  resample: 0 | 1 (2x
-// nearest up) | 2 (2x2 mean down).  gamma == NULL: no normalisation (conversion / resampling only).
+// nearest up) | 2 (2x2 mean down).  gamma == NULL: no normalisation (conversion / resampling only).  y_raw (out_fmt 2): resample 0 -
+// the un-normalised input in operand form; resample 1 | 2 (round 6) - the RESAMPLED un-normalised input as a plain tensor [B][Ho][Wo][C].
 extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, int B, int H, int W, int G, const float* stats,
                                const float* gamma, const float* beta, const float* fscale, const float* fshift, int film_stride,
                                int act, int resample, int out_fmt, void* y, void* y_raw, void* stream) {
@@ -723,7 +779,7 @@ extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, i
     DP_REQUIRE(resample >= 0 && resample <= 2, "dp_gn_apply_h16: resample mode %d (0 | 1 | 2; the FIR modes run on the fp32 stream)", resample);
     DP_REQUIRE(resample != 2 || (H % 2 == 0 && W % 2 == 0), "dp_gn_apply_h16: 2x down-sampling needs even H, W");
     DP_REQUIRE(out_fmt == 2 || out_fmt == 3, "dp_gn_apply_h16: out_fmt must be 2 (bordered fp16 operand) or 3 (plain fp16), got %d", out_fmt);
-    DP_REQUIRE(!y_raw || (out_fmt == 2 && resample == 0), "dp_gn_apply_h16: the raw operand output needs out_fmt=2 and no resampling");
+    DP_REQUIRE(!y_raw || out_fmt == 2, "dp_gn_apply_h16: the raw second output comes with the operand form (out_fmt=2)");
     DP_REQUIRE(dp_aligned16(x1) && (C2 == 0 || dp_aligned16(x2)) && dp_aligned16(y) && (!y_raw || dp_aligned16(y_raw)) &&
                    (!gamma || (dp_aligned16(gamma) && dp_aligned16(beta))), "dp_gn_apply_h16: misaligned tensor");
     DP_REQUIRE(!fscale || (film_stride % 4 == 0 && dp_aligned16(fscale) && dp_aligned16(fshift)), "dp_gn_apply_h16: misaligned FiLM rows");
@@ -737,15 +793,23 @@ extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, i
     {   // algorithmic HBM bytes: every source element the output needs once (2 B) + every output element once (2 B)
         const double in_px = resample == 1 ? (double)H * W : (double)p.Ho * p.Wo * (resample ? 4 : 1);
         const double out_px = (double)(out_fmt == 2 ? (p.Ho + 2) * (p.Wo + 2) : p.Ho * p.Wo);
-        dp_prof_begin(DP_PROF_GN_APPLY, 0.0, (double)B * C * 2.0 * (in_px + out_px * (y_raw ? 2 : 1)), (hipStream_t)stream, &rec);
+        const double raw_px = !y_raw ? 0.0 : (resample ? (double)p.Ho * p.Wo : out_px);
+        dp_prof_begin(DP_PROF_GN_APPLY, 0.0, (double)B * C * 2.0 * (in_px + out_px + raw_px), (hipStream_t)stream, &rec);
     }
+#define GN_H16_LAUNCH(ACT_, BORDER_)                                                                                                  \
+    do {                                                                                                                              \
+        if (resample == 0) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);      \
+        else if (resample == 1) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots); \
+        else hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 2>), g, blk, 0, (hipStream_t)stream, p, COT, slots);                    \
+    } while (0)
     if (out_fmt == 2) {
-        if (act) hipLaunchKernelGGL((gn_apply_h16_kernel<true, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
-        else hipLaunchKernelGGL((gn_apply_h16_kernel<false, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
+        if (act) GN_H16_LAUNCH(true, 1);
+        else GN_H16_LAUNCH(false, 1);
     } else {
-        if (act) hipLaunchKernelGGL((gn_apply_h16_kernel<true, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
-        else hipLaunchKernelGGL((gn_apply_h16_kernel<false, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);
+        if (act) GN_H16_LAUNCH(true, 0);
+        else GN_H16_LAUNCH(false, 0);
     }
+#undef GN_H16_LAUNCH
     dp_prof_end(rec, (hipStream_t)stream);
     DP_LAUNCH_CHECK("gn_apply_h16");
     return 0;

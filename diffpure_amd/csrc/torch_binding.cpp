@@ -310,8 +310,9 @@ std::tuple<Tensor, Tensor> gn_apply_h16(const Tensor& x, const c10::optional<Ten
     Tensor y = out_fmt == 2 ? at::zeros({B, Ho + 2, Wo + 2, C}, x.options()) : at::empty({B, Ho, Wo, C}, x.options());
     Tensor yr;
     if (raw) {
-        TORCH_CHECK(out_fmt == 2 && resample == 0, "diffpure_hip: the raw second output exists for the un-resampled operand form");
-        yr = at::zeros_like(y);
+        TORCH_CHECK(out_fmt == 2, "diffpure_hip: the raw second output comes with the operand form (out_fmt 2)");
+        // resample 0: the raw input in operand form; 1 | 2 (ABI 8): the resampled raw input as a plain tensor (identity skip of an up / down block)
+        yr = resample == 0 ? at::zeros_like(y) : at::empty({B, Ho, Wo, C}, x.options());
     }
     DP_CALL(dp_gn_apply_h16(x.data_ptr(), (int)C1, x2p, (int)C2, (int)B, (int)H, (int)W, (int)groups, opt_ptr(stats, "stats"), opt_ptr(gamma, "gamma"),
                             opt_ptr(beta, "beta"), fs, fh, fstride, act ? 1 : 0, (int)resample, (int)out_fmt, y.data_ptr(), raw ? yr.data_ptr() : nullptr,

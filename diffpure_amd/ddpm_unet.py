@@ -211,7 +211,7 @@ class DdpmUNet:
             self._pool.finalize()
             for k, v in list(P.items()):
                 if isinstance(v, ops.PoolSlot):
-                    P[k] = self._pool.view(v.name)
+                    self._pool.bind(P, k, v.name)
 
     def reround(self, key):
         """precision "f16sr": re-round every fp16 weight panel stochastically for this network call (one launch); the

@@ -313,7 +313,7 @@ class GuidedUNet:
             self._pool.finalize()
             for k, v in list(P.items()):
                 if isinstance(v, ops.PoolSlot):
-                    P[k] = self._pool.view(v.name)
+                    self._pool.bind(P, k, v.name)
 
     def reround(self, key):
         """precision "f16sr": re-round every fp16 weight panel stochastically for this network call (one launch); the
@@ -349,10 +349,14 @@ class GuidedUNet:
         fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w2s") in P
                  and ops.takes_segments(ho, wo, 3, co, co, c1, r["cin"] - c1))
         want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False) and not fused
+        # up / down block on the fp16 stream: the resampled identity skip (unet.py:245-250) is a second output of the same pass (round 6)
+        want_skip = bool(mode) and r["cin"] == co and x.dtype == torch.float16 and x2 is None and os.environ.get("DIFFPURE_SKIP_FUSED", "1") != "0"
         h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
-                           raw=want_raw)
+                           raw=want_raw or want_skip)
         if want_raw:
             h, xraw = h
+        elif want_skip:
+            h, xskip = h
         # (below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
         mid16 = self._lean and (tape is None or self._tape16) and r["h2_1"] and r["h2_2"] and (ho * wo) % 64 == 0
@@ -368,7 +372,7 @@ class GuidedUNet:
         if fused:
             return conv2(h, P[n + ".w2s"], co, 3, bias=P[n + ".c2s"], segs=(x,) if x2 is None else (x, x2), colstats=True, **o16)
         if mode:
-            skip = ops.resample(x, mode)
+            skip = xskip if want_skip else ops.resample(x, mode)
         elif want_raw:
             skip = self._ch2(xraw, P[n + ".ws"], co, 1, bias=P[n + ".cs"], **o16)
         elif r["cin"] != co:
@@ -514,7 +518,7 @@ class GuidedUNet:
             if self._pool._last_key is not None:
                 gpool.round(self._pool._last_key)
             for name in pooled:
-                P[name] = gpool.view(name)
+                gpool.bind(P, name, name)
         self._grad_ready = True
         return self
 

@@ -244,7 +244,7 @@ class NCSNpp:
                         and all(r["h2"] for r in recs if r["kind"] == "attn"))
         if self._lean16:
             for r in res_recs:      # Conv_2 (1x1 shortcut) as K-segments of Conv_1: one fused panel next to the separate ones
-                if r["cin"] != r["cout"] and not r["mode"]:
+                if r["cin"] != r["cout"] or r["mode"]:       # (round 6: also the up / down blocks - their Conv_2 reads the RESAMPLED raw input)
                     p, n = M + str(r["idx"]), str(r["idx"])
                     P[n + ".w1s"] = self._pack_h2w(ops.fuse_skip_weight(sd[p + ".Conv_1.weight"], sd[p + ".Conv_2.weight"]))
                     P[n + ".c1s"] = (sd[p + ".Conv_1.bias"].detach().float() + sd[p + ".Conv_2.bias"].detach().float()).contiguous().to(dev)
@@ -269,7 +269,7 @@ class NCSNpp:
             self._pool.finalize()
             for k, v in list(P.items()):
                 if isinstance(v, ops.PoolSlot):
-                    P[k] = self._pool.view(v.name)
+                    self._pool.bind(P, k, v.name)
 
     def _rmode(self, mode):
         """plan mode (0 / up / down) -> kernel resampling mode: nearest / mean, or upfirdn2d when the config says fir: True"""
@@ -308,11 +308,18 @@ class NCSNpp:
         c1 = x.shape[3]
         fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
                  and ops.takes_segments(ho, wo, 3, co, co, c1, r["cin"] - c1))
+        # up / down block (round 6): GroupNorm-apply hands out the resampled raw input as a plain fp16 tensor in the same pass, and Conv_2 -
+        # the 1x1 shortcut over it (layerspp.py:245-258, 268-272) - becomes K-segments of Conv_1 like the shortcut of a channel-changing block
+        fused_rs = (out16 and bool(mode) and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
+                    and mode in (ops.RESAMPLE_UP, ops.RESAMPLE_DOWN) and ops.takes_segments(ho, wo, 3, co, co, r["cin"], 0)
+                    and os.environ.get("DIFFPURE_SKIP_FUSED", "1") != "0")
         want_raw = h2s and not mode and not fused
         h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
-                           resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw, fir=fir)
+                           resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw or fused_rs, fir=fir)
         if want_raw:
             h, xraw = h
+        elif fused_rs:
+            h, xres = h
         off = r["dense_off"]
         # (below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
@@ -326,6 +333,8 @@ class NCSNpp:
         if fused:
             return conv1(h, P[n + ".w1s"], co, 3, bias=P[n + ".c1s"], segs=(x,) if x2 is None else (x, x2), scale=INV_SQRT2,
                          colstats=True, **o16)
+        if fused_rs:
+            return conv1(h, P[n + ".w1s"], co, 3, bias=P[n + ".c1s"], segs=(xres,), scale=INV_SQRT2, colstats=True, **o16)
         if mode:
             if h2s:
                 skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"], **o16)
@@ -461,7 +470,7 @@ class NCSNpp:
             if self._pool._last_key is not None:
                 gpool.round(self._pool._last_key)
             for key in pooled:
-                P[key] = gpool.view(key)
+                gpool.bind(P, key, key)
         self._grad_ready = True
         return self
 

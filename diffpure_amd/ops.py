@@ -161,6 +161,11 @@ class WeightPool:
     def __init__(self, device, stochastic, seed=0x5EEDC0DE):
         self.device, self.stochastic, self.seed = torch.device(device), bool(stochastic), int(seed)
         self._pending, self.master, self.work, self._views, self._last_key = [], None, None, {}, None
+        # round 6: the NEXT call's rounding runs on a side stream into a second fp16 buffer while this call's convolutions read the first
+        # (see round()); DIFFPURE_ROUND_PREFETCH=0 keeps the one-buffer, in-stream form of rounds 2-5
+        self._other, self._views_other, self._bound, self._pre, self._side = None, {}, [], None, None
+        self._prefetch = (self.stochastic and self.device.type == "cuda" and os.environ.get("DIFFPURE_ROUND_PREFETCH", "1") != "0"
+                          and os.environ.get("DIFFPURE_GRAPH", "0") == "0")       # (a captured graph holds the panel addresses)
 
     def add(self, name, w):
         """register the OIHW / OI / OIk weight `w` under `name`; the panel view is available after finalize()"""
@@ -171,6 +176,8 @@ class WeightPool:
         pad = (-total) % 8
         self.master = torch.empty(total + pad, dtype=torch.float32, device=self.device)
         self.work = torch.empty(total + pad, dtype=torch.float16, device=self.device)
+        if self._prefetch and total:
+            self._other = torch.empty_like(self.work)
         if pad:
             self.master[total:].zero_()
         off = 0
@@ -178,6 +185,8 @@ class WeightPool:
             n = p.numel()
             self.master[off:off + n].copy_(p.reshape(-1))       # host -> its slice of the flat buffer directly (no staging tensor + device copy)
             self._views[name] = self.work[off:off + n].view(p.shape)
+            if self._other is not None:
+                self._views_other[name] = self._other[off:off + n].view(p.shape)
             off += n
         self._pending = []
         self.round(0)
@@ -186,15 +195,52 @@ class WeightPool:
     def view(self, name):
         return self._views[name]
 
+    def bind(self, table, key, name):
+        """table[key] = the panel `name` of the CURRENT buffer, now and after every buffer flip of round() (the engines' parameter dicts)"""
+        table[key] = self._views[name]
+        self._bound.append((table, key, name))
+
+    def _flip(self):
+        self.work, self._other = self._other, self.work
+        self._views, self._views_other = self._views_other, self._views
+        for table, key, name in self._bound:
+            table[key] = self._views[name]
+
+    def _launch(self, dst, key):
+        _lib.call("dp_round_weights", _ptr(self.master), _ptr(dst), self.master.numel(), 1 if self.stochastic else 0, self.seed, int(key), _stream())
+
     def round(self, key):
-        """master fp32 -> working fp16 panels.  Round-to-nearest pools are rounded once (key ignored afterwards)."""
+        """master fp32 -> working fp16 panels.  Round-to-nearest pools are rounded once (key ignored afterwards).
+        Stochastic pools (round 6): the loops ask for keys k, k + 1, ... (or descending: the adjoints); once two consecutive keys have
+        been seen, the rounding of the NEXT key is launched on a side stream into the second buffer right away - behind everything
+        already queued on the main stream, i.e. the previous call's convolutions, which were that buffer's last readers - and runs
+        under this call's convolutions (HBM-bound work under MFMA-bound work); the next round() then only waits for its event and
+        flips the buffers (the bound parameter-dict entries are re-pointed).  Same bits as the in-stream form: the rounding is a
+        pure function of (master, seed, key).  A key that was not predicted is rounded in-stream as before."""
         if not self.stochastic and self._last_key is not None:
             return
         if self.master is None or self.master.numel() == 0:
             return
-        _lib.call("dp_round_weights", _ptr(self.master), _ptr(self.work), self.master.numel(), 1 if self.stochastic else 0,
-                  self.seed, int(key), _stream())
+        if self._pre is not None and self._pre[0] == key and self._other is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._pre[1])
+            self._flip()
+        else:
+            if self._pre is not None and self._other is not None:      # an unused prefetch may still be writing the other buffer: harmless, but
+                torch.cuda.current_stream(self.device).wait_event(self._pre[1])      # order it before anything that could flip onto it
+            self._launch(self.work, key)
+        self._pre = None
+        stride = None if self._last_key is None else key - self._last_key
         self._last_key = key
+        if self._other is not None and stride in (1, -1) and not prof_enabled():
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream(self.device)
+            self._side.wait_stream(main)            # the other buffer's last readers (the previous call) are queued on the main stream
+            with torch.cuda.stream(self._side):
+                self._launch(self._other, key + stride)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            self._pre = (key + stride, ev)
 
 
 def _chk_h2(t, name):
@@ -519,7 +565,8 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
     split=True / "h2" writes the split-fp16 operand format of conv2d_h2 with its one-pixel zero border
     ([B, Ho+2, Wo+2, 2C] fp16), split="h1" the plain-fp16 operand ([B, Ho+2, Wo+2, C] fp16).  raw=True (with
     split, no resampling) additionally returns the un-normalised cat(x, x2) in the same operand format (input of
-    a 1x1 skip convolution).
+    a 1x1 skip convolution); fp16 inputs only: raw=True WITH 2x resampling additionally returns the resampled un-normalised
+    cat(x, x2) as a plain fp16 tensor [B, Ho, Wo, C] (the identity skip of an up / down ResBlock; a K-segment of its second convolution).
     x (and x2) may be PLAIN fp16 tensors [B, H, W, C] (a convolution's fp16 output / the fp16 residual stream): then `stats`
     is required, split must be "h1", and the pass moves 4 instead of 6 bytes per element (dp_gn_apply_h16)."""
     if isinstance(x, torch.Tensor) and x.dtype == torch.float16:
@@ -566,8 +613,8 @@ def _group_norm_h16(x, groups, gamma, beta, stats, x2, film, act, resample, out_
     y = torch.empty((b, ho + 2, wo + 2, c) if out_fmt == 2 else (b, ho, wo, c), device=x.device, dtype=torch.float16)
     yr = None
     if raw:
-        assert out_fmt == 2 and resample == RESAMPLE_NONE
-        yr = torch.empty_like(y)
+        assert out_fmt == 2
+        yr = torch.empty_like(y) if resample == RESAMPLE_NONE else torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float16)
     _lib.call("dp_gn_apply_h16", _ptr(x), c1, _ptr(x2), c2, b, h, w, groups, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh),
               fstride, 1 if act else 0, resample, out_fmt, _ptr(y), _ptr(yr), _stream())
     return (y, yr) if raw else y
@@ -1004,7 +1051,7 @@ def prof_enabled():
     return _PROF_ON
 
 
-PROF_KINDS = ("pp3x3", "conv1x1", "other3x3", "pp1x1", "gn_apply")       # DP_PROF_* of include/diffpure_hip.h
+PROF_KINDS = ("pp3x3", "conv1x1", "other3x3", "pp1x1", "gn_apply", "dh3x3", "dh1x1")       # DP_PROF_* of include/diffpure_hip.h
 
 
 def prof_collect():

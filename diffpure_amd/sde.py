@@ -228,6 +228,22 @@ class Purifier:
         self._entry_lock = threading.RLock()
 
     # -- shared pieces ----------------------------------------------------------------------------
+    @staticmethod
+    def _normalise_cotangent(a):
+        """-> (a * 2^-e, 2^e) with 2^e the power of two nearest max|a|.  The adjoint solves are LINEAR in the cotangent, and in the fp16 x fp16
+        modes the network VJP rounds gradient operands to plain fp16 (dgrad convolutions, the attention backward's dO / dP / dS): an attack's
+        cotangent (cross-entropy dL/dx: 1e-3 ... 1e-6 per pixel) would put dS = P (dP - sum) - another factor 1/T below it - under fp16's
+        normal range (6e-5) or under its smallest subnormal (6e-8) and lose the dQ / dK terms silently (advisor, round 5).  Scaling by a
+        power of two is exact in fp32, so the solve runs on a unit-scale cotangent and the result is scaled back: one max-abs reduction
+        (one host synchronisation) per adjoint solve, none per step.  Zero / non-finite cotangents pass through unscaled."""
+        amax = float(a.abs().max())
+        if not (amax > 0.0 and math.isfinite(amax)):
+            return a, 1.0
+        e = round(math.log2(amax))
+        if e == 0:
+            return a, 1.0
+        return a * (2.0 ** -e), 2.0 ** e
+
     def _diffuse(self, x0, t_int, noise, seed, sample0, abar=None):
         sa, s1a = diffusion_coeffs(t_int, self._abar if abar is None else abar)
         if noise is not None:
@@ -255,13 +271,17 @@ class Purifier:
         self._check_finite(eps, k)
         return eps
 
-    def _check_finite(self, eps, k):
+    def _check_finite(self, eps, k, grad=None):
         """DIFFPURE_CHECK_FINITE=1 (validation switch, off by default: it synchronises with the host every step): the fp16 residual
         stream of the fp16 x fp16 modes stores activations with a plain fp32 -> fp16 conversion (no saturation), so a block output
         beyond 65504 becomes inf and the next GroupNorm turns the whole sample into NaN - silently.  The seeded synthetic weights
         stay far below that range; the published checkpoints could not be checked here (they are not available - the reference's own
         `use_fp16` torso, configs/imagenet.yml:18, makes the same assumption about them).  With the switch on, the first UNet call of a
-        forward solve whose output is not finite raises and names the step, instead of the loop returning NaN images."""
+        forward solve whose output is not finite raises and names the step, instead of the loop returning NaN images.  Round 6 (advisor):
+        the graph-replay path and the taped forwards / input gradients of the adjoint solves are checked too."""
+        if _CHECK_FINITE and grad is not None and not bool(torch.isfinite(grad).all()):
+            raise FloatingPointError(f"input gradient of the score network is not finite at adjoint step {k} (precision {getattr(self.net, 'precision', '?')}): "
+                                     "an activation or a gradient operand overflowed fp16; run with DIFFPURE_TAPE16=0 / DIFFPURE_GRAD16=0 or precision f16x3")
         if _CHECK_FINITE and not bool(torch.isfinite(eps).all()):
             raise FloatingPointError(f"score network output is not finite at solver step {k} (precision {getattr(self.net, 'precision', '?')}): "
                                      "an activation overflowed the fp16 residual stream; run with DIFFPURE_LEAN16=0 (fp32 stream) or precision f16x3")
@@ -305,6 +325,7 @@ class Purifier:
             ent["row"].copy_(table[k:k + 1])
             self._reround(k if key is None else key)     # outside the captured graph: the panels are rewritten in place
             ent["graph"].replay()
+            self._check_finite(ent["eps"], k)
             return ent["eps"]
 
         return ent["x"], eps_of
@@ -337,7 +358,7 @@ class Purifier:
                            a_k = a_{k+1} + h_k (df/dy)^T a_{k+1}.
         -> dL/dx at t'_0 (before the forward-diffusion scaling), NCHW."""
         y = _state_in(x_final_nchw, self.device, nhwc).clone()
-        a = _state_in(grad_out_nchw, self.device, nhwc)
+        a, back = self._normalise_cotangent(_state_in(grad_out_nchw, self.device, nhwc))
         sched = sde_schedule(self.kind, t_int, dt)
         # coefficients at the END point t_{k+1} of every interval: the schedule entry of step k+1, plus one
         # more entry for the final time t'_end
@@ -350,6 +371,7 @@ class Purifier:
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             gj = self.net.vjp(tape, a)                      # (d eps / d y)^T a
             del tape
+            self._check_finite(eps, k, gj)
             kk = (-1.0 / en["sc"]) if en["div"] else en["sc"]   # score = kk * eps
             h = st["h"]
             # f = -(nhb*y - gg*score)  =>  (df/dy)^T a = -nhb*a + gg*kk*J^T a
@@ -359,7 +381,7 @@ class Purifier:
             y = ops.em_step(y, eps, en["nhb"], en["gg"], en["sc"], en["div"], -h, -en["g"], st["sqrt_h"], noise=z, seed=seed,
                             sample0=sample0, step=k, out=y)
             a = a_new
-        return _state_out(a, nhwc)
+        return _state_out(a if back == 1.0 else a * back, nhwc)
 
     # -- probability-flow ODE forward (OdeGuidedDiffusion.image_editing_sample) -------------------
     @_on_own_device
@@ -387,7 +409,7 @@ class Purifier:
         reference also integrates (106.6 M values nobody reads) are not formed - dL/dx does not
         depend on them.  -> dL/dx at s = t/1000 (before the forward-diffusion scaling), NCHW."""
         y = _state_in(x_final_nchw, self.device, nhwc).clone()
-        a = _state_in(grad_out_nchw, self.device, nhwc)
+        a, back = self._normalise_cotangent(_state_in(grad_out_nchw, self.device, nhwc))
         sched = ode_schedule(self.kind, t_int, step, reverse=True)
         table = self._tables(("ode_rev", t_int, step), sched)
         for k, st in enumerate(sched):
@@ -403,12 +425,13 @@ class Purifier:
             eps = self.net.forward(y, table_row=table[k:k + 1], tape=tape)
             g = self.net.vjp(tape, a)                       # (d eps / d y)^T a
             del tape
+            self._check_finite(eps, k, g)
             kk = (-1.0 / st["sc"]) if st["div"] else st["sc"]   # score = kk * eps
             ds = st["h"]
             a_new = ops.axpby(a, 1.0 - ds * st["nhb"], g, ds * st["gg"] * kk)
             y = ops.em_step(y, eps, st["nhb"], st["gg"], st["sc"], st["div"], -ds, 0.0, 0.0, out=y)   # y + ds * F(y)
             a = a_new
-        return _state_out(a, nhwc)
+        return _state_out(a if back == 1.0 else a * back, nhwc)
 
     def diffuse_scale(self, t_int):
         """d x(t) / d x0 of the forward diffusion x = x0*sqrt(abar) + e*sqrt(1-abar)."""
@@ -489,7 +512,7 @@ class Purifier:
         anchor x_init is a plain tensor attribute and not an adjoint parameter).  Same scheme as `sde_vjp`:
         y_k = y_{k+1} - f(y_{k+1}) h - g dW_k,  a_k = a_{k+1} + h (df/dy)^T a_{k+1},  (df/dy)^T a = -kk a + 0.5 lambda c J^T a."""
         y = _state_in(x_final_nchw, self.device, nhwc).clone()
-        a = _state_in(grad_out_nchw, self.device, nhwc)
+        a, back = self._normalise_cotangent(_state_in(grad_out_nchw, self.device, nhwc))
         x_init = _state_in(x_init_nchw, self.device, nhwc)
         s = torch.zeros((), dtype=torch.float32) + 1e-2
         coef, div, mt = _score_scalars(self.kind, s)
@@ -505,6 +528,7 @@ class Purifier:
             eps = self.net.forward(y, table_row=table[0:1], tape=tape)
             gj = self.net.vjp(tape, a)
             del tape
+            self._check_finite(eps, k, gj)
             a_new = ops.axpby(a, 1.0 - h * kk, gj, h * 0.5 * lambda_ld * c)
             z = to_nhwc(noise["z"][k].to(self.device, torch.float32)) if noise is not None else None
             # y - f h - g dW with f = -(kk y - 0.5 lambda score) + kk x_init: the fused step with (h, g) -> (-h, -g), then the anchor
@@ -512,4 +536,4 @@ class Purifier:
                             step=k, out=y)
             y.copy_(ops.axpby(y, 1.0, x_init, -kk * h))
             a = a_new
-        return _state_out(a, nhwc)
+        return _state_out(a if back == 1.0 else a * back, nhwc)

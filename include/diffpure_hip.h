@@ -48,7 +48,9 @@ enum { DP_PROF_3X3_PP = 0,      /* 3x3 convolutions on the 256-wide tile kernels
        DP_PROF_1X1_PP = 3,      /* 1x1 convolutions that ran on the ping-pong kernel (a rocprofv3 per-kernel total covers kinds 0 + 3) */
        DP_PROF_GN_APPLY = 4,    /* GroupNorm-apply launches (dp_gn_apply / dp_gn_apply_h16): the HBM-bound second kernel of a step; flop = 0,
                                    bytes = every input element once + every output element once */
-       DP_PROF_KINDS = 5 };
+       DP_PROF_3X3_DH = 5,      /* ABI 8: 3x3 convolutions on the 4-wave half-height kernel (conv_igemm_dh, un-split launches) - kinds 0 / 3 are then */
+       DP_PROF_1X1_DH = 6,      /*        1x1 ones.  One kind per kernel NAME, so that a rocprofv3 per-kernel row covers exactly (0 + 3) or (5 + 6) */
+       DP_PROF_KINDS = 7 };
 int dp_prof_enable(int on);
 int dp_prof_collect(double* ms, long long* n, double* flop, double* bytes, long long* dropped);
 
@@ -243,7 +245,9 @@ int dp_gn_apply(const float* x1, int C1, const float* x2, int C2, int B, int H, 
  * reference's own use_fp16 arithmetic keeps h in fp16: guided_diffusion/unet.py:626-632) and the skip tensors of the up path
  * (the th.cat of unet.py:667 is two source pointers).  Same contract as dp_gn_apply otherwise: optional normalisation (gamma ==
  * NULL: none) + FiLM + SiLU, resample 0 | 1 (nearest x2) | 2 (mean 2x2) - the FIR modes stay on the fp32 stream -, optional raw
- * second output.  out_fmt 2 = the zero-bordered "h1" operand [B][Ho+2][Wo+2][C]; out_fmt 3 = a plain fp16 tensor [B][Ho][Wo][C]
+ * second output (out_fmt 2 only): with resample 0 the un-normalised input in the same bordered operand form (input of a 1x1 skip
+ * convolution); with resample 1 | 2 (ABI 8) the RESAMPLED un-normalised input as a plain tensor [B][Ho][Wo][C] - the identity skip of an
+ * up / down ResBlock (unet.py:245-250), formed from the values the pass holds in registers instead of by a second launch.  out_fmt 2 = the zero-bordered "h1" operand [B][Ho+2][Wo+2][C]; out_fmt 3 = a plain fp16 tensor [B][Ho][Wo][C]
  * (the resampled identity skip of an up / down ResBlock, unet.py:245-250: the residual of its second convolution, res_fmt 1).
  * C1 % 8 == 0, C % 8 == 0.  Same arithmetic per element as dp_gn_apply(out_fmt 2) on the up-converted tensors (identical bytes):
  * 4 HBM bytes per element instead of 6. */

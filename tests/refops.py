@@ -250,6 +250,8 @@ def group_norm(x, groups, eps, gamma, beta, x2=None, film=None, act=False, resam
         y = F.silu(y)
     y = _resample(y, resample, fir).contiguous()
     enc = _operand_encoder(split)
+    if raw and resample:       # fp16 stream: the resampled raw input as a plain fp16 tensor (dp_gn_apply_h16, ABI 8)
+        return enc(F.pad(y, (0, 0, 1, 1, 1, 1))), _resample(xin.float(), resample, fir).half().contiguous()
     if raw:
         return enc(F.pad(y, (0, 0, 1, 1, 1, 1))), enc(F.pad(xin, (0, 0, 1, 1, 1, 1)))
     return enc(F.pad(y, (0, 0, 1, 1, 1, 1))) if enc else y

@@ -989,6 +989,14 @@ def test_group_norm_fp16_input_equals_group_norm_of_the_upconverted_tensors(dev,
     y0, yr0 = ops.group_norm(xf, G, 1e-5, gamma, beta, x2=x2f, act=True, split="h1", stats=stats, raw=True)
     ulp_close(y, y0, "raw")
     assert torch.equal(yr, yr0)
+    # round 6: with 2x resampling the raw second output is the RESAMPLED input as a plain fp16 tensor (the identity skip of an up / down
+    # ResBlock) - the bytes of the stand-alone resampler - and the operand is the one of the call without it
+    for rs in (1, 2) if H % 2 == 0 and W % 2 == 0 else (1,):
+        for act in (True, False):
+            y1, s1 = ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, act=act, resample=rs, split="h1", stats=stats, raw=True)
+            y2 = ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, act=act, resample=rs, split="h1", stats=stats)
+            cat = x16 if x2_16 is None else torch.cat([x16, x2_16], dim=3)
+            assert torch.equal(y1, y2) and s1.dtype == torch.float16 and torch.equal(s1, ops.resample(cat, rs)), (case, rs, act)
     if C2 == 0:
         assert torch.equal(ops.group_norm_f16in(x16, G, gamma, beta, stats, act=True), y)
         for rs in (0, 1, 2) if H % 2 == 0 and W % 2 == 0 else (0, 1):
@@ -1140,8 +1148,8 @@ def test_conv2d_half_height_tile_kernel_is_bit_identical(dev, case, tune):
         assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
     ops.prof_enable(False)
     prof = ops.prof_collect()
-    if H * W > 64:      # (un-split launches are booked with the 256-wide tile kernels, i.e. they did not run on the generic tiles)
-        assert prof["pp3x3"]["n"] == 2 and prof["other3x3"]["n"] == 0, prof
+    if H * W > 64:      # (un-split launches are booked under the kernel's own kind since ABI 8, i.e. they did not run on the generic tiles)
+        assert prof["dh3x3"]["n"] == 2 and prof["other3x3"]["n"] == 0 and prof["pp3x3"]["n"] == 0, prof
     if N % 256 != 0:    # the 256x128 form (DP_H2_DH = 3): same bits as the 512x128 one-wave-per-SIMD tiles the default takes
         tune.setenv("DP_H2_DH", "3")
         got3, got3_cs = run()

@@ -66,6 +66,9 @@ def main():
         ops.prof_enable(False)
         prof = ops.prof_collect()
         assert torch.isfinite(y).all()
+        for k in ("ms", "n", "flop", "bytes"):       # the 256-wide-tile kernels as one group, as in rounds 4-5: conv_igemm_dw + conv_igemm_dh
+            prof["pp3x3"][k] += prof["dh3x3"][k]
+            prof["pp1x1"][k] += prof["dh1x1"][k]
         tf = lambda k: (prof[k]["flop"] / (prof[k]["ms"] * 1e-3) / 1e12) if prof[k]["ms"] > 0 else None
         conv_ms = sum(prof[k]["ms"] for k in ("pp3x3", "other3x3", "pp1x1", "conv1x1"))
         conv_fl = sum(prof[k]["flop"] for k in ("pp3x3", "other3x3", "pp1x1", "conv1x1"))

@@ -19,8 +19,11 @@ import sys
 
 
 def short(name):
-    if "conv_igemm_dw" in name or "conv_igemm_dh" in name or "conv_igemm_sw" in name or "conv_igemm_halo" in name or "conv_igemm_h2_pp" in name:
-        return "conv_igemm_h2_pp"            # the dominant kernel: the 256-wide-tile convolution in its one-wave-per-SIMD / ping-pong variants
+    # round 6: one row per kernel NAME (round 5 folded the 256-wide-tile kernels into one row, whose per-launch average over 232 launches
+    # of three kernels could not be compared with the algorithmic bytes of the dominant kernel's own launches)
+    m = re.search(r"(conv_igemm_dw|conv_igemm_dh|conv_igemm_sw|conv_igemm_h2_pp|conv_igemm_nn|conv_stem_h16)", name)
+    if m:
+        return m.group(1)
     m = re.search(r"(conv_igemm_h2|conv_igemm_f32|splitk_epilogue|gn_apply_h16|gn_apply_h2q|gn_apply|round_weights|gn_finalize_cols|gn_stats|"
                   r"gn_finalize|attn_flash|attn_pack|em_step|ddpm_step|temb|softmax_rows|gemm_strided|philox|axpby|silu|pack_h2)", name)
     return m.group(1) if m else name[:60]
@@ -59,16 +62,29 @@ def main():
                       hbm_bytes_per_launch=(fb or 0) + (wb or 0), avg_ms_under_profiler=ms,
                       hbm_tb_per_s_under_profiler=((fb or 0) + (wb or 0)) / (ms * 1e-3) / 1e12 if ms else None)
     json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
-    dom = out.get("conv_igemm_h2_pp")
+    dom = out.get("conv_igemm_dw") or out.get("conv_igemm_sw") or out.get("conv_igemm_h2_pp")
     B = a.batch or (64 if a.workload == "imagenet256_guided" else (128 if a.workload.endswith("_adjoint") else 256))
     if dom:
-        row = dict(workload=a.workload, per_gpu_batch=B, precision=a.precision, kernel="conv_igemm_dw + conv_igemm_sw + conv_igemm_h2_pp (the 256-wide-tile fp16 convolution: the 8-wave free-running kernel, the one-wave-per-SIMD kernel where a launch has < 256 tiles or N % 256 != 0, the ping-pong kernel on what is left; 3x3 and 1x1 launches)",
-                   launches_profiled=dom["launches"], fetch_bytes_per_launch=dom["fetch_bytes_per_launch"],
+        keep = ("conv_igemm_dw", "conv_igemm_dh", "conv_igemm_sw", "conv_igemm_h2_pp", "conv_igemm_h2", "conv_igemm_nn", "conv_stem_h16",
+                "gn_apply_h16", "gn_finalize_cols", "round_weights", "attn_flash", "splitk_epilogue")
+        row = dict(workload=a.workload, per_gpu_batch=B, precision=a.precision,
+                   kernel="conv_igemm_dw (the dominant kernel: every launch of it in two UNet calls, 3x3 and 1x1); per_kernel holds one row per kernel name",
+                   launches_profiled=dom["launches"], unet_calls_profiled=2, fetch_bytes_per_launch=dom["fetch_bytes_per_launch"],
                    write_bytes_per_launch=dom["write_bytes_per_launch"], hbm_bytes_per_launch=dom["hbm_bytes_per_launch"],
+                   per_kernel={k: out[k] for k in keep if k in out},
                    corrections="FETCH_SIZE x2 (gfx950 reports one half for 16 B/lane streaming reads), KB -> bytes; WRITE_SIZE as reported",
                    source="tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over bench.py --t 2")
         print(json.dumps(row))
         json.dump(row, open(os.path.join(d, "row.json"), "w"), indent=1)
+        # fold it into profiles/pmc_traffic.json when asked to (the row of the same workload / batch / precision moves to `history`)
+        if os.environ.get("PMC_TRAFFIC_UPDATE"):
+            tab_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+            tab = json.load(open(tab_path))
+            key = lambda r: (r.get("workload"), r.get("per_gpu_batch"), r.get("precision"))
+            old = [r for r in tab["rows"] if key(r) == key(row)]
+            tab["rows"] = [r for r in tab["rows"] if key(r) != key(row)] + [dict(row, note=os.environ["PMC_TRAFFIC_UPDATE"])]
+            tab.setdefault("history", []).extend(old)
+            json.dump(tab, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
     gn = out.get("gn_apply_h16")
     if gn:          # the second kernel of the step
         json.dump(dict(kernel="gn_apply_h16", **gn), open(os.path.join(d, "row_gn.json"), "w"), indent=1)

@@ -40,6 +40,15 @@ stem)
 tests)
   gputests
   ;;
+fuse)    # resampled identity skip as a second output of GroupNorm-apply; weight rounding prefetched on a side stream
+  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_grad.py -m gpu -q -s -k "fp16_input_equals or tiny_cotangent or taped_and or finite_differences or half_height or stem or torch_ops or round_weights or stochastic" > "$O/fuse_tests.log" 2>&1; echo "rc=$?" >> "$O/fuse_tests.log"; lap fuse_tests
+  grep -E "passed|failed|^FAILED|^E  |cotangent|probe direction|ode_vjp" "$O/fuse_tests.log" | head -40
+  ab DIFFPURE_SKIP_FUSED guided_t20_skip --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_ROUND_PREFETCH guided_t20_prefetch --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_SKIP_FUSED cifar_t50_skip --workload cifar32_ncsnpp --t 50 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_ROUND_PREFETCH cifar_t50_prefetch --workload cifar32_ncsnpp --t 50 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_ROUND_PREFETCH cifar_adj_t20_prefetch --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ;;
 *)
   echo "unknown stage $STAGE"; exit 1;;
 esac
