@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
             return h;
         };
         half8* yrow = reinterpret_cast<half8*>(p.y) + orow * CO + co;
-        half8* rrow = p.y_raw ? reinterpret_cast<half8*>(p.y_raw) + orow * CO + co : nullptr;
+        // (RS != 0: y_raw is the un-bordered resampled tensor, addressed by `srow` below - never through the bordered geometry)
+        half8* rrow = (RS == 0 && p.y_raw) ? reinterpret_cast<half8*>(p.y_raw) + orow * CO + co : nullptr;
         if (zrow) {
             for (int qx = slot; qx < Wq; qx += slots) {
                 yrow[(size_t)qx * CO] = zero8;

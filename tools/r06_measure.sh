@@ -6,6 +6,8 @@ STAGE=${1:-stem}
 O="$R/gpurun_out/r06/$STAGE"
 rm -rf "$O"; mkdir -p "$O"
 export TMPDIR=/tmp
+ulimit -c 0                      # a faulting kernel must not fill the box's disk with host / GPU core dumps (it took the rest of a call with it)
+export HSA_ENABLE_COREDUMP=0 AMD_GPU_COREDUMP=0
 S=$(date +%s)
 lap() { echo "[$(( $(date +%s) - S )) s] $1" >> "$O/timeline.log"; }
 : > "$O/timeline.log"
