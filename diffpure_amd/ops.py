@@ -161,10 +161,14 @@ class WeightPool:
     def __init__(self, device, stochastic, seed=0x5EEDC0DE):
         self.device, self.stochastic, self.seed = torch.device(device), bool(stochastic), int(seed)
         self._pending, self.master, self.work, self._views, self._last_key = [], None, None, {}, None
-        # round 6: the NEXT call's rounding runs on a side stream into a second fp16 buffer while this call's convolutions read the first
-        # (see round()); DIFFPURE_ROUND_PREFETCH=0 keeps the one-buffer, in-stream form of rounds 2-5
+        # round 6, verdict item 1b - MEASURED AND OFF BY DEFAULT (DIFFPURE_ROUND_PREFETCH=1 switches it on): the NEXT call's rounding on a
+        # side stream into a second fp16 buffer while this call's convolutions read the first (see round()).  Same-box A/B
+        # (profiles/r06/*_prefetch_ab.log): headline 21.06 -> 21.02 images/s at t = 20 (-0.2 %), CIFAR B = 256 312.0 -> 305.0 (-2.3 %), CIFAR
+        # adjoint 147.0 -> 143.4 (-2.5 %): the HBM-bound rounding kernel does not hide under the convolutions - it takes CUs from the
+        # launches on the critical path (at CIFAR sizes every launch is short of workgroups already) and the chip is at its power cap
+        # under the big ones, so the 0.56 % of the step it costs in-stream is the cheaper form.
         self._other, self._views_other, self._bound, self._pre, self._side = None, {}, [], None, None
-        self._prefetch = (self.stochastic and self.device.type == "cuda" and os.environ.get("DIFFPURE_ROUND_PREFETCH", "1") != "0"
+        self._prefetch = (self.stochastic and self.device.type == "cuda" and os.environ.get("DIFFPURE_ROUND_PREFETCH", "0") == "1"
                           and os.environ.get("DIFFPURE_GRAPH", "0") == "0")       # (a captured graph holds the panel addresses)
 
     def add(self, name, w):

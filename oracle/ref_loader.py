@@ -41,18 +41,22 @@ def _load(module, sd):
     return module.eval()
 
 
-def guided_unet(model_cfg, state_dict):
-    """guided_diffusion.script_util.create_model(**cfg) with `state_dict` loaded, fp32 (use_fp16=False), eval mode."""
+def guided_unet(model_cfg, state_dict, use_fp16=False):
+    """guided_diffusion.script_util.create_model(**cfg) with `state_dict` loaded, eval mode; fp32 (use_fp16=False), or the reference's own
+    fp16 torso - created with use_fp16=True and converted as its runners do (runners/diffpure_sde.py:169-170 -> unet.py:626-632)."""
     assert available(), "oracle/_ref is missing or does not match oracle/ref_modules.sha256"
     _enter()
     from guided_diffusion.script_util import create_model, model_and_diffusion_defaults
     mc = model_and_diffusion_defaults()
     mc.update(model_cfg)
-    mc["use_fp16"] = False
+    mc["use_fp16"] = bool(use_fp16)
     keys = ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma", "class_cond", "attention_resolutions",
             "num_heads", "num_head_channels", "num_heads_upsample", "use_scale_shift_norm", "resblock_updown", "use_fp16",
             "use_new_attention_order")
-    return _load(create_model(**{k: mc[k] for k in keys}), state_dict)
+    model = _load(create_model(**{k: mc[k] for k in keys}), state_dict)
+    if use_fp16:
+        model.convert_to_fp16()
+    return model
 
 
 def ncsnpp(config_dict, state_dict):

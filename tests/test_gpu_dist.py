@@ -78,6 +78,30 @@ def test_two_rank_sharded_runner_equals_single_process_bitwise(n):
         assert torch.equal(gx, ref_g), rank              # and the whole dL/dx
 
 
+def test_eight_rank_sharded_runner_equals_single_process_bitwise():
+    """Round 6: EIGHT ranks of the real engine (BASELINE configs[3]'s world size) sharing the one GPU of this box, gloo carrying the
+    all-gather through the host: eight concurrent engine builds, eight host threads' worth of launches on one device, a ragged batch
+    (11 images: ceil(11 / 8) = 2 per rank, the last ranks hold one or none) - forward and the gradient of an adaptive attack reproduce
+    the single-process result bit for bit on every rank."""
+    n, world = 11, 8
+    ref_out, ref_o2, ref_g = _run(True, n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, out, o2, gx in res:
+        assert torch.equal(out, ref_out), rank
+        assert torch.equal(o2, ref_o2), rank
+        assert torch.equal(gx, ref_g), rank
+
+
 def test_bench_multirank_code_path_runs_on_rccl_at_world_size_1():
     """The driver's own launch line with ONE rank and bench.py's --force-dist hook: `init_process_group("nccl", device_id=...)`,
     the device-side `all_gather_into_tensor` of the purified shard inside the timed region, `dist.barrier()` and the MAX

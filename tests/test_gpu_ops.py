@@ -496,6 +496,37 @@ def test_conv2d_fp16_weights_single_pass(dev, case, tune):
     assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
 
 
+def test_weight_pool_side_stream_prefetch_gives_the_in_stream_bits(dev, monkeypatch):
+    """Round 6 (opt-in, DIFFPURE_ROUND_PREFETCH=1; measured slower and off by default): the next key's stochastic rounding on a side
+    stream into a second buffer, the bound parameter-dict entries re-pointed at every flip - ascending keys, a descending run (the
+    adjoints), a repeated key and a jump all give the panels of the one-buffer pool, and a convolution queued right after round() reads
+    the new panels."""
+    from diffpure_amd import ops
+    w1, w2 = rnd(64, 32, 3, 3, seed=1, scale=0.05), rnd(96, 64, 1, 1, seed=2, scale=0.1)
+
+    def build(prefetch):
+        monkeypatch.setenv("DIFFPURE_ROUND_PREFETCH", "1" if prefetch else "0")
+        pool = ops.WeightPool(dev, stochastic=True, seed=7)
+        pool.add("a", w1)
+        pool.add("b", w2)
+        pool.finalize()
+        table = {}
+        pool.bind(table, "wa", "a")
+        pool.bind(table, "wb", "b")
+        return pool, table
+
+    ref, rt = build(False)
+    pre, pt = build(True)
+    assert pre._other is not None and ref._other is None
+    x = torch.nn.functional.pad(rnd(2, 8, 8, 32, seed=3), (0, 0, 1, 1, 1, 1)).half().to(dev)
+    for key in [0, 1, 2, 3, 4, 4, 9, 8, 7, 6, 2, 3]:
+        ref.round(key)
+        pre.round(key)
+        assert torch.equal(pt["wa"], rt["wa"]) and torch.equal(pt["wb"], rt["wb"]), key
+        assert torch.equal(ops.conv2d_h2(x, pt["wa"], 64, 3, w_fmt=1), ops.conv2d_h2(x, rt["wa"], 64, 3, w_fmt=1)), key
+    torch.cuda.synchronize()
+
+
 def test_round_weights_nearest_and_stochastic(dev):
     """dp_round_weights: round-to-nearest equals torch's .half(); stochastic rounding returns one of the two fp16
     neighbours, is unbiased (the mean over many keys converges to the fp32 value), reproducible per (seed, key), and

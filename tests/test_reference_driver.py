@@ -225,3 +225,113 @@ def test_reference_driver_under_nn_data_parallel_on_the_hip_engine(ref_driver_gp
         with torch.no_grad():
             c = dp(x)
         assert torch.equal(c, order_a) or torch.equal(c, order_b)
+
+
+# ---- round 6: the SECOND caller of the boundary - the unchanged eval_sde_adv_bpda.py and the attack class it drives -------
+REF_BPDA = "/root/reference/eval_sde_adv_bpda.py"
+REF_ATTACK = "/root/reference/bpda_eot/bpda_eot_attack.py"
+FIX_DIR = os.path.join(ROOT, "tests", "golden", "_ref_driver")
+needs_bpda_fixture = pytest.mark.skipif(not os.path.exists(os.path.join(FIX_DIR, "eval_sde_adv_bpda.py")),
+                                        reason="tests/golden/_ref_driver/eval_sde_adv_bpda.py not generated (make_ref_driver_fixture.py)")
+
+
+def _load_bpda_driver(driver_path, attack_path, tmp_path, monkeypatch):
+    """eval_sde_adv_bpda.py as it is (its SDE_Adv_Model: :53-118) with bpda_eot/bpda_eot_attack.py as it is (BPDA_EOT_Attack: the
+    class that calls model(x, mode=...)); stubbed: utils (classifier zoo, data loaders) - outside the scope contract."""
+    monkeypatch.setenv("DIFFPURE_SYNTH_WEIGHTS", "1")
+    (tmp_path / "bpda_eot").mkdir()
+    shutil.copyfile(attack_path, tmp_path / "bpda_eot" / "bpda_eot_attack.py")
+    (tmp_path / "bpda_eot" / "__init__.py").write_text("")
+    scratch = tmp_path / "eval_sde_adv_bpda.py"
+    shutil.copyfile(driver_path, scratch)
+    ut = types.ModuleType("utils")
+    ut.str2bool = lambda v: str(v).lower() in ("1", "true", "yes")
+    ut.get_accuracy = lambda *a, **k: 0.0
+    ut.load_data = lambda *a, **k: None
+    ut.get_image_classifier = lambda name: _Classifier()
+    ut.Logger = object
+    monkeypatch.setitem(sys.modules, "utils", ut)
+    for k in [k for k in sys.modules if k == "runners" or k.startswith("runners.") or k == "bpda_eot" or k.startswith("bpda_eot.")]:
+        monkeypatch.delitem(sys.modules, k)
+    monkeypatch.syspath_prepend(ROOT)                         # `runners` = this repository's drop-in package
+    monkeypatch.syspath_prepend(str(tmp_path))                # `bpda_eot` = the scratch copy of the reference's package
+    spec = importlib.util.spec_from_file_location("ref_eval_sde_adv_bpda", str(scratch))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.RevGuidedDiffusion.__module__ == "runners.diffpure_sde" and mod.Diffusion.__module__ == "runners.diffpure_ddpm"
+    assert mod.BPDA_EOT_Attack.__module__ == "bpda_eot.bpda_eot_attack"
+    return mod
+
+
+def _bpda_round_trip(mod, args, config, x, reps, device):
+    """what eval_bpda does with the model (eval_sde_adv_bpda.py:121-178 -> bpda_eot_attack.py:98-125), minus the data loader"""
+    model = mod.SDE_Adv_Model(args, config)                   # the reference's class, unchanged
+    assert isinstance(model.runner, torch.nn.Module) and type(model.runner).__module__.startswith("runners.")
+    model = model.eval().to(device)
+    mod.config = config                                       # reset_counter reads a module-global `config` (:76-77: it exists when the file runs as __main__)
+    model.reset_counter()
+    model.set_tag("no_adv")
+    with torch.no_grad():
+        pur = model(x, mode="purify")
+        cls = model(x, mode="classify")
+        both = model(x, mode="purify_and_classify")
+    assert pur.shape == x.shape and torch.isfinite(pur).all() and cls.shape == (x.shape[0], 7) and both.shape == (x.shape[0], 7)
+    assert int(model.counter.item()) == 2                      # two purifications so far
+    with pytest.raises(NotImplementedError):
+        model(x, mode="nonsense")
+    y = torch.tensor([1, 4], device=device)
+    adv = mod.BPDA_EOT_Attack(model, adv_eps=8.0 / 255, eot_defense_reps=3, eot_attack_reps=reps)
+    model.set_tag()
+    correct, grad = adv.purify_and_predict(x, y, purify_reps=reps)        # X.repeat(reps) -> model(mode='purify') -> classify with grad
+    assert correct.shape == (2,) and grad.shape == x.shape and torch.isfinite(grad).all() and grad.abs().max() > 0
+    defended, grad2 = adv.eval_and_bpda_eot_grad(x, y, torch.ones(2, dtype=torch.bool, device=device))
+    assert defended.shape == (2,) and grad2.shape == x.shape
+    x_adv = adv.pgd_update(x.clone(), grad2, x, "l_inf", 8.0 / 255, 2.0 / 255)
+    assert (x_adv - x).abs().max() <= 8.0 / 255 + 1e-6
+    return model, pur
+
+
+@needs_reference
+@pytest.mark.parametrize("diffusion_type", ["sde", "ddpm"])
+def test_reference_bpda_driver_over_the_drop_in_runners(tmp_path, monkeypatch, diffusion_type):
+    refops.patch_ops(monkeypatch)
+    monkeypatch.setenv("DIFFPURE_PRECISION", "f32")
+    mod = _load_bpda_driver(REF_BPDA, REF_ATTACK, tmp_path, monkeypatch)
+    if diffusion_type == "sde":
+        g = load_golden("ncsnpp_small.pt")
+        config, hw = _ns(g["cfg"]), 16
+        args = _args("sde", tmp_path, dt=5e-2)
+    else:
+        g = load_golden("guided_small.pt")
+        config, hw = _ns(dict(model=g["cfg"], data=dict(dataset="ImageNet", image_size=32))), 32
+        args = _args("ddpm", tmp_path, t=3, score_type="guided_diffusion")
+    config.device = torch.device("cpu")
+    x = torch.rand(2, 3, hw, hw, generator=torch.Generator().manual_seed(1))
+    _bpda_round_trip(mod, args, config, x, 3, config.device)
+
+
+@needs_bpda_fixture
+@pytest.mark.gpu
+@pytest.mark.parametrize("diffusion_type", ["sde", "ddpm"])
+def test_reference_bpda_driver_on_the_hip_engine(tmp_path, monkeypatch, diffusion_type):
+    """The travelling copies of eval_sde_adv_bpda.py and bpda_eot_attack.py (sha256 checked) over the HIP engine at the shipped precision:
+    SDE_Adv_Model(args, config), the three forward modes, and BPDA_EOT_Attack.purify_and_predict with 15 EOT replicas per image."""
+    import hashlib
+    from diffpure_amd import factory
+    want = dict(line.split()[::-1] for line in open(FIXTURE_SHA).read().splitlines())
+    for name in ("eval_sde_adv_bpda.py", "bpda_eot_attack.py"):
+        assert hashlib.sha256(open(os.path.join(FIX_DIR, name), "rb").read()).hexdigest() == want[name], f"{name} is not the reference's file"
+    monkeypatch.delenv("DIFFPURE_PRECISION", raising=False)
+    mod = _load_bpda_driver(os.path.join(FIX_DIR, "eval_sde_adv_bpda.py"), os.path.join(FIX_DIR, "bpda_eot_attack.py"), tmp_path, monkeypatch)
+    if diffusion_type == "sde":
+        g = load_golden("ncsnpp_small.pt")
+        config, hw = _ns(g["cfg"]), 16
+        args = _args("sde", tmp_path, dt=5e-2)
+    else:
+        g = load_golden("guided_small.pt")
+        config, hw = _ns(dict(model=g["cfg"], data=dict(dataset="ImageNet", image_size=32))), 32
+        args = _args("ddpm", tmp_path, t=4, score_type="guided_diffusion")
+    config.device = torch.device("cuda:0")
+    x = torch.rand(2, 3, hw, hw, generator=torch.Generator().manual_seed(1)).to(config.device)
+    model, pur = _bpda_round_trip(mod, args, config, x, 15, config.device)
+    assert model.runner.model.precision == factory.DEFAULT_PRECISION and pur.is_cuda
