@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["igemm.hip", "igemm_h2.hip", "igemm_h2_pp.hip", "igemm_h2_sw.hip", "igemm_h2_dw.hip", "igemm_h2_dh.hip", "igemm_h2_nn.hip", "norm.hip", "norm_bwd.hip", "elementwise.hip", "resize.hip", "attention.hip", "gemm_h16.hip", "stem.hip"]
+SOURCES = ["igemm.hip", "igemm_h2.hip", "igemm_h2_pp.hip", "igemm_h2_sw.hip", "igemm_h2_dw.hip", "igemm_h2_dh.hip", "igemm_h2_nn.hip", "norm.hip", "norm_bwd.hip", "elementwise.hip", "resize.hip", "attention.hip", "gemm_h16.hip", "stem.hip", "boundary.hip"]
 OUT = os.path.join(CSRC, "libdiffpure_hip.so")
 
 

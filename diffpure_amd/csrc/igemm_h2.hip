@@ -500,12 +500,14 @@ extern "C" int dp_conv2d_nhwc_h2_takes_segments(int H, int W, int KS, int C, int
     return 1;
 }
 
-extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
-                                 const float* bias, const float* temb, int temb_stride, const void* res, int ldr,
-                                 float scale, void* out, int ldo, float* colstats, int* tile_rows, void* work,
-                                 long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, int res_fmt,
-                                 const void* seg1, int segC1, const void* seg2, int segC2, void* stream) {
-    DP_REQUIRE(x && w && out, "dp_conv2d_nhwc_h2: null pointer");
+// partials_only (dp_conv2d_nhwc_h2_partials): a split-K layer stops after its partial-sum kernel - the reduction and the epilogue
+// belong to the fused block boundary (boundary.hip, dp_splitk_gn)
+static int h2_conv(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
+                   const float* bias, const float* temb, int temb_stride, const void* res, int ldr,
+                   float scale, void* out, int ldo, float* colstats, int* tile_rows, void* work,
+                   long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, int res_fmt,
+                   const void* seg1, int segC1, const void* seg2, int segC2, void* stream, bool partials_only) {
+    DP_REQUIRE(x && w && (out || partials_only), "dp_conv2d_nhwc_h2: null pointer");
     DP_REQUIRE(res_fmt == 0 || (res_fmt == 1 && ldr % 2 == 0 && ((size_t)res & 3) == 0),
                "dp_conv2d_nhwc_h2: res_fmt must be 0 (fp32) or 1 (fp16; even row stride, 4-byte aligned), got %d", res_fmt);
     DP_REQUIRE((!seg1 && !seg2 && segC1 == 0 && segC2 == 0) ||
@@ -542,6 +544,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
 
     p.ksplit = h2_ksplit(H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
+    DP_REQUIRE(!partials_only || p.ksplit > 1, "dp_conv2d_nhwc_h2_partials: this layer is not reduced with split-K (dp_conv2d_nhwc_h2_workspace() == 0)");
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
                                  ldo % 4 == 0 && (!res || (ldr % 4 == 0 && ((size_t)res & (res_fmt ? 7 : 15)) == 0))),
                "dp_conv2d_nhwc_h2: this layer is reduced with split-K and needs dp_conv2d_nhwc_h2_workspace() bytes of scratch, row "
@@ -616,7 +619,7 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
         if (dp_tune(DP_T_H2_DH) >= 2 && dp_tune(DP_T_H2_PP) != 0 && p.ksplit > 1 && dh_enough(tiles(128, 256) * p.ksplit) && dp_conv_dh_applies(p, 256)) {
             dp_launch_conv_dh(p, s, 256);
             DP_LAUNCH_CHECK("conv_igemm_dh (split-K)");
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, s, p);
+            if (!partials_only) hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, s, p);
             if (tile_rows) *tile_rows = 64;
             dp_prof_end(rec, s);
             DP_LAUNCH_CHECK("splitk_epilogue");
@@ -668,11 +671,56 @@ extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int 
     if (N <= 64 || tiles(128, 128) * p.ksplit < 256) DP_H2_LAUNCH(64, 64, 32, 0);
     else DP_H2_LAUNCH(128, 128, 32, 0);
 #undef DP_H2_LAUNCH
-    if (p.ksplit > 1)
+    if (p.ksplit > 1 && !partials_only)
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0, s, p);
     if (tile_rows) *tile_rows = 64;   // column-sum records are per 64 output rows in every variant
     dp_prof_end(rec, s);
     DP_LAUNCH_CHECK("conv_igemm_h2");
+    return 0;
+}
+
+extern "C" int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS, const void* w, int N,
+                                 const float* bias, const float* temb, int temb_stride, const void* res, int ldr,
+                                 float scale, void* out, int ldo, float* colstats, int* tile_rows, void* work,
+                                 long long work_bytes, int passes, int a_fmt, int w_fmt, int out_fmt, int res_fmt,
+                                 const void* seg1, int segC1, const void* seg2, int segC2, void* stream) {
+    return h2_conv(x, C, B, H, W, KS, w, N, bias, temb, temb_stride, res, ldr, scale, out, ldo, colstats, tile_rows, work, work_bytes, passes, a_fmt,
+                   w_fmt, out_fmt, res_fmt, seg1, segC1, seg2, segC2, stream, false);
+}
+
+// The split-K partial sums of a convolution and nothing else: work[s][B*H*W][N] fp32, s = 0 .. S-1 (*n_parts = S), for dp_splitk_gn to
+// reduce.  Only for layers dp_conv2d_nhwc_h2_workspace() reports scratch for (<= 64 pixels per sample); same kernels, same partial
+// sums as dp_conv2d_nhwc_h2 forms before its own reduction pass.
+extern "C" int dp_conv2d_nhwc_h2_partials(const void* x, int C, int B, int H, int W, int KS, const void* w, int N, void* work,
+                                          long long work_bytes, int passes, int a_fmt, int w_fmt, const void* seg1, int segC1,
+                                          const void* seg2, int segC2, int* n_parts, void* stream) {
+    DP_REQUIRE(n_parts, "dp_conv2d_nhwc_h2_partials: n_parts is null");
+    *n_parts = h2_ksplit(H, W, KS, C, N);
+    // (the epilogue arguments are unused; ldo = N satisfies the split-K path's row-stride check)
+    return h2_conv(x, C, B, H, W, KS, w, N, nullptr, nullptr, 0, nullptr, 0, 1.0f, nullptr, N, nullptr, nullptr, work, work_bytes, passes, a_fmt, w_fmt,
+                   0, 0, seg1, segC1, seg2, segC2, stream, true);
+}
+
+extern "C" int dp_splitk_epilogue(const float* work, int n_parts, int B, int H, int W, int N, const float* bias, const float* temb,
+                                  int temb_stride, const void* res, int res_fmt, float scale, void* out, int out_fmt, float* colstats,
+                                  int* tile_rows, void* stream) {
+    DP_REQUIRE(work && out && n_parts >= 1 && B > 0 && H > 0 && W > 0 && N > 0 && N % 4 == 0, "dp_splitk_epilogue: bad arguments");
+    DP_REQUIRE((long long)B * H * W < (1ll << 31), "dp_splitk_epilogue: M overflows int32");
+    DP_REQUIRE(out_fmt == 0 || out_fmt == 1, "dp_splitk_epilogue: out_fmt %d", out_fmt);
+    DP_REQUIRE(res_fmt == 0 || res_fmt == 1, "dp_splitk_epilogue: res_fmt %d", res_fmt);
+    DP_REQUIRE(dp_aligned16(work) && (!res || ((size_t)res & (res_fmt ? 7 : 15)) == 0) && ((size_t)out & (out_fmt ? 7 : 15)) == 0,
+               "dp_splitk_epilogue: misaligned tensor (the kernel reads and writes quads)");
+    DP_REQUIRE(!colstats || tile_rows, "dp_splitk_epilogue: colstats needs tile_rows");
+    ConvH2Args p = {};
+    p.B = B; p.H = H; p.W = W; p.M = B * H * W; p.N = N;
+    p.bias = bias; p.temb = temb; p.temb_stride = temb_stride;
+    p.res = static_cast<const float*>(res); p.ldr = N; p.rfmt = res_fmt;
+    p.out = static_cast<float*>(out); p.ldo = N; p.ofmt = out_fmt;
+    p.scale = scale; p.ksplit = n_parts; p.ws = const_cast<float*>(work); p.colstats = colstats;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((p.M + 63) / 64)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    if (tile_rows) *tile_rows = 64;
+    DP_LAUNCH_CHECK("splitk_epilogue");
     return 0;
 }
 

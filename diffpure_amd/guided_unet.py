@@ -192,6 +192,9 @@ class GuidedUNet:
         # fp16 x fp16 modes: a ResBlock's first convolution stores its output as fp16 (its only reader is the GroupNorm-apply
         # that emits the fp16 operand of the second one) and the attention output reaches proj_out as an fp16 operand
         self._lean = self._pool is not None and os.environ.get("DIFFPURE_LEAN", "1") != "0"
+        # round 6: fused block boundaries of the <= 64-pixel levels (csrc/boundary.hip; ops.Deferred) - fp16 x fp16 modes (the kernel emits
+        # plain fp16 operands); DIFFPURE_BOUNDARY=0 restores the four-launch chain
+        self._bfuse = self._pool is not None and self._ofmt == "h1"
         # ... and (round 4, DIFFPURE_LEAN16=0 switches it off) the RESIDUAL STREAM itself travels as plain fp16 between the blocks -
         # the reference's own arithmetic for this network (`use_fp16: True`, configs/imagenet.yml:18: convert_to_fp16 casts the
         # whole torso, unet.py:626-632, so h IS fp16 there) with fp32 accumulation / epilogues / GroupNorm statistics on top.
@@ -332,45 +335,65 @@ class GuidedUNet:
         return self._lean16 and (tape is None or self._tape16) and hw % 64 == 0
 
     def _res(self, r, xa, x2a, film_table, tape=None):
-        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors; fp32, or plain
-        fp16 on the fp16 residual stream"""
-        x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
+        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left), ops.Deferred (a split-K convolution output whose
+        reduction / epilogue waits for this block's GroupNorm - the fused block boundary of the 8 x 8 level, csrc/boundary.hip) or plain
+        tensors; fp32, or plain fp16 on the fp16 residual stream"""
+        x2 = ops.tensor_of(x2a)
+        xs, xdt = xa.shape, ops.dtype_of(xa)
         P, n, co = self.p, r["name"], r["cout"]
         G, eps = self.GN_GROUPS, self.GN_EPS
         mode = r["mode"]
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
         conv2 = self._ch2 if r["h2_2"] else ops.conv2d
-        b = x.shape[0]
-        ho, wo = ops._out_hw(x.shape[1], x.shape[2], mode)
+        b = xs[0]
+        ho, wo = ops._out_hw(xs[1], xs[2], mode)
         out16 = self._o16(ho * wo, tape)
-        st1 = ops.group_norm_stats(xa, G, eps, x2a)
         # channel-changing block: the 1x1 skip as K-segments of the second convolution (fp16 stream, launches the 8-wave kernel takes)
-        c1 = x.shape[3]
-        fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w2s") in P
+        c1 = xs[3]
+        fused = (out16 and not mode and r["cin"] != co and xdt == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w2s") in P
                  and ops.takes_segments(ho, wo, 3, co, co, c1, r["cin"] - c1))
         want_raw = (not mode) and r["cin"] != co and r.get("h2_s", False) and not fused
         # up / down block on the fp16 stream: the resampled identity skip (unet.py:245-250) is a second output of the same pass (round 6)
-        want_skip = bool(mode) and r["cin"] == co and x.dtype == torch.float16 and x2 is None and os.environ.get("DIFFPURE_SKIP_FUSED", "1") != "0"
-        h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
-                           raw=want_raw or want_skip)
-        if want_raw:
-            h, xraw = h
-        elif want_skip:
-            h, xskip = h
+        want_skip = bool(mode) and r["cin"] == co and xdt == torch.float16 and x2 is None and os.environ.get("DIFFPURE_SKIP_FUSED", "1") != "0"
+        if self._bfuse and r["h2_1"] and ops.deferred_fusable(xa, x2a, G, mode):
+            # in_layers' GroupNorm IS the block boundary of the previous convolution (split-K reduction + epilogue + normalisation + operand)
+            h, st1, xraw = ops.group_norm_deferred(xa, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, raw=want_raw, want_out=True,
+                                                   want_stats=tape is not None)
+            x = xa.t
+        else:
+            x = ops.tensor_of(xa)
+            st1 = ops.group_norm_stats(xa, G, eps, x2a)
+            h = ops.group_norm(x, G, eps, P[n + ".g1"], P[n + ".b1"], x2=x2, act=True, resample=mode, split=r["h2_1"] and self._ofmt, stats=st1,
+                               raw=want_raw or want_skip)
+            if want_raw:
+                h, xraw = h
+            elif want_skip:
+                h, xskip = h
         # (below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
         mid16 = self._lean and (tape is None or self._tape16) and r["h2_1"] and r["h2_2"] and (ho * wo) % 64 == 0
-        h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True, **({"out_f16": True} if mid16 else {}))
         off = r["emb_off"]
         film = (film_table[:, off:off + co], film_table[:, off + co:off + 2 * co])
-        st2 = ops.group_norm_stats(h, G, eps)
-        h = h.t
-        if tape is not None:
-            tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
-        h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
+        if self._bfuse and r["h2_1"] and r["h2_2"] and ops.conv_defers(ho, wo, 3, r["cin"], co) and ops.splitk_gn_ok(ho, wo, co, 0, G):
+            # in_layers' convolution -> out_layers' GroupNorm (FiLM) inside the block: the tensor between them is written only for a tape
+            dd = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], defer=True, **({"out_f16": True} if mid16 else {}))
+            h2, st2, _ = ops.group_norm_deferred(dd, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, want_out=tape is not None,
+                                                 want_stats=tape is not None)
+            if tape is not None:
+                tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=dd.t, st2=st2, film=film))
+            h = h2
+        else:
+            h = conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], colstats=True, **({"out_f16": True} if mid16 else {}))
+            st2 = ops.group_norm_stats(h, G, eps)
+            h = h.t
+            if tape is not None:
+                tape.append(dict(r=r, x=x, x2=x2, st1=st1, hmid=h, st2=st2, film=film))
+            h = ops.group_norm(h, G, eps, P[n + ".g2"], P[n + ".b2"], film=film, act=True, split=r["h2_2"] and self._ofmt, stats=st2)
         o16 = {"out_f16": True} if out16 else {}
+        # the block's output convolution leaves its reduction / epilogue to the NEXT GroupNorm where the level is a split-K one
+        last = {"defer": True} if (self._bfuse and r["h2_2"] and ops.conv_defers(ho, wo, 3, co, co)) else {"colstats": True}
         if fused:
-            return conv2(h, P[n + ".w2s"], co, 3, bias=P[n + ".c2s"], segs=(x,) if x2 is None else (x, x2), colstats=True, **o16)
+            return conv2(h, P[n + ".w2s"], co, 3, bias=P[n + ".c2s"], segs=(x,) if x2 is None else (x, x2), **last, **o16)
         if mode:
             skip = xskip if want_skip else ops.resample(x, mode)
         elif want_raw:
@@ -379,14 +402,19 @@ class GuidedUNet:
             skip = ops.conv2d(x, P[n + ".ws"], co, 1, bias=P[n + ".cs"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip, colstats=True, **o16)
+        return conv2(h, P[n + ".w2"], co, 3, bias=P[n + ".c2"], res=skip, **last, **o16)
 
     def _attn(self, r, xa, tape=None):
         P, n, c = self.p, r["name"], r["ch"]
-        x = ops.tensor_of(xa)
-        b, hh, ww, _ = x.shape
-        st = ops.group_norm_stats(xa, self.GN_GROUPS, self.GN_EPS)
-        xn = ops.group_norm(x, self.GN_GROUPS, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
+        b, hh, ww, _ = xa.shape
+        G = self.GN_GROUPS
+        if self._bfuse and r["h2"] and ops.deferred_fusable(xa, None, G):      # the attention block's GroupNorm as the block boundary (8 x 8)
+            xn, st, _ = ops.group_norm_deferred(xa, G, self.GN_EPS, P[n + ".g"], P[n + ".b"], act=False, want_out=True, want_stats=tape is not None)
+            x = xa.t
+        else:
+            x = ops.tensor_of(xa)
+            st = ops.group_norm_stats(xa, G, self.GN_EPS)
+            xn = ops.group_norm(x, G, self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
         # fp16 x fp16 modes (with or without a tape: the backward pass recomputes the probabilities from the taped qkv): qkv is stored as plain fp16 by the
         # convolution and the flash kernel runs ONE fp16 pass on it, Q and K read in place (csrc/attention.hip; the arithmetic of the
         # reference's use_fp16 attention, unet.py:358-361)
@@ -401,7 +429,8 @@ class GuidedUNet:
             tape.append(dict(r=r, x=x, st=st, qkv=qkv, layout=layout))
         if fused:
             ah = ops.attention_fused(qkv.view(b, hh * ww, 3 * c), r["heads"], layout, operand_hw=(hh, ww))
-            return self._ch2(ah, P[n + ".wproj16"], c, 1, bias=P[n + ".cproj"], res=x, colstats=True,
+            last = {"defer": True} if (self._bfuse and ops.conv_defers(hh, ww, 1, c, c)) else {"colstats": True}
+            return self._ch2(ah, P[n + ".wproj16"], c, 1, bias=P[n + ".cproj"], res=x, **last,
                              **({"out_f16": True} if self._o16(hh * ww, tape) else {}))
         a = ops.attention(qkv.view(b, hh * ww, 3 * c), r["heads"], layout)
         # shapes the fused kernel does not cover: proj_out on the fp32 path (fp32 residual), the result in the stream's format of this level
@@ -450,6 +479,7 @@ class GuidedUNet:
         h = self._run(self.plan["mid"], h, None, film, tape)
         for blk in self.plan["out"]:
             h = self._run(blk, h, hs.pop(), film, tape)
+        h = ops.resolved(h)
         st = ops.group_norm_stats(h, self.GN_GROUPS, self.GN_EPS)
         h = ops.tensor_of(h)
         if tape is not None:

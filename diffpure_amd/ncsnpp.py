@@ -153,6 +153,9 @@ class NCSNpp:
         self._ch2 = functools.partial(ops.conv2d_h2, passes=passes, w_fmt=1 if self._pool is not None else 0)
         # fp16 x fp16 modes: the first convolution of a ResBlock stores its output as fp16 (see GuidedUNet)
         self._lean = self._pool is not None and os.environ.get("DIFFPURE_LEAN", "1") != "0"
+        # round 6: fused block boundaries of the <= 64-pixel levels (csrc/boundary.hip; ops.Deferred) - fp16 x fp16 modes (the kernel emits
+        # plain fp16 operands); DIFFPURE_BOUNDARY=0 restores the four-launch chain
+        self._bfuse = self._pool is not None and self._ofmt == "h1"
         self._lean16 = False         # fp16 residual stream: decided in load_state_dict
         self._tape16 = os.environ.get("DIFFPURE_TAPE16", "1") != "0"     # round 5: the taped forward runs on it too (GuidedUNet._o16)
         self.device = torch.device(device)
@@ -290,51 +293,72 @@ class NCSNpp:
         return self._lean16 and (tape is None or self._tape16) and hw % 64 == 0
 
     def _res(self, r, xa, x2a, dense, tape=None):
-        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left) or plain tensors; fp32, or plain
-        fp16 on the fp16 residual stream"""
-        x, x2 = ops.tensor_of(xa), ops.tensor_of(x2a)
+        """xa, x2a: ops.Act (tensor + the column statistics its producing convolution left), ops.Deferred (a split-K convolution output whose
+        reduction / epilogue waits for this block's GroupNorm: the fused block boundary of the <= 64-pixel levels, csrc/boundary.hip) or
+        plain tensors; fp32, or plain fp16 on the fp16 residual stream"""
+        x2 = ops.tensor_of(x2a)
+        xs, xdt = xa.shape, ops.dtype_of(xa)
         P, n, co = self.p, str(r["idx"]), r["cout"]
         mode = self._rmode(r["mode"])
         fir = self._fir
         conv0 = self._ch2 if r["h2_0"] else ops.conv2d
         conv1 = self._ch2 if r["h2_1"] else ops.conv2d
-        b = x.shape[0]
-        ho, wo = ops._out_hw(x.shape[1], x.shape[2], mode)
+        b = xs[0]
+        ho, wo = ops._out_hw(xs[1], xs[2], mode)
         out16 = self._o16(ho * wo, tape)
         o16 = {"out_f16": True} if out16 else {}
-        st0 = ops.group_norm_stats(xa, self._groups(r["cin"]), self.GN_EPS, x2a)
+        G0, G1 = self._groups(r["cin"]), self._groups(co)
         h2s = r.get("h2_s", False)
         # channel-changing block without resampling: Conv_2 (the 1x1 shortcut, layerspp.py:268-272) as K-segments of Conv_1
-        c1 = x.shape[3]
-        fused = (out16 and not mode and r["cin"] != co and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
+        c1 = xs[3]
+        fused = (out16 and not mode and r["cin"] != co and xdt == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
                  and ops.takes_segments(ho, wo, 3, co, co, c1, r["cin"] - c1))
         # up / down block (round 6): GroupNorm-apply hands out the resampled raw input as a plain fp16 tensor in the same pass, and Conv_2 -
         # the 1x1 shortcut over it (layerspp.py:245-258, 268-272) - becomes K-segments of Conv_1 like the shortcut of a channel-changing block
-        fused_rs = (out16 and bool(mode) and x.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
+        fused_rs = (out16 and bool(mode) and xdt == torch.float16 and (x2 is None or x2.dtype == torch.float16) and (n + ".w1s") in P
                     and mode in (ops.RESAMPLE_UP, ops.RESAMPLE_DOWN) and ops.takes_segments(ho, wo, 3, co, co, r["cin"], 0)
                     and os.environ.get("DIFFPURE_SKIP_FUSED", "1") != "0")
         want_raw = h2s and not mode and not fused
-        h = ops.group_norm(x, self._groups(r["cin"]), self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
-                           resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw or fused_rs, fir=fir)
-        if want_raw:
-            h, xraw = h
-        elif fused_rs:
-            h, xres = h
+        if self._bfuse and r["h2_0"] and ops.deferred_fusable(xa, x2a, G0, mode):
+            # GroupNorm_0 IS the block boundary of the previous convolution: its split-K reduction, epilogue, this normalisation and the
+            # operand of Conv_0 in one launch; the stream tensor (residual / shortcut input of this block, skip of the up path) comes with it
+            h, st0, xraw = ops.group_norm_deferred(xa, G0, self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True, raw=want_raw,
+                                                   want_out=True, want_stats=tape is not None)
+            x = xa.t
+        else:
+            x = ops.tensor_of(xa)
+            st0 = ops.group_norm_stats(xa, G0, self.GN_EPS, x2a)
+            h = ops.group_norm(x, G0, self.GN_EPS, P[n + ".g0"], P[n + ".b0"], x2=x2, act=True,
+                               resample=mode, split=r["h2_0"] and self._ofmt, stats=st0, raw=want_raw or fused_rs, fir=fir)
+            if want_raw:
+                h, xraw = h
+            elif fused_rs:
+                h, xres = h
         off = r["dense_off"]
         # (below 64 pixels per sample the column records straddle samples and
         #  GroupNorm reduces the tensor itself, which it reads as fp32)
-        mid16 = (self._lean and (tape is None or self._tape16) and r["h2_0"] and r["h2_1"] and co % (4 * self._groups(co)) == 0 and (ho * wo) % 64 == 0)
-        h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True, **({"out_f16": True} if mid16 else {}))
-        st1 = ops.group_norm_stats(h, self._groups(co), self.GN_EPS)
-        h = h.t
-        if tape is not None:
-            tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
-        h = ops.group_norm(h, self._groups(co), self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
+        mid16 = (self._lean and (tape is None or self._tape16) and r["h2_0"] and r["h2_1"] and co % (4 * G1) == 0 and (ho * wo) % 64 == 0)
+        if self._bfuse and r["h2_0"] and r["h2_1"] and ops.conv_defers(ho, wo, 3, r["cin"], co) and ops.splitk_gn_ok(ho, wo, co, 0, G1):
+            # Conv_0 -> GroupNorm_1 inside the block: the tensor between the two convolutions is written only for a tape
+            dd = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], defer=True, **({"out_f16": True} if mid16 else {}))
+            h2, st1, _ = ops.group_norm_deferred(dd, G1, self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, want_out=tape is not None,
+                                                 want_stats=tape is not None)
+            if tape is not None:
+                tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=dd.t, st1=st1))
+            h = h2
+        else:
+            h = conv0(h, P[n + ".w0"], co, 3, bias=P[n + ".c0"], temb=dense[:, off:off + co], colstats=True, **({"out_f16": True} if mid16 else {}))
+            st1 = ops.group_norm_stats(h, G1, self.GN_EPS)
+            h = h.t
+            if tape is not None:
+                tape.append(dict(r=r, x=x, x2=x2, st0=st0, hmid=h, st1=st1))
+            h = ops.group_norm(h, G1, self.GN_EPS, P[n + ".g1"], P[n + ".b1"], act=True, split=r["h2_1"] and self._ofmt, stats=st1)
+        # the block's output convolution leaves its reduction / epilogue to the NEXT GroupNorm where the level is a split-K one
+        last = {"defer": True} if (self._bfuse and r["h2_1"] and ops.conv_defers(ho, wo, 3, co, co)) else {"colstats": True}
         if fused:
-            return conv1(h, P[n + ".w1s"], co, 3, bias=P[n + ".c1s"], segs=(x,) if x2 is None else (x, x2), scale=INV_SQRT2,
-                         colstats=True, **o16)
+            return conv1(h, P[n + ".w1s"], co, 3, bias=P[n + ".c1s"], segs=(x,) if x2 is None else (x, x2), scale=INV_SQRT2, **last, **o16)
         if fused_rs:
-            return conv1(h, P[n + ".w1s"], co, 3, bias=P[n + ".c1s"], segs=(xres,), scale=INV_SQRT2, colstats=True, **o16)
+            return conv1(h, P[n + ".w1s"], co, 3, bias=P[n + ".c1s"], segs=(xres,), scale=INV_SQRT2, **last, **o16)
         if mode:
             if h2s:
                 skip = self._ch2(ops.to_h2(x, mode, fmt=self._ofmt, fir=fir), P[n + ".w2"], co, 1, bias=P[n + ".c2"], **o16)
@@ -346,11 +370,11 @@ class NCSNpp:
             skip = ops.conv2d(x, P[n + ".w2"], co, 1, bias=P[n + ".c2"], x2=x2)
         else:
             skip = x if x2 is None else torch.cat([x, x2], dim=3)
-        return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2, colstats=True, **o16)
+        return conv1(h, P[n + ".w1"], co, 3, bias=P[n + ".c1"], res=skip, scale=INV_SQRT2, **last, **o16)
 
     def _attn(self, r, xa, tape=None):
         P, n, c = self.p, str(r["idx"]), r["ch"]
-        x = ops.tensor_of(xa)
+        x = ops.tensor_of(xa)          # (attention sits at 16 x 16: never behind a split-K convolution; a Deferred would be finished here)
         b, hh, ww, _ = x.shape
         st = ops.group_norm_stats(xa, self._groups(c), self.GN_EPS)
         hn = ops.group_norm(x, self._groups(c), self.GN_EPS, P[n + ".g"], P[n + ".b"], split=r["h2"] and self._ofmt, stats=st)
@@ -406,6 +430,7 @@ class NCSNpp:
                 h = self._res(r, h, None, dense, tape)
         assert not hs
         g = self._groups(self.plan["final_ch"])
+        h = ops.resolved(h)
         sth = ops.group_norm_stats(h, g, self.GN_EPS)
         h = ops.tensor_of(h)
         if tape is not None:

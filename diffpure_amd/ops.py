@@ -279,9 +279,62 @@ class Act:
         return self.t.shape
 
 
+class Deferred(Act):
+    """The output of a split-K convolution (a <= 64-pixel level) whose reduction and epilogue have NOT run yet: the partial sums and the
+    epilogue's arguments, waiting for their consumer.  A GroupNorm that the fused block boundary serves (group_norm_deferred,
+    csrc/boundary.hip) reduces, finishes, normalises and emits the next convolution's operand in ONE launch and leaves the stream tensor
+    (+ its column records) behind as `t` / `cols`; any other consumer calls resolve() - the plain reduction + epilogue launch - first.
+    Either way the object IS an Act afterwards."""
+    __slots__ = ("ws", "parts", "bias", "temb", "ts", "res", "scale", "out_f16", "dims")
+
+    def __init__(self, ws, parts, bias, temb, ts, res, scale, out_f16, dims):
+        super().__init__(None, None)
+        self.ws, self.parts, self.bias, self.temb, self.ts, self.res, self.scale, self.out_f16, self.dims = ws, parts, bias, temb, ts, res, scale, out_f16, dims
+
+    @property
+    def shape(self):
+        return torch.Size(self.dims)
+
+    @property
+    def dtype(self):
+        return torch.float16 if self.out_f16 else torch.float32
+
+    @property
+    def device(self):
+        return self.ws.device
+
+    @property
+    def resolved(self):
+        return self.t is not None
+
+    def resolve(self):
+        """the plain reduction + epilogue (what conv2d_h2 runs behind its partial sums) -> self (an Act with tensor and column records)"""
+        if self.t is None:
+            b, h, w, n = self.dims
+            out = torch.empty(self.dims, device=self.ws.device, dtype=self.dtype)
+            cs, tr = _colstats_alloc(b * h * w, n, self.ws.device)
+            _lib.call("dp_splitk_epilogue", _ptr(self.ws), self.parts, b, h, w, n, _ptr(self.bias), _ptr(self.temb), self.ts, _ptr(self.res),
+                      0 if self.res is None or self.res.dtype != torch.float16 else 1, float(self.scale), _ptr(out), 1 if self.out_f16 else 0,
+                      _ptr(cs), ctypes.addressof(tr), _stream())
+            self.t, self.cols = out, ColStats(cs, tr.value, n)
+            self.ws = None
+        return self
+
+
 def tensor_of(x):
-    """Act | Tensor | None -> Tensor | None"""
+    """Act | Tensor | None -> Tensor | None  (a Deferred convolution output is finished first)"""
+    if isinstance(x, Deferred):
+        return x.resolve().t
     return x.t if isinstance(x, Act) else x
+
+
+def resolved(x):
+    """Act | Tensor | None, with a Deferred convolution output finished"""
+    return x.resolve() if isinstance(x, Deferred) else x
+
+
+def dtype_of(x):
+    return x.dtype if isinstance(x, Deferred) else tensor_of(x).dtype
 
 
 def _colstats_alloc(m, n, device):
@@ -319,8 +372,14 @@ def _fmt_of(split):
     raise ValueError(f"unknown operand format {split!r}")
 
 
+def conv_defers(h, w, ksize, c, n_out):
+    """is this LAYER reduced with split-K, so that its reduction + epilogue can be left to the fused block boundary?  (<= 64 pixels per
+    sample; a function of the layer shape only.)  DIFFPURE_BOUNDARY=0 switches the fused boundaries off."""
+    return os.environ.get("DIFFPURE_BOUNDARY", "1") != "0" and int(_lib.load().dp_conv2d_nhwc_h2_workspace(1, h, w, ksize, c, n_out)) > 0
+
+
 def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False,
-              segs=None):
+              segs=None, defer=False):
     """conv2d on the fp16 matrix cores; same epilogue contract as conv2d.  wh: [N, 2*K] fp16 (h2, pack_conv_weight_h2),
     or with w_fmt=1 the plain fp16 panel [N32, K] in the block layout of order_conv_weight_w16 (WeightPool; one pass, h1
     activations).
@@ -331,7 +390,8 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     the unrounded values).  res: fp32 or plain fp16 [B, H, W, N] (the fp16 residual stream).
     segs=(s1,) | (s1, s2): 1x1 K-segments - plain fp16 NHWC tensors [B, H, W, Cs] whose weight columns follow the KS x KS
     part in `wh` (fuse_skip_weight): out += cat(s1, s2) . wh[:, KS*KS*C:] - a ResBlock's 1x1 skip folded into this
-    convolution.  Only where takes_segments(...) says so."""
+    convolution.  Only where takes_segments(...) says so.
+    defer=True (fp16 x fp16 only, where conv_defers(...) says so): only the split-K partial sums are formed; -> Deferred."""
     _chk_h2(x, "conv2d_h2.x")
     _chk_h2(wh, "conv2d_h2.w")
     b, h, w = x.shape[0], x.shape[1] - 2, x.shape[2] - 2
@@ -365,7 +425,6 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
         assert temb.is_cuda and temb.dtype == torch.float32 and temb.dim() == 2 and temb.stride(1) == 1
         assert temb.shape[0] in (1, b) and temb.shape[1] >= n_out
         ts = 0 if temb.shape[0] == 1 else temb.stride(0)
-    out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
     ldr, rfmt = 0, 0
     if res is not None:
         if res.dtype == torch.float16:
@@ -374,8 +433,18 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
             rfmt = 1
         else:
             _chk(res, "conv2d_h2.res", 4)
-        assert res.shape == out.shape, (res.shape, out.shape)
+        assert tuple(res.shape) == (b, h, w, n_out), (res.shape, (b, h, w, n_out))
         ldr = n_out
+    if defer:
+        if not (w_fmt == 1 and a_fmt == 1 and conv_defers(h, w, ksize, c, n_out)):
+            raise _lib.DiffpureHipError("conv2d_h2: defer=True needs an fp16 x fp16 split-K layer (conv_defers)")
+        wbytes = int(_lib.load().dp_conv2d_nhwc_h2_workspace(b, h, w, ksize, c, n_out))
+        work = torch.empty((wbytes // 4,), device=x.device, dtype=torch.float32)
+        parts = ctypes.c_int(0)
+        _lib.call("dp_conv2d_nhwc_h2_partials", _ptr(x), c, b, h, w, ksize, _ptr(wh), n_out, _ptr(work), wbytes, int(passes), a_fmt, int(w_fmt),
+                  sp[0], sc[0], sp[1], sc[1], ctypes.addressof(parts), _stream())
+        return Deferred(work, parts.value, bias, temb, ts, res, scale, bool(out_f16), (b, h, w, n_out))
+    out = torch.empty((b, h, w, n_out), device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
     cs, tr = _colstats_alloc(b * h * w, n_out, x.device) if colstats else (None, None)
     # low-resolution levels are reduced with split-K (factor fixed by the layer shape): scratch for the partial sums
     wbytes = int(_lib.load().dp_conv2d_nhwc_h2_workspace(b, h, w, ksize, c, n_out))
@@ -517,6 +586,7 @@ def group_norm_stats(x, groups, eps, x2=None):
     column records (from the producing convolutions' epilogues) make the pass over the data unnecessary.  fp16 tensors
     (a convolution's fp16 output, the fp16 residual stream) exist ONLY with their records: their statistics are those of the
     unrounded values the epilogue summed."""
+    x, x2 = resolved(x), resolved(x2)          # (an unfinished split-K convolution output is finished first: its records come with it)
     k1 = x.cols if isinstance(x, Act) else None
     k2 = x2.cols if isinstance(x2, Act) else None
     x, x2 = tensor_of(x), tensor_of(x2)
@@ -544,6 +614,51 @@ def group_norm_stats(x, groups, eps, x2=None):
     _lib.call("dp_gn_stats", _ptr(x), c1, _ptr(x2), c2, b, hw, groups, ns, _ptr(partial), s)
     _lib.call("dp_gn_finalize", _ptr(partial), b, ns, groups, hw * ((c1 + c2) // groups), float(eps), _ptr(stats), s)
     return stats
+
+
+def splitk_gn_ok(h, w, n, c2, groups):
+    """does the fused block boundary serve (convolution output [.., h, w, n], second source of c2 channels, `groups` groups)?"""
+    return bool(_lib.load().dp_splitk_gn_ok(h, w, n, c2, groups))
+
+
+def deferred_fusable(xa, x2a, groups, resample=RESAMPLE_NONE, fir=None):
+    """can the GroupNorm over cat(xa, x2a) be the fused block boundary of the unfinished convolution output xa?"""
+    if not (isinstance(xa, Deferred) and not xa.resolved) or resample != RESAMPLE_NONE:
+        return False
+    x2 = tensor_of(x2a)
+    b, h, w, n = xa.dims
+    if x2 is not None and not (x2.is_cuda and x2.is_contiguous() and x2.dim() == 4 and tuple(x2.shape[:3]) == (b, h, w)
+                               and x2.dtype in (torch.float16, torch.float32)):
+        return False
+    return splitk_gn_ok(h, w, n, 0 if x2 is None else x2.shape[3], groups)
+
+
+def group_norm_deferred(d, groups, eps, gamma, beta, x2=None, film=None, act=False, raw=False, want_out=True, want_stats=False):
+    """The fused block boundary (csrc/boundary.hip): finishes the split-K convolution output `d` (Deferred) and applies the GroupNorm
+    (+FiLM) (+SiLU) of cat(d, x2) in ONE launch.  -> (y, stats | None, y_raw | None): y the zero-bordered "h1" operand
+    [B, H+2, W+2, N + C2]; with want_out `d` becomes a finished Act (stream tensor, + column records at 64 pixels per sample)."""
+    assert isinstance(d, Deferred) and not d.resolved
+    b, h, w, n = d.dims
+    x2 = tensor_of(x2)
+    c2 = 0 if x2 is None else x2.shape[3]
+    c = n + c2
+    dev = d.ws.device
+    fs, fh, fstride = _film_args(film, b, c)
+    out = torch.empty(d.dims, device=dev, dtype=d.dtype) if want_out else None
+    cs = tr = None
+    if want_out and h * w == 64:
+        cs, tr = _colstats_alloc(b * 64, n, dev)
+    stats = torch.empty((b, groups, 2), device=dev, dtype=torch.float32) if want_stats else None
+    y = torch.empty((b, h + 2, w + 2, c), device=dev, dtype=torch.float16)
+    yr = torch.empty_like(y) if raw else None
+    _lib.call("dp_splitk_gn", _ptr(d.ws), d.parts, b, h, w, n, _ptr(d.bias), _ptr(d.temb), d.ts, _ptr(d.res),
+              0 if d.res is None or d.res.dtype != torch.float16 else 1, float(d.scale), _ptr(out), 1 if d.out_f16 else 0, _ptr(cs), _ptr(x2),
+              0 if x2 is None or x2.dtype != torch.float16 else 1, c2, groups, float(eps), _ptr(gamma), _ptr(beta), _ptr(fs), _ptr(fh), fstride,
+              1 if act else 0, _ptr(stats), _ptr(y), _ptr(yr), _stream())
+    if want_out:
+        d.t, d.cols = out, (ColStats(cs, 64, n) if cs is not None else None)
+    d.ws = None
+    return y, stats, yr
 
 
 def _film_args(film, b, c):

@@ -167,6 +167,36 @@ int dp_conv2d_nhwc_h2_takes_segments(int H, int W, int KS, int C, int N, int seg
  * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
  * layer shape only, never on B, so that results do not depend on how a batch is sharded. */
 long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, int C, int N);
+/* ---- fused block boundary of the <= 64-pixel levels (ABI 8; csrc/boundary.hip) -------------------------------------------------
+ * Replaces, per ResBlock boundary at 8x8 / 4x4 (score_sde/models/layerspp.py:242-274, guided_diffusion/unet.py:244-264), the launch
+ * chain  convolution partials -> split-K reduction + epilogue -> GroupNorm statistics -> GroupNorm-apply  by  partials -> ONE launch.
+ *
+ * dp_conv2d_nhwc_h2_partials: the convolution of dp_conv2d_nhwc_h2 (same operand formats, same kernels) for a layer that is reduced
+ *   with split-K (dp_conv2d_nhwc_h2_workspace() > 0: H*W <= 64), stopping after the partial sums: work[s][B*H*W][N] fp32,
+ *   s = 0 .. *n_parts - 1.
+ * dp_splitk_epilogue: the reduction + epilogue on its own (what dp_conv2d_nhwc_h2 runs behind its partial sums): out = scale * (res +
+ *   temb[b] + bias + sum_s work[s]), column records as dp_conv2d_nhwc_h2 - for a consumer the fused form does not serve.
+ * dp_splitk_gn: reduction + epilogue + GroupNorm (+FiLM) (+SiLU) of cat(out, x2) in one launch.  One workgroup per (sample, 128- or
+ *   256-channel block of whole groups) keeps the sample's slab in registers.
+ *     out (optional): the stream tensor [B*H*W][N], fp32 (out_fmt 0) or plain fp16 (out_fmt 1; out_fmt also names the format the
+ *       VALUE THAT IS NORMALISED has - the fp16-rounded one for a fp16 stream - when out itself is not wanted);
+ *     colstats (optional, H*W == 64): [B][2][N], the 64-row column records of out (one per sample);
+ *     x2 (optional): second source [B][H*W][C2] fp32 (x2_fmt 0) / plain fp16 (1): the other half of a skip concatenation;
+ *     stats (optional): [B][G][2] (mean, rstd) of cat(out, x2) - statistics of the UNROUNDED values, formed as dp_gn_finalize forms them;
+ *     y: the operand [B][H+2][W+2][N + C2] plain fp16, zero border written; y_raw (optional): the un-normalised cat(out, x2) in the
+ *       same form (input of a 1x1 shortcut convolution).
+ *   dp_splitk_gn_ok: H*W in {64, 16}, channel blocks of whole groups, (N + C2) / G a multiple of 4.  A function of the layer shape only. */
+int dp_conv2d_nhwc_h2_partials(const void* x, int C, int B, int H, int W, int KS, const void* w, int N, void* work, long long work_bytes,
+                               int passes, int a_fmt, int w_fmt, const void* seg1, int segC1, const void* seg2, int segC2, int* n_parts,
+                               void* stream);
+int dp_splitk_epilogue(const float* work, int n_parts, int B, int H, int W, int N, const float* bias, const float* temb, int temb_stride,
+                       const void* res, int res_fmt, float scale, void* out, int out_fmt, float* colstats, int* tile_rows, void* stream);
+int dp_splitk_gn_ok(int H, int W, int N, int C2, int G);
+int dp_splitk_gn(const float* work, int n_parts, int B, int H, int W, int N, const float* bias, const float* temb, int temb_stride,
+                 const void* res, int res_fmt, float scale, void* out, int out_fmt, float* colstats, const void* x2, int x2_fmt, int C2,
+                 int G, float eps, const float* gamma, const float* beta, const float* fscale, const float* fshift, int film_stride,
+                 int act, float* stats, void* y, void* y_raw, void* stream);
+
 /* fp32 [rows][ld] (first `cols` columns, cols % 8 == 0) -> h2 [rows][cols/8][2][8] fp16. */
 int dp_pack_h2(const float* src, long long rows, int cols, int ld, void* dst, void* stream);
 /* fp32 -> fp16 over a flat buffer of n elements (n % 8 == 0; every fp16 weight panel of a network lives in ONE buffer so

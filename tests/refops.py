@@ -10,6 +10,8 @@ The product never imports this module.
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -60,8 +62,79 @@ def _h2_hi(t):
     return t.reshape(-1, shp[-1] // 16, 2, 8).double()[:, :, 0].reshape(*shp[:-1], shp[-1] // 2)
 
 
+def _h2_ksplit(h, w, ksize, c, n_out):
+    """igemm_h2.hip::h2_ksplit - the split-K factor of a layer (a function of its shape only)"""
+    nt = ksize * ksize * c // 32
+    if h * w > 64 or n_out % 4 != 0:
+        return 1
+    if h * w <= 16 and nt >= 32 and nt % 4 == 0:
+        return 4
+    if nt >= 16 and nt % 2 == 0:
+        return 2
+    return 1
+
+
+def conv_defers(h, w, ksize, c, n_out):
+    return os.environ.get("DIFFPURE_BOUNDARY", "1") != "0" and _h2_ksplit(h, w, ksize, c, n_out) > 1
+
+
+def splitk_gn_ok(h, w, n, c2, groups):
+    """dp_splitk_gn_ok"""
+    hw, c = h * w, n + c2
+    if hw not in (64, 16) or c % groups != 0:
+        return False
+    cpg, cb = c // groups, (256 if n % 256 == 0 and c2 % 256 == 0 else 128)
+    return cpg % 4 == 0 and n % cb == 0 and c2 % cb == 0 and cb % cpg == 0 and cb // cpg <= 64
+
+
+def _deferred_value(d):
+    """the finished value of a stand-in Deferred: its `ws` holds the plain convolution sum (one part)"""
+    b, h, w, n = d.dims
+    y = d.ws.double()
+    if d.bias is not None:
+        y = y + d.bias[:n]
+    if d.temb is not None:
+        y = y + d.temb[:, :n].reshape(-1, 1, 1, n)
+    if d.res is not None:
+        y = y + d.res.double()
+    return (y * d.scale).float().contiguous()
+
+
+def deferred_resolve(d):
+    from diffpure_amd import ops
+    if d.t is None:
+        y = _deferred_value(d)
+        d.t, d.cols, d.ws = (y.half() if d.out_f16 else y), None, None
+    return d
+
+
+def group_norm_deferred(d, groups, eps, gamma, beta, x2=None, film=None, act=False, raw=False, want_out=True, want_stats=False):
+    """dp_splitk_gn: split-K reduction + epilogue + GroupNorm (+FiLM) (+SiLU) of cat(d, x2) -> (operand, stats | None, raw operand | None)"""
+    from diffpure_amd import ops
+    v = _deferred_value(d)
+    x2 = ops.tensor_of(x2)
+    stored = v.half().float() if d.out_f16 else v
+    full = stored if x2 is None else torch.cat([stored, x2.float()], dim=3)
+    unr = v if x2 is None else torch.cat([v, x2.float()], dim=3)
+    stats = group_norm_stats(unr, groups, eps)
+    b, h, w, c = full.shape
+    mean, rstd = stats[:, :, 0], stats[:, :, 1]
+    y = (full.reshape(b, h * w, groups, c // groups) - mean[:, None, :, None]) * rstd[:, None, :, None]
+    y = y.reshape(b, h, w, c) * gamma + beta
+    if film is not None:
+        fs, fh = film
+        y = y * (1 + fs.reshape(-1, 1, 1, fs.shape[-1])) + fh.reshape(-1, 1, 1, fh.shape[-1])
+    if act:
+        y = F.silu(y)
+    if want_out:
+        d.t, d.cols = (v.half() if d.out_f16 else v), None
+    d.ws = None
+    pad = lambda t: F.pad(t, (0, 0, 1, 1, 1, 1)).half().contiguous()
+    return pad(y), (stats if want_stats else None), (pad(full) if raw else None)
+
+
 def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False,
-              segs=None):
+              segs=None, defer=False):
     """Statement of the fp16-matrix-core contract (include/diffpure_hip.h, dp_conv2d_nhwc_h2): exact products of the
     operands each mode keeps - f16x3 (h2 activations, passes 3): (hi+lo) x (hi+lo) (the dropped lo*lo term is ~2^-22
     relative, below the test tolerance); passes 12: (hi+lo) x w_hi; h1 activations (plain fp16): passes 2: a x (w_hi+w_lo),
@@ -88,6 +161,10 @@ def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, co
     y = F.conv2d(xin.permute(0, 3, 1, 2), wt, None, padding=ksize // 2).permute(0, 2, 3, 1)
     if wseg is not None:
         y = y + torch.cat([sg.double() for sg in segs], dim=3) @ wseg.double().t()
+    if defer:       # the split-K partial sums only (one part here); the epilogue belongs to the consumer (ops.Deferred)
+        from diffpure_amd import ops
+        assert w_fmt == 1 and h1 and conv_defers(xin.shape[1], xin.shape[2], ksize, cin, n_out)
+        return ops.Deferred(y.float().contiguous(), 1, bias, temb, 0, res, scale, bool(out_f16), tuple(y.shape))
     if bias is not None:
         y = y + bias[:n_out]
     if temb is not None:
@@ -495,7 +572,7 @@ def resize_affine_bwd(dy, in_size, scale, in_nhwc=False, out_nhwc=False):
 
 PATCHED = ["resize_affine", "resize_affine_bwd", "conv2d", "conv2d_stem", "conv2d_stem_ok", "conv2d_h2", "pack_h2", "pack_conv_weight_h2", "linear", "attention_bwd", "group_norm_bwd", "gn_bwd_fused_ok",
            "resample_bwd", "add", "to_h2", "group_norm_stats", "group_norm", "group_norm_f16in", "resample", "attention", "attention_fused",
-           "attention_fused_ok", "attention_h16_serves", "silu", "axpby", "takes_segments",
+           "attention_fused_ok", "attention_h16_serves", "silu", "axpby", "takes_segments", "conv_defers", "splitk_gn_ok", "group_norm_deferred",
            "timestep_embedding", "philox_normal", "em_step", "ddpm_step"]
 
 
@@ -516,3 +593,4 @@ def patch_ops(monkeypatch):
         self._last_key = key
 
     monkeypatch.setattr(ops.WeightPool, "round", pool_round)
+    monkeypatch.setattr(ops.Deferred, "resolve", deferred_resolve)

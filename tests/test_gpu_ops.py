@@ -1303,3 +1303,109 @@ def test_stem_kernel_rejects_shapes_it_does_not_serve(dev):
     assert not ops.conv2d_stem_ok(4, 2, 32, 32, 128) and not ops.conv2d_stem_ok(3, 1, 5, 5, 128) and not ops.conv2d_stem_ok(3, 2, 32, 32, 96)
     with pytest.raises(_lib.DiffpureHipError):
         ops.conv2d_stem(torch.zeros(1, 5, 5, 3, device=dev), ops.pack_stem_weight(torch.zeros(128, 3, 3, 3)).to(dev), 128)
+
+
+# ---- round 6: the fused block boundary of the <= 64-pixel levels (csrc/boundary.hip) -----------------------------------------------
+BOUNDARY_CASES = [
+    # B, H, C, N, C2, G, out16, temb, res, film, act, raw
+    (3, 8, 256, 256, 0, 32, True, True, False, False, True, False),      # NCSN++ Conv_0 -> GroupNorm_1 at 8 x 8 (additive temb)
+    (3, 8, 256, 256, 0, 32, True, False, True, False, True, False),      # Conv_1 (+ residual, 1/sqrt 2) -> next block's GroupNorm_0
+    (2, 8, 256, 256, 256, 32, True, False, True, False, True, False),    # ... over a skip concatenation (up path)
+    (5, 4, 256, 256, 0, 32, False, True, False, False, True, False),     # 4 x 4: fp32 stream, four split-K parts
+    (4, 4, 512, 256, 256, 32, False, False, True, False, True, True),    # 4 x 4 up path: concatenation + the raw operand of the 1x1 shortcut
+    (2, 8, 1024, 1024, 0, 32, True, False, True, True, True, False),     # guided 8 x 8: FiLM, 1024 channels = four channel blocks
+    (2, 8, 1024, 1024, 1024, 32, True, False, True, False, True, False), # guided 8 x 8 output block: 2048-channel concatenation
+    (2, 8, 1024, 1024, 0, 32, True, False, True, False, False, False),   # attention block's GroupNorm (no SiLU)
+    (2, 8, 384, 128, 0, 32, True, True, False, False, True, False),      # 128-channel blocks
+]
+
+
+@pytest.mark.parametrize("case", BOUNDARY_CASES, ids=str)
+def test_fused_block_boundary_equals_the_four_launch_chain(dev, case):
+    """dp_conv2d_nhwc_h2_partials + dp_splitk_gn against conv2d_h2 (its own reduction + epilogue) -> group_norm_stats -> group_norm: the stream
+    tensor is IDENTICAL (same partial sums, same reduction order, same epilogue arithmetic), the statistics agree to fp32 summation noise,
+    the operand up to one fp16 ulp in a few elements (the statistics differ in the last place; SiLU on the hardware units in both), and its
+    border is zero; Deferred.resolve() - the fallback for consumers the fused form does not serve - gives the convolution's own result."""
+    from diffpure_amd import ops
+    B, H, C, N, C2, G, out16, has_temb, has_res, has_film, act, raw = case
+    W = H
+    assert ops.conv_defers(H, W, 3, C, N) and ops.splitk_gn_ok(H, W, N, C2, G)
+    x = _h1_bordered(rnd(B, H, W, C, seed=1), dev)
+    w16 = ops.order_conv_weight_w16(rnd(N, C, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * C))).half().to(dev)
+    bias = rnd(N, seed=3).to(dev)
+    table = rnd(B, N + 8, seed=4).to(dev) if has_temb else None
+    temb = None if table is None else table[:, 4:4 + N]
+    res = None
+    if has_res:
+        res = rnd(B, H, W, N, seed=5).to(dev)
+        res = res.half() if out16 else res
+    x2 = None
+    if C2:
+        x2 = (rnd(B, H, W, C2, seed=6) * 1.5 + 0.2).to(dev)
+        x2 = x2.half() if out16 else x2
+    Ct = N + C2
+    gamma, beta = (1 + 0.1 * rnd(Ct, seed=7)).to(dev), (0.1 * rnd(Ct, seed=8)).to(dev)
+    ftab = (0.3 * rnd(B, 2 * Ct, seed=9)).to(dev) if has_film else None
+    film = None if ftab is None else (ftab[:, :Ct], ftab[:, Ct:])
+    scale = 0.70710678
+    kw = dict(bias=bias, temb=temb, res=res, scale=scale, w_fmt=1, out_f16=out16)
+    # the four-launch chain
+    ya = ops.conv2d_h2(x, w16, N, 3, colstats=True, **kw)
+    if out16:
+        x2a = None if x2 is None else ops.Act(x2, _records_of(x2, dev))
+        st = ops.group_norm_stats(ya, G, 1e-6, x2a)
+        ref = ops.group_norm(ya.t, G, 1e-6, gamma, beta, x2=x2, film=film, act=act, split="h1", stats=st, raw=raw)
+    else:
+        st = ops.group_norm_stats(ya.t, G, 1e-6, x2)
+        ref = ops.group_norm(ya.t, G, 1e-6, gamma, beta, x2=x2, film=film, act=act, split="h1", stats=st, raw=raw)
+    ref, ref_raw = ref if raw else (ref, None)
+    # the fused boundary
+    d = ops.conv2d_h2(x, w16, N, 3, defer=True, **kw)
+    assert isinstance(d, ops.Deferred) and not d.resolved and d.shape == ya.t.shape and d.dtype == ya.t.dtype
+    assert ops.deferred_fusable(d, x2, G)
+    y, st2, yr = ops.group_norm_deferred(d, G, 1e-6, gamma, beta, x2=x2, film=film, act=act, raw=raw, want_out=True, want_stats=True)
+    assert d.resolved and torch.equal(d.t, ya.t)
+    close(st2[:, :, 0], st[:, :, 0].cpu(), rtol=1e-5, atol=1e-6)
+    close(st2[:, :, 1], st[:, :, 1].cpu(), rtol=1e-5, atol=0)
+    assert y.shape == ref.shape and y.dtype == torch.float16
+    diff = (y.float() - ref.float()).abs()
+    assert (diff <= ref.float().abs() * 2.0 ** -9 + 2e-3 * (0 if out16 else 1) + 1e-6).all(), diff.max().item()
+    assert (y != ref).float().mean().item() < (0.02 if out16 else 0.5), (y != ref).float().mean().item()
+    border = torch.ones_like(y, dtype=torch.bool)
+    border[:, 1:-1, 1:-1, :] = False
+    assert (y[border] == 0).all()
+    if raw:
+        assert torch.equal(yr, ref_raw)
+    if H * W == 64:     # the sample's one 64-row record: what group_norm_stats of a later consumer reads
+        rec = ya.cols.buf[:B]
+        close(d.cols.buf[:B], rec.cpu(), rtol=1e-5, atol=1e-4)
+        st3 = ops.group_norm_stats(d, G, 1e-6, None) if C2 == 0 else None
+        if st3 is not None:
+            close(st3, st.cpu(), rtol=1e-5, atol=1e-6)
+    else:
+        assert d.cols is None
+    # the fallback: the plain reduction + epilogue on the partial sums
+    d2 = ops.conv2d_h2(x, w16, N, 3, defer=True, **kw)
+    assert torch.equal(ops.tensor_of(d2), ya.t) and torch.equal(d2.cols.buf[:(B * H * W + 63) // 64], ya.cols.buf[:(B * H * W + 63) // 64])
+    # without the stream tensor (the tensor between a block's two convolutions, no tape): same operand
+    d3 = ops.conv2d_h2(x, w16, N, 3, defer=True, **kw)
+    y3, s3, _ = ops.group_norm_deferred(d3, G, 1e-6, gamma, beta, x2=x2, film=film, act=act, want_out=False)
+    assert torch.equal(y3, y) and s3 is None and d3.t is None
+    # batch invariance: the first sample alone
+    d4 = ops.conv2d_h2(x[:1].contiguous(), w16, N, 3, defer=True, bias=bias, temb=None if temb is None else table[:1, 4:4 + N],
+                       res=None if res is None else res[:1].contiguous(), scale=scale, w_fmt=1, out_f16=out16)
+    y4, _, _ = ops.group_norm_deferred(d4, G, 1e-6, gamma, beta, x2=None if x2 is None else x2[:1].contiguous(),
+                                       film=None if film is None else (ftab[:1, :Ct], ftab[:1, Ct:]), act=act)
+    assert torch.equal(y4, y[:1]) and torch.equal(d4.t, d.t[:1])
+
+
+def _records_of(t16, dev):
+    """64-row column records of an fp16 NHWC tensor (stand-in for what its producing convolution would have left)"""
+    from diffpure_amd import ops
+    b, h, w, c = t16.shape
+    m = b * h * w
+    v = t16.float().reshape(m // 64, 64, c)
+    buf, _ = ops._colstats_alloc(m, c, dev)
+    buf[:m // 64, 0] = v.sum(dim=1)
+    buf[:m // 64, 1] = (v * v).sum(dim=1)
+    return ops.ColStats(buf, 64, c)

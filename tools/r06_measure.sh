@@ -42,6 +42,16 @@ stem)
 tests)
   gputests
   ;;
+boundary)    # fused block boundary of the <= 64-pixel levels
+  timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -s -k "boundary or prefetch or fp16_input_equals" > "$O/boundary_tests.log" 2>&1; echo "rc=$?" >> "$O/boundary_tests.log"; lap boundary_tests
+  grep -E "passed|failed|^FAILED|^E  " "$O/boundary_tests.log" | head -40
+  timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_grad.py tests/test_reference_driver.py tests/test_gpu_dist.py -m gpu -q -s -x > "$O/model_tests.log" 2>&1; echo "rc=$?" >> "$O/model_tests.log"; lap model_tests
+  grep -E "passed|failed|^FAILED|^E  |gain " "$O/model_tests.log" | head -40
+  ab DIFFPURE_BOUNDARY cifar_t50_boundary --workload cifar32_ncsnpp --t 50 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_BOUNDARY cifar_adj_t20_boundary --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_BOUNDARY guided_t20_boundary --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_BOUNDARY guided_b4_t20_boundary --batch 4 --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ;;
 fuse)    # resampled identity skip as a second output of GroupNorm-apply; weight rounding prefetched on a side stream
   timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_grad.py -m gpu -q -s -k "fp16_input_equals or tiny_cotangent or taped_and or finite_differences or half_height or stem or torch_ops or round_weights or stochastic" > "$O/fuse_tests.log" 2>&1; echo "rc=$?" >> "$O/fuse_tests.log"; lap fuse_tests
   grep -E "passed|failed|^FAILED|^E  |cotangent|probe direction|ode_vjp" "$O/fuse_tests.log" | head -40
