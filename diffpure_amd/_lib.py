@@ -49,6 +49,7 @@ SIGNATURES = {
     "dp_conv2d_nhwc_h2": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _f, _p, _i, _p, _p, _p, _ll, _i, _i, _i, _i, _i,
                           _p, _i, _p, _i, _p],
     "dp_conv2d_nhwc_h2_takes_segments": [_i, _i, _i, _i, _i, _i, _i],
+    "dp_conv2d_nhwc_h2_splits_by_shape": [_i, _i, _i, _i, _i],
     "dp_conv2d_nhwc_h2_partials": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _i, _i, _p, _i, _p, _i, _p, _p],
     "dp_splitk_epilogue": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _f, _p, _i, _p, _p, _p],
     "dp_splitk_gn_ok": [_i, _i, _i, _i, _i],

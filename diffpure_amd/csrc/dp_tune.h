@@ -1,7 +1,7 @@
 // Tuning switches of libdiffpure_hip.so.  Each switch is read from its environment variable ONCE, when the library first
 // asks for any of them; after that the environment is never consulted again (a variable set mid-process changes nothing).
 // Probes and tests flip a switch in-process through the C ABI (dp_set_tuning, include/diffpure_hip.h).  None of these
-// switches changes a result: every variant they select is bit-identical to the others (tests/test_gpu_ops.py).  The timing
+// switches but the last (DIFFPURE_BATCH_INVARIANT, see below) changes a result: every variant they select is bit-identical to the others (tests/test_gpu_ops.py).  The timing
 // ablations that DO break results (DP_ABLATE builds) are not part of this library: tests/probes/build_ablate.py compiles
 // them into a separate libdiffpure_hip_ablate.so.  The switches are PROCESS-WIDE (relaxed atomics: a thread that flips one
 // while another thread launches is well-defined, and the other thread's launches pick either variant - same bits either way).
@@ -18,6 +18,10 @@ enum DpTune {
     DP_T_H2_DH,            // DP_H2_DH: the 4-wave 128x256 kernel (igemm_h2_dh.hip) on launches of fewer than 256 tiles of 256x256 - 0 off, 1 un-split layers only, 2 also the split-K levels
     DP_T_H2_DH_MIN,        // DP_H2_DH_MIN: fewest 128x256 half tiles (x split-K parts) of a launch that kernel takes (default 32; below: the generic tiles)
     DP_T_GN_FINALIZE_SAMPLE, // DP_GN_FINALIZE_SAMPLE: small feature maps - one finalize workgroup per sample instead of per (sample, group) - 0 off
+    DP_T_BATCH_INVARIANT,  // DIFFPURE_BATCH_INVARIANT (round 6) - THE ONE SWITCH THAT CHANGES BITS (not accuracy): 0 (default) = few-tile / long-K
+                           // convolution launches are split along K by a factor chosen per (layer shape, batch bucket), so a sample's low-order
+                           // bits depend on the bucket its per-GPU batch falls in; 1 = the split factor is a function of the layer shape only
+                           // (rounds 1-5): bit-identical results for ANY batch size / sharding, at the price of starved launches at small batches
     DP_T_COUNT
 };
 

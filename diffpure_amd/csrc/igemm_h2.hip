@@ -478,7 +478,7 @@ const char* zero_page() {
 // the batch - so that any sharding of a batch takes the same arithmetic path.  Low-resolution levels (<= 64 pixels per
 // sample) have few output tiles and long reductions (K = 2304 .. 18432): without the split a 4x4 level at B=128 runs
 // 128 workgroups of 144 sequential k-tiles on 256 CUs.
-static int h2_ksplit(int H, int W, int KS, int C, int N) {
+static int h2_ksplit_shape(int H, int W, int KS, int C, int N) {
     const int nt = KS * KS * C / 32;
     if (H * W > 64 || N % 4 != 0) return 1;
     if (H * W <= 16 && nt >= 32 && nt % 4 == 0) return 4;
@@ -486,10 +486,32 @@ static int h2_ksplit(int H, int W, int KS, int C, int N) {
     return 1;
 }
 
+// Round 6: the same starvation at SMALL BATCHES of the big levels - the reference's own ImageNet scripts run 4 images per GPU
+// (run_scripts/imagenet/run_in_rand_inf.sh:16): the 32 x 32 / 16 x 16 / 8 x 8 levels of the guided UNet are then 64 / 32 / 8 tiles of
+// 128 x 256 with 144 - 576 sequential k-tiles each, and a third of the step ran at 0.04 of the matrix peak (profiles/r05/
+// closing_batch_table.md).  Such launches are split along K by a power of two chosen from the number of 128 x 256 tiles the launch has -
+// i.e. per (layer shape, batch BUCKET) - until ~192 workgroups exist, keeping >= 36 k-tiles per part.  A sample's low-order bits then
+// depend on the bucket its batch falls in (1e-3 parity against the reference holds in every bucket: tests/test_gpu_loops.py);
+// DIFFPURE_BATCH_INVARIANT=1 restores the shape-only rule of rounds 1-5 (bit-identity across batch sizes and shardings).
+static int h2_ksplit(int B, int H, int W, int KS, int C, int N) {
+    const int s0 = h2_ksplit_shape(H, W, KS, C, N);
+    if (dp_tune(DP_T_BATCH_INVARIANT) != 0 || N % 256 != 0 || C % 32 != 0) return s0;
+    const long long M = (long long)B * H * W;
+    if (M % 128 != 0) return s0;
+    const long long wg = (M / 128) * (N / 256);
+    const int nt = KS * KS * C / 32;
+    int s = 1;
+    while (wg * s < 192 && s < 8 && nt % (2 * s) == 0 && nt / (2 * s) >= 36) s *= 2;
+    return s > s0 ? s : s0;
+}
+
 extern "C" long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, int C, int N) {
-    const int s = h2_ksplit(H, W, KS, C, N);
+    const int s = h2_ksplit(B, H, W, KS, C, N);
     return s > 1 ? (long long)s * B * H * W * N * 4 : 0;
 }
+
+// the split factor of the shape-only rule (<= 64-pixel levels): what the fused block boundary is offered for
+extern "C" int dp_conv2d_nhwc_h2_splits_by_shape(int H, int W, int KS, int C, int N) { return h2_ksplit_shape(H, W, KS, C, N) > 1; }
 
 // May an fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) of this LAYER shape carry 1x1 K-segments?  A function of the layer shape
 // only - never of the batch - so that any sharding of a batch takes the same arithmetic (fused or not); every fp16 x fp16 tile variant
@@ -542,7 +564,7 @@ static int h2_conv(const void* x, int C, int B, int H, int W, int KS, const void
     p.wfmt = w_fmt;
     p.ofmt = out_fmt;
 
-    p.ksplit = h2_ksplit(H, W, KS, C, N);
+    p.ksplit = h2_ksplit(B, H, W, KS, C, N);
     p.ws = static_cast<float*>(work);
     DP_REQUIRE(!partials_only || p.ksplit > 1, "dp_conv2d_nhwc_h2_partials: this layer is not reduced with split-K (dp_conv2d_nhwc_h2_workspace() == 0)");
     DP_REQUIRE(p.ksplit == 1 || (work && work_bytes >= dp_conv2d_nhwc_h2_workspace(B, H, W, KS, C, N) && dp_aligned16(work) &&
@@ -695,7 +717,7 @@ extern "C" int dp_conv2d_nhwc_h2_partials(const void* x, int C, int B, int H, in
                                           long long work_bytes, int passes, int a_fmt, int w_fmt, const void* seg1, int segC1,
                                           const void* seg2, int segC2, int* n_parts, void* stream) {
     DP_REQUIRE(n_parts, "dp_conv2d_nhwc_h2_partials: n_parts is null");
-    *n_parts = h2_ksplit(H, W, KS, C, N);
+    *n_parts = h2_ksplit(B, H, W, KS, C, N);
     // (the epilogue arguments are unused; ldo = N satisfies the split-K path's row-stride check)
     return h2_conv(x, C, B, H, W, KS, w, N, nullptr, nullptr, 0, nullptr, 0, 1.0f, nullptr, N, nullptr, nullptr, work, work_bytes, passes, a_fmt, w_fmt,
                    0, 0, seg1, segC1, seg2, segC2, stream, true);

@@ -375,7 +375,7 @@ def _fmt_of(split):
 def conv_defers(h, w, ksize, c, n_out):
     """is this LAYER reduced with split-K, so that its reduction + epilogue can be left to the fused block boundary?  (<= 64 pixels per
     sample; a function of the layer shape only.)  DIFFPURE_BOUNDARY=0 switches the fused boundaries off."""
-    return os.environ.get("DIFFPURE_BOUNDARY", "1") != "0" and int(_lib.load().dp_conv2d_nhwc_h2_workspace(1, h, w, ksize, c, n_out)) > 0
+    return os.environ.get("DIFFPURE_BOUNDARY", "1") != "0" and bool(_lib.load().dp_conv2d_nhwc_h2_splits_by_shape(h, w, ksize, c, n_out))
 
 
 def conv2d_h2(x, wh, n_out, ksize, bias=None, temb=None, res=None, scale=1.0, colstats=False, passes=None, w_fmt=0, out_f16=False,

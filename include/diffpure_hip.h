@@ -163,9 +163,12 @@ int dp_conv2d_nhwc_h2(const void* x, int C, int B, int H, int W, int KS,
 /* 1 when an fp16 x fp16 launch (a_fmt 1, w_fmt 1, passes 1) of this layer shape may carry 1x1 K-segments of segC1 (+ segC2) channels
  * (whole 32-channel slices everywhere), else 0.  A function of the layer shape only. */
 int dp_conv2d_nhwc_h2_takes_segments(int H, int W, int KS, int C, int N, int segC1, int segC2);
-/* Scratch the call above needs for this layer shape (0 for most): low-resolution levels (H*W <= 64) are reduced with
- * split-K - partial sums per k-range, then one reduction + epilogue pass - with a split factor that depends on the
- * layer shape only, never on B, so that results do not depend on how a batch is sharded. */
+/* Scratch the call above needs (0 for most launches): split-K - partial sums per k-range, then one reduction + epilogue pass.
+ *   Shape rule: the low-resolution levels (H*W <= 64), with a factor that depends on the layer shape only.
+ *   Batch rule (ABI 8, default): launches of fewer than 128 tiles of 128 x 256 with long reductions - the big levels at small per-GPU
+ *   batches, e.g. the reference's own 4 images per GPU (run_scripts/imagenet/run_in_rand_inf.sh:16) - are split by a power of two chosen
+ *   from the tile count, i.e. per (layer shape, batch bucket); a sample's low-order bits then depend on the bucket.  The tuning switch
+ *   DIFFPURE_BATCH_INVARIANT=1 (dp_set_tuning / environment) keeps the shape rule alone: bit-identical results for any batch sharding. */
 long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, int C, int N);
 /* ---- fused block boundary of the <= 64-pixel levels (ABI 8; csrc/boundary.hip) -------------------------------------------------
  * Replaces, per ResBlock boundary at 8x8 / 4x4 (score_sde/models/layerspp.py:242-274, guided_diffusion/unet.py:244-264), the launch
@@ -186,6 +189,7 @@ long long dp_conv2d_nhwc_h2_workspace(int B, int H, int W, int KS, int C, int N)
  *     y: the operand [B][H+2][W+2][N + C2] plain fp16, zero border written; y_raw (optional): the un-normalised cat(out, x2) in the
  *       same form (input of a 1x1 shortcut convolution).
  *   dp_splitk_gn_ok: H*W in {64, 16}, channel blocks of whole groups, (N + C2) / G a multiple of 4.  A function of the layer shape only. */
+int dp_conv2d_nhwc_h2_splits_by_shape(int H, int W, int KS, int C, int N);     /* 1: split by the shape-only rule (<= 64-pixel levels) */
 int dp_conv2d_nhwc_h2_partials(const void* x, int C, int B, int H, int W, int KS, const void* w, int N, void* work, long long work_bytes,
                                int passes, int a_fmt, int w_fmt, const void* seg1, int segC1, const void* seg2, int segC2, int* n_parts,
                                void* stream);

@@ -18,6 +18,9 @@ torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
+    config.addinivalue_line("markers", "batch_invariant: runs under DIFFPURE_BATCH_INVARIANT=1 - the split-K factor a function of the layer shape "
+                                       "only (rounds 1-5's rule), under which results are bit-identical for ANY batch size / sharding; the default since "
+                                       "round 6 also splits few-tile launches per (layer shape, batch bucket)")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -73,3 +76,18 @@ def tune():
     t = _Tune()
     yield t
     t.restore()
+
+
+@pytest.fixture(autouse=True)
+def _batch_invariant_mode(request, monkeypatch):
+    """tests marked `batch_invariant` compare DIFFERENT batch sizes / shardings bit for bit: the library's switch for this process (it read
+    its environment once) and the environment variable for the processes the test starts"""
+    if request.node.get_closest_marker("batch_invariant") is None:
+        yield
+        return
+    from diffpure_amd import ops
+    monkeypatch.setenv("DIFFPURE_BATCH_INVARIANT", "1")
+    old = ops.get_tuning("DIFFPURE_BATCH_INVARIANT")
+    ops.set_tuning("DIFFPURE_BATCH_INVARIANT", 1)
+    yield
+    ops.set_tuning("DIFFPURE_BATCH_INVARIANT", old)

@@ -75,6 +75,7 @@ def _h2_ksplit(h, w, ksize, c, n_out):
 
 
 def conv_defers(h, w, ksize, c, n_out):
+    """dp_conv2d_nhwc_h2_splits_by_shape (the shape-only rule: <= 64-pixel levels)"""
     return os.environ.get("DIFFPURE_BOUNDARY", "1") != "0" and _h2_ksplit(h, w, ksize, c, n_out) > 1
 
 

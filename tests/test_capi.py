@@ -215,14 +215,41 @@ def test_torch_dispatcher_registration():
         torch.ops.diffpure_hip.attention(torch.zeros(1, 64, 3 * 64), 1, True)
 
 
-def test_split_k_factor_depends_on_the_layer_shape_only():
-    """dp_conv2d_nhwc_h2_workspace is a pure host function: the split-K factor it implies (bytes / (B*H*W*N*4)) must not
-    change with the batch - that is what keeps results identical for any sharding of a batch - and only the <= 64-pixel
-    levels are split."""
+def test_split_k_factor_rules():
+    """dp_conv2d_nhwc_h2_workspace is a pure host function; the split-K factor it implies is bytes / (B*H*W*N*4).
+    DIFFPURE_BATCH_INVARIANT=1 (rounds 1-5): a function of the layer shape only - what keeps results identical for ANY sharding of a
+    batch - and only the <= 64-pixel levels are split.  Default (round 6): few-tile / long-K launches are also split per (layer shape,
+    batch bucket): never below the shape rule, never more than 8 parts, >= 36 k-tiles per part, none once the launch has 128 tiles of
+    128 x 256 - so the reference's per-GPU batch of 4 fills the chip, and a fixed per-GPU batch (weak scaling) always takes one rule."""
+    import ctypes as C
     from diffpure_amd import _lib
     lib = _lib.load()
-    for (h, w, ks, c, n) in [(4, 4, 3, 256, 256), (8, 8, 3, 512, 256), (8, 8, 3, 1024, 1024), (2, 2, 3, 128, 128), (8, 8, 1, 1024, 768)]:
-        factors = {lib.dp_conv2d_nhwc_h2_workspace(b, h, w, ks, c, n) // (b * h * w * n * 4) for b in (1, 2, 7, 64, 256, 1000)}
-        assert len(factors) == 1 and factors.pop() in (2, 4), (h, w, ks, c, n)
-    for (h, w, ks, c, n) in [(16, 16, 3, 256, 256), (32, 32, 3, 128, 128), (256, 256, 3, 256, 256), (8, 8, 1, 256, 768), (9, 9, 3, 512, 256)]:
-        assert all(lib.dp_conv2d_nhwc_h2_workspace(b, h, w, ks, c, n) == 0 for b in (1, 16, 256)), (h, w, ks, c, n)
+    factor = lambda b, h, w, ks, c, n: lib.dp_conv2d_nhwc_h2_workspace(b, h, w, ks, c, n) // (b * h * w * n * 4)
+    old = C.c_int(0)
+    assert lib.dp_get_tuning(b"DIFFPURE_BATCH_INVARIANT", C.addressof(old)) == 0
+    try:
+        assert lib.dp_set_tuning(b"DIFFPURE_BATCH_INVARIANT", 1) == 0
+        for (h, w, ks, c, n) in [(4, 4, 3, 256, 256), (8, 8, 3, 512, 256), (8, 8, 3, 1024, 1024), (2, 2, 3, 128, 128), (8, 8, 1, 1024, 768)]:
+            factors = {factor(b, h, w, ks, c, n) for b in (1, 2, 7, 64, 256, 1000)}
+            assert len(factors) == 1 and factors.pop() in (2, 4), (h, w, ks, c, n)
+            assert lib.dp_conv2d_nhwc_h2_splits_by_shape(h, w, ks, c, n) == 1
+        for (h, w, ks, c, n) in [(16, 16, 3, 256, 256), (32, 32, 3, 128, 128), (256, 256, 3, 256, 256), (8, 8, 1, 256, 768), (9, 9, 3, 512, 256)]:
+            assert all(lib.dp_conv2d_nhwc_h2_workspace(b, h, w, ks, c, n) == 0 for b in (1, 16, 256)), (h, w, ks, c, n)
+            assert lib.dp_conv2d_nhwc_h2_splits_by_shape(h, w, ks, c, n) == 0
+        assert lib.dp_set_tuning(b"DIFFPURE_BATCH_INVARIANT", 0) == 0
+        # the guided UNet's middle levels at the reference's per-GPU batch of 4 / at 8 / at the benchmark's 64
+        for (h, c, n) in [(32, 512, 512), (32, 1024, 512), (16, 1024, 1024), (16, 2048, 1024), (8, 1024, 1024)]:
+            f4, f8, f64 = (factor(b, h, h, 3, c, n) for b in (4, 8, 64))
+            nt = 9 * c // 32
+            assert f4 in (2, 4, 8) and f4 >= f8 >= max(f64, 1), (h, c, n, f4, f8, f64)
+            assert nt // f4 >= 36 and (4 * h * h // 128) * (n // 256) * f4 <= 384, (h, c, n, f4)
+            assert f64 == (2 if h == 8 else 0), (h, c, n, f64)                     # B = 64: only the shape rule's 8 x 8 level
+        for b in (1, 4, 64):        # layers that fill the chip, 1x1 layers and shapes the 128 x 256 tiles do not take: never split
+            assert factor(b, 64, 64, 3, 512, 512) == 0 or b == 1
+            assert lib.dp_conv2d_nhwc_h2_workspace(b, 32, 32, 1, 1024, 512) == 0 and lib.dp_conv2d_nhwc_h2_workspace(b, 32, 32, 3, 512, 128) == 0
+        # NCSN++ at the benchmark batches: exactly the shape rule (the CIFAR numbers of rounds 2-5 are unchanged by the new rule)
+        for b in (128, 256):
+            assert factor(b, 8, 8, 3, 256, 256) == 2 and factor(b, 4, 4, 3, 256, 256) == 4 and factor(b, 4, 4, 3, 512, 256) == 4
+            assert lib.dp_conv2d_nhwc_h2_workspace(b, 16, 16, 3, 256, 256) == 0 and lib.dp_conv2d_nhwc_h2_workspace(b, 32, 32, 3, 128, 128) == 0
+    finally:
+        lib.dp_set_tuning(b"DIFFPURE_BATCH_INVARIANT", old.value)

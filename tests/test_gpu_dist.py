@@ -54,11 +54,14 @@ def _worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out, o2, gx = _run(True, n)
-        q.put((rank, out, o2, gx))
+        # by VALUE (numpy): a tensor travels through the queue as a file descriptor served by the sending process, which may be gone
+        # before the parent fetches it - with eight ranks it was
+        q.put((rank, out.numpy(), o2.numpy(), gx.numpy()))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.batch_invariant
 @pytest.mark.parametrize("n", [4, 3])
 def test_two_rank_sharded_runner_equals_single_process_bitwise(n):
     ref_out, ref_o2, ref_g = _run(True, n)                # world size 1: shard_batch is a no-op, global indices 0..n-1
@@ -73,11 +76,12 @@ def test_two_rank_sharded_runner_equals_single_process_bitwise(n):
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, out, o2, gx in res:
-        assert torch.equal(out, ref_out), rank           # every rank holds the whole purified batch
-        assert torch.equal(o2, ref_o2), rank
-        assert torch.equal(gx, ref_g), rank              # and the whole dL/dx
+        assert torch.equal(torch.from_numpy(out), ref_out), rank           # every rank holds the whole purified batch
+        assert torch.equal(torch.from_numpy(o2), ref_o2), rank
+        assert torch.equal(torch.from_numpy(gx), ref_g), rank              # and the whole dL/dx
 
 
+@pytest.mark.batch_invariant
 def test_eight_rank_sharded_runner_equals_single_process_bitwise():
     """Round 6: EIGHT ranks of the real engine (BASELINE configs[3]'s world size) sharing the one GPU of this box, gloo carrying the
     all-gather through the host: eight concurrent engine builds, eight host threads' worth of launches on one device, a ragged batch
@@ -97,9 +101,9 @@ def test_eight_rank_sharded_runner_equals_single_process_bitwise():
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world))
     for rank, out, o2, gx in res:
-        assert torch.equal(out, ref_out), rank
-        assert torch.equal(o2, ref_o2), rank
-        assert torch.equal(gx, ref_g), rank
+        assert torch.equal(torch.from_numpy(out), ref_out), rank
+        assert torch.equal(torch.from_numpy(o2), ref_o2), rank
+        assert torch.equal(torch.from_numpy(gx), ref_g), rank
 
 
 def test_bench_multirank_code_path_runs_on_rccl_at_world_size_1():

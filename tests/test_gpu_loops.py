@@ -158,6 +158,7 @@ def test_guided_loop_more_noise_seeds_vs_reference_golden():
         assert err < 1e-3, (seed, err)
 
 
+@pytest.mark.batch_invariant
 def test_guided_loop_at_batch_64_reproduces_the_golden_samples_bit_for_bit():
     """BASELINE.json's batch: at B=64 every level of the UNet takes the tile variants the benchmark takes (at B=2 the 32^2 and
     16^2 levels have too few tiles for the 256-wide kernels and run on the generic ones).  The two golden images lead a batch
@@ -269,6 +270,7 @@ def test_guided_sde_stochastic_adjoint_100_plus_100_steps_vs_reference_golden(pr
     assert err_g < 5e-3 * scale, (err_g, scale)
 
 
+@pytest.mark.batch_invariant
 def test_guided_full_stochastic_adjoint_at_batch_8_reproduces_the_golden_sample_bit_for_bit():
     """The same golden sample leading a batch of EIGHT (twice the reference's own per-GPU batch of 4): x(t'_end) and dL/dx of sample
     0 equal the B=1 run bit for bit (taped forward, dgrad tile variants and the one-pass GroupNorm backward are batch-invariant),
@@ -298,6 +300,7 @@ def test_guided_full_stochastic_adjoint_at_batch_8_reproduces_the_golden_sample_
 
 
 # ---- round 4: the configurations BASELINE.json benchmarks, at THEIR batch; the stochastic adjoint at the product grid ----------
+@pytest.mark.batch_invariant
 def test_ncsnpp_loop_at_batch_256_reproduces_the_golden_samples_bit_for_bit():
     """BASELINE.json configs[1] runs B=256: the 32^2 / 16^2 levels then take the 256-wide tile kernels (`conv_igemm_dw`, the
     512x128 one-wave-per-SIMD tiles) that a B=4 batch never reaches.  The four golden images lead a batch of 256: bit-identical
@@ -314,6 +317,7 @@ def test_ncsnpp_loop_at_batch_256_reproduces_the_golden_samples_bit_for_bit():
     assert err < 1e-3, err
 
 
+@pytest.mark.batch_invariant
 def test_config5_adjoint_at_batch_128_reproduces_the_golden_samples_bit_for_bit():
     """BASELINE.json configs[4] runs B=128: forward ODE + continuous adjoint with the two golden samples leading a batch of 128 -
     x(1e-5) and dL/dx of those samples bit-identical to the B=2 run (every gradient tile variant and split-K choice included),

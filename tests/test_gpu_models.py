@@ -151,6 +151,7 @@ def test_ode_and_ddpm_loops_small_vs_oracle():
     assert maxabs(out, ref) < 1e-3, maxabs(out, ref)
 
 
+@pytest.mark.batch_invariant
 def test_shard_invariance_bitwise():
     """Philox noise is keyed by the global sample index and no kernel mixes samples: purifying a
     batch of 4 at once or as two shards of 2 (as two GPUs would) gives identical bits."""
@@ -254,6 +255,7 @@ def test_f16_config1_cifar_b4_20steps_vs_oracle(precision):
     assert torch.equal(pur.sde(x0, 100, 5e-3, seed=5, sample0=0), torch.cat([a, b]))
 
 
+@pytest.mark.batch_invariant
 def test_shard_invariance_across_kernel_variants():
     """A batch of 160 and its two shards of 80 pick different convolution tile shapes (128- vs 64-row
     tiles); results - including the GroupNorm statistics taken from the convolution epilogues - must still
@@ -329,6 +331,7 @@ def test_ddpm_unet_full_vs_reference_golden():
     assert abs(out.abs().mean().item() - g["y_abs_mean"].item()) < 1e-4
 
 
+@pytest.mark.batch_invariant
 @pytest.mark.parametrize("precision", SHIPPED)
 def test_celeba_ddpm_runner_vs_oracle_and_shard_invariance(tmp_path, precision):
     import argparse

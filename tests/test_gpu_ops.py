@@ -675,6 +675,7 @@ def test_fast_silu_accuracy_and_extremes(dev):
     assert (err <= 4e-7 * ref.abs() + 2e-36).all(), (err / ref.abs().clamp_min(1e-30)).max()
 
 
+@pytest.mark.batch_invariant
 @pytest.mark.parametrize("case", [(6, 4, 4, 256, 256, 3), (6, 8, 8, 512, 256, 3), (4, 8, 8, 1024, 768, 1), (5, 2, 2, 128, 128, 3)], ids=str)
 def test_conv2d_h2_split_k_levels_are_batch_shard_invariant(dev, case):
     """Low-resolution levels (H*W <= 64) are reduced with split-K; the split factor is a function of the layer shape
@@ -1320,6 +1321,7 @@ BOUNDARY_CASES = [
 ]
 
 
+@pytest.mark.batch_invariant        # (its last paragraph compares a sample alone with the same sample inside the batch)
 @pytest.mark.parametrize("case", BOUNDARY_CASES, ids=str)
 def test_fused_block_boundary_equals_the_four_launch_chain(dev, case):
     """dp_conv2d_nhwc_h2_partials + dp_splitk_gn against conv2d_h2 (its own reduction + epilogue) -> group_norm_stats -> group_norm: the stream
@@ -1409,3 +1411,51 @@ def _records_of(t16, dev):
     buf[:m // 64, 0] = v.sum(dim=1)
     buf[:m // 64, 1] = (v * v).sum(dim=1)
     return ops.ColStats(buf, 64, c)
+
+
+BUCKET_CASES = [(4, 32, 512, 512, 0), (4, 32, 1024, 512, 512), (4, 16, 1024, 1024, 0), (8, 16, 2048, 1024, 0), (4, 8, 1024, 1024, 0), (2, 64, 512, 512, 0)]
+
+
+@pytest.mark.parametrize("case", BUCKET_CASES, ids=str)
+def test_batch_bucketed_split_k_of_few_tile_launches(dev, case, tune):
+    """Round 6: at small per-GPU batches (the reference's own 4 images per GPU) the middle levels of the guided UNet are a few dozen tiles with
+    144 - 576 sequential k-tiles each; by default such launches are split along K per (layer shape, batch bucket).  Against the fp64
+    convolution of the fp16-rounded operands (fp32-accumulation accuracy), against the shape-only rule (DIFFPURE_BATCH_INVARIANT=1: the same
+    sums in another order - fp32 noise), with a residual, fp16 output, column records that give the same GroupNorm statistics, and 1x1
+    K-segments running through the split; reproducible run to run."""
+    from diffpure_amd import ops, _lib
+    B, H, C, N, CS = case
+    lib = _lib.load()
+    parts = lib.dp_conv2d_nhwc_h2_workspace(B, H, H, 3, C, N) // (B * H * H * N * 4)
+    tune.setenv("DIFFPURE_BATCH_INVARIANT", 1)
+    parts_inv = lib.dp_conv2d_nhwc_h2_workspace(B, H, H, 3, C, N) // (B * H * H * N * 4)
+    tune.delenv("DIFFPURE_BATCH_INVARIANT")
+    assert parts in (2, 4, 8) and parts > parts_inv, (parts, parts_inv)
+    x = rnd(B, H, H, C, seed=1)
+    w3 = rnd(N, C, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * C))
+    bias = rnd(N, seed=3).to(dev)
+    res = rnd(B, H, H, N, seed=4).half().to(dev)
+    segs, ws = None, None
+    if CS:
+        ws = rnd(N, CS, 1, 1, seed=5, scale=1.0 / math.sqrt(CS))
+        segs = (rnd(B, H, H, CS, seed=6).half().to(dev),)
+        wf = ops.order_conv_weight_w16(ops.fuse_skip_weight(w3, ws)).half().to(dev)
+    else:
+        wf = ops.order_conv_weight_w16(w3).half().to(dev)
+    xh = _h1_bordered(x, dev)
+    run = lambda f16: ops.conv2d_h2(xh, wf, N, 3, bias=bias, res=res, scale=0.5, colstats=True, w_fmt=1, out_f16=f16, segs=segs)
+    y32, y16 = run(False), run(True)
+    again = run(True)
+    assert torch.equal(again.t, y16.t) and torch.equal(again.cols.buf, y16.cols.buf)
+    assert torch.equal(y16.t, y32.t.half()) and torch.equal(y16.cols.buf, y32.cols.buf)
+    tune.setenv("DIFFPURE_BATCH_INVARIANT", 1)
+    inv = run(False)
+    tune.delenv("DIFFPURE_BATCH_INVARIANT")
+    close(y32.t, inv.t.cpu(), rtol=2e-5, atol=2e-5)
+    sub = slice(0, 1)
+    ref = torch.nn.functional.conv2d(x[sub].half().double().permute(0, 3, 1, 2), w3.half().double(), None, padding=1).permute(0, 2, 3, 1) + bias.cpu().double()
+    if CS:
+        ref = ref + segs[0][sub].cpu().double() @ ws[:, :, 0, 0].half().double().t()
+    ref = ((ref + res[sub].cpu().double()) * 0.5).float()
+    close(y32.t[sub], ref, rtol=1e-4, atol=1e-4)
+    close(ops.group_norm_stats(y16, 32, 1e-5), ops.group_norm_stats(inv, 32, 1e-5).cpu(), rtol=1e-4, atol=1e-5)

@@ -42,6 +42,15 @@ stem)
 tests)
   gputests
   ;;
+bucket)    # batch-bucketed split-K: the whole GPU suite, then the batch table and the small-batch adjoint with and without it
+  gputests
+  ab DIFFPURE_BATCH_INVARIANT guided_b4_t20_invariant --batch 4 --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_BATCH_INVARIANT guided_b8_t20_invariant --batch 8 --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_BATCH_INVARIANT guided_b16_t20_invariant --batch 16 --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ab DIFFPURE_BATCH_INVARIANT guided_adj_b4_t10_invariant --workload imagenet256_guided_sde_adjoint --batch 4 --t 10 --steps 1 --warmup 0 --no-conv-profile
+  timeout 500 python tools/batch_table.py > "$O/batch_table.json" 2> "$O/batch_table.md"; lap batch_table
+  cat "$O/batch_table.md"
+  ;;
 boundary)    # fused block boundary of the <= 64-pixel levels
   timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -s -k "boundary or prefetch or fp16_input_equals" > "$O/boundary_tests.log" 2>&1; echo "rc=$?" >> "$O/boundary_tests.log"; lap boundary_tests
   grep -E "passed|failed|^FAILED|^E  " "$O/boundary_tests.log" | head -40
