@@ -86,8 +86,8 @@ def _batch_invariant_mode(request, monkeypatch):
         yield
         return
     from diffpure_amd import ops
+    old = ops.get_tuning("DIFFPURE_BATCH_INVARIANT")       # BEFORE the environment is touched: the library reads it at its first query
     monkeypatch.setenv("DIFFPURE_BATCH_INVARIANT", "1")
-    old = ops.get_tuning("DIFFPURE_BATCH_INVARIANT")
     ops.set_tuning("DIFFPURE_BATCH_INVARIANT", 1)
     yield
     ops.set_tuning("DIFFPURE_BATCH_INVARIANT", old)
