@@ -501,7 +501,8 @@ static int h2_ksplit(int B, int H, int W, int KS, int C, int N) {
     const long long wg = (M / 128) * (N / 256);
     const int nt = KS * KS * C / 32;
     int s = 1;
-    while (wg * s < 192 && s < 8 && nt % (2 * s) == 0 && nt / (2 * s) >= 36) s *= 2;
+    const int want = dp_tune(DP_T_KSPLIT_WG), minkt = dp_tune(DP_T_KSPLIT_MINKT);
+    while (wg * s < want && s < 8 && nt % (2 * s) == 0 && nt / (2 * s) >= minkt) s *= 2;
     return s > s0 ? s : s0;
 }
 
