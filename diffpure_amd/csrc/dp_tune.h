@@ -22,8 +22,6 @@ enum DpTune {
                            // convolution launches are split along K by a factor chosen per (layer shape, batch bucket), so a sample's low-order
                            // bits depend on the bucket its per-GPU batch falls in; 1 = the split factor is a function of the layer shape only
                            // (rounds 1-5): bit-identical results for ANY batch size / sharding, at the price of starved launches at small batches
-    DP_T_KSPLIT_WG,        // DIFFPURE_KSPLIT_WG / DIFFPURE_KSPLIT_MINKT: the two constants of the batch rule (workgroups to reach: 192; fewest k-tiles per
-    DP_T_KSPLIT_MINKT,     // part: 36) - like the switch above they change low-order bits, not accuracy; probes only
     DP_T_COUNT
 };
 

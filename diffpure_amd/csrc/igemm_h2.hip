@@ -500,9 +500,10 @@ static int h2_ksplit(int B, int H, int W, int KS, int C, int N) {
     if (M % 128 != 0) return s0;
     const long long wg = (M / 128) * (N / 256);
     const int nt = KS * KS * C / 32;
+    // (the two constants were swept on the B = 4 / 8 / 16 purification - 192 / 256 / 384 workgroups x 36 / 18 k-tiles per part: within 0.3 % of each
+    //  other up to 256, -1.5 % at 384: profiles/r06/ksplit_constants_sweep.log)
     int s = 1;
-    const int want = dp_tune(DP_T_KSPLIT_WG), minkt = dp_tune(DP_T_KSPLIT_MINKT);
-    while (wg * s < want && s < 8 && nt % (2 * s) == 0 && nt / (2 * s) >= minkt) s *= 2;
+    while (wg * s < 192 && s < 8 && nt % (2 * s) == 0 && nt / (2 * s) >= 36) s *= 2;
     return s > s0 ? s : s0;
 }
 

@@ -89,9 +89,16 @@ def test_guided_loop_100_steps_vs_reference_golden(precision):
     err = maxabs(out, g["out"])
     print(f"guided 100-step loop [{precision}]: purified max-abs vs reference modules {err:.3e}, mean-abs {(out - g['out']).abs().mean():.3e}")
     assert err < 1e-3, err
-    # shards reproduce the batch bit for bit on this path as well (sample 1 alone, keyed by its global index)
-    one = pur.sde(g["x0"][1:], g["t"], g["dt"], seed=g["noise_seed"], sample0=1).cpu()
-    assert torch.equal(one, out[1:])
+    # shards reproduce the batch bit for bit on this path as well (sample 1 alone, keyed by its global index) - under the shape-only
+    # split-K rule (DIFFPURE_BATCH_INVARIANT=1); the default since round 6 splits few-tile launches per (layer shape, batch bucket), and
+    # B = 1 and B = 2 fall into different buckets on the 64 x 64 ... 8 x 8 levels: the two rules agree to rounding noise
+    from diffpure_amd import ops
+    with ops.tuning(DIFFPURE_BATCH_INVARIANT=1):
+        inv = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+        one = pur.sde(g["x0"][1:], g["t"], g["dt"], seed=g["noise_seed"], sample0=1).cpu()
+    assert torch.equal(one, inv[1:])
+    print(f"   bucketed split-K (default) vs shape-only rule: max-abs {maxabs(out, inv):.3e}; shape-only rule vs reference {maxabs(inv, g['out']):.3e}")
+    assert maxabs(inv, g["out"]) < 1e-3 and maxabs(out, inv) < 1e-3
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f16sr"])
@@ -109,8 +116,12 @@ def test_guided_ddpm_loop_100_steps_vs_reference_golden(precision):
     print(f"guided DDPM 100-step loop [{precision}]: purified max-abs vs the reference's p_sample loop {err:.3e}, "
           f"mean-abs {(out - g['out']).abs().mean():.3e}")
     assert err < 1e-3, err
-    one = pur.ddpm(g["x0"][1:], g["t"], seed=g["noise_seed"], sample0=1).cpu()      # shard == batch, bit for bit
-    assert torch.equal(one, out[1:])
+    from diffpure_amd import ops
+    with ops.tuning(DIFFPURE_BATCH_INVARIANT=1):     # shard == batch, bit for bit, under the shape-only split-K rule (see the SDE loop above)
+        inv = pur.ddpm(g["x0"], g["t"], seed=g["noise_seed"], sample0=0).cpu()
+        one = pur.ddpm(g["x0"][1:], g["t"], seed=g["noise_seed"], sample0=1).cpu()
+    assert torch.equal(one, inv[1:])
+    assert maxabs(inv, g["out"]) < 1e-3 and maxabs(out, inv) < 1e-3
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f16sr"])

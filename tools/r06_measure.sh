@@ -42,13 +42,6 @@ stem)
 tests)
   gputests
   ;;
-ksplit)   # constants of the batch rule
-  for WG in 192 256 384; do for KT in 36 18; do
-    for B in 4 8 16; do
-      DIFFPURE_KSPLIT_WG=$WG DIFFPURE_KSPLIT_MINKT=$KT timeout 300 python bench.py --batch $B --t 20 --steps 1 --warmup 1 --no-conv-profile --no-cpu-baseline --no-resident-call > "$O/b.json" 2>> "$O/err.log"
-      val "$O/b.json" "B=$B WG=$WG MINKT=$KT" | cut -c1-60 | tee -a "$O/ksplit_constants.log"
-    done; done; done; lap ksplit
-  ;;
 bucket)    # batch-bucketed split-K: the whole GPU suite, then the batch table and the small-batch adjoint with and without it
   gputests
   ab DIFFPURE_BATCH_INVARIANT guided_b4_t20_invariant --batch 4 --t 20 --steps 1 --warmup 1 --no-conv-profile
