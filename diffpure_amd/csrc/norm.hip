@@ -482,7 +482,8 @@ struct Apply16Args {
 
 // RS: the resampling mode as a template parameter (round 6) - the resampling loops keep eight loads in flight and must not cost the
 // un-resampled instantiation (92 registers: five resident waves per SIMD) its occupancy
-template <bool ACT, int BORDER, int RS>
+// NTM (probe, DP_GN_NT): non-temporal hints on the streaming accesses of the un-resampled path - bit 0 the loads, bit 1 the stores
+template <bool ACT, int BORDER, int RS, int NTM = 0>
 __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int COT, int slots) {
     const int C = p.C1 + p.C2, CO = C / 8;
     const int Hq = p.Ho + 2 * BORDER, Wq = p.Wo + 2 * BORDER;
@@ -567,11 +568,13 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
                 for (int k = 0; k < 4; ++k) {
                     const int ox = qx + k * slots - BORDER;
                     in[k] = (unsigned)ox < (unsigned)p.Wo;
-                    rv[k] = in[k] ? xrow[(size_t)ox * so] : zero8;
+                    if constexpr (NTM & 1) rv[k] = in[k] ? __builtin_nontemporal_load(xrow + (size_t)ox * so) : zero8;
+                    else rv[k] = in[k] ? xrow[(size_t)ox * so] : zero8;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    yrow[(size_t)(qx + k * slots) * CO] = in[k] ? xf(rv[k]) : zero8;
+                    if constexpr (NTM & 2) __builtin_nontemporal_store(in[k] ? xf(rv[k]) : zero8, yrow + (size_t)(qx + k * slots) * CO);
+                    else yrow[(size_t)(qx + k * slots) * CO] = in[k] ? xf(rv[k]) : zero8;
                     if (rrow) rrow[(size_t)(qx + k * slots) * CO] = rv[k];
                 }
             }
@@ -797,9 +800,13 @@ extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, i
         const double raw_px = !y_raw ? 0.0 : (resample ? (double)p.Ho * p.Wo : out_px);
         dp_prof_begin(DP_PROF_GN_APPLY, 0.0, (double)B * C * 2.0 * (in_px + out_px + raw_px), (hipStream_t)stream, &rec);
     }
+    const int ntm = dp_tune(DP_T_GN_NT);
 #define GN_H16_LAUNCH(ACT_, BORDER_)                                                                                                  \
     do {                                                                                                                              \
-        if (resample == 0) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);      \
+        if (resample == 0 && ntm == 1) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 0, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);      \
+        else if (resample == 0 && ntm == 2) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 0, 2>), g, blk, 0, (hipStream_t)stream, p, COT, slots); \
+        else if (resample == 0 && ntm == 3) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 0, 3>), g, blk, 0, (hipStream_t)stream, p, COT, slots); \
+        else if (resample == 0) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 0>), g, blk, 0, (hipStream_t)stream, p, COT, slots);      \
         else if (resample == 1) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots); \
         else hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 2>), g, blk, 0, (hipStream_t)stream, p, COT, slots);                    \
     } while (0)

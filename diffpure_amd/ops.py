@@ -967,7 +967,7 @@ def _gemm(h16, a, a16, a_args, bm, b16, b_args, c_args, m, n, k, zb, zh, alpha, 
     """one strided batched GEMM: on the fp16 matrix cores (dp_gemm_strided_h16: operands rounded to fp16 on their way into LDS - or read in
     place where they ARE fp16 (a16 / b16) -, fp32 accumulation) where `h16` asks for it and the shape is one that kernel serves, else
     the fp32-input MFMA kernel (fp32 operands only).  a_args / b_args = (ld, batch stride, head stride, trans) in elements."""
-    if h16 and _lib.load().dp_gemm_strided_h16_ok(m, n, k):
+    if h16 and _h16_ok(m, n, k):
         _lib.call("dp_gemm_strided_h16", a, 1 if a16 else 0, *a_args, bm, 1 if b16 else 0, *b_args, *c_args, m, n, k, zb, zh, float(alpha), s)
         return
     if a16 or b16:
@@ -975,11 +975,15 @@ def _gemm(h16, a, a16, a_args, bm, b16, b_args, c_args, m, n, k, zb, zh, alpha, 
     _lib.call("dp_gemm_strided", a, *a_args, bm, *b_args, *c_args, m, n, k, zb, zh, float(alpha), s)
 
 
+def _h16_ok(m, n, k):
+    """dp_gemm_strided_h16 serves the shape (DIFFPURE_H16_N64=0: only its 128 x 128 tile - round 5's coverage, for A/B runs)"""
+    return bool(_lib.load().dp_gemm_strided_h16_ok(m, n, k)) and (n % 128 == 0 or os.environ.get("DIFFPURE_H16_N64", "1") != "0")
+
+
 def attention_h16_serves(t, d):
     """do all five products of the attention backward (q k^T, dV, dP, dQ, dK) have shapes dp_gemm_strided_h16 serves?  Then the taped
     fp16 qkv is read in place; else (head dimension 64: N = 64 in dV / dQ / dK) the caller hands in an fp32 qkv."""
-    ok = _lib.load().dp_gemm_strided_h16_ok
-    return bool(ok(t, t, d) and ok(t, d, t))
+    return bool(_h16_ok(t, t, d) and _h16_ok(t, d, t))
 
 
 def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=False):

@@ -36,7 +36,13 @@ def main():
         n = x.numel()
         t32 = timeit(lambda: ops.group_norm(x, 32, 1e-5, gamma, beta, film=film, act=True, split="h1", stats=stats))
         t16 = timeit(lambda: ops.group_norm_f16in(x16, 32, gamma, beta, stats, film=film, act=True))
-        print(f"{H:4d}^2 x {C:5d} B={B} | fp32 in {t32:7.3f} ms {6 * n / t32 / 1e9:6.2f} TB/s | fp16 in {t16:7.3f} ms {4 * n / t16 / 1e9:6.2f} TB/s", flush=True)
+        print(f"{H:4d}^2 x {C:5d} B={B} | fp32 in {t32:7.3f} ms {6 * n / t32 / 1e9:6.2f} TB/s | fp16 in {t16:7.3f} ms {4 * n / t16 / 1e9:6.2f} TB/s", end="", flush=True)
+        # round 6 probe: non-temporal hints on the streaming loads (bit 0) / stores (bit 1) of the fp16 pass
+        for nt in (1, 2, 3):
+            with ops.tuning(DP_GN_NT=nt):
+                tn = timeit(lambda: ops.group_norm_f16in(x16, 32, gamma, beta, stats, film=film, act=True))
+            print(f" | NT={nt}: {4 * n / tn / 1e9:5.2f}", end="", flush=True)
+        print(flush=True)
 
 
 if __name__ == "__main__":

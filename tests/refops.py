@@ -369,7 +369,7 @@ def attention(qkv, n_heads, layout, return_probs=False, probs_only=False, h16=Fa
 
 
 def attention_h16_serves(t, d):
-    return t % 128 == 0 and d % 128 == 0
+    return t % 128 == 0 and t % 32 == 0 and d % 64 == 0 and d % 32 == 0
 
 
 def attention_bwd(qkv, probs, dout, n_heads, layout, h16=False):

@@ -1200,20 +1200,22 @@ def test_conv2d_half_height_tile_kernel_is_bit_identical(dev, case, tune):
     assert err < (2e-3 if out16 else 3e-5) * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("N", [128, 64, 192])
 @pytest.mark.parametrize("trans", [(0, 0), (0, 1), (1, 0), (1, 1)], ids=str)
-def test_gemm_strided_on_the_fp16_matrix_cores(dev, trans):
+def test_gemm_strided_on_the_fp16_matrix_cores(dev, trans, N):
     """Round 5: dp_gemm_strided_h16 - the strided batched GEMM with operands rounded to fp16 on their way into LDS, one fp16 MFMA pass,
     fp32 accumulation - against the exact fp64 product of the fp16-rounded operands, in all four storage forms, with batch and head
-    strides that differ from the dense ones (the attention backward reads q, k, v in place inside qkv)."""
+    strides that differ from the dense ones (the attention backward reads q, k, v in place inside qkv).  Round 6: N = 64 / 192 take the
+    128 x 64 tile (dV / dQ / dK of the guided UNet's 64-wide heads)."""
     from diffpure_amd import _lib
     ta, tb = trans
-    ZB, ZH, M, N, K = 2, 3, 256, 128, 96
+    ZB, ZH, M, K = 2, 3, 256, 96
     lda, ldb, ldc = (M if ta else K) + 8, (K if tb else N) + 16, N + 12
     ra, rb = (K if ta else M), (N if tb else K)            # stored rows
     A = rnd(ZB, ZH, ra, lda, seed=1).to(dev)
     B = rnd(ZB, ZH, rb, ldb, seed=2).to(dev)
     Cm = torch.zeros(ZB, ZH, M, ldc, device=dev)
-    assert _lib.load().dp_gemm_strided_h16_ok(M, N, K) == 1 and _lib.load().dp_gemm_strided_h16_ok(M, 64, K) == 0
+    assert _lib.load().dp_gemm_strided_h16_ok(M, N, K) == 1 and _lib.load().dp_gemm_strided_h16_ok(M, 32, K) == 0 and _lib.load().dp_gemm_strided_h16_ok(64, N, K) == 0
     s_ = torch.cuda.current_stream().cuda_stream
     _lib.call("dp_gemm_strided_h16", A.data_ptr(), 0, lda, ZH * ra * lda, ra * lda, ta, B.data_ptr(), 0, ldb, ZH * rb * ldb, rb * ldb, tb,
               Cm.data_ptr(), ldc, ZH * M * ldc, M * ldc, M, N, K, ZB, ZH, 0.25, s_)

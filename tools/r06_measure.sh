@@ -42,6 +42,19 @@ stem)
 tests)
   gputests
   ;;
+h16n64)  # attention backward of the 64-wide heads on the fp16 matrix cores
+  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_grad.py tests/test_gpu_loops.py -m gpu -q -s -k "gemm_strided or attention_backward or attention_bwd or guided_small_vjp or guided_full_vjp or guided_sde_stochastic_adjoint or bucketed" > "$O/h16_tests.log" 2>&1; echo "rc=$?" >> "$O/h16_tests.log"; lap h16_tests
+  grep -E "passed|failed|^FAILED|^E  |attention backward|adjoint" "$O/h16_tests.log" | head -30
+  ab DIFFPURE_H16_N64 guided_adj_b32_t5_h16n64 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0 --no-conv-profile
+  ;;
+gnnt)   # non-temporal hints in GroupNorm-apply
+  timeout 300 python tests/probes/gn_bench.py > "$O/gn_bench_nt.log" 2>&1; lap gn_bench
+  cat "$O/gn_bench_nt.log"
+  for V in 0 3 0 3; do
+    DP_GN_NT=$V timeout 400 python bench.py --t 20 --steps 1 --warmup 1 --no-conv-profile --no-cpu-baseline --no-resident-call > "$O/bench_gnnt_$V.json" 2>> "$O/bench_ab.err"
+    val "$O/bench_gnnt_$V.json" "guided t20 DP_GN_NT=$V" | cut -c1-70 | tee -a "$O/gnnt_ab.log"
+  done; lap ab_gnnt
+  ;;
 bucket)    # batch-bucketed split-K: the whole GPU suite, then the batch table and the small-batch adjoint with and without it
   gputests
   ab DIFFPURE_BATCH_INVARIANT guided_b4_t20_invariant --batch 4 --t 20 --steps 1 --warmup 1 --no-conv-profile
