@@ -22,7 +22,8 @@ enum DpTune {
                            // convolution launches are split along K by a factor chosen per (layer shape, batch bucket), so a sample's low-order
                            // bits depend on the bucket its per-GPU batch falls in; 1 = the split factor is a function of the layer shape only
                            // (rounds 1-5): bit-identical results for ANY batch size / sharding, at the price of starved launches at small batches
-    DP_T_GN_NT,            // DP_GN_NT (probe): non-temporal hints in GroupNorm-apply over the fp16 stream - bit 0 loads, bit 1 stores (same bits)
+    DP_T_GN_NT,            // DP_GN_NT: non-temporal hints in GroupNorm-apply over the fp16 stream - -1 (default) by tensor size, 0 never, 1 | 2 | 3 forced
+                           // (bit 0 loads, bit 1 stores); same bits
     DP_T_COUNT
 };
 

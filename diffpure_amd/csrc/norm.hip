@@ -800,7 +800,16 @@ extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, i
         const double raw_px = !y_raw ? 0.0 : (resample ? (double)p.Ho * p.Wo : out_px);
         dp_prof_begin(DP_PROF_GN_APPLY, 0.0, (double)B * C * 2.0 * (in_px + out_px + raw_px), (hipStream_t)stream, &rec);
     }
-    const int ntm = dp_tune(DP_T_GN_NT);
+    // non-temporal hints on the streaming accesses (round 6; same bits): a tensor far beyond the 256 MB of last-level cache gains nothing
+    // from occupying it on its way through - measured (tests/probes/gn_bench.py, profiles/r06/gn_bench_nt.log): 256^2 x 256 at B = 64
+    // 5.15 -> 5.35 TB/s with both hints, 64^2 x 512 4.85 -> 5.69 with the store hint alone, the small levels (whose operand the next
+    // convolution finds in cache) LOSE with either; headline purification 20.77 -> 20.89 images/s at t = 20 (+0.6 %).
+    // DP_GN_NT: -1 (default) by tensor size, 0 never, 1 | 2 | 3 forced (bit 0 loads, bit 1 stores).
+    int ntm = dp_tune(DP_T_GN_NT);
+    if (ntm < 0) {
+        const double in_bytes = (double)B * H * W * C * 2.0;
+        ntm = in_bytes >= 400e6 ? 3 : (in_bytes >= 128e6 ? 2 : 0);
+    }
 #define GN_H16_LAUNCH(ACT_, BORDER_)                                                                                                  \
     do {                                                                                                                              \
         if (resample == 0 && ntm == 1) hipLaunchKernelGGL((gn_apply_h16_kernel<ACT_, BORDER_, 0, 1>), g, blk, 0, (hipStream_t)stream, p, COT, slots);      \
