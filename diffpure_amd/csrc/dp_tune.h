@@ -24,8 +24,6 @@ enum DpTune {
                            // (rounds 1-5): bit-identical results for ANY batch size / sharding, at the price of starved launches at small batches
     DP_T_GN_NT,            // DP_GN_NT: non-temporal hints in GroupNorm-apply over the fp16 stream - -1 (default) by tensor size, 0 never, 1 | 2 | 3 forced
                            // (bit 0 loads, bit 1 stores); same bits
-    DP_T_CONV_NT,          // DP_CONV_NT: non-temporal hints on the output stores / residual fetch of the 256-wide tile kernels' epilogue - -1 (default) by
-                           // output size, 0 never, 1 always; same bits
     DP_T_COUNT
 };
 

@@ -38,8 +38,6 @@ struct ConvH2Args {
     const char* seg1;
     const char* seg2;
     int segC1, segC2;
-    int nt;             // non-temporal hint on the epilogue's output stores and residual fetch of the 256-wide tile kernels (round 6): an output tensor
-                        // far beyond the last-level cache must not evict the activation rows the nine taps re-read from L2 (same bits)
 };
 
 // residual value of output element (row, col) in the format p.rfmt names (generic per-element path)

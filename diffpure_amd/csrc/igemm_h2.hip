@@ -565,10 +565,6 @@ static int h2_conv(const void* x, int C, int B, int H, int W, int KS, const void
     p.afmt = a_fmt;
     p.wfmt = w_fmt;
     p.ofmt = out_fmt;
-    {   // DP_CONV_NT: -1 (default) by output size, 0 never, 1 always
-        const int t = dp_tune(DP_T_CONV_NT);
-        p.nt = t < 0 ? ((double)B * H * W * N * (out_fmt ? 2.0 : 4.0) >= 400e6) : (t != 0);
-    }
 
     p.ksplit = h2_ksplit(B, H, W, KS, C, N);
     p.ws = static_cast<float*>(work);

@@ -94,7 +94,6 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                 tvv[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tb, (unsigned)(col0 + j * 32) * 4u, ((row0 + i * 32) / HW) * p.temb_stride * 4, 0));
     }
     const f32x2 sc = {p.scale, p.scale};
-    const bool ntst = p.nt != 0;                    // (wave-uniform) non-temporal output stores
     // lane offsets (bytes) inside a 32-row tile; the row of pair k, {0, 2}[k & 1] + 8 (k >> 1) (+ 1 for its second value), is a
     // wave-uniform addend of the base
     const unsigned vr0 = RK == 2 ? ((unsigned)(4 * lk + odd) * (unsigned)p.ldr + (unsigned)(lr - odd)) * 2u      // pair load
@@ -111,17 +110,10 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
         __builtin_amdgcn_sched_barrier(0);          // nothing that waits on the loads above is scheduled in between the DMA issues
         const int lane = lk * 32 + lr;
         const char* src = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)(row0 + (lane >> 4)) * p.ldr + colw + (lane & 15) * 8);
-        if (p.nt) {                                 // (wave-uniform) read-once data: non-temporal
-#pragma unroll
-            for (int b = 0; b < 16 * NQ; ++b)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(4 * b) * ldr_b),
-                                                 (__attribute__((address_space(3))) void*)(lds_wave + b * SW_EPI_PITCH), 16, 0, 2);
-        } else {
 #pragma unroll
         for (int b = 0; b < 16 * NQ; ++b)           // block b = rows 4b .. 4b + 3 of the wave tile; lane l lands at block + 16 l
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(4 * b) * ldr_b),
                                              (__attribute__((address_space(3))) void*)(lds_wave + b * SW_EPI_PITCH), 16, 0, 0);
-        }
         // the wave reads only what it brought in itself: its own vmcnt, no barrier (the compiler does not order LDS reads behind LDS-DMA).
         // First the blocks of the first 32-row MFMA tile row (loads return in issue order: 8 (NQ - 1) + 8 younger DMAs may still fly);
         // the rest is waited for before the second tile row, under whose arithmetic it lands (a CU's L2 -> LDS path moves the 128 KB
@@ -178,12 +170,7 @@ __device__ __forceinline__ void sw_epilogue(const ConvH2Args& p, f32x16 (&acc)[2
                     q2 = q2 + vsq;
                     if constexpr (OUT16) {
                         const unsigned own = sw_pack_half2(v[0], v[1]);
-                        const unsigned pk = __builtin_amdgcn_perm(sw_swap1u(own), own, sel);
-                        if (ntst) __builtin_amdgcn_raw_buffer_store_b32(pk, ob, vo0, row_of_pair(k) * ldo_b, 2);
-                        else __builtin_amdgcn_raw_buffer_store_b32(pk, ob, vo0, row_of_pair(k) * ldo_b, 0);
-                    } else if (ntst) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), ob, vo0, row_of_pair(k) * ldo_b, 2);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), ob, vo0, (row_of_pair(k) + 1) * ldo_b, 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(sw_swap1u(own), own, sel), ob, vo0, row_of_pair(k) * ldo_b, 0);
                     } else {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), ob, vo0, row_of_pair(k) * ldo_b, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), ob, vo0, (row_of_pair(k) + 1) * ldo_b, 0);

@@ -147,7 +147,6 @@ extern "C" int dp_conv2d_stem(const float* x, int Cin, int B, int H, int W, cons
     p.scale = 1.0f;
     p.colstats = colstats;
     p.ofmt = out_fmt; p.rfmt = 0;
-    p.nt = (double)p.M * N * (out_fmt ? 2.0 : 4.0) >= 400e6;      // a write-once stream far beyond the last-level cache
     hipStream_t s = static_cast<hipStream_t>(stream);
     void* rec = nullptr;
     dp_prof_begin(DP_PROF_3X3_OTHER, 2.0 * p.M * (double)N * 9 * Cin,

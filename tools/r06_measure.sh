@@ -47,13 +47,6 @@ h16n64)  # attention backward of the 64-wide heads on the fp16 matrix cores
   grep -E "passed|failed|^FAILED|^E  |attention backward|adjoint" "$O/h16_tests.log" | head -30
   ab DIFFPURE_H16_N64 guided_adj_b32_t5_h16n64 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0 --no-conv-profile
   ;;
-convnt)  # non-temporal hints in the convolution epilogue
-  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "stem or half_height or k_segments or fp16_output or boundary" > "$O/convnt_tests.log" 2>&1; echo "rc=$?" >> "$O/convnt_tests.log"; lap convnt_tests
-  tail -3 "$O/convnt_tests.log"
-  timeout 200 python tests/probes/stem_bench.py > "$O/stem_bench.log" 2>&1; lap stem_bench
-  head -2 "$O/stem_bench.log"
-  ab DP_CONV_NT guided_t20_convnt --t 20 --steps 1 --warmup 1 --no-conv-profile
-  ;;
 gnnt)   # non-temporal hints in GroupNorm-apply
   timeout 300 python tests/probes/gn_bench.py > "$O/gn_bench_nt.log" 2>&1; lap gn_bench
   cat "$O/gn_bench_nt.log"
