@@ -42,6 +42,14 @@ stem)
 tests)
   gputests
   ;;
+profiles)   # rocprofv3 kernel stats of the four workloads at HEAD
+  rocstats cifar_t10 200 --workload cifar32_ncsnpp --t 10 --steps 1 --warmup 0
+  rocstats cifar_adjoint_t10 200 --workload cifar32_ncsnpp_adjoint --t 10 --steps 1 --warmup 0
+  rocstats guided_b4_t10 200 --batch 4 --t 10 --steps 1 --warmup 0
+  rocstats guided_sde_adjoint_b32_t5 300 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0
+  rocstats default 400 --steps 1 --warmup 0
+  for f in "$O"/*_kernel_stats.csv; do echo "== $f"; head -14 "$f" | cut -c1-150; done
+  ;;
 h16n64)  # attention backward of the 64-wide heads on the fp16 matrix cores
   timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_grad.py tests/test_gpu_loops.py -m gpu -q -s -k "gemm_strided or attention_backward or attention_bwd or guided_small_vjp or guided_full_vjp or guided_sde_stochastic_adjoint or bucketed" > "$O/h16_tests.log" 2>&1; echo "rc=$?" >> "$O/h16_tests.log"; lap h16_tests
   grep -E "passed|failed|^FAILED|^E  |attention backward|adjoint" "$O/h16_tests.log" | head -30
