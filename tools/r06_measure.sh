@@ -50,6 +50,10 @@ profiles)   # rocprofv3 kernel stats of the four workloads at HEAD
   rocstats default 400 --steps 1 --warmup 0
   for f in "$O"/*_kernel_stats.csv; do echo "== $f"; head -14 "$f" | cut -c1-150; done
   ;;
+taprobe)   # how fast a CU takes MFMA A-fragments straight from L2 (fragment addressing vs quad-contiguous addressing)
+  timeout 120 tests/probes/bin/ta_rate_probe > "$O/ta_rate_probe.log" 2>&1; lap ta_rate_probe
+  cat "$O/ta_rate_probe.log"
+  ;;
 h16n64)  # attention backward of the 64-wide heads on the fp16 matrix cores
   timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_grad.py tests/test_gpu_loops.py -m gpu -q -s -k "gemm_strided or attention_backward or attention_bwd or guided_small_vjp or guided_full_vjp or guided_sde_stochastic_adjoint or bucketed" > "$O/h16_tests.log" 2>&1; echo "rc=$?" >> "$O/h16_tests.log"; lap h16_tests
   grep -E "passed|failed|^FAILED|^E  |attention backward|adjoint" "$O/h16_tests.log" | head -30
