@@ -196,7 +196,7 @@ def pmc_mfma_busy():
     """MFMA utilisation of the dominant kernel by rocprofv3's own counter, from the committed PMC pass over its most common
     shape (3x3 256->256 at 256^2, B=64; tools/pmc_conv.sh): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
     Collected offline (counters cannot be read from inside the timed process), at the profiler's clock.  None if absent."""
-    for rnd in ("r05", "r04"):      # the newest committed pass (the kernel itself did not change in round 5)
+    for rnd in ("r06", "r05", "r04"):      # the newest committed pass (the kernel itself did not change in rounds 5-6)
         rel = os.path.join("profiles", rnd, "pmc_conv_igemm_dw_256x256_256to256_b64_res16_out16.json")
         try:
             row = json.load(open(os.path.join(ROOT, rel)))["conv_igemm_dw"]

@@ -14,7 +14,7 @@ enum DpTune {
     DP_T_H2_PP = 0,        // DP_H2_PP: 256-wide tile kernels at all (ping-pong / one-wave-per-SIMD / 8-wave) - 0 never, 1 whenever the shape allows, 2 when it also fills the chip
     DP_T_H2_SW,            // DP_H2_SW: one-wave-per-SIMD kernel (igemm_h2_sw.hip) - 0 off, 1 its 256x256 tiles only, 2 also 512x128 tiles (N % 256 != 0)
     DP_T_H2_NN,            // DP_H2_NN: few-output-channels kernel - 0 off
-    DP_T_H2_DW,            // DP_H2_DW: the 8-wave 256x256 kernel (igemm_h2_dw.hip) on launches of >= 256 tiles - 0 off
+    DP_T_H2_DW,            // DP_H2_DW: the 8-wave kernel (igemm_h2_dw.hip) on launches of >= 256 tiles - 0 off, 1 its 256x256 tiles only, 2 (default, round 6) also 512x128 tiles (N % 256 != 0)
     DP_T_H2_DH,            // DP_H2_DH: the 4-wave 128x256 kernel (igemm_h2_dh.hip) on launches of fewer than 256 tiles of 256x256 - 0 off, 1 un-split layers only, 2 also the split-K levels
     DP_T_H2_DH_MIN,        // DP_H2_DH_MIN: fewest 128x256 half tiles (x split-K parts) of a launch that kernel takes (default 32; below: the generic tiles)
     DP_T_GN_FINALIZE_SAMPLE, // DP_GN_FINALIZE_SAMPLE: small feature maps - one finalize workgroup per sample instead of per (sample, group) - 0 off

@@ -63,10 +63,11 @@ void dp_launch_conv_h2_pp(ConvH2Args& p, hipStream_t s, int bn);
 bool dp_conv_sw_applies(const ConvH2Args& p, int bn);
 void dp_launch_conv_sw(ConvH2Args& p, hipStream_t s, int bn);
 
-// One 8-wave workgroup per CU on 256x256 tiles, two free-running waves per SIMD sharing the tile (igemm_h2_dw.hip): fp16 x fp16;
-// the launcher fills p.tiles.
-bool dp_conv_dw_applies(const ConvH2Args& p);
-void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s);
+// One 8-wave workgroup per CU, two free-running waves per SIMD sharing the tile (igemm_h2_dw.hip): fp16 x fp16; bn = 256: 256x256 tiles
+// (M % 256 == 0, N % 256 == 0), bn = 128: 512x128 tiles (M % 512 == 0, N % 128 == 0 - layers with 128 output channels); the launcher
+// fills p.tiles.
+bool dp_conv_dw_applies(const ConvH2Args& p, int bn = 256);
+void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int bn = 256);
 
 // The same wave tiles on 128x256 tiles, four waves per workgroup, two workgroups per CU (igemm_h2_dh.hip): launches that do not fill
 // the chip with 256x256 tiles; the launcher fills p.tiles.

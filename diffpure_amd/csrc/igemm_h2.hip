@@ -606,6 +606,17 @@ static int h2_conv(const void* x, int C, int B, int H, int W, int KS, const void
             DP_LAUNCH_CHECK("conv_igemm_dw");
             return 0;
         }
+        // round 6: layers with 128 output channels (N % 256 != 0: the 32x32 level of NCSN++) on the same kernel's 512x128 tiles, eight
+        // waves stacked along the pixels, where they fill the chip (>= 256 tiles; fewer: the 4-wave kernel's 256x128 form below).
+        // DP_H2_DW = 1 keeps these launches on the one-wave-per-SIMD kernel (rounds 3-5).  3x3 only, like that kernel's 512x128 form.
+        if (dp_tune(DP_T_H2_DW) >= 2 && dp_tune(DP_T_H2_PP) != 0 && N % 256 != 0 && KS == 3 && tiles(512, 128) >= 256 && dp_conv_dw_applies(p, 128)) {
+            dp_launch_conv_dw(p, s, 128);
+            dp_prof_set_kind(rec, DP_PROF_3X3_PP);
+            if (tile_rows) *tile_rows = 64;
+            dp_prof_end(rec, s);
+            DP_LAUNCH_CHECK("conv_igemm_dw<512x128>");
+            return 0;
+        }
     }
     {   // fp16 x fp16 launches that leave CUs idle on 256x256 tiles (fewer than 256 of them): the 4-wave kernel on 128x256 tiles
         // (igemm_h2_dh.hip) - twice the workgroups, up to two per CU.  From DP_H2_DH_MIN half tiles up (default 32: measured on the guided

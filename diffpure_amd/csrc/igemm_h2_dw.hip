@@ -22,6 +22,14 @@
 // Same operand formats, reduction order and epilogue arithmetic as every other variant: bit-identical output.
 // Needs: fp16 activations and weights (a_fmt 1, w_fmt 1, passes 1), M % 256 == 0, N % 256 == 0, C % 32 == 0, >= 4 k-tiles.
 //
+// SHAPE 1 (round 6): the same kernel on 512 (pixels) x 128 (channels) tiles for layers with 128 output channels (N % 256 != 0: the 32x32
+// level of NCSN++, 36 % of the convolution time of a CIFAR-10 UNet call, until then on the one-wave-per-SIMD kernel's 512 x 128 tiles at
+// 659 TFLOP/s).  The eight waves are stacked along the pixels - wave w owns rows [64 w, 64 w + 64) and ALL 128 columns - so the wave
+// tile is the 64 x 128 of the square form: the same fragment reads (2 A + 4 B per eight MFMAs), the same accumulators, the same epilogue
+// (igemm_sw_common.h, NQ = 1), the same bits.  What changes is the staging: an activation k-tile is 512 rows (32 KB, four pieces per wave),
+// a weight k-tile 128 rows (8 KB, one piece per wave); the older wave of a SIMD issues its own 1 + 4 pieces inside segment A and its partner's
+// 1 + 4 behind its vmcnt wait.  40 KB instead of 32 KB of operands per k-tile for the same 128 MFMAs.
+//
 // 1x1 K-SEGMENTS (round 4; the rolled kernel only): after the KS*KS*C/32 k-tiles over the zero-bordered operand the loop runs on
 // over the channels of up to two plain fp16 NHWC tensors (p.seg1, p.seg2; no border) - the raw input(s) of a ResBlock whose
 // 1x1 skip_connection is thereby folded into its second 3x3 convolution (igemm_h2.h).  Only the address of an activation
@@ -35,13 +43,14 @@
 namespace {
 
 constexpr int NXCD = 8;
-constexpr int BTILE = 256 * 64;                 // weight tile of one k-tile: 256 rows x 64 bytes (32 fp16)
 constexpr int BDEPTH = 3;
 
 template <int N>
 __device__ __forceinline__ void dw_wait_vm() {
-    static_assert(N == 8 || N == 4 || N == 0, "add the immediate");
-    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N == 10 || N == 8 || N == 5 || N == 4 || N == 0, "add the immediate");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -70,13 +79,17 @@ __device__ __forceinline__ void dw_buf_lds16(sw_rsrc r, char* lds, unsigned voff
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int MODE>
+template <int MODE, int SHAPE = 0>
 __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     constexpr int ADEPTH = 3, DA = ADEPTH - 1;  // ring stages / prefetch distance of both operands
-    constexpr int BMT = 256;                    // tile rows: every wave stages 32 of them (2 pieces) and 32 weight rows (2 pieces)
-    constexpr int ATILE = BMT * 64;             // activation tile of one k-tile
-    constexpr int NPB = 2;                      // weight pieces per wave and k-tile
+    constexpr int BMT = SHAPE ? 512 : 256;      // tile rows: every wave owns BMT / 8 of them (2 | 4 pieces of 16 rows) ...
+    constexpr int BNT = SHAPE ? 128 : 256;      // ... and BNT / 8 weight rows (2 | 1 pieces)
+    constexpr int ATILE = BMT * 64;             // activation tile of one k-tile: 64 bytes (32 fp16) per row
+    constexpr int BTILE = BNT * 64;             // weight tile of one k-tile
+    constexpr int NAO = BMT / 128, NBO = BNT / 128;   // a wave's OWN activation / weight pieces per k-tile
+    constexpr int NPB = NBO;
     constexpr int BBASE = ADEPTH * ATILE;
+    static_assert(SHAPE == 0 || (MODE & (128 | 512)) == 0, "the 512 x 128 form exists in the asymmetric pointer-form staging only");
     // the operand rings (96 KB); after the k-loop the same memory is the landing zone of the fp16 residual (igemm_sw_common.h, 136 KB)
     constexpr int RINGS = ADEPTH * ATILE + BDEPTH * BTILE;
     __shared__ __attribute__((aligned(1024))) char smem[RINGS > SW_EPI_LDS ? RINGS : SW_EPI_LDS];
@@ -85,14 +98,14 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     if constexpr (MODE & 256) life0 = (unsigned)__builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = SHAPE ? wave : wave >> 1, wc = SHAPE ? 0 : wave & 1;      // SHAPE 1: the waves are stacked along the pixels
     int tile;
     {   // XCD-aware bijective remap (speed only)
         const int b = blockIdx.x, x = b % NXCD, q = p.tiles / NXCD, r = p.tiles % NXCD;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / NXCD;
     }
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-    const int m0 = tile_m * BMT, n0 = tile_n * 256;
+    const int m0 = tile_m * BMT, n0 = tile_n * BNT;
     const int HW = p.H * p.W, Wp = p.W + 2, taps = p.KS * p.KS;
     const int nt = p.K / 32;
 
@@ -109,13 +122,15 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     // no LDS-DMA at all: 1 320 -> 1 270 cycles per k-tile, +2.1 ... +3.7 % TFLOP/s on every shape measured, identical bits.
     // (Measured and not kept: the younger wave keeping 1 or 2 of its pieces: -2.5 / -0.5 %; every wave issuing its own pieces late:
     // -0.7 ... -1.8 %, the DMA latency is no longer covered; s_setprio 1 on either wave on top: -2.2 / +0.0 %.)
-    // Piece index it: 0, 1 = own rows, 2, 3 = the partner's (wave + 4).
+    // Piece index it: [0, NAO) / [0, NBO) = own rows, the rest = the partner's (wave + 4).
     constexpr bool ASYM = (MODE & 128) == 0;
     constexpr bool BUF = (MODE & 512) != 0;
-    constexpr int NPIECE = ASYM ? 4 : 2;
+    constexpr int NPIECE = ASYM ? 2 * NAO : NAO;     // activation pieces a staging wave issues per k-tile (4 | 8; symmetric form 2)
+    constexpr int NPIECEB = ASYM ? 2 * NBO : NBO;    // weight pieces (4 | 2; symmetric form 2)
     const char* actr[NPIECE];                   // centre pixel of the lane's A row (segments: the lane's pixel), + slot
-    const char* bptr[NPIECE];
-    auto rows_of_piece = [&](int it) { return (wave + (it >> 1) * 4) * 32 + (it & 1) * 16; };
+    const char* bptr[NPIECEB];
+    auto rows_of_piece = [&](int it) { return (wave + (it / NAO) * 4) * (BMT / 8) + (it % NAO) * 16; };
+    auto rows_of_pieceB = [&](int it) { return (wave + (it / NBO) * 4) * (BNT / 8) + (it % NBO) * 16; };
 #pragma unroll
     for (int it = 0; it < NPIECE; ++it) {
         const int m = m0 + rows_of_piece(it) + lrow;
@@ -124,8 +139,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
         actr[it] = p.x + ((size_t)(b * (p.H + 2) + oy + 1) * Wp + ox + 1) * p.C * 2 + ls * 16;
     }
 #pragma unroll
-    for (int it = 0; it < NPIECE; ++it) {
-        const int n = n0 + rows_of_piece(it) + lrow;                // block layout of the fp16 panels (ops.order_conv_weight_w16)
+    for (int it = 0; it < NPIECEB; ++it) {
+        const int n = n0 + rows_of_pieceB(it) + lrow;               // block layout of the fp16 panels (ops.order_conv_weight_w16)
         bptr[it] = p.w + (size_t)(n >> 5) * p.K * 64 + (n & 31) * 16 + ls * 512;
     }
     // buffer-form staging (MODE 512): descriptors + constant lane offsets + scalar offsets
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
 #pragma unroll
         for (int it = 0; it < NPIECE; ++it) {
             voA[it] = (unsigned)((pix(m0 + rows_of_piece(it) + lrow) - P0) * p.C * 2 + ls * 16);
-            const int n = n0 + rows_of_piece(it) + lrow;
+            const int n = n0 + rows_of_pieceB(it % NPIECEB) + lrow;     // (buffer form: SHAPE 0 only, NPIECEB == NPIECE)
             voB[it] = (unsigned)(((n >> 5) - (n0 >> 5)) * p.K * 64 + (n & 31) * 16 + ls * 512);
         }
     }
@@ -188,11 +203,11 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     };
     auto pieceB = [&](int boff, int it) {
         if constexpr (BUF) {
-            dw_buf_lds16(rsB, smem + boff + rows_of_piece(it) * 64, voB[it], soB);
-            if (it == NPIECE - 1) soB += 2048;  // the pieces of a k-tile are issued in order 0 .. NPIECE - 1
+            dw_buf_lds16(rsB, smem + boff + rows_of_pieceB(it) * 64, voB[it], soB);
+            if (it == NPIECEB - 1) soB += 2048; // the pieces of a k-tile are issued in order 0 .. NPIECEB - 1
         } else {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[it],
-                                         (__attribute__((address_space(3))) void*)(smem + boff + rows_of_piece(it) * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + boff + rows_of_pieceB(it) * 64), 16, 0, 0);
         bptr[it] += 2048;
         }
     };
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     };
     auto issueB = [&](int boff) {
 #pragma unroll
-        for (int it = 0; it < NPIECE; ++it) pieceB(boff, it);
+        for (int it = 0; it < NPIECEB; ++it) pieceB(boff, it);
     };
 
     // ---- fragments: lane -> row lr of a 32-row MFMA tile, k-half lk; 64-byte rows, slot (s*2 + lk) ^ key, key = (row >> 2) & 3
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
         issueA(ar[0]);
         issueA(ar[1]);
         issueB(br[1]);
-        dw_wait_vm<2 * NPIECE>();               // k-tile 0 landed; A(1), B(1) may fly
+        dw_wait_vm<NPIECE + NPIECEB>();         // k-tile 0 landed; A(1), B(1) may fly
     }
     SW_BARRIER();
     read_frags(0, ar[0], br[0]);
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     // the vmcnt wait), 2 = younger wave (no LDS-DMA)
     auto steady = [&](auto role_tag) __attribute__((always_inline)) {
         constexpr int ROLE = decltype(role_tag)::value;
-        constexpr int NDMA = ROLE == 2 ? 0 : NPB + 2;        // pieces interleaved into segment A
+        constexpr int NDMA = ROLE == 2 ? 0 : NBO + NAO;      // pieces interleaved into segment A: the wave's own (4 | 5 of the 6 slots)
     for (; t + DA < nt; ++t) {
         if constexpr (MODE & 64) {
             __builtin_amdgcn_sched_barrier(0);
@@ -291,10 +306,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
                 else readB(1, br[0], k - 2);
             }
             if constexpr (NDMA != 0) {
-                if (k < NPB) {
+                if (k < NBO) {
                     if constexpr (!(MODE & 33)) pieceB(br[2], k);
-                } else if (k < NPB + 2) {
-                    if constexpr (!(MODE & 17)) pieceA(ar[DA], k - NPB);
+                } else if (k < NBO + NAO) {
+                    if constexpr (!(MODE & 17)) pieceA(ar[DA], k - NBO);
                 }
             }
         }
@@ -321,10 +336,16 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
         }
         // outstanding in issue order: [.., B(t+1), A(t+1)] from iteration t-1, [B(t+2), A(t+2)] from this one
         // (older wave: its late pieces of k-tile t+1 sit in front of these four in issue order, so the same count covers them)
-        if constexpr (!(MODE & 3) && ROLE != 2) dw_wait_vm<NPB + 2>();
-        if constexpr (ROLE == 1 && !(MODE & 1)) {   // the partner wave's four pieces of k-tile t+2, in what was this wave's barrier idle time
-            if constexpr (!(MODE & 32)) { pieceB(br[2], 2); pieceB(br[2], 3); }
-            if constexpr (!(MODE & 16)) { pieceA(ar[DA], 2); pieceA(ar[DA], 3); }
+        if constexpr (!(MODE & 3) && ROLE != 2) dw_wait_vm<NBO + NAO>();
+        if constexpr (ROLE == 1 && !(MODE & 1)) {   // the partner wave's pieces of k-tile t+2 (2 + 2 | 1 + 4), in what was this wave's barrier idle time
+            if constexpr (!(MODE & 32)) {
+#pragma unroll
+                for (int it = NBO; it < 2 * NBO; ++it) pieceB(br[2], it);
+            }
+            if constexpr (!(MODE & 16)) {
+#pragma unroll
+                for (int it = NAO; it < 2 * NAO; ++it) pieceA(ar[DA], it);
+            }
         }
         if constexpr (MODE & 64) {
             tl_s3 = stamp();
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
     unsigned tl_e0 = 0;
     if constexpr (MODE & (64 | 256)) tl_e0 = stamp();
     if constexpr (!(MODE & 8)) sw_epilogue_any<1>(p, acc, m0 + wr * 64, n0 + wc * 128, tile_m * (BMT / 64) + wr, lr, lk, HW, smem + wave * (16 * SW_EPI_PITCH));
+    static_assert(RINGS <= 160 * 1024 && SW_EPI_LDS <= 160 * 1024, "LDS");
     if constexpr (MODE & 64) {
         const unsigned tl_e1 = stamp();
         if (p.ws && lane == 0) {
@@ -419,15 +441,22 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_dw(ConvH2Args p) {
 
 }  // namespace
 
-bool dp_conv_dw_applies(const ConvH2Args& p) {
+bool dp_conv_dw_applies(const ConvH2Args& p, int bn) {
     const bool seg_ok = (!p.seg1 || (p.segC1 > 0 && p.segC1 % 32 == 0)) && (!p.seg2 || (p.seg1 && p.segC2 > 0 && p.segC2 % 32 == 0));
-    return p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % 256 == 0 && p.N % 256 == 0 && p.C % 32 == 0 &&
+    if (bn != 256 && bn != 128) return false;
+    return p.wfmt == 1 && p.afmt == 1 && p.passes == 1 && p.ksplit == 1 && p.M % (bn == 256 ? 256 : 512) == 0 && p.N % bn == 0 && p.C % 32 == 0 &&
            p.K >= 4 * 32 && (!p.temb || (p.H * p.W) % 32 == 0) && seg_ok && (p.rfmt == 0 || p.ofmt == 1) &&
            // the fp16 residual lands through 16-byte LDS-DMA pieces: rows and base 16-byte aligned, or the generic tiles take the launch
            (p.rfmt == 0 || (dp_aligned16(p.res) && p.ldr % 8 == 0));
 }
 
-void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s) {
+void dp_launch_conv_dw(ConvH2Args& p, hipStream_t s, int bn) {
+    if (bn == 128) {        // 512 x 128 tiles (SHAPE 1)
+        p.tiles_n = p.N / 128;
+        p.tiles = (p.M / 512) * p.tiles_n;
+        hipLaunchKernelGGL((conv_igemm_dw<0, 1>), dim3((unsigned)p.tiles), dim3(512u), 0, s, p);
+        return;
+    }
     p.tiles_n = p.N / 256;
     p.tiles = (p.M / 256) * p.tiles_n;
 

@@ -41,6 +41,9 @@ Round 4:
 Round 5:
   guided_loop150_dt0.0015.pt  BASELINE.json configs[2] AS WRITTEN: t*=0.15 in 100 EM steps, i.e. dt=1.5e-3 (B=1; every rounding enters the
                            state 1.5x larger than on the dt=1e-3 grid of guided_loop150.pt)          [target: guided_loop150_dt]
+Round 6:
+  ncsnpp_loop20_dt0.005.pt BASELINE.json configs[0] AS WRITTEN: CIFAR NCSN++, B=4, t*=0.1 in 20 EM steps of dt=5e-3      [target: ncsnpp_loop20; ~1 min]
+Round 5 (continued):
   guided_sde_adjoint100.pt the stochastic adjoint on the full guided UNet at the PRODUCT grid: t=100, 100 EM steps + 100 adjoint
                            steps, B=1 (what run_scripts/imagenet/run_in_rand_inf.sh differentiates, at t=100)   [target: guided_sde_adjoint100; ~35 min]
 """
@@ -131,6 +134,19 @@ def ncsnpp_loop():
     torch.save(dict(cfg=cfg, seed=SEED, noise_seed=SEED, t=100, dt=1e-3, steps=n, x0=x0, out=x, snaps=keep),
                os.path.join(HERE, "ncsnpp_loop100.pt"))
     print("ncsnpp_loop100", n, float(x.abs().mean()))
+
+
+def ncsnpp_loop20():
+    """BASELINE.json configs[0] as written: CIFAR NCSN++, B=4, t*=0.1 in 20 EM steps (dt=5e-3) - the reference's CPU-runnable case."""
+    RevVPSDE = mg.ref_module("ref_diffpure_sde", "runners/diffpure_sde.py").RevVPSDE
+    mod, cfg = build_ncsnpp()
+    rv = RevVPSDE(model=mod, score_type="score_sde", img_shape=(3, 32, 32), model_kwargs=None)
+    x0 = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(97)) * 2 - 1
+    with torch.no_grad():
+        x, keep, n = em_loop(rv, x0, 100, 5e-3, SEED, snaps=(5,))
+    torch.save(dict(cfg=cfg, seed=SEED, noise_seed=SEED, t=100, dt=5e-3, steps=n, x0=x0, out=x, snaps=keep),
+               os.path.join(HERE, "ncsnpp_loop20_dt0.005.pt"))
+    print("ncsnpp_loop20", n, float(x.abs().mean()))
 
 
 def ode_adjoint():
@@ -323,6 +339,8 @@ def main():
             guided_loop()
         elif w == "ncsnpp_loop":
             ncsnpp_loop()
+        elif w == "ncsnpp_loop20":
+            ncsnpp_loop20()
         elif w == "ode_adjoint":
             ode_adjoint()
         elif w == "guided_full":

@@ -200,6 +200,21 @@ def test_ncsnpp_loop_100_steps_vs_reference_golden(precision):
     assert err < 1e-3, err
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16sr"])
+def test_config1_cifar_b4_20_steps_vs_reference_golden(precision):
+    """BASELINE.json configs[0] AS WRITTEN - CIFAR-10 NCSN++ (full size), B=4, t*=0.1 in 20 EM steps of dt=5e-3 - product path (in-kernel
+    Philox) against a file written by the reference's own NCSNpp + RevVPSDE.f / .g (make_golden_loops.py ncsnpp_loop20; round 5 held this
+    config to the oracle only, tests/test_gpu_models.py).  dt is five times the product step: every rounding enters the state five times larger."""
+    from diffpure_amd.sde import Purifier, sde_schedule
+    g = load_golden("ncsnpp_loop20_dt0.005.pt")
+    assert g["steps"] == 20 == len(sde_schedule("ncsnpp", g["t"], g["dt"]))
+    pur = Purifier(ncsnpp_full(precision), "ncsnpp", DEV)
+    out = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    err = maxabs(out, g["out"])
+    print(f"configs[0] (NCSN++ B=4, 20 steps of dt=5e-3) [{precision}]: purified max-abs vs reference modules {err:.3e}")
+    assert err < 1e-3, err
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16sr"])
 def test_config5_adjoint_ode_100_plus_100_steps_vs_reference_golden(precision):
     """BASELINE.json configs[4] at B=2 and FULL length: 100 Euler steps of the probability-flow ODE, then 100 steps of the

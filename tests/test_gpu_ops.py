@@ -1138,6 +1138,74 @@ DH_CASES = [
 ]
 
 
+DW128_CASES = [
+    # B, H, W, C, N, temb rows (0 none / 1 shared / 2 per sample), residual (0 / 16 / 32), fp16 output, (C1, C2) K-segments, scale
+    (128, 32, 32, 128, 128, 2, 16, True, (0, 0), 0.70710678),     # NCSN++ 32x32 level, stream form: 256 tiles of 512x128 - one round
+    (128, 32, 32, 128, 128, 0, 32, False, (128, 128), 0.70710678),  # fp32 stream + the 1x1 skip as two K-segments
+    (128, 32, 32, 256, 128, 1, 16, True, (0, 0), 1.0),            # 256 -> 128 (up path), shared time-embedding row
+    (160, 32, 32, 128, 128, 0, 0, True, (256, 0), 1.0),           # 320 tiles: a second, partial round; one segment
+    (128, 32, 32, 128, 128, 0, 0, False, (0, 0), 1.0),            # as an input-gradient convolution (fp32 out, nothing else)
+    (32, 64, 64, 384, 128, 2, 16, True, (0, 0), 1.0),             # 64x64 maps, 108 k-tiles
+]
+
+
+@pytest.mark.parametrize("case", DW128_CASES, ids=[str(c) for c in DW128_CASES])
+def test_conv2d_eight_wave_kernel_on_512x128_tiles_is_bit_identical(dev, case, tune):
+    """Round 6: the 8-wave kernel's 512x128 form (conv_igemm_dw<0, 1>: eight waves stacked along the pixels, the wave tile, fragment reads
+    and epilogue of the square form) takes the 3x3 layers with 128 output channels on launches of >= 256 tiles.  Identical bits to the
+    generic tiles and to the one-wave-per-SIMD kernel's 512x128 tiles it replaces (DP_H2_DW = 1) - output (fp16 or fp32) and column
+    records - with time-embedding rows, fp16 / fp32 residual and 1x1 K-segments; fp64 reference on two samples."""
+    from diffpure_amd import ops
+    B, H, W, C, N, temb_rows, res_kind, out16, (C1, C2), scale = case
+    assert (B * H * W) % 512 == 0 and (B * H * W // 512) * (N // 128) >= 256
+    h = rnd(B, H, W, C, seed=1)
+    w3 = rnd(N, C, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * C))
+    hh = _h1_bordered(h, dev)
+    bias = rnd(N, seed=3).to(dev)
+    table = rnd(B if temb_rows == 2 else 1, N + 8, seed=4).to(dev) if temb_rows else None
+    res = None
+    if res_kind:
+        res = rnd(B, H, W, N, seed=5).to(dev)
+        res = res.half() if res_kind == 16 else res
+    segs = None
+    if C1:
+        ws = rnd(N, C1 + C2, 1, 1, seed=6, scale=1.0 / math.sqrt(C1 + C2))
+        wf = ops.order_conv_weight_w16(ops.fuse_skip_weight(w3, ws)).half().to(dev)
+        segs = (rnd(B, H, W, C1, seed=7).half().to(dev),) + ((rnd(B, H, W, C2, seed=8).half().to(dev),) if C2 else ())
+    else:
+        wf = ops.order_conv_weight_w16(w3).half().to(dev)
+
+    def run():
+        y = ops.conv2d_h2(hh, wf, N, 3, bias=bias, temb=None if table is None else table[:, 4:4 + N], res=res, scale=scale, colstats=True,
+                          w_fmt=1, out_f16=out16, segs=segs)
+        return y.t, y.cols.buf.clone()
+
+    tune.setenv("DP_H2_PP", "0")                    # generic tiles
+    base, base_cs = run()
+    tune.delenv("DP_H2_PP")
+    tune.setenv("DP_H2_DW", "1")                    # what took these launches in rounds 3-5: the one-wave-per-SIMD kernel's 512x128 tiles
+    old, old_cs = run()
+    assert torch.equal(old, base) and torch.equal(old_cs, base_cs)
+    tune.setenv("DP_H2_DW", "2")
+    for _ in range(3):
+        got, got_cs = run()
+        assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
+    tune.delenv("DP_H2_DW")
+    got, got_cs = run()                             # the dispatcher's own choice (= 2)
+    assert torch.equal(got, base) and torch.equal(got_cs, base_cs)
+    sub = slice(0, 2)                               # fp64 reference on two samples
+    ref = torch.nn.functional.conv2d(h[sub].half().double().permute(0, 3, 1, 2), w3.half().double(), None, padding=1).permute(0, 2, 3, 1) + bias.cpu().double()
+    if segs:
+        ref = ref + torch.cat([s_[sub].cpu() for s_ in segs], dim=3).double() @ ws[:, :, 0, 0].half().double().t()
+    if table is not None:
+        ref = ref + table[:, 4:4 + N].cpu().double()[:2 if temb_rows == 2 else 1].view(-1, 1, 1, N)
+    if res is not None:
+        ref = ref + res[sub].cpu().double()
+    ref = (ref * scale).float()
+    err = (got[sub].float().cpu() - ref).abs().max().item()
+    assert err < (2e-3 if out16 else 2e-5) * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("case", DH_CASES, ids=[str(c) for c in DH_CASES])
 def test_conv2d_half_height_tile_kernel_is_bit_identical(dev, case, tune):
     """Round 5: conv_igemm_dh (128x256 tiles, four waves, two workgroups per CU) takes the fp16 x fp16 launches that leave CUs idle on

@@ -194,6 +194,21 @@ def test_oracle_stochastic_adjoint_at_the_product_grid_vs_reference_golden():
     assert (a - snap["a"]).abs().max() < 1e-4 * snap["a"].abs().max(), ((a - snap["a"]).abs().max(), snap["a"].abs().max())
 
 
+def test_oracle_config1_loop_vs_reference_golden():
+    """BASELINE.json configs[0] as written (CIFAR NCSN++, B=4, t*=0.1 in 20 EM steps of dt=5e-3): the oracle's restated loop against the file
+    the reference's own NCSNpp + RevVPSDE.f / .g wrote on the same Philox path (make_golden_loops.py ncsnpp_loop20).  ~10 s of CPU."""
+    import refops
+    g, cfg, sd = _ncsnpp("ncsnpp_loop20_dt0.005.pt")
+    score = osol.make_score_fn("ncsnpp", sd, cfg)
+    x0, seed = g["x0"], g["noise_seed"]
+    b, c, h, w = x0.shape
+    ph = lambda step: refops.philox_normal((b, h, w, c), seed, 0, step).permute(0, 3, 1, 2).contiguous()
+    assert g["steps"] == 20
+    with torch.no_grad():
+        xf = osol.sde_purify(score, x0, ph(-1), [ph(k) for k in range(20)], g["t"], g["dt"])
+    assert (xf - g["out"]).abs().max() < 2e-5, (xf - g["out"]).abs().max()
+
+
 # ---- round 5: the oracle against the reference's OWN modules, live (oracle/_ref travels to the GPU box; skipped where it is absent) -------------
 @pytest.mark.parametrize("kind", ["guided", "ncsnpp"])
 def test_oracle_equals_the_reference_modules_of_oracle_ref_on_fresh_inputs(kind):

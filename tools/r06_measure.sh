@@ -31,7 +31,24 @@ ab() {   # ab <env var> <label> <bench args...>: same-box A/B of one switch, 0 1
     val "$O/bench_${label}_$V.json" "$label $var=$V" | tee -a "$O/${label}_ab.log"
   done; lap "ab_$label"
 }
+abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box A/B of one switch, A B A B
+  local var=$1 va=$2 vb=$3 label=$4; shift 4
+  for V in $va $vb $va $vb; do
+    env $var=$V timeout 400 python bench.py "$@" --no-cpu-baseline --no-resident-call > "$O/bench_${label}_$V.json" 2>> "$O/bench_ab.err"
+    val "$O/bench_${label}_$V.json" "$label $var=$V" | tee -a "$O/${label}_ab.log"
+  done; lap "ab_$label"
+}
 case "$STAGE" in
+dw128)   # the 8-wave kernel's 512x128 form on the layers with 128 output channels (NCSN++ 32x32 level)
+  timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "512x128 or fp16_weights_single_pass or k_segments or half_height or fp16_output" > "$O/dw128_tests.log" 2>&1; echo "rc=$?" >> "$O/dw128_tests.log"; lap dw128_tests
+  grep -E "passed|failed|^FAILED|^E  " "$O/dw128_tests.log" | head -20
+  DP_H2_DW=1 timeout 300 python tests/probes/cifar_conv_shapes.py > "$O/cifar_conv_shapes_dw1.log" 2>&1; lap shapes_dw1
+  DP_H2_DW=2 timeout 300 python tests/probes/cifar_conv_shapes.py > "$O/cifar_conv_shapes_dw2.log" 2>&1; lap shapes_dw2
+  grep -E "^ 32|weighted" "$O/cifar_conv_shapes_dw1.log" | head -12; echo ---; grep -E "^ 32|weighted" "$O/cifar_conv_shapes_dw2.log" | head -12
+  abv DP_H2_DW 1 2 cifar_t50_dw128 --workload cifar32_ncsnpp --t 50 --steps 1 --warmup 1 --no-conv-profile
+  abv DP_H2_DW 1 2 cifar_adj_t20_dw128 --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-conv-profile
+  abv DP_H2_DW 1 2 guided_t20_dw128 --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ;;
 stem)
   timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "stem" > "$O/stem_tests.log" 2>&1; echo "rc=$?" >> "$O/stem_tests.log"; lap stem_tests
   tail -15 "$O/stem_tests.log"
@@ -49,6 +66,17 @@ profiles)   # rocprofv3 kernel stats of the four workloads at HEAD
   rocstats guided_sde_adjoint_b32_t5 300 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0
   rocstats default 400 --steps 1 --warmup 0
   for f in "$O"/*_kernel_stats.csv; do echo "== $f"; head -14 "$f" | cut -c1-150; done
+  ;;
+pmc)   # HBM traffic per kernel NAME (FETCH_SIZE / WRITE_SIZE in separate passes) + MFMA-busy of the dominant shape; configs[0] golden test
+  timeout 300 python -m pytest tests/test_gpu_loops.py -m gpu -q -s -k "config1_cifar" > "$O/c1_tests.log" 2>&1; echo "rc=$?" >> "$O/c1_tests.log"; lap c1_tests
+  grep -E "passed|failed|configs\[0\]" "$O/c1_tests.log"
+  PMC_TRAFFIC_UPDATE="round 6 (tools/r06_measure.sh pmc): one row per kernel name" timeout 500 bash tools/pmc_traffic.sh --precision f16sr > "$O/pmc.log" 2>&1; lap pmc_traffic
+  find "$R/gpurun_out/pmc_traffic" -name "*counter_collection.csv" -delete
+  cp "$R"/gpurun_out/pmc_traffic/*.json "$O/" 2>/dev/null
+  tail -14 "$O/pmc.log"
+  PMC_GROUPS="sq1 grbm" timeout 400 bash tools/pmc_conv.sh dw_r06 --dw 1 --res16 --f16out > "$O/pmc_conv.log" 2>&1; lap pmc_conv
+  cp "$R/gpurun_out/pmc_conv/dw_r06.json" "$O/" 2>/dev/null
+  tail -30 "$O/pmc_conv.log"
   ;;
 taprobe)   # how fast a CU takes MFMA A-fragments straight from L2 (fragment addressing vs quad-contiguous addressing)
   timeout 120 tests/probes/bin/ta_rate_probe > "$O/ta_rate_probe.log" 2>&1; lap ta_rate_probe
