@@ -24,6 +24,8 @@ enum DpTune {
                            // (rounds 1-5): bit-identical results for ANY batch size / sharding, at the price of starved launches at small batches
     DP_T_GN_NT,            // DP_GN_NT: non-temporal hints in GroupNorm-apply over the fp16 stream - -1 (default) by tensor size, 0 never, 1 | 2 | 3 forced
                            // (bit 0 loads, bit 1 stores); same bits
+    DP_T_GN_WG,            // DP_GN_WG (round 6): GroupNorm-apply over the fp16 stream cuts an output row across several workgroups while the launch has
+                           // fewer workgroups than this (default 2048; 0 = always one workgroup per row, rounds 3-5); same bits
     DP_T_COUNT
 };
 

@@ -491,12 +491,15 @@ __global__ __launch_bounds__(256) void gn_apply_h16_kernel(Apply16Args p, int CO
     const int oy = qy - BORDER;
     const bool zrow = BORDER && (unsigned)oy >= (unsigned)p.Ho;
     const float* st = p.gamma ? p.stats + (size_t)b * p.G * 2 : nullptr;
-    const int slot = threadIdx.x / COT;
+    // pixel slot of this thread among ALL workgroups of the row: gridDim.y > 1 (round 6) cuts a row's pixels across several workgroups
+    // where one workgroup per row would leave the chip short of them (small batches / low levels); `slots` counts the row's slots
+    const int lslot = threadIdx.x / COT;
+    const int slot = blockIdx.y * (blockDim.x / COT) + lslot;
     const size_t orow = ((size_t)b * Hq + qy) * Wq;
     half8 zero8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero8[j] = (_Float16)0.f;
-    for (int co = threadIdx.x - slot * COT; co < CO; co += COT) {
+    for (int co = threadIdx.x - lslot * COT; co < CO; co += COT) {
         const int c0 = co * 8;
         float a[8], d[8];                                  // y = x*a + d before act
 #pragma unroll
@@ -790,9 +793,22 @@ extern "C" int dp_gn_apply_h16(const void* x1, int C1, const void* x2, int C2, i
     Apply16Args p{(const _Float16*)x1, (const _Float16*)x2, C1, C2, B, H, W, G, stats, gamma, beta, fscale, fshift, film_stride, resample,
                   (char*)y, (char*)y_raw, gamma ? C / G : C, resample == 1 ? 2 * H : (resample == 2 ? H / 2 : H),
                   resample == 1 ? 2 * W : (resample == 2 ? W / 2 : W)};
-    const int CO = C / 8, COT = CO < 256 ? CO : 256, slots = 256 / COT;
+    const int CO = C / 8, COT = CO < 256 ? CO : 256;
     const unsigned rows = (unsigned)(B * (out_fmt == 2 ? p.Ho + 2 : p.Ho));
-    const dim3 g(rows), blk((unsigned)(COT * slots));
+    // workgroups per output row (round 6): one, unless that leaves fewer than DP_GN_WG workgroups (default 2048 = eight per CU) - then the
+    // row's pixels are cut across up to Wq / (slots per workgroup) of them.  Elementwise: same bits for any cut.
+    int ysplit = 1;
+    {
+        const int want = dp_tune(DP_T_GN_WG), per_wg = 256 / COT, wq = (resample == 1 ? p.W : p.Wo) + (resample == 0 && out_fmt == 2 ? 2 : 0);
+        if (want > 0 && (int)rows < want) {
+            ysplit = (want + (int)rows - 1) / (int)rows;
+            const int most = (wq + per_wg - 1) / per_wg;
+            if (ysplit > most) ysplit = most;
+            if (ysplit < 1) ysplit = 1;
+        }
+    }
+    const int slots = (256 / COT) * ysplit;
+    const dim3 g(rows, (unsigned)ysplit), blk((unsigned)(COT * (256 / COT)));
     void* rec = nullptr;
     {   // algorithmic HBM bytes: every source element the output needs once (2 B) + every output element once (2 B)
         const double in_px = resample == 1 ? (double)H * W : (double)p.Ho * p.Wo * (resample ? 4 : 1);

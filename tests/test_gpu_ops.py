@@ -1040,6 +1040,41 @@ def test_group_norm_fp16_input_equals_group_norm_of_the_upconverted_tensors(dev,
         ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, act=True, split="h2", stats=stats)      # fp16 in -> "h1" only
 
 
+@pytest.mark.parametrize("case", H16_CASES + [(4, 64, 64, 256, 0, 32), (2, 32, 32, 512, 512, 32)], ids=str)
+def test_group_norm_fp16_rows_cut_across_workgroups_same_bits(dev, case, tune):
+    """Round 6: dp_gn_apply_h16 cuts an output row across several workgroups (grid.y) while the launch would have fewer than DP_GN_WG
+    (default 2048) of them - small batches, low levels.  Elementwise work: the same bytes as one workgroup per row (DP_GN_WG=0) and as
+    the most cuts a row admits (DP_GN_WG=10^6), for every resampling mode, with and without the raw second output, borders included."""
+    from diffpure_amd import ops
+    B, H, W, C1, C2, G = case
+    C = C1 + C2
+    x16 = (rnd(B, H, W, C1, seed=1) * 2 + 0.5).half().to(dev)
+    x2_16 = (rnd(B, H, W, C2, seed=2) - 0.3).half().to(dev) if C2 else None
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
+    stats = ops.group_norm_stats(x16.float(), G, 1e-5, None if x2_16 is None else x2_16.float())
+    table = rnd(B, 2 * C + 8, seed=7).to(dev)
+    film = (table[:, 4:4 + C], table[:, 4 + C:4 + 2 * C])
+
+    def run():
+        outs = []
+        for rs in (0, 1, 2) if H % 2 == 0 and W % 2 == 0 else (0, 1):
+            for raw in (False, True):
+                r = ops.group_norm(x16, G, 1e-5, gamma, beta, x2=x2_16, film=film, act=True, resample=rs, split="h1", stats=stats, raw=raw)
+                outs += list(r) if raw else [r]
+            outs.append(ops.to_h2(x16, rs, fmt="h1"))
+            if rs and C2 == 0:
+                outs.append(ops.resample(x16, rs))           # plain fp16 output (out_fmt 3)
+        return outs
+
+    tune.setenv("DP_GN_WG", "0")
+    base = run()
+    for wg in ("2048", "1000000"):
+        tune.setenv("DP_GN_WG", wg)
+        got = run()
+        assert len(got) == len(base) and all(torch.equal(a, b) for a, b in zip(got, base)), (case, wg)
+    tune.delenv("DP_GN_WG")
+
+
 def test_attention_fused_operand_output(dev):
     """dp_attention_fused out_fmt 1: the attention output lands as the zero-bordered fp16 operand of proj_out - the fp32
     result rounded to nearest in the interior pixels, zeros on the border."""

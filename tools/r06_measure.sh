@@ -39,6 +39,16 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+smallb)   # small per-GPU batches (the reference's own B = 4): GroupNorm-apply rows cut across workgroups; weight rounding prefetched on a side stream
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "group_norm or resample or to_h2 or operand" > "$O/gnwg_tests.log" 2>&1; echo "rc=$?" >> "$O/gnwg_tests.log"; lap gnwg_tests
+  grep -E "passed|failed|^FAILED|^E  " "$O/gnwg_tests.log" | head -20
+  for B in 4 8 16; do
+    abv DP_GN_WG 0 2048 guided_b${B}_t20_gnwg --batch $B --t 20 --steps 1 --warmup 1 --no-conv-profile
+    ab DIFFPURE_ROUND_PREFETCH guided_b${B}_t20_prefetch --batch $B --t 20 --steps 1 --warmup 1 --no-conv-profile
+  done
+  abv DP_GN_WG 0 2048 cifar_t50_gnwg --workload cifar32_ncsnpp --t 50 --steps 1 --warmup 1 --no-conv-profile
+  abv DP_GN_WG 0 2048 guided_adj_b4_t10_gnwg --workload imagenet256_guided_sde_adjoint --batch 4 --t 10 --steps 1 --warmup 0 --no-conv-profile
+  ;;
 dw128)   # the 8-wave kernel's 512x128 form on the layers with 128 output channels (NCSN++ 32x32 level)
   timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "512x128 or fp16_weights_single_pass or k_segments or half_height or fp16_output" > "$O/dw128_tests.log" 2>&1; echo "rc=$?" >> "$O/dw128_tests.log"; lap dw128_tests
   grep -E "passed|failed|^FAILED|^E  " "$O/dw128_tests.log" | head -20
