@@ -117,6 +117,10 @@ class SclkSampler:
             d = os.path.dirname(self.path)
             pc = sorted(glob.glob(os.path.join(d, "hwmon/hwmon*/power1_average"))) + sorted(glob.glob(os.path.join(d, "hwmon/hwmon*/power1_input")))
             self.pow_path = pc[0] if pc else None
+            # junction / memory temperatures of the same card (millidegrees): a 20-step run holds the cap for minutes, and the clock the
+            # power manager grants at the cap drifts with the temperature (round 6: first / last quarter of the clock samples are reported)
+            self.temp_paths = sorted(glob.glob(os.path.join(d, "hwmon/hwmon*/temp*_input")))
+            self.temps = []
             self._th = threading.Thread(target=self._run, daemon=True)
 
     def _read(self):
@@ -138,6 +142,14 @@ class SclkSampler:
                     self.power.append(float(open(self.pow_path).read().strip()) * 1e-6)
                 except Exception:
                     pass
+            t_ = []
+            for tp in getattr(self, "temp_paths", []):
+                try:
+                    t_.append(float(open(tp).read().strip()) * 1e-3)
+                except Exception:
+                    pass
+            if t_:
+                self.temps.append(max(t_))
             self._stop.wait(0.5)
 
     def start(self):
@@ -152,6 +164,11 @@ class SclkSampler:
             return None
         s_ = sorted(self.samples)
         out = dict(median=s_[len(s_) // 2], min=s_[0], max=s_[-1], samples=len(s_), source=self.path)
+        q = max(1, len(self.samples) // 4)
+        med = lambda v: sorted(v)[len(v) // 2]
+        out.update(first_quarter_median=med(self.samples[:q]), last_quarter_median=med(self.samples[-q:]))
+        if getattr(self, "temps", None):
+            out.update(temp_c_max_first_quarter=max(self.temps[:max(1, len(self.temps) // 4)]), temp_c_max=max(self.temps))
         if self.power:
             p_ = sorted(self.power)
             out.update(power_w_median=p_[len(p_) // 2], power_w_max=p_[-1], power_source=self.pow_path)
@@ -743,6 +760,8 @@ def main():
                     "sampled_step_ms": window_ms,
                     # scalars (the driver's parser keeps scalars of this object, not nested ones): the clock and socket power this run held
                     "sclk_mhz_median": held, "power_w_median": (sclk or {}).get("power_w_median"),
+                    "sclk_mhz_first_quarter": (sclk or {}).get("first_quarter_median"), "sclk_mhz_last_quarter": (sclk or {}).get("last_quarter_median"),
+                    "temp_c_max": (sclk or {}).get("temp_c_max"),
                     "algorithmic_bytes_per_launch_note": "3x3 launches of the dominant kernel only (the set `achieved` is computed over); the set "
                                                          "`traffic` is measured over has its own key, algorithmic_bytes_per_launch_same_set",
                     "other_kernels_share_of_step": {"3x3 on other tile variants (stem, head, split-K levels)": prof["other3x3"]["ms"] / window_ms,

@@ -931,6 +931,11 @@ def _bordered_f16(shape, device):
     stream and thread: the engines consume it at once (the proj_out / NIN_3 convolution); a caller that wants to keep it clones it
     (torch.ops.diffpure_hip.attention_fused allocates a fresh one per call)."""
     import threading
+    if torch.cuda.is_current_stream_capturing():
+        # under graph capture (DIFFPURE_GRAPH=1) a cached buffer would either live in this graph's private pool - and be handed, un-zeroed,
+        # to later captures - or be dropped by clear() while a captured graph still addresses it: a capture gets its own tensor and its own
+        # memset node (round 6, advisor)
+        return torch.zeros(shape, device=device, dtype=torch.float16)
     key = (device.index, _stream(), threading.get_ident(), tuple(shape))
     buf = _BORDERED.get(key)
     if buf is None:

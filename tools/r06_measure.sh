@@ -39,6 +39,15 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+driver)   # the driver's own command, as BENCH_r05.json records it (20 timed + 5 warm-up purifications: ~7 minutes at the power cap)
+  timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver_command.json" 2> "$O/bench_driver_command.err"; lap driver_command
+  python - "$O/bench_driver_command.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
+print("value", round(d["value"], 4), "ms/step", round(d["ms_per_step"], 1), "frac", round(r["frac"], 4), "share", round(r["time_share_of_step"], 4),
+      "sclk", r.get("sclk_mhz"), "traffic/alg", r.get("traffic_over_algorithmic"), "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
+PY
+  ;;
 smallb)   # small per-GPU batches (the reference's own B = 4): GroupNorm-apply rows cut across workgroups; weight rounding prefetched on a side stream
   timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "group_norm or resample or to_h2 or operand" > "$O/gnwg_tests.log" 2>&1; echo "rc=$?" >> "$O/gnwg_tests.log"; lap gnwg_tests
   grep -E "passed|failed|^FAILED|^E  " "$O/gnwg_tests.log" | head -20
