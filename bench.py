@@ -190,7 +190,7 @@ def pmc_traffic(workload, batch, precision):
     return None
 
 
-def traffic_keys(row, prof):
+def traffic_keys(row, prof, unet_calls=1):
     """roofline.traffic and the algorithmic bytes it is compared with, over the SAME launch set (round 6; round 5 printed a counter
     average over 232 launches of three kernels next to the algorithmic bytes of the 3x3 launches of one).  rocprofv3 aggregates per
     kernel NAME, the in-process profile per launch kind, and since ABI 8 a kind belongs to one kernel: the row's `per_kernel` entry of
@@ -203,7 +203,7 @@ def traffic_keys(row, prof):
     alg = (prof["pp3x3"]["bytes"] + prof["pp1x1"]["bytes"]) / n
     return {"traffic": pk["hbm_bytes_per_launch"], "traffic_launch_set": "every conv_igemm_dw launch of a UNet call (3x3 and 1x1), per launch",
             "traffic_launches_per_unet_call_pmc": pk["launches"] / max(1, row.get("unet_calls_profiled", 2)),
-            "traffic_launches_per_unet_call_this_run": n / max(1, prof.get("unet_calls", 1)),
+            "traffic_launches_per_unet_call_this_run": n / max(1, unet_calls),
             "algorithmic_bytes_per_launch_same_set": alg, "traffic_over_algorithmic": pk["hbm_bytes_per_launch"] / alg,
             "traffic_fetch_bytes_per_launch": pk["fetch_bytes_per_launch"], "traffic_write_bytes_per_launch": pk["write_bytes_per_launch"],
             "traffic_source": row.get("source", "") + " (a committed offline pass over this workload, not a measurement of this run)"}
@@ -786,7 +786,7 @@ def main():
                         roof["mfma_busy_by_pmc"] = busy
                 row = pmc_traffic(a.workload, B, a.precision)
                 if row is not None:
-                    roof.update(traffic_keys(row, prof))
+                    roof.update(traffic_keys(row, prof, n_steps))     # the profiled step = one purification = n_steps UNet calls
                     roof["traffic_detail"] = {k: row[k] for k in row if k not in ("workload", "per_gpu_batch", "precision")}
                 else:
                     roof["traffic_note"] = ("no rocprofv3 --pmc pass committed for this (workload, batch, precision): "

@@ -180,12 +180,18 @@ def test_guided_loop_at_batch_64_reproduces_the_golden_samples_bit_for_bit():
     pur = Purifier(guided_full("f16sr"), "guided", DEV)
     small = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
     fill = torch.rand(62, 3, 256, 256, generator=torch.Generator().manual_seed(3)) * 2 - 1
-    big = pur.sde(torch.cat([g["x0"], fill]), g["t"], g["dt"], seed=g["noise_seed"], sample0=0)[:2].cpu()
+    whole = pur.sde(torch.cat([g["x0"], fill]), g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    big = whole[:2]
     torch.cuda.empty_cache()
     err = maxabs(big, g["out"])
     print(f"guided 100-step loop [f16sr] at B=64: first two samples vs reference modules {err:.3e}; equal to the B=2 run: {torch.equal(big, small)}")
     assert torch.equal(big, small)
     assert err < 1e-3, err
+    # round 6 (verdict r5, weak 1e): not only the LEADING samples - the last two of the batch (the tail of the last tile of every launch)
+    # and two from the middle equal their own B=2 runs at the same global sample indices
+    for lo in (62, 31):
+        alone = pur.sde(torch.cat([g["x0"], fill])[lo:lo + 2], g["t"], g["dt"], seed=g["noise_seed"], sample0=lo).cpu()
+        assert torch.equal(whole[lo:lo + 2], alone), lo
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x2", "f16sr"])
@@ -336,11 +342,16 @@ def test_ncsnpp_loop_at_batch_256_reproduces_the_golden_samples_bit_for_bit():
     pur = Purifier(ncsnpp_full("f16sr"), "ncsnpp", DEV)
     small = pur.sde(g["x0"], g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
     fill = torch.rand(252, 3, 32, 32, generator=torch.Generator().manual_seed(3)) * 2 - 1
-    big = pur.sde(torch.cat([g["x0"], fill]), g["t"], g["dt"], seed=g["noise_seed"], sample0=0)[:4].cpu()
+    whole = pur.sde(torch.cat([g["x0"], fill]), g["t"], g["dt"], seed=g["noise_seed"], sample0=0).cpu()
+    big = whole[:4]
     err = maxabs(big, g["out"])
     print(f"NCSN++ 100-step loop [f16sr] at B=256: first four samples vs reference modules {err:.3e}; equal to the B=4 run: {torch.equal(big, small)}")
     assert torch.equal(big, small)
     assert err < 1e-3, err
+    # round 6: the LAST four samples of the batch and four from its middle equal their own B=4 runs at the same global sample indices
+    for lo in (252, 126):
+        alone = pur.sde(torch.cat([g["x0"], fill])[lo:lo + 4], g["t"], g["dt"], seed=g["noise_seed"], sample0=lo).cpu()
+        assert torch.equal(whole[lo:lo + 4], alone), lo
 
 
 @pytest.mark.batch_invariant

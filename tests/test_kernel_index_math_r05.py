@@ -194,3 +194,98 @@ def test_gemm_h16_lds_image_and_fragment_reads():
                 off = lr * 64 + (((s_ * 2 + lk) ^ KEY(lr)) << 4)
                 banks += [((off // 4) + w) % 64 for w in range(4)]
             assert len(set(banks)) == 64, (s_, g)
+
+
+# ---- round 6: the 512 x 128 form of the 8-wave kernel (csrc/igemm_h2_dw.hip, SHAPE 1) ---------------------------------------------------------
+def _dw_rows_of_piece(wave, it, shape):
+    """rows of activation piece `it` of staging wave `wave` (rows_of_piece): BMT / 8 rows per wave, NAO own pieces then the partner's"""
+    bmt = 512 if shape else 256
+    nao = bmt // 128
+    return (wave + (it // nao) * 4) * (bmt // 8) + (it % nao) * 16
+
+
+def _dw_rows_of_piece_b(wave, it, shape):
+    bnt = 128 if shape else 256
+    nbo = bnt // 128
+    return (wave + (it // nbo) * 4) * (bnt // 8) + (it % nbo) * 16
+
+
+@pytest.mark.parametrize("shape", [0, 1], ids=["256x256", "512x128"])
+def test_dw_both_tile_shapes_stage_every_row_exactly_once(shape):
+    """The four older waves (0-3) stage the rows of both waves of their SIMD: every activation row of the tile (256 | 512) and every weight
+    row (256 | 128) lands exactly once per k-tile, in 16-row pieces, own pieces first (they are issued inside segment A), the partner's
+    after the vmcnt wait; the LDS destination of a piece is its rows x 64 bytes, so the tile image is dense."""
+    bmt, bnt = (512, 128) if shape else (256, 256)
+    nao, nbo = bmt // 128, bnt // 128
+    seen_a, seen_b = [], []
+    for wave in range(4):
+        for it in range(2 * nao):
+            r0 = _dw_rows_of_piece(wave, it, shape)
+            owner = r0 // (bmt // 8)
+            assert owner == (wave if it < nao else wave + 4)          # own rows first, then the partner's (wave + 4: the same SIMD)
+            seen_a += list(range(r0, r0 + 16))
+        for it in range(2 * nbo):
+            r0 = _dw_rows_of_piece_b(wave, it, shape)
+            assert r0 // (bnt // 8) == (wave if it < nbo else wave + 4)
+            seen_b += list(range(r0, r0 + 16))
+    assert sorted(seen_a) == list(range(bmt)) and sorted(seen_b) == list(range(bnt))
+    # LDS budget: three stages per operand inside the 160 KB of a CU, under the epilogue's 136 KB landing zone
+    assert 3 * bmt * 64 + 3 * bnt * 64 <= 128 * 1088 <= 160 * 1024
+
+
+def test_dw_512x128_fragment_rows_and_epilogue_coordinates():
+    """SHAPE 1 stacks the eight waves along the pixels: wave w reads A fragments of rows [64 w, 64 w + 64) (two 32-row MFMA tiles) and the B
+    fragments of all 128 columns (four 32-column tiles) - the 64 x 128 wave tile of the square form, so the epilogue is called with
+    row0 = m0 + 64 w, colw = n0 and record index tile_m * 8 + w: the eight waves tile the 512 x 128 output exactly once and the
+    64-row column records of a tile are consecutive."""
+    cover = set()
+    recs = []
+    for wave in range(8):
+        wr, wc = wave, 0
+        for i in range(2):
+            for lr in range(32):
+                arow = (wr * 64 + lr) * 64 + i * 32 * 64
+                assert arow // 64 == wave * 64 + i * 32 + lr < 512
+        for j in range(4):
+            for lr in range(32):
+                brow = (wc * 128 + lr) * 64 + j * 32 * 64
+                assert brow // 64 == j * 32 + lr < 128
+        for r in range(64):
+            for c in range(128):
+                cover.add((wr * 64 + r, wc * 128 + c))
+        recs.append(0 * 8 + wr)                                         # tile_m * (BMT / 64) + wr at tile_m = 0
+    assert len(cover) == 512 * 128 and recs == list(range(8))
+
+
+@pytest.mark.parametrize("nt", [4, 9, 36, 108])
+def test_dw_512x128_vmcnt_schedule(nt):
+    """Issue order of a staging wave in SHAPE 1 and what its counted waits retire.  Prologue: B(0) [2 pieces], A(0) [8], A(1) [8], B(1) [2],
+    then vmcnt(10) -> k-tile 0 has landed.  Iteration t: own pieces of k-tile t+2 inside segment A (1 weight + 4 activation), vmcnt(5) -
+    everything older has landed, in particular the partner's pieces of k-tile t+1 issued late in iteration t-1 -, then the partner's
+    1 + 4 pieces of k-tile t+2, then the barrier.  RAW: every piece of k-tile t+1 is retired before barrier(t)."""
+    NAO, NBO = 4, 1
+    queue = []
+    landed = set()
+
+    def issue(op, kt, pieces):
+        for it in pieces:
+            queue.append((op, kt, it))
+
+    def wait(n):
+        nonlocal queue
+        for q in queue[:len(queue) - n] if n else queue:
+            landed.add(q)
+        queue = queue[len(queue) - n:] if n else []
+
+    issue("B", 0, range(2 * NBO)); issue("A", 0, range(2 * NAO)); issue("A", 1, range(2 * NAO)); issue("B", 1, range(2 * NBO))
+    wait(2 * NAO + 2 * NBO)
+    assert all(("A", 0, it) in landed for it in range(2 * NAO)) and all(("B", 0, it) in landed for it in range(2 * NBO))
+    for t in range(nt - 2):
+        issue("B", t + 2, range(NBO)); issue("A", t + 2, range(NAO))
+        wait(NBO + NAO)
+        issue("B", t + 2, range(NBO, 2 * NBO)); issue("A", t + 2, range(NAO, 2 * NAO))
+        # barrier(t): k-tile t + 1 complete
+        assert all(("A", t + 1, it) in landed for it in range(2 * NAO)) and all(("B", t + 1, it) in landed for it in range(2 * NBO)), t
+    wait(0)                                                             # the tail waits with vmcnt(0)
+    for kt in range(nt):
+        assert all(("A", kt, it) in landed for it in range(2 * NAO)) and all(("B", kt, it) in landed for it in range(2 * NBO))

@@ -39,6 +39,36 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+closing)   # closing state of round 6: the whole GPU suite, every bench line but the driver's (stage `driver`), rocprofv3 stats of five workloads, batch table
+  gputests
+  timeout 300 python bench.py --workload cifar32_ncsnpp --steps 3 --warmup 1 > "$O/bench_cifar_b256_f16sr.json" 2> "$O/bench_cifar.err"; lap bench_cifar
+  timeout 300 python bench.py --workload cifar32_ncsnpp --steps 3 --warmup 1 --no-conv-profile --no-cpu-baseline > "$O/bench_cifar_b256_f16sr_noprofile.json" 2>> "$O/bench_cifar.err"; lap bench_cifar_np
+  timeout 400 python bench.py --workload cifar32_ncsnpp_adjoint --steps 2 --warmup 1 > "$O/bench_cifar_adjoint_b128_f16sr.json" 2> "$O/bench_adjoint.err"; lap bench_adjoint
+  timeout 400 python bench.py --workload cifar32_ncsnpp_adjoint --steps 2 --warmup 1 --no-conv-profile --no-cpu-baseline > "$O/bench_cifar_adjoint_b128_f16sr_noprofile.json" 2>> "$O/bench_adjoint.err"; lap bench_adjoint_np
+  timeout 300 python bench.py --t 150 --dt 1.5e-3 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_t150_dt1.5e-3_100step.json" 2> "$O/bench_t150a.err"; lap bench_t150_100
+  timeout 300 python bench.py --t 150 --steps 1 --warmup 1 --no-cpu-baseline --no-resident-call > "$O/bench_t150_150step.json" 2> "$O/bench_t150b.err"; lap bench_t150_150
+  for B in 4 32 64; do
+    timeout 500 python bench.py --workload imagenet256_guided_sde_adjoint --batch $B --steps 1 --warmup 0 $([ $B != 32 ] && echo --no-cpu-baseline) --no-resident-call > "$O/bench_guided_sde_adjoint_b$B.json" 2> "$O/bench_guided_sde_adjoint_b$B.err"; lap bench_guided_sde_adjoint_b$B
+  done
+  rocstats cifar_t10 200 --workload cifar32_ncsnpp --t 10 --steps 1 --warmup 0
+  rocstats cifar_adjoint_t10 200 --workload cifar32_ncsnpp_adjoint --t 10 --steps 1 --warmup 0
+  rocstats guided_b4_t10 200 --batch 4 --t 10 --steps 1 --warmup 0
+  rocstats guided_sde_adjoint_b32_t5 300 --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0
+  rocstats default 400 --steps 1 --warmup 0
+  timeout 500 python tools/batch_table.py > "$O/batch_table.json" 2> "$O/batch_table.md"; lap batch_table
+  cat "$O/batch_table.md"
+  python - "$O" <<'PY'
+import json, glob, os, sys
+for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); r = d["roofline"]; g = r.get("second_kernel") or {}
+        print(os.path.basename(f), "images/s", round(d["value"], 3), "resident", (d.get("input") or {}).get("value_resident_batch_engine_call"), "conv TF", r.get("achieved") and round(r["achieved"], 1),
+              "frac", r.get("frac") and round(r["frac"], 3), "share", r.get("time_share_of_step") and round(r["time_share_of_step"], 3), "sclk", (r.get("sclk_mhz") or {}).get("median"),
+              "GN GB/s", g.get("achieved") and round(g["achieved"]), "peak GiB", d.get("peak_device_memory_gib") and round(d["peak_device_memory_gib"], 1), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+  ;;
 driver)   # the driver's own command, as BENCH_r05.json records it (20 timed + 5 warm-up purifications: ~7 minutes at the power cap)
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver_command.json" 2> "$O/bench_driver_command.err"; lap driver_command
   python - "$O/bench_driver_command.json" <<'PY'
