@@ -12,6 +12,7 @@
 // block; forward mean-2x2 -> 0.25 * dy[y/2][x/2]; the FIR resamplers of `fir: True` networks (modes 3 / 4,
 // csrc/norm.hip fir_up2 / fir_down2) -> the transposed 4-tap stencils of fir_adjoint below.
 #include "dp_common.h"
+#include "dp_tune.h"
 
 namespace {
 
@@ -44,17 +45,29 @@ struct BwdArgs {
     const float* add1;
     const float* add2;
     float add_scale;
+    // round 6 (DP_GNB_NT): non-temporal hints on the streaming accesses of the three-launch form - bit 0 the loads of x / dy / the addend
+    // (un-resampled dy only), bit 1 the stores of dx.  Same bits.  Set by tensor size: a gradient map far beyond the 256 MB of last-level
+    // cache gains nothing from occupying it between the statistics pass and the apply pass.
+    int nt;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4s(const float* p, int nt) {     // a streaming quad: with the non-temporal hint when nt & 1
+    return (nt & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
+}
+__device__ __forceinline__ void st4s(float* p, f32x4 v, int nt) {
+    if (nt & 2) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    else *reinterpret_cast<f32x4*>(p) = v;
+}
 typedef _Float16 half4q __attribute__((ext_vector_type(4)));
 // a channel quad of the forward's INPUT tensor in its stored format (element index e from the tensor's base)
-__device__ __forceinline__ f32x4 ld4x(const float* base, size_t e, int x_fmt) {
+__device__ __forceinline__ f32x4 ld4x(const float* base, size_t e, int x_fmt, int nt = 0) {
     if (x_fmt) {
-        const half4q h = *reinterpret_cast<const half4q*>(reinterpret_cast<const _Float16*>(base) + e);
+        const half4q* src = reinterpret_cast<const half4q*>(reinterpret_cast<const _Float16*>(base) + e);
+        const half4q h = (nt & 1) ? __builtin_nontemporal_load(src) : *src;
         return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
     }
-    return ld4(base + e);
+    return ld4s(base + e, nt);
 }
 
 // Transposes of the FIR x2 resamplers (forward per axis, zero outside the image - csrc/norm.hip):
@@ -107,7 +120,7 @@ __device__ __forceinline__ f32x4 fir_adjoint(const float* dy, int b, int Ho, int
 template <bool FIR>
 __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, int c) {
     const int C = p.C4 * 4;
-    if (p.resample == 0) return ld4(p.dy + (((size_t)b * p.Ho + y) * p.Wo + x) * C + c);
+    if (p.resample == 0) return ld4s(p.dy + (((size_t)b * p.Ho + y) * p.Wo + x) * C + c, p.nt);
     if (p.resample == 1) {  // forward was nearest x2
         const float* r0 = p.dy + (((size_t)b * p.Ho + 2 * y) * p.Wo + 2 * x) * C + c;
         const f32x4 a = ld4(r0), b2 = ld4(r0 + C), c2 = ld4(r0 + (size_t)p.Wo * C), d = ld4(r0 + (size_t)p.Wo * C + C);
@@ -126,7 +139,7 @@ __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, 
 // returns dxh and xh for one channel quad of one input pixel
 template <bool FIR>
 __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, int y, int x, int c, f32x4& dxh, f32x4& xh) {
-    const f32x4 xv = (c < p.C1) ? ld4x(p.x1, pix * p.C1 + c, p.x_fmt) : ld4x(p.x2, pix * p.C2 + (c - p.C1), p.x_fmt);
+    const f32x4 xv = (c < p.C1) ? ld4x(p.x1, pix * p.C1 + c, p.x_fmt, p.nt) : ld4x(p.x2, pix * p.C2 + (c - p.C1), p.x_fmt, p.nt);
     const int g = c / p.cpg;
     const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
     const f32x4 ga = ld4(p.gamma + c), be = ld4(p.beta + c);
@@ -244,7 +257,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
             half8 hv;
 #pragma unroll
             for (int j = 0; j < 8; ++j) hv[j] = (_Float16)o[j >> 2][j & 3];
-            *reinterpret_cast<half8*>(reinterpret_cast<char*>(p.dx1) + ((size_t)qpix * C8 + c8) * 16) = hv;
+            half8* dsth = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.dx1) + ((size_t)qpix * C8 + c8) * 16);
+            if (p.nt & 2) __builtin_nontemporal_store(hv, dsth);
+            else *dsth = hv;
         } else if (p.out_fmt) {
             half8 hi, lo;
 #pragma unroll
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
             const size_t e = first ? pix * p.C1 + c : pix * p.C2 + (c - p.C1);
             const float* ad = first ? p.add1 : p.add2;
             if (ad) {
-                const f32x4 a0 = ld4(ad + e), a1 = ld4(ad + e + 4);
+                const f32x4 a0 = ld4s(ad + e, p.nt), a1 = ld4s(ad + e + 4, p.nt);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     o[0][j] += p.add_scale * a0[j];
@@ -270,8 +285,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
                 }
             }
             float* d = (first ? p.dx1 : p.dx2) + e;
-            *reinterpret_cast<f32x4*>(d) = o[0];
-            *reinterpret_cast<f32x4*>(d + 4) = o[1];
+            st4s(d, o[0], p.nt);
+            st4s(d + 4, o[1], p.nt);
         }
     }
 }
@@ -480,6 +495,14 @@ inline unsigned grid_cap(long long items, int block, int cap) {
     return (unsigned)g;
 }
 
+// DP_GNB_NT: -1 (default) by size - both hints from 800 MB of x + dy up -, 0 never, 1 | 2 | 3 forced
+int gnb_nt(int B, int H, int W, int C, int x_fmt) {
+    const int t = dp_tune(DP_T_GNB_NT);
+    if (t >= 0) return t & 3;
+    const double bytes = (double)B * H * W * C * (4.0 + (x_fmt ? 2.0 : 4.0));
+    return bytes >= 800e6 ? 3 : 0;
+}
+
 int fill_common(BwdArgs& p, const char* fn, const void* x1, int C1, const void* x2, int C2, int x_fmt, int B, int H, int W, int G,
                 const float* stats, const float* gamma, const float* beta, const float* fscale, const float* fshift,
                 int film_stride, int act, int resample, const float* fir4, const float* dy) {
@@ -518,6 +541,7 @@ extern "C" int dp_gn_bwd_stats(const void* x1, int C1, const void* x2, int C2, i
     DP_REQUIRE(partial && sums && nsplit > 0, "dp_gn_bwd_stats: scratch missing");
     DP_REQUIRE(p.C4 <= 1024 && G <= p.C4, "dp_gn_bwd_stats: C too wide");
     p.nsplit = nsplit; p.partial = partial; p.cpg4 = p.C4 / G;
+    p.nt = gnb_nt(B, H, W, C1 + C2, x_fmt) & 1;
     p.ppb = p.C4 >= 256 ? 1 : 256 / p.C4;
     const int block = p.C4 * p.ppb;
     hipStream_t s = (hipStream_t)stream;
@@ -543,6 +567,7 @@ extern "C" int dp_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, i
     DP_REQUIRE((!add1 || dp_aligned16(add1)) && (!add2 || (C2 > 0 && dp_aligned16(add2))), "dp_gn_bwd_apply: addend");
     p.sums = sums; p.dx1 = (float*)dx1; p.dx2 = dx2; p.out_fmt = out_fmt;
     p.add1 = add1; p.add2 = add2; p.add_scale = add_scale;
+    p.nt = gnb_nt(B, H, W, C1 + C2, x_fmt);
     const int border = out_fmt ? 1 : 0;
     const long long total = (long long)B * (H + 2 * border) * (W + 2 * border) * (p.C4 / 2);
     if (resample >= 3) hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);

@@ -159,6 +159,40 @@ def test_group_norm_bwd_one_pass_form_with_folded_skip_gradient(case):
     assert torch.equal(s1[0], g1[1])
 
 
+@pytest.mark.parametrize("x16", [False, True], ids=["fp32 tape", "fp16 tape"])
+def test_group_norm_bwd_three_launch_form_non_temporal_hints_same_bits(x16):
+    """Round 6: the statistics and apply passes of the three-launch GroupNorm backward take non-temporal hints on their streaming
+    accesses for gradient maps far beyond the last-level cache (DP_GNB_NT: -1 by size, 0 never, 3 forced).  Pure addressing hints:
+    the same bytes, for the fp32 output with both addends and for the fp16 operand output."""
+    from diffpure_amd import ops
+    B, H, W, C1, C2, G = 2, 32, 32, 128, 128, 32
+    C = C1 + C2
+    d = lambda t: None if t is None else t.to(DEV)
+    x, x2 = d(rnd(B, H, W, C1, seed=1) * 2 + 0.5), d(rnd(B, H, W, C2, seed=2) - 1.0)
+    gamma, beta = d(1 + 0.1 * rnd(C, seed=3)), d(0.1 * rnd(C, seed=4))
+    tab = d(0.3 * rnd(B, 2 * C, seed=5))
+    film = (tab[:, :C], tab[:, C:])
+    dy, ad, ad2 = d(rnd(B, H, W, C, seed=6)), d(rnd(B, H, W, C1, seed=7)), d(rnd(B, H, W, C2, seed=8))
+    st = ops.group_norm_stats(x, G, 1e-5, x2)
+    if x16:
+        x, x2 = x.half(), x2.half()
+    film1 = (tab[:, :C1].contiguous(), tab[:, C:C + C1].contiguous())
+    st1 = ops.group_norm_stats(x.float(), G, 1e-5)
+
+    def run():
+        a = ops.group_norm_bwd(x, G, gamma, beta, st, dy, x2=x2, film=film, act=True, addend=ad, addend2=ad2, addend_scale=0.7, one_pass=False)
+        b = ops.group_norm_bwd(x, G, gamma[:C1].contiguous(), beta[:C1].contiguous(), st1, dy[..., :C1].contiguous(), film=film1, act=True,
+                               split="h1", one_pass=False)
+        return [a[0], a[1], b[0]]
+
+    with ops.tuning(DP_GNB_NT=0):
+        base = run()
+    for nt in (1, 2, 3, -1):
+        with ops.tuning(DP_GNB_NT=nt):
+            got = run()
+        assert all(torch.equal(g, b) for g, b in zip(got, base)), nt
+
+
 @pytest.mark.parametrize("case", [(2, 16, 256, 1, "split"), (2, 64, 128, 2, "legacy"), (1, 256, 256, 4, "legacy"), (2, 64, 128, 2, "split")],
                          ids=str)
 def test_attention_bwd(case):

@@ -39,6 +39,14 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+gnbnt)   # non-temporal hints in the three-launch GroupNorm backward (ImageNet adjoint: 17.5 % of the step)
+  timeout 600 python -m pytest tests/test_gpu_grad.py -m gpu -q -x -k "group_norm_bwd" > "$O/gnbnt_tests.log" 2>&1; echo "rc=$?" >> "$O/gnbnt_tests.log"; lap gnbnt_tests
+  grep -E "passed|failed|^FAILED|^E  " "$O/gnbnt_tests.log" | head
+  for V in 0 -1 0 -1 3; do
+    DP_GNB_NT=$V timeout 400 python bench.py --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0 --no-conv-profile --no-cpu-baseline --no-resident-call > "$O/bench_gnbnt_$V.json" 2>> "$O/bench_ab.err"
+    val "$O/bench_gnbnt_$V.json" "guided_adj_b32_t5 DP_GNB_NT=$V" | cut -c1-100 | tee -a "$O/guided_adj_b32_t5_gnbnt_ab.log"
+  done; lap ab
+  ;;
 closing)   # closing state of round 6: the whole GPU suite, every bench line but the driver's (stage `driver`), rocprofv3 stats of five workloads, batch table
   gputests
   timeout 300 python bench.py --workload cifar32_ncsnpp --steps 3 --warmup 1 > "$O/bench_cifar_b256_f16sr.json" 2> "$O/bench_cifar.err"; lap bench_cifar
