@@ -27,6 +27,7 @@ enum DpTune {
     DP_T_GN_WG,            // DP_GN_WG (round 6): GroupNorm-apply over the fp16 stream cuts an output row across several workgroups while the launch has
                            // fewer workgroups than this (default 2048; 0 = always one workgroup per row, rounds 3-5); same bits
     DP_T_GNB_NT,           // DP_GNB_NT (round 6): non-temporal hints in the three-launch GroupNorm backward - -1 (default) by tensor size, 0 never, 1 | 2 | 3 forced; same bits
+    DP_T_GNB_LEAN,         // DP_GNB_LEAN (round 6): the lean apply pass of the three-launch GroupNorm backward (un-resampled, fp16 tape) - 0 off; same bits
     DP_T_COUNT
 };
 

@@ -14,6 +14,12 @@
 #include "dp_common.h"
 #include "dp_tune.h"
 
+// Round 6: the compiler's own mul + add contraction is OFF in this file and every fused multiply-add is spelled `fmaf` in ONE set of
+// helpers (gnb_quad, gnb_out, gnb_add below) that the statistics pass, the generic and the lean apply pass and the one-pass kernel share:
+// left to itself the compiler fused `dxh - m1 - xh * m2` (and half a dozen products of the chain) in one kernel and not in its twin, so two
+// forms of the same pass differed in the last bit of a third of their elements.
+#pragma clang fp contract(off)
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -136,6 +142,34 @@ __device__ __forceinline__ f32x4 load_da(const BwdArgs& p, int b, int y, int x, 
     return v;
 }
 
+// The arithmetic of the pass, spelled once.  xh = (x - mean) * rstd ; u = fma(fma(xh, gamma, beta), m, fh) ;
+// du = da * (sg * fma(u, 1 - sg, 1)) ; dxh = (du * m) * gamma ; dx = rstd * fma(-xh, m2, dxh - m1) ; dx = fma(add_scale, addend, dx)
+__device__ __forceinline__ void gnb_quad(bool act, f32x4 xv, f32x4 da, float mean, float rstd, f32x4 ga, f32x4 be, f32x4 m, f32x4 fh, f32x4& dxh,
+                                         f32x4& xh) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xh[j] = (xv[j] - mean) * rstd;
+        float du = da[j];
+        if (act) {
+            const float u = fmaf(fmaf(xh[j], ga[j], be[j]), m[j], fh[j]);
+            const float sg = dp_sigmoid_f(u);
+            du *= sg * fmaf(u, 1.f - sg, 1.f);
+        }
+        dxh[j] = (du * m[j]) * ga[j];
+    }
+}
+__device__ __forceinline__ f32x4 gnb_out(f32x4 dxh, f32x4 xh, float rstd, float m1, float m2) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = rstd * fmaf(-xh[j], m2, dxh[j] - m1);
+    return o;
+}
+__device__ __forceinline__ f32x4 gnb_add(f32x4 o, float scale, f32x4 a) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaf(scale, a[j], o[j]);
+    return o;
+}
+
 // returns dxh and xh for one channel quad of one input pixel
 template <bool FIR>
 __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, int y, int x, int c, f32x4& dxh, f32x4& xh) {
@@ -151,17 +185,7 @@ __device__ __forceinline__ void quad_grad(const BwdArgs& p, int b, size_t pix, i
         for (int j = 0; j < 4; ++j) m[j] = 1.f + fs[j];
     }
     const f32x4 da = load_da<FIR>(p, b, y, x, c);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        xh[j] = (xv[j] - mean) * rstd;
-        float du = da[j];
-        if (p.act) {
-            const float u = (xh[j] * ga[j] + be[j]) * m[j] + fh[j];
-            const float sg = dp_sigmoid_f(u);
-            du *= sg * (1.f + u * (1.f - sg));
-        }
-        dxh[j] = du * m[j] * ga[j];
-    }
+    gnb_quad(p.act != 0, xv, da, mean, rstd, ga, be, m, fh, dxh, xh);
 }
 
 template <bool FIR>
@@ -182,6 +206,71 @@ __global__ void gn_bwd_stats_kernel(BwdArgs p) {
         s += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
         q += (dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3]);
     }
+    red_s[t] = s;
+    red_q[t] = q;
+    __syncthreads();
+    if (t < p.G) {
+        double ds = 0.0, dq = 0.0;
+        for (int l = 0; l < p.ppb; ++l)
+            for (int k = 0; k < p.cpg4; ++k) {
+                const int idx = l * p.C4 + t * p.cpg4 + k;
+                ds += red_s[idx];
+                dq += red_q[idx];
+            }
+        float* dst = p.partial + ((size_t)(b * p.nsplit + sp) * p.G + t) * 2;
+        dst[0] = (float)ds;
+        dst[1] = (float)dq;
+    }
+}
+
+// LEAN statistics pass (round 6; see the lean apply pass below): no resampling, plain fp16 tape.  Same thread geometry, same per-thread
+// accumulation order and the same reduction as gn_bwd_stats_kernel - hence the same partial sums bit for bit - but the quad's constants
+// (statistics, gamma, beta, FiLM) are loaded ONCE, nothing divides inside the loop, and two pixels are in flight per iteration.
+template <bool ACT>
+__global__ void gn_bwd_stats_lean_kernel(BwdArgs p) {
+    __shared__ float red_s[1024];
+    __shared__ float red_q[1024];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / p.nsplit, sp = blockIdx.x - b * p.nsplit;
+    const int HW = p.H * p.W;
+    const int per = (HW + p.nsplit - 1) / p.nsplit;
+    const int p0 = sp * per, p1 = min(HW, p0 + per);
+    const int pl = t / p.C4, cq = t - pl * p.C4;
+    const int c = cq * 4, C = p.C4 * 4;
+    const bool first = c < p.C1;
+    const int Cs = first ? p.C1 : p.C2, cs = first ? c : c - p.C1;
+    const _Float16* xs = reinterpret_cast<const _Float16*>(first ? p.x1 : p.x2) + (size_t)b * HW * Cs + cs;
+    const float* dys = p.dy + (size_t)b * HW * C + c;
+    const int g = c / p.cpg;
+    const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+    const f32x4 ga = ld4(p.gamma + c), be = ld4(p.beta + c);
+    f32x4 m = {1.f, 1.f, 1.f, 1.f}, fh = {0.f, 0.f, 0.f, 0.f};
+    if (p.fscale) {
+        const f32x4 fs = ld4(p.fscale + (size_t)b * p.film_stride + c);
+        fh = ld4(p.fshift + (size_t)b * p.film_stride + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = 1.f + fs[j];
+    }
+    auto ldx = [&](int px) {
+        const half4q* src = reinterpret_cast<const half4q*>(xs + (size_t)px * Cs);
+        const half4q h = (p.nt & 1) ? __builtin_nontemporal_load(src) : *src;
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    };
+    float s = 0.f, q = 0.f;
+    auto acc = [&](f32x4 xv, f32x4 da) {
+        f32x4 dxh, xh;
+        gnb_quad(ACT, xv, da, mean, rstd, ga, be, m, fh, dxh, xh);
+        s += (dxh[0] + dxh[1]) + (dxh[2] + dxh[3]);
+        q += (dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3]);
+    };
+    int px = p0 + pl;
+    for (; px + p.ppb < p1; px += 2 * p.ppb) {              // two pixels in flight, accumulated in pixel order
+        const f32x4 xa = ldx(px), xb = ldx(px + p.ppb);
+        const f32x4 da = ld4s(dys + (size_t)px * C, p.nt), db = ld4s(dys + (size_t)(px + p.ppb) * C, p.nt);
+        acc(xa, da);
+        acc(xb, db);
+    }
+    if (px < p1) acc(ldx(px), ld4s(dys + (size_t)px * C, p.nt));
     red_s[t] = s;
     red_q[t] = q;
     __syncthreads();
@@ -250,8 +339,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
             const int g = c / p.cpg;
             const float m1 = p.sums[(b * p.G + g) * 2], m2 = p.sums[(b * p.G + g) * 2 + 1];
             const float rstd = p.stats[(b * p.G + g) * 2 + 1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[h][j] = rstd * (dxh[j] - m1 - xh[j] * m2);
+            o[h] = gnb_out(dxh, xh, rstd, m1, m2);
         }
         if (p.out_fmt == 2) {       // plain fp16 operand ("h1") of a one-pass fp16 x fp16 dgrad convolution
             half8 hv;
@@ -278,15 +366,122 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(BwdArgs p) {
             const float* ad = first ? p.add1 : p.add2;
             if (ad) {
                 const f32x4 a0 = ld4s(ad + e, p.nt), a1 = ld4s(ad + e + 4, p.nt);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[0][j] += p.add_scale * a0[j];
-                    o[1][j] += p.add_scale * a1[j];
-                }
+                o[0] = gnb_add(o[0], p.add_scale, a0);
+                o[1] = gnb_add(o[1], p.add_scale, a1);
             }
             float* d = (first ? p.dx1 : p.dx2) + e;
             st4s(d, o[0], p.nt);
             st4s(d + 4, o[1], p.nt);
+        }
+    }
+}
+
+
+// ---- LEAN apply pass (round 6) ------------------------------------------------------------------------------------------------------
+// The generic apply kernel above spends most of its issue slots OUTSIDE the gradient arithmetic: three 64-bit div / mod pairs per work item
+// to find (sample, pixel, channel octet), a re-load of gamma / beta / FiLM / statistics / group sums for every item, and the format
+// branches of every operand - ~420 vector instructions per 64 bytes of HBM traffic at 106 registers, i.e. a kernel that is VALU-bound below
+// 5 TB/s (the 256^2 maps of the guided UNet's adjoint ran it at 2.8-3.9 TB/s: 11.3 % of the ImageNet adjoint step).  This form serves the hot
+// case - no resampling, plain fp16 tape (x_fmt 1), fewer than 2^31 items, a channel-octet count that divides the thread count of the grid -
+// with the SAME arithmetic (gnb_quad / gnb_out / gnb_add are shared with it: identical bits, tests/test_gpu_grad.py) and
+//   * a thread keeps ONE channel octet for its whole life: gamma / beta once, the per-sample values (mean, rstd, the two group sums, the
+//     FiLM rows) re-loaded only when its pixel walk crosses into the next sample;
+//   * the pixel walk is incremental in (sample, y, x) - no division in the loop;
+//   * OUTF / ADD are template parameters; the zero border of the operand form is written by a short second loop.
+// OUTF: 0 = fp32 dx (two sources, optional addends), 2 = the zero-bordered plain-fp16 operand (single source)
+template <int OUTF, bool ADD, bool ACT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_lean_kernel(BwdArgs p, int C8, int PS, int dB, int dY, int dX) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int c8 = gid % C8, pl = gid / C8;                    // this thread's channel octet and its first pixel (of B * H * W)
+    const int c = c8 * 8, C = C8 * 8;
+    const int HW = p.H * p.W;
+    const int total = p.B * HW;
+    const bool first = c < p.C1;
+    const int Cs = first ? p.C1 : p.C2, cs = first ? c : c - p.C1;      // source tensor of this octet (the split C1 is a multiple of 8)
+    const _Float16* xs = reinterpret_cast<const _Float16*>(first ? p.x1 : p.x2);
+    const f32x4 ga0 = ld4(p.gamma + c), ga1 = ld4(p.gamma + c + 4), be0 = ld4(p.beta + c), be1 = ld4(p.beta + c + 4);
+    const int g0 = c / p.cpg, g1 = (c + 4) / p.cpg;
+    int b = pl / HW, rem = pl - b * HW;
+    int y = rem / p.W, x = rem - y * p.W;
+    int cur_b = -1;
+    float mean0 = 0.f, rstd0 = 0.f, mean1 = 0.f, rstd1 = 0.f, s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
+    f32x4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = m0, fh0 = {0.f, 0.f, 0.f, 0.f}, fh1 = fh0;
+    for (int px = pl; px < total; px += PS) {
+        if (b != cur_b) {                                      // crossed into another sample: its statistics, group sums and FiLM rows
+            cur_b = b;
+            const float* st = p.stats + (size_t)b * p.G * 2;
+            const float* su = p.sums + (size_t)b * p.G * 2;
+            mean0 = st[g0 * 2]; rstd0 = st[g0 * 2 + 1]; mean1 = st[g1 * 2]; rstd1 = st[g1 * 2 + 1];
+            s10 = su[g0 * 2]; s20 = su[g0 * 2 + 1]; s11 = su[g1 * 2]; s21 = su[g1 * 2 + 1];
+            if (p.fscale) {
+                const f32x4 a0 = ld4(p.fscale + (size_t)b * p.film_stride + c), a1 = ld4(p.fscale + (size_t)b * p.film_stride + c + 4);
+                fh0 = ld4(p.fshift + (size_t)b * p.film_stride + c);
+                fh1 = ld4(p.fshift + (size_t)b * p.film_stride + c + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m0[j] = 1.f + a0[j];
+                    m1[j] = 1.f + a1[j];
+                }
+            }
+        }
+        const size_t pix = (size_t)px;
+        const half8* xp = reinterpret_cast<const half8*>(xs + pix * Cs + cs);
+        const half8 xh8 = (p.nt & 1) ? __builtin_nontemporal_load(xp) : *xp;
+        const float* dyp = p.dy + pix * C + c;
+        const f32x4 d0 = ld4s(dyp, p.nt), d1 = ld4s(dyp + 4, p.nt);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        if (ADD) {
+            const float* ad = (first ? p.add1 : p.add2) + pix * Cs + cs;
+            a0 = ld4s(ad, p.nt);
+            a1 = ld4s(ad + 4, p.nt);
+        }
+        const f32x4 x0 = {(float)xh8[0], (float)xh8[1], (float)xh8[2], (float)xh8[3]}, x1 = {(float)xh8[4], (float)xh8[5], (float)xh8[6], (float)xh8[7]};
+        f32x4 dxh0, xh0, dxh1, xh1, o0, o1;
+        gnb_quad(ACT, x0, d0, mean0, rstd0, ga0, be0, m0, fh0, dxh0, xh0);
+        gnb_quad(ACT, x1, d1, mean1, rstd1, ga1, be1, m1, fh1, dxh1, xh1);
+        o0 = gnb_out(dxh0, xh0, rstd0, s10, s20);
+        o1 = gnb_out(dxh1, xh1, rstd1, s11, s21);
+        if (OUTF == 2) {
+            half8 hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hv[j] = (_Float16)o0[j];
+                hv[4 + j] = (_Float16)o1[j];
+            }
+            const size_t qpix = ((size_t)b * (p.H + 2) + y + 1) * (p.W + 2) + x + 1;
+            half8* dst = reinterpret_cast<half8*>(reinterpret_cast<char*>(p.dx1) + (qpix * C8 + c8) * 16);
+            if (p.nt & 2) __builtin_nontemporal_store(hv, dst);
+            else *dst = hv;
+        } else {
+            if (ADD) {
+                o0 = gnb_add(o0, p.add_scale, a0);
+                o1 = gnb_add(o1, p.add_scale, a1);
+            }
+            float* d = (first ? p.dx1 : p.dx2) + pix * Cs + cs;
+            st4s(d, o0, p.nt);
+            st4s(d + 4, o1, p.nt);
+        }
+        // the next pixel of this thread: px + PS = (dB samples, dY rows, dX columns) further, carried without a division
+        x += dX;
+        if (x >= p.W) { x -= p.W; ++y; }
+        y += dY;
+        if (y >= p.H) { y -= p.H; ++b; }
+        b += dB;
+    }
+    if (OUTF == 2) {                                           // zero border of the operand: frame pixels of every sample, this grid's octets
+        const int Wq = p.W + 2, Hq = p.H + 2;
+        const int nb = 2 * Wq + 2 * p.H;
+        half8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+        for (int f = pl; f < p.B * nb; f += PS) {
+            const int bb = f / nb, r = f - bb * nb;
+            int yy, xx;
+            if (r < Wq) { yy = 0; xx = r; }
+            else if (r < 2 * Wq) { yy = Hq - 1; xx = r - Wq; }
+            else { const int k = r - 2 * Wq; yy = 1 + (k >> 1); xx = (k & 1) ? Wq - 1 : 0; }
+            const size_t qpix = ((size_t)bb * Hq + yy) * Wq + xx;
+            *reinterpret_cast<half8*>(reinterpret_cast<char*>(p.dx1) + (qpix * C8 + c8) * 16) = z;
         }
     }
 }
@@ -306,6 +501,7 @@ struct FusedArgs {
     const float* add2;
     float add_scale;            // dx += add_scale * add
     int CB, QB, PL;             // channels / quads per block, pixel lanes (512 / QB)
+    int lean;                   // DP_GNB_LEAN: 1 = constants once + all loads up front (round 6), 0 = rounds 4-5's item-by-item loop (A/B; same bits)
 };
 
 template <int ITEMS>
@@ -323,14 +519,54 @@ __global__ __launch_bounds__(512) void gn_bwd_fused_kernel(FusedArgs a) {
     const int c = cb * a.CB + q * 4;                    // this thread's channel quad (one group: cpg % 4 == 0)
     f32x4 dxh[ITEMS], xh[ITEMS];
     float s = 0.f, sq = 0.f;
+    if (!a.lean) {
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        const int px = pl + k * a.PL;
-        if (px < HW) {
-            const int y = px / p.W, x = px - y * p.W;
-            quad_grad<false>(p, b, (size_t)b * HW + px, y, x, c, dxh[k], xh[k]);
-            s += (dxh[k][0] + dxh[k][1]) + (dxh[k][2] + dxh[k][3]);
-            sq += (dxh[k][0] * xh[k][0] + dxh[k][1] * xh[k][1]) + (dxh[k][2] * xh[k][2] + dxh[k][3] * xh[k][3]);
+        for (int k = 0; k < ITEMS; ++k) {
+            const int px = pl + k * a.PL;
+            if (px < HW) {
+                const int y = px / p.W, x = px - y * p.W;
+                quad_grad<false>(p, b, (size_t)b * HW + px, y, x, c, dxh[k], xh[k]);
+                s += (dxh[k][0] + dxh[k][1]) + (dxh[k][2] + dxh[k][3]);
+                sq += (dxh[k][0] * xh[k][0] + dxh[k][1] * xh[k][1]) + (dxh[k][2] * xh[k][2] + dxh[k][3] * xh[k][3]);
+            }
+        }
+    } else {   // round 6: the quad's constants are loaded ONCE (a thread keeps its channel quad and its sample), and ALL of the thread's x / dy
+        // loads are issued before the first use (rounds 4-5 went through quad_grad per item: constants re-loaded behind every `px < HW`
+        // branch, a division per item, one item's loads waited for before the next item's were issued).  Same arithmetic (gnb_quad).
+        const bool first = c < p.C1;
+        const int g = c / p.cpg;
+        const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+        const f32x4 ga = ld4(p.gamma + c), be = ld4(p.beta + c);
+        f32x4 m = {1.f, 1.f, 1.f, 1.f}, fh = {0.f, 0.f, 0.f, 0.f};
+        if (p.fscale) {
+            const f32x4 fs = ld4(p.fscale + (size_t)b * p.film_stride + c);
+            fh = ld4(p.fshift + (size_t)b * p.film_stride + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = 1.f + fs[j];
+        }
+        f32x4 xv[ITEMS], da[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int px = pl + k * a.PL;
+            if (px < HW) {
+                const size_t pix = (size_t)b * HW + px;
+                xv[k] = first ? ld4x(p.x1, pix * p.C1 + c, p.x_fmt) : ld4x(p.x2, pix * p.C2 + (c - p.C1), p.x_fmt);
+                if (p.resample == 0) {
+                    da[k] = ld4(p.dy + pix * (size_t)(p.C4 * 4) + c);
+                } else {
+                    const int y = px / p.W, x = px - y * p.W;
+                    da[k] = load_da<false>(p, b, y, x, c);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int px = pl + k * a.PL;
+            if (px < HW) {
+                gnb_quad(p.act != 0, xv[k], da[k], mean, rstd, ga, be, m, fh, dxh[k], xh[k]);
+                s += (dxh[k][0] + dxh[k][1]) + (dxh[k][2] + dxh[k][3]);
+                sq += (dxh[k][0] * xh[k][0] + dxh[k][1] * xh[k][1]) + (dxh[k][2] * xh[k][2] + dxh[k][3] * xh[k][3]);
+            }
         }
     }
     red_s[t] = s;
@@ -374,18 +610,14 @@ __global__ __launch_bounds__(512) void gn_bwd_fused_kernel(FusedArgs a) {
     for (int k = 0; k < ITEMS; ++k) {
         const int px = pl + k * a.PL;
         if (px >= HW) continue;
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rstd * (dxh[k][j] - m1 - xh[k][j] * m2);
+        f32x4 o = gnb_out(dxh[k], xh[k], rstd, m1, m2);
         const size_t pix = (size_t)b * HW + px;
         if (p.out_fmt == 0) {
             const bool first = c < p.C1;
             float* d = first ? p.dx1 + pix * p.C1 + c : p.dx2 + pix * p.C2 + (c - p.C1);
             const float* ad = first ? (a.add1 ? a.add1 + pix * p.C1 + c : nullptr) : (a.add2 ? a.add2 + pix * p.C2 + (c - p.C1) : nullptr);
             if (ad) {
-                const f32x4 e = ld4(ad);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] += a.add_scale * e[j];
+                o = gnb_add(o, a.add_scale, ld4(ad));
             }
             *reinterpret_cast<f32x4*>(d) = o;
         } else {
@@ -545,7 +777,10 @@ extern "C" int dp_gn_bwd_stats(const void* x1, int C1, const void* x2, int C2, i
     p.ppb = p.C4 >= 256 ? 1 : 256 / p.C4;
     const int block = p.C4 * p.ppb;
     hipStream_t s = (hipStream_t)stream;
-    if (resample >= 3) hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
+    if (dp_tune(DP_T_GNB_LEAN) != 0 && resample == 0 && x_fmt == 1) {       // the lean form: same partial sums, bit for bit
+        if (act) hipLaunchKernelGGL(gn_bwd_stats_lean_kernel<true>, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
+        else hipLaunchKernelGGL(gn_bwd_stats_lean_kernel<false>, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
+    } else if (resample >= 3) hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
     else hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3((unsigned)(B * nsplit)), dim3(block), 0, s, p);
     const double inv = 1.0 / ((double)H * W * p.cpg);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, partial, B, nsplit, G, inv, sums);
@@ -570,6 +805,39 @@ extern "C" int dp_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, i
     p.nt = gnb_nt(B, H, W, C1 + C2, x_fmt);
     const int border = out_fmt ? 1 : 0;
     const long long total = (long long)B * (H + 2 * border) * (W + 2 * border) * (p.C4 / 2);
+    {   // the lean form (DP_GNB_LEAN, default 1): un-resampled, fp16 tape, fp32 or plain-fp16-operand output - identical bits
+        const int C8 = p.C4 / 2;
+        const long long items = (long long)B * H * W * C8;
+        if (dp_tune(DP_T_GNB_LEAN) != 0 && resample == 0 && x_fmt == 1 && (out_fmt == 0 || out_fmt == 2) && items < (1ll << 31) &&
+            (long long)B * (H + 2) * (W + 2) * C8 < (1ll << 31) && (long long)B * H * W < (1ll << 30)) {
+            // both addends or none (a concatenated source with ONE addend goes to the generic kernel)
+            const bool add = add1 != nullptr;
+            if (!(C2 > 0 && ((add1 != nullptr) != (add2 != nullptr))) && !(C2 == 0 && add2 != nullptr)) {
+                // workgroups: at most 4096, and a thread count that is a multiple of C8, so that a thread keeps its octet for life
+                long long wg = (items + 255) / 256;
+                if (wg > 4096) wg = 4096;
+                while (wg > 0 && (wg * 256) % C8 != 0) --wg;
+                if (wg > 0) {
+                    const int PS = (int)(wg * 256 / C8);
+                    const int HW = H * W;
+                    const int dB = PS / HW, remp = PS - dB * HW, dY = remp / W, dX = remp - dY * W;
+                    const dim3 g((unsigned)wg), blk(256);
+                    hipStream_t st_ = (hipStream_t)stream;
+#define GNB_LEAN(OUTF_, ADD_)                                                                                                      \
+    do {                                                                                                                         \
+        if (act) hipLaunchKernelGGL((gn_bwd_apply_lean_kernel<OUTF_, ADD_, true>), g, blk, 0, st_, p, C8, PS, dB, dY, dX);       \
+        else hipLaunchKernelGGL((gn_bwd_apply_lean_kernel<OUTF_, ADD_, false>), g, blk, 0, st_, p, C8, PS, dB, dY, dX);          \
+    } while (0)
+                    if (out_fmt == 2) GNB_LEAN(2, false);
+                    else if (add) GNB_LEAN(0, true);
+                    else GNB_LEAN(0, false);
+#undef GNB_LEAN
+                    DP_LAUNCH_CHECK("gn_bwd_apply_lean");
+                    return 0;
+                }
+            }
+        }
+    }
     if (resample >= 3) hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(grid_cap(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p);
     DP_LAUNCH_CHECK("gn_bwd_apply");
@@ -614,6 +882,7 @@ extern "C" int dp_gn_bwd_fused(const void* x1, int C1, const void* x2, int C2, i
     DP_REQUIRE(a.CB != 0, "dp_gn_bwd_fused: shape %dx%d x %d channels / %d groups does not fit one workgroup per channel block (ask dp_gn_bwd_fused_ok)", H, W, C, G);
     a.QB = a.CB / 4;
     a.PL = 512 / a.QB;
+    a.lean = dp_tune(DP_T_GNB_LEAN) != 0;
     a.add1 = add1; a.add2 = add2; a.add_scale = add_scale;
     a.b.dx1 = (float*)dx1; a.b.dx2 = dx2; a.b.out_fmt = out_fmt;
     const int items = (H * W + a.PL - 1) / a.PL;

@@ -159,6 +159,64 @@ def test_group_norm_bwd_one_pass_form_with_folded_skip_gradient(case):
     assert torch.equal(s1[0], g1[1])
 
 
+LEAN_CASES = [
+    # B, H, W, C1, C2, G, act, film rows (0 none / 1 shared / B per sample), addends (0 / 1 / 2)
+    (2, 32, 32, 128, 128, 32, True, 2, 2),        # concatenated skip, both addends, per-sample FiLM (an up-path ResBlock)
+    (3, 16, 16, 256, 0, 32, True, 3, 1),          # single source, one addend
+    (2, 6, 10, 64, 0, 16, True, 1, 0),            # ragged pixel count, groups of 4 channels (an octet spans two groups), shared FiLM row
+    (5, 8, 8, 512, 256, 32, False, 0, 2),         # C = 768: 96 channel octets (not a power of two), no activation (attention pre-norm)
+    (1, 64, 64, 64, 64, 32, True, 1, 0),          # one sample, groups of 4 channels
+    (4, 4, 4, 1024, 0, 32, True, 4, 1),           # more octets than a workgroup has threads / 2
+    (2, 16, 16, 128, 128, 32, True, 2, 1),        # ONE addend on a concatenated source: served by the generic kernel (must still agree)
+]
+
+
+@pytest.mark.parametrize("case", LEAN_CASES, ids=str)
+def test_group_norm_bwd_lean_apply_pass_same_bits(case):
+    """Round 6: the lean apply pass of the three-launch GroupNorm backward (gn_bwd_apply_lean_kernel: a thread keeps one channel octet,
+    per-sample values re-loaded only at sample boundaries, an incremental pixel walk without divisions, output format and addends as
+    template parameters) against the generic apply kernel it replaces on the un-resampled fp16-tape launches (DP_GNB_LEAN=0): identical
+    bytes for the fp32 output (with and without addends, two sources) and for the zero-bordered fp16 operand (border included)."""
+    from diffpure_amd import ops
+    B, H, W, C1, C2, G, act, frows, nadd = case
+    C = C1 + C2
+    d = lambda t: None if t is None else t.to(DEV)
+    x = d(rnd(B, H, W, C1, seed=1) * 2 + 0.5)
+    x2 = d(rnd(B, H, W, C2, seed=2) - 1.0) if C2 else None
+    gamma, beta = d(1 + 0.1 * rnd(C, seed=3)), d(0.1 * rnd(C, seed=4))
+    tab = d(0.3 * rnd(frows, 2 * C, seed=5)) if frows else None
+    film = None if tab is None else (tab[:, :C], tab[:, C:])
+    dy = d(rnd(B, H, W, C, seed=6))
+    ad = d(rnd(B, H, W, C1, seed=7)) if nadd >= 1 else None
+    ad2 = d(rnd(B, H, W, C2, seed=8)) if nadd >= 2 and C2 else None
+    x16, x2_16 = x.half(), None if x2 is None else x2.half()
+    st = ops.group_norm_stats(x16.float(), G, 1e-5, None if x2_16 is None else x2_16.float())     # statistics of the values the tape holds
+
+    def run():
+        outs = list(ops.group_norm_bwd(x16, G, gamma, beta, st, dy, x2=x2_16, film=film, act=act, addend=ad, addend2=ad2, addend_scale=0.7071,
+                                       one_pass=False))
+        if C2 == 0:
+            outs.append(ops.group_norm_bwd(x16, G, gamma, beta, st, dy, film=film, act=act, split="h1", one_pass=False)[0])
+        return [o for o in outs if o is not None]
+
+    with ops.tuning(DP_GNB_LEAN=0):
+        base = run()
+    with ops.tuning(DP_GNB_LEAN=1):
+        got = run()
+        with ops.tuning(DP_GNB_NT=3):
+            got_nt = run()
+    assert len(got) == len(base) and all(torch.equal(g, b) for g, b in zip(got, base)), case
+    assert all(torch.equal(g, b) for g, b in zip(got_nt, base)), case
+    # against the fp64 reference as well (the fp16-rounded tape values are the inputs)
+    d64 = lambda t: None if t is None else t.cpu().double()
+    ref1, ref2 = refops.group_norm_bwd(x16.cpu().double(), G, d64(gamma), d64(beta), d64(st), d64(dy), d64(x2_16),
+                                       None if tab is None else (d64(tab[:, :C]).expand(B, C), d64(tab[:, C:]).expand(B, C)), act, 0,
+                                       addend=d64(ad), addend2=d64(ad2), addend_scale=0.7071)
+    assert relerr(got[0].cpu(), ref1.float()) < 2e-4
+    if C2:
+        assert relerr(got[1].cpu(), ref2.float()) < 2e-4
+
+
 @pytest.mark.parametrize("x16", [False, True], ids=["fp32 tape", "fp16 tape"])
 def test_group_norm_bwd_three_launch_form_non_temporal_hints_same_bits(x16):
     """Round 6: the statistics and apply passes of the three-launch GroupNorm backward take non-temporal hints on their streaming

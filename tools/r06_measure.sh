@@ -39,6 +39,19 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+gnblean)   # the lean apply pass of the three-launch GroupNorm backward
+  timeout 600 python -m pytest tests/test_gpu_grad.py -m gpu -q -x -k "group_norm_bwd" > "$O/gnblean_tests.log" 2>&1; echo "rc=$?" >> "$O/gnblean_tests.log"; lap gnblean_tests
+  grep -E "passed|failed|^FAILED|^E  " "$O/gnblean_tests.log" | head
+  for V in 0 1; do DP_GNB_LEAN=$V PROBE_WHOLE_ONLY=1 timeout 300 python tests/probes/gn_bwd_chunk_probe.py > "$O/gn_bwd_probe_lean$V.log" 2>&1; done; lap probe
+  paste -d'\n' "$O/gn_bwd_probe_lean0.log" "$O/gn_bwd_probe_lean1.log" | grep "whole" | cut -c1-110
+  abv DP_GNB_LEAN 0 1 guided_adj_b32_t5_gnblean --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0 --no-conv-profile
+  abv DP_GNB_LEAN 0 1 guided_adj_b4_t10_gnblean --workload imagenet256_guided_sde_adjoint --batch 4 --t 10 --steps 1 --warmup 0 --no-conv-profile
+  abv DP_GNB_LEAN 0 1 cifar_adj_t20_gnblean --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ;;
+gnbchunk)   # does the Infinity Cache serve the apply pass of the GroupNorm backward when statistics + apply run sample by sample?
+  timeout 600 python tests/probes/gn_bwd_chunk_probe.py > "$O/gn_bwd_chunk_probe.log" 2>&1; lap probe
+  cat "$O/gn_bwd_chunk_probe.log"
+  ;;
 gnbnt)   # non-temporal hints in the three-launch GroupNorm backward (ImageNet adjoint: 17.5 % of the step)
   timeout 600 python -m pytest tests/test_gpu_grad.py -m gpu -q -x -k "group_norm_bwd" > "$O/gnbnt_tests.log" 2>&1; echo "rc=$?" >> "$O/gnbnt_tests.log"; lap gnbnt_tests
   grep -E "passed|failed|^FAILED|^E  " "$O/gnbnt_tests.log" | head
