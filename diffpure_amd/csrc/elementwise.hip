@@ -248,6 +248,34 @@ __global__ void softmax_rows_kernel(float* x, long long rows, int cols) {
     for (int c = lane; c < cols; c += 64) r[c] *= inv;
 }
 
+// The same pass with the row held in registers (round 6): cols = 64 NE, lane l owns columns l, l + 64, ... exactly as above - the same
+// per-lane order of every max / exp / sum, hence the same bits - but the row is read ONCE (all NE loads in flight together) and written
+// once, where the three-sweep form issues 3 NE loads + 2 NE stores per lane (T = 1 024: 2.5 TB/s of row traffic through L2).
+template <int NE>
+__global__ void softmax_rows_reg_kernel(float* x, long long rows) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = x + row * (64 * NE);
+    float v[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) v[k] = r[lane + 64 * k];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) m = fmaxf(m, v[k]);
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        v[k] = expf(v[k] - m);
+        s += v[k];
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) r[lane + 64 * k] = v[k] * inv;
+}
+
 }  // namespace
 
 extern "C" int dp_silu(const float* x, float* y, long long n, void* stream) {
@@ -279,7 +307,10 @@ extern "C" int dp_softmax_rows(float* x, long long rows, int cols, void* stream)
     DP_REQUIRE(x && rows > 0 && cols > 0, "dp_softmax_rows: bad args");
     const long long grid = (rows + 3) / 4;
     DP_REQUIRE(grid < (1ll << 31), "dp_softmax_rows: too many rows");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, rows, cols);
+    if (cols == 1024) hipLaunchKernelGGL(softmax_rows_reg_kernel<16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, rows);
+    else if (cols == 256) hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, rows);
+    else if (cols == 64) hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, rows);
+    else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, rows, cols);
     DP_LAUNCH_CHECK("softmax_rows");
     return 0;
 }

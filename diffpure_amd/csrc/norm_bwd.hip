@@ -710,6 +710,29 @@ __global__ void softmax_bwd_rows_kernel(const float* pm, float* dp, long long ro
     for (int c = lane; c < cols; c += 64) dr[c] = pr[c] * (dr[c] - s);
 }
 
+// the same pass with both rows in registers (round 6; cols = 64 NE, the lane -> column map and the summation order of the kernel above:
+// same bits): P and dP are read once, dS written once
+template <int NE>
+__global__ void softmax_bwd_rows_reg_kernel(const float* pm, float* dp, long long rows) {
+    const int lane = threadIdx.x & 63;
+    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = pm + row * (64 * NE);
+    float* dr = dp + row * (64 * NE);
+    float pv[NE], dv[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        pv[k] = pr[lane + 64 * k];
+        dv[k] = dr[lane + 64 * k];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) s += pv[k] * dv[k];
+    s = wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < NE; ++k) dr[lane + 64 * k] = pv[k] * (dv[k] - s);
+}
+
 __global__ void add_kernel(const float* a, const float* b, float* out, long long n4) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const f32x4 x = ld4(a + i * 4), y = ld4(b + i * 4);
@@ -914,7 +937,10 @@ extern "C" int dp_softmax_bwd_rows(const float* p, float* dp, long long rows, in
     DP_REQUIRE(p && dp && rows > 0 && cols > 0, "dp_softmax_bwd_rows: bad args");
     const long long grid = (rows + 3) / 4;
     DP_REQUIRE(grid < (1ll << 31), "dp_softmax_bwd_rows: too many rows");
-    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, dp, rows, cols);
+    if (cols == 1024) hipLaunchKernelGGL(softmax_bwd_rows_reg_kernel<16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, dp, rows);
+    else if (cols == 256) hipLaunchKernelGGL(softmax_bwd_rows_reg_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, dp, rows);
+    else if (cols == 64) hipLaunchKernelGGL(softmax_bwd_rows_reg_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, dp, rows);
+    else hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, dp, rows, cols);
     DP_LAUNCH_CHECK("softmax_bwd_rows");
     return 0;
 }

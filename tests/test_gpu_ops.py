@@ -195,6 +195,28 @@ def test_attention_fused_one_pass_fp16(dev, case):
     assert (diff <= want.float().abs() * 2.0 ** -10 + 1e-7).all() and (op != want).float().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize("cols", [64, 256, 1024, 200, 2048])
+def test_softmax_rows_and_backward_register_forms(dev, cols):
+    """Round 6: rows of 64 / 256 / 1 024 columns (the attention sizes of both networks) run the softmax and its backward with the row
+    held in registers - one read, one write - on the lane -> column map and summation order of the three-sweep kernels (other widths
+    still take those): against fp64, forward and dS = P (dP - sum dP P), incl. a row of large logits and a ragged row count."""
+    from diffpure_amd import _lib
+    rows = 37
+    x = rnd(rows, cols, seed=3) * 3.0
+    x[5] *= 40.0
+    xd = x.to(dev).clone()
+    s_ = torch.cuda.current_stream().cuda_stream
+    _lib.call("dp_softmax_rows", xd.data_ptr(), rows, cols, s_)
+    ref = torch.softmax(x.double(), -1)
+    close(xd, ref.float(), rtol=1e-5, atol=1e-7)
+    dp = rnd(rows, cols, seed=4)
+    dpd = dp.to(dev).clone()
+    _lib.call("dp_softmax_bwd_rows", xd.data_ptr(), dpd.data_ptr(), rows, cols, s_)
+    p64 = xd.cpu().double()
+    want = p64 * (dp.double() - (dp.double() * p64).sum(-1, keepdim=True))
+    close(dpd, want.float(), rtol=1e-4, atol=1e-6)
+
+
 def test_softmax_forced_large_logits(dev):
     from diffpure_amd import _lib
     x = rnd(37, 200, seed=12) * 30
