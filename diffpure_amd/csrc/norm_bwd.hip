@@ -873,6 +873,9 @@ extern "C" int dp_gn_bwd_apply(const void* x1, int C1, const void* x2, int C2, i
 static int gn_bwd_fused_block(int HW, int C, int G, int C1) {
     const int cpg = C / G;
     if (cpg % 4 != 0 || HW <= 0) return 0;
+    // (round 6 measured the opposite preference - blocks of at most FOUR quads per thread, 103 registers, two workgroups per CU instead of
+    //  one at 175 - on the CIFAR adjoint: 150.7 -> 149.3 images/s at t = 20: the 8-channel blocks halve the contiguous run per pixel (32 B of
+    //  dy), and that costs more than the second resident workgroup hides.  Not kept.)
     int best = 0;
     for (int cb = cpg; cb <= C && cb <= 256; cb += cpg) {
         if (C % cb != 0 || cb % 8 != 0 || 512 % (cb / 4) != 0) continue;
