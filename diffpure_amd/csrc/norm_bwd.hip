@@ -518,6 +518,14 @@ __global__ __launch_bounds__(512) void gn_bwd_fused_kernel(FusedArgs a) {
     const int q = t % a.QB, pl = t / a.QB;
     const int c = cb * a.CB + q * 4;                    // this thread's channel quad (one group: cpg % 4 == 0)
     f32x4 dxh[ITEMS], xh[ITEMS];
+    f32x4 adv[ITEMS];                                   // round 6: the skip branch's gradient, fetched WITH x and dy (lean path) instead of inside the store loop
+    const float* adp = nullptr;                         // this thread's addend column (fp32 output only)
+    if (p.out_fmt == 0) {
+        const bool first_ = c < p.C1;
+        const float* ab = first_ ? a.add1 : a.add2;
+        if (ab) adp = ab + (first_ ? c : c - p.C1);
+    }
+    const int adC = c < p.C1 ? p.C1 : p.C2;
     float s = 0.f, sq = 0.f;
     if (!a.lean) {
 #pragma unroll
@@ -557,6 +565,7 @@ __global__ __launch_bounds__(512) void gn_bwd_fused_kernel(FusedArgs a) {
                     const int y = px / p.W, x = px - y * p.W;
                     da[k] = load_da<false>(p, b, y, x, c);
                 }
+                if (adp) adv[k] = ld4(adp + pix * adC);
             }
         }
 #pragma unroll
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(512) void gn_bwd_fused_kernel(FusedArgs a) {
             float* d = first ? p.dx1 + pix * p.C1 + c : p.dx2 + pix * p.C2 + (c - p.C1);
             const float* ad = first ? (a.add1 ? a.add1 + pix * p.C1 + c : nullptr) : (a.add2 ? a.add2 + pix * p.C2 + (c - p.C1) : nullptr);
             if (ad) {
-                o = gnb_add(o, a.add_scale, ld4(ad));
+                o = gnb_add(o, a.add_scale, a.lean ? adv[k] : ld4(ad));
             }
             *reinterpret_cast<f32x4*>(d) = o;
         } else {

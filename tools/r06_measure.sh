@@ -39,6 +39,11 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+fusedadd)   # one-pass GroupNorm backward: the skip gradient fetched with x and dy
+  timeout 600 python -m pytest tests/test_gpu_grad.py -m gpu -q -x -k "group_norm_bwd or ncsnpp or vjp" > "$O/tests.log" 2>&1; echo "rc=$?" >> "$O/tests.log"; lap tests
+  grep -E "passed|failed|^FAILED|^E  " "$O/tests.log" | head
+  abv DP_GNB_LEAN 0 1 cifar_adj_t20_fusedadd --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ;;
 gnblean)   # the lean apply pass of the three-launch GroupNorm backward
   timeout 600 python -m pytest tests/test_gpu_grad.py -m gpu -q -x -k "group_norm_bwd" > "$O/gnblean_tests.log" 2>&1; echo "rc=$?" >> "$O/gnblean_tests.log"; lap gnblean_tests
   grep -E "passed|failed|^FAILED|^E  " "$O/gnblean_tests.log" | head
