@@ -30,7 +30,9 @@ extern "C" {
 int dp_abi_version(void);
 const char* dp_last_error(void);
 
-/* Tuning switches (csrc/dp_tune.h lists them: kernel-variant selectors, all bit-identical in their results).  Each is read
+/* Tuning switches (csrc/dp_tune.h lists them: kernel-variant selectors, bit-identical in their results - all but
+ * DIFFPURE_BATCH_INVARIANT, which decides whether a convolution's split of K may depend on the batch bucket: see
+ * dp_conv2d_nhwc_h2_workspace).  Each is read
  * from the environment variable of the same name ONCE, on first use, and never again; dp_set_tuning() is the only way to
  * change one afterwards (probes, A/B tests).  Unknown name -> non-zero.  No reference counterpart (the reference tunes
  * through cudnn.benchmark, eval_sde_adv.py:303). */
