@@ -39,6 +39,11 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+headprof)   # rocprofv3 kernel stats of the default command and of the reference's per-GPU batch at HEAD
+  rocstats default 400 --steps 1 --warmup 0
+  rocstats guided_b4_t10 200 --batch 4 --t 10 --steps 1 --warmup 0
+  for f in "$O"/*_kernel_stats.csv; do echo "== $f"; head -16 "$f" | cut -c1-150; done
+  ;;
 fusedadd)   # one-pass GroupNorm backward: the skip gradient fetched with x and dy
   timeout 600 python -m pytest tests/test_gpu_grad.py -m gpu -q -x -k "group_norm_bwd or ncsnpp or vjp" > "$O/tests.log" 2>&1; echo "rc=$?" >> "$O/tests.log"; lap tests
   grep -E "passed|failed|^FAILED|^E  " "$O/tests.log" | head
