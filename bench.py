@@ -757,6 +757,8 @@ def main():
                     "sampled_launches": dom["n"], "sampled_of_total": 1.0 / a.steps,
                     "launches_in_timed_region": launches_per_call * a.steps, "dropped_records": prof["dropped"],
                     "time_share_of_step": dom["ms"] / window_ms,
+                    # the same kernel's 1x1 launches counted as well (rocprofv3 books them under the one kernel name: profiles/r06/*_kernel_stats.csv)
+                    "time_share_of_step_incl_1x1_launches": (dom["ms"] + prof["pp1x1"]["ms"]) / window_ms,
                     "sampled_step_ms": window_ms,
                     # scalars (the driver's parser keeps scalars of this object, not nested ones): the clock and socket power this run held
                     "sclk_mhz_median": held, "power_w_median": (sclk or {}).get("power_w_median"),
