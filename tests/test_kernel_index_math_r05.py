@@ -289,3 +289,76 @@ def test_dw_512x128_vmcnt_schedule(nt):
     wait(0)                                                             # the tail waits with vmcnt(0)
     for kt in range(nt):
         assert all(("A", kt, it) in landed for it in range(2 * NAO)) and all(("B", kt, it) in landed for it in range(2 * NBO))
+
+
+# ---- round 6: the lean apply pass of the GroupNorm backward (csrc/norm_bwd.hip gn_bwd_apply_lean_kernel) ------------------------------------
+def _lean_grid(B, H, W, C8):
+    """the launcher's geometry: at most 4096 workgroups of 256 threads, a thread count that is a multiple of C8"""
+    items = B * H * W * C8
+    wg = min(4096, (items + 255) // 256)
+    while wg > 0 and (wg * 256) % C8 != 0:
+        wg -= 1
+    if wg == 0:
+        return None
+    PS = wg * 256 // C8
+    HW = H * W
+    dB, remp = divmod(PS, HW)
+    dY, dX = divmod(remp, W)
+    return wg, PS, dB, dY, dX
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 32), (3, 6, 10, 8), (5, 8, 8, 96), (1, 64, 64, 16), (4, 4, 4, 128), (7, 5, 3, 24), (2, 256, 256, 32)], ids=str)
+def test_gn_bwd_lean_apply_pixel_walk_and_border(shape):
+    """A thread of the lean apply pass keeps channel octet gid % C8 and walks pixels pl, pl + PS, ... of the B*H*W pixels, carrying
+    (sample, y, x) forward by the decomposition of PS = dB * HW + dY * W + dX with two carries - no division in the loop.  Restated: the
+    walk visits every (pixel, octet) pair exactly once, its (sample, y, x) is the pixel's own at every step, the sample changes
+    monotonically (the per-sample constants are re-loaded only then), and the second loop writes every frame pixel of the zero-bordered
+    operand exactly once per octet and no interior pixel."""
+    B, H, W, C8 = shape
+    g = _lean_grid(B, H, W, C8)
+    assert g is not None
+    wg, PS, dB, dY, dX = g
+    assert (wg * 256) % C8 == 0 and PS * C8 == wg * 256 and dB * H * W + dY * W + dX == PS and 0 <= dX < W and 0 <= dY < H
+    total, HW = B * H * W, H * W
+    lanes = range(PS) if PS <= 4096 else list(range(0, PS, max(1, PS // 512))) + [PS - 1]     # every pixel lane, or a sample of them on big grids
+    seen = 0
+    for pl in lanes:
+        b, rem = divmod(pl, HW)
+        y, x = divmod(rem, W)
+        last_b = -1
+        px = pl
+        while px < total:
+            assert (b, y, x) == (px // HW, (px % HW) // W, px % W), (pl, px)
+            assert b >= last_b
+            last_b = b
+            seen += 1
+            x += dX
+            if x >= W:
+                x -= W
+                y += 1
+            y += dY
+            if y >= H:
+                y -= H
+                b += 1
+            b += dB
+            px += PS
+    if PS <= 4096:
+        assert seen == total            # each pixel exactly once per octet (lanes 0 .. PS-1 partition the pixels by px % PS)
+    # border loop: frame pixels f = 0 .. B * nb - 1 of the [B][H+2][W+2] operand, walked with the same lane / stride
+    Wq, Hq = W + 2, H + 2
+    nb = 2 * Wq + 2 * H
+    if B * nb <= 200000:
+        frame = set()
+        for f in range(B * nb):
+            bb, r = divmod(f, nb)
+            if r < Wq:
+                yy, xx = 0, r
+            elif r < 2 * Wq:
+                yy, xx = Hq - 1, r - Wq
+            else:
+                k = r - 2 * Wq
+                yy, xx = 1 + (k >> 1), (Wq - 1 if k & 1 else 0)
+            assert (bb, yy, xx) not in frame
+            frame.add((bb, yy, xx))
+        want = {(bb, yy, xx) for bb in range(B) for yy in range(Hq) for xx in range(Wq) if yy in (0, Hq - 1) or xx in (0, Wq - 1)}
+        assert frame == want
