@@ -39,6 +39,14 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+final2)   # adjoint workloads at HEAD (after the one-pass kernel's addend prefetch)
+  for B in 4 64; do
+    timeout 500 python bench.py --workload imagenet256_guided_sde_adjoint --batch $B --steps 1 --warmup 0 --no-cpu-baseline --no-resident-call > "$O/bench_guided_sde_adjoint_b$B.json" 2> "$O/bench_guided_sde_adjoint_b$B.err"; lap bench_guided_sde_adjoint_b$B
+    val "$O/bench_guided_sde_adjoint_b$B.json" "guided_sde_adjoint B=$B" | cut -c1-110
+  done
+  rocstats cifar_adjoint_t10 200 --workload cifar32_ncsnpp_adjoint --t 10 --steps 1 --warmup 0
+  head -12 "$O/cifar_adjoint_t10_kernel_stats.csv" | cut -c1-150
+  ;;
 headprof)   # rocprofv3 kernel stats of the default command and of the reference's per-GPU batch at HEAD
   rocstats default 400 --steps 1 --warmup 0
   rocstats guided_b4_t10 200 --batch 4 --t 10 --steps 1 --warmup 0
