@@ -24,6 +24,7 @@
 // so attn_pack shrinks to the transposition of V (attn_pack_vt); the 1/sqrt(d) goes onto the scores.  LDS rows are 64 bytes
 // (32 k-values) with the swizzle of igemm_h2_dw.hip: half the bytes through L2 -> LDS of a kernel that re-reads K and V T/128 times.
 #include "dp_common.h"
+#include "dp_tune.h"
 
 namespace {
 
@@ -142,6 +143,7 @@ struct FlashArgs {
     // one-pass form: qh / kh point at q / k of head 0 inside qkv16 (fp16), rows of row_bytes, heads head_bytes apart; qscale on the scores
     int row_bytes, head_bytes;
     float qscale;
+    int xcd_map;        // round 6 (DP_XCD_MAP): the query blocks of one (sample, head) on ONE XCD - they all stream the same K / V^T
 };
 
 #define AT_GLDS(src, dst)                                                                      \
@@ -164,7 +166,15 @@ __global__ __launch_bounds__(QW * 64) __attribute__((amdgpu_waves_per_eu(1, D > 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lk = lane >> 5;
     const int qblocks = p.T / (QW * 32);
-    const int z = blockIdx.x / qblocks, qb = blockIdx.x - z * qblocks;
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  The T / 128 query blocks of one (sample, head) all stream that head's
+    // whole K and V^T: in blockIdx order they land on DIFFERENT XCDs and every L2 fetches every head (PMC, round 6: 418 MB fetched per
+    // launch at 32 x 32 against 201 MB of qkv).  XCD x owns a contiguous range of logical blocks instead (the convolution kernels' map).
+    int bid = blockIdx.x;
+    if (p.xcd_map) {
+        const int x = bid & 7, per = gridDim.x >> 3, rem = gridDim.x & 7;
+        bid = (x < rem ? x * (per + 1) : rem * (per + 1) + (x - rem) * per) + (bid >> 3);
+    }
+    const int z = bid / qblocks, qb = bid - z * qblocks;
     const int q0 = qb * (QW * 32) + wave * 32;
     const int nkb = p.T / KB;
 
@@ -352,7 +362,7 @@ extern "C" int dp_attention_fused(const void* qkv, int qkv_fmt, int B, int T, in
         else hipLaunchKernelGGL(attn_pack_vt_kernel<256>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pv);
         DP_LAUNCH_CHECK("attn_pack_vt");
         FlashArgs fa{reinterpret_cast<const char*>(q16 + oq), reinterpret_cast<const char*>(q16 + ok), (const char*)work, static_cast<float*>(out),
-                     T, C, n_heads, out_fmt, out_fmt ? W : 1, 3 * C * 2, sh * 2, qscale};
+                     T, C, n_heads, out_fmt, out_fmt ? W : 1, 3 * C * 2, sh * 2, qscale, dp_tune(DP_T_XCD_MAP) != 0};
         if (D == 256) hipLaunchKernelGGL((attn_flash_kernel<4, 256, true>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
         else if (T % 128 == 0) hipLaunchKernelGGL((attn_flash_kernel<4, 64, true>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((attn_flash_kernel<2, 64, true>), dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);
@@ -368,7 +378,7 @@ extern "C" int dp_attention_fused(const void* qkv, int qkv_fmt, int B, int T, in
     if (D == 64) hipLaunchKernelGGL(attn_pack_kernel<64>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
     else hipLaunchKernelGGL(attn_pack_kernel<256>, dim3((unsigned)(Z * (T / KB))), dim3(256), 0, s, pa);
     DP_LAUNCH_CHECK("attn_pack");
-    FlashArgs fa{pa.qh, pa.kh, pa.vt, static_cast<float*>(out), T, C, n_heads, out_fmt, out_fmt ? W : 1, 0, 0, 1.0f};
+    FlashArgs fa{pa.qh, pa.kh, pa.vt, static_cast<float*>(out), T, C, n_heads, out_fmt, out_fmt ? W : 1, 0, 0, 1.0f, dp_tune(DP_T_XCD_MAP) != 0};
     if (D == 256) hipLaunchKernelGGL((attn_flash_kernel<4, 256, false>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
     else if (T % 128 == 0) hipLaunchKernelGGL((attn_flash_kernel<4, 64, false>), dim3((unsigned)(Z * (T / 128))), dim3(256), 0, s, fa);
     else hipLaunchKernelGGL((attn_flash_kernel<2, 64, false>), dim3((unsigned)(Z * (T / 64))), dim3(128), 0, s, fa);

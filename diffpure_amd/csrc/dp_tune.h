@@ -28,6 +28,10 @@ enum DpTune {
                            // fewer workgroups than this (default 2048; 0 = always one workgroup per row, rounds 3-5); same bits
     DP_T_GNB_NT,           // DP_GNB_NT (round 6): non-temporal hints in the three-launch GroupNorm backward - -1 (default) by tensor size, 0 never, 1 | 2 | 3 forced; same bits
     DP_T_GNB_LEAN,         // DP_GNB_LEAN (round 6): the lean apply pass of the three-launch GroupNorm backward (un-resampled, fp16 tape) - 0 off; same bits
+    DP_T_XCD_MAP,          // DP_XCD_MAP (round 6): XCD-aware workgroup maps of the secondary kernels - workgroups are dealt to the 8 XCDs round-robin by
+                           // blockIdx, so neighbours in blockIdx order that share cache lines (gn_finalize_cols: four groups per 128-byte record line;
+                           // one-pass GroupNorm backward: two 16-channel blocks per line) or stream the same operand (flash attention: the query blocks of
+                           // a head; gemm_strided_h16: the tiles of a batch entry) are re-dealt onto ONE XCD - 0 off; same bits
     DP_T_COUNT
 };
 

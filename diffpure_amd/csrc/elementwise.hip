@@ -27,7 +27,7 @@ namespace {
 struct TuneEntry { const char* name; int def; };
 const TuneEntry kTune[DP_T_COUNT] = {
     {"DP_H2_PP", 2}, {"DP_H2_SW", 2}, {"DP_H2_NN", 1}, {"DP_H2_DW", 2}, {"DP_H2_DH", 2}, {"DP_H2_DH_MIN", 32}, {"DP_GN_FINALIZE_SAMPLE", 1},
-    {"DIFFPURE_BATCH_INVARIANT", 0}, {"DP_GN_NT", -1}, {"DP_GN_WG", 2048}, {"DP_GNB_NT", -1}, {"DP_GNB_LEAN", 1},
+    {"DIFFPURE_BATCH_INVARIANT", 0}, {"DP_GN_NT", -1}, {"DP_GN_WG", 2048}, {"DP_GNB_NT", -1}, {"DP_GNB_LEAN", 1}, {"DP_XCD_MAP", 1},
 };
 std::atomic<int> g_tune[DP_T_COUNT];       // relaxed: read on every launch, possibly from several host threads (DataParallel replicas)
 std::once_flag g_tune_once;

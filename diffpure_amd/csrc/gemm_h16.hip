@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dp_common.h"
+#include "dp_tune.h"
 
 namespace {
 
@@ -40,6 +41,7 @@ struct GemmHArgs {
     float alpha;
     int tiles_n, tiles_mn;
     int afmt, bfmt;             // 0: the operand is fp32 in memory, 1: plain fp16
+    int xcd_map;                // round 6: the tiles of one batch entry on ONE XCD (they share its operand rows); speed only
 };
 
 // KCONTIG: the operand is stored [row][k] (k contiguous); else [k][row] (row contiguous).  `row` = m for A, n for B.  ROWS: rows of the tile.
@@ -114,7 +116,12 @@ __global__ __launch_bounds__(NT) void gemm_strided_h16(GemmHArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * 128 * 64];      // [buffer][A | B][<= 128 rows x 64 bytes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int z = blockIdx.x / p.tiles_mn, tz = blockIdx.x - z * p.tiles_mn;
+    int bid = blockIdx.x;
+    if (p.xcd_map) {            // XCD x (= blockIdx % 8) owns a contiguous range of logical tiles (the convolution kernels' map)
+        const int x = bid & 7, per = gridDim.x >> 3, rem = gridDim.x & 7;
+        bid = (x < rem ? x * (per + 1) : rem * (per + 1) + (x - rem) * per) + (bid >> 3);
+    }
+    const int z = bid / p.tiles_mn, tz = bid - z * p.tiles_mn;
     const int tile_n = tz % p.tiles_n, tile_m = tz / p.tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * BN;
     const int zb = z / p.ZH, zh = z - zb * p.ZH;
@@ -206,6 +213,7 @@ extern "C" int dp_gemm_strided_h16(const void* A, int a_fmt, int lda, long long 
     const int bn = N % 128 == 0 ? 128 : 64;
     p.tiles_n = N / bn;
     p.tiles_mn = p.tiles_n * (M / 128);
+    p.xcd_map = dp_tune(DP_T_XCD_MAP) != 0;
     const long long grid = (long long)ZB * ZH * p.tiles_mn;
     DP_REQUIRE(grid < (1ll << 31), "dp_gemm_strided_h16: grid too large");
     const dim3 g((unsigned)grid), b(NT);

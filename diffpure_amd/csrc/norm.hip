@@ -81,10 +81,17 @@ __global__ void gn_finalize_kernel(const float* partial, int B, int nsplit, int 
 // leave behind: source s has C_s channels and one [2][C_s] record per tile of tr_s output rows;
 // a sample owns HW / tr_s consecutive tiles.  One workgroup per (sample, group); fixed-order tree.
 __global__ void gn_finalize_cols_kernel(const float* cs1, int C1, int tr1, const float* cs2, int C2, int tr2, int HW,
-                                        int G, float eps, float* stats) {
+                                        int G, float eps, float* stats, int xcd_group) {
     __shared__ double rs[256];
     __shared__ double rq[256];
-    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    // round 6: four NEIGHBOURING groups of a sample share every 128-byte line of a record (8 channels x 4 bytes each) and workgroups are
+    // dealt to the 8 XCDs round-robin: inside every 32 workgroups, physical r, r + 8, r + 16, r + 24 (one XCD) take logical 4k .. 4k + 3
+    int bid = blockIdx.x;
+    if (xcd_group && (int)(gridDim.x - (gridDim.x & 31)) > bid) {
+        const int r = bid & 31;
+        bid = (bid & ~31) + 4 * (r & 7) + (r >> 3);
+    }
+    const int b = bid / G, g = bid - b * G;
     const int C = C1 + C2, cpg = C / G;
     const int ch0 = g * cpg, ch1 = ch0 + cpg;
     double s = 0.0, q = 0.0;
@@ -736,7 +743,7 @@ extern "C" int dp_gn_finalize_cols(const float* cs1, int C1, int tile_rows1, con
         return 0;
     }
     hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3((unsigned)(B * G)), dim3(256), 0, (hipStream_t)stream, cs1, C1, tile_rows1,
-                       cs2, C2, C2 ? tile_rows2 : 1, HW, G, eps, stats);
+                       cs2, C2, C2 ? tile_rows2 : 1, HW, G, eps, stats, dp_tune(DP_T_XCD_MAP) != 0 ? 1 : 0);
     DP_LAUNCH_CHECK("gn_finalize_cols");
     return 0;
 }

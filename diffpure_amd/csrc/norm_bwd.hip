@@ -501,6 +501,7 @@ struct FusedArgs {
     const float* add2;
     float add_scale;            // dx += add_scale * add
     int CB, QB, PL;             // channels / quads per block, pixel lanes (512 / QB)
+    int xcd_pair;               // DP_XCD_MAP (round 6): neighbouring channel blocks on the same XCD (see the kernel)
     int lean;                   // DP_GNB_LEAN: 1 = constants once + all loads up front (round 6), 0 = rounds 4-5's item-by-item loop (A/B; same bits)
 };
 
@@ -513,7 +514,17 @@ __global__ __launch_bounds__(512) void gn_bwd_fused_kernel(FusedArgs a) {
     __shared__ float gsum[2 * 64];                      // (m1, m2) of the block's groups (CB / cpg <= 64)
     const int t = threadIdx.x;
     const int nblk = (p.C4 * 4) / a.CB;
-    const int b = blockIdx.x / nblk, cb = blockIdx.x - b * nblk;
+    // round 6: workgroups are dealt to the 8 XCDs round-robin by blockIdx, and two NEIGHBOURING channel blocks of a sample share every
+    // 128-byte line of dy / addend / dx when a block is 16 channels (64 bytes per pixel): dealt in order they land on different XCDs and
+    // each L2 fetches the whole line for half of it.  Inside every group of 16 workgroups, physical r and r + 8 (the same XCD) take
+    // logical blocks 2k and 2k + 1.  (speed only; a.xcd_pair = 0: identity)
+    int bid = blockIdx.x;
+    if (a.xcd_pair && (int)(gridDim.x - (gridDim.x & 15)) > bid) {
+        const int r = bid & 15;
+        bid = (bid & ~15) + 2 * (r & 7) + (r >> 3);
+    }
+    // (four neighbours per XCD - the fp16 x lines are shared four ways - measured +0.2 %: noise; pairs: +0.9 % on the CIFAR adjoint)
+    const int b = bid / nblk, cb = bid - b * nblk;
     const int HW = p.H * p.W;
     const int q = t % a.QB, pl = t / a.QB;
     const int c = cb * a.CB + q * 4;                    // this thread's channel quad (one group: cpg % 4 == 0)
@@ -918,6 +929,7 @@ extern "C" int dp_gn_bwd_fused(const void* x1, int C1, const void* x2, int C2, i
     a.QB = a.CB / 4;
     a.PL = 512 / a.QB;
     a.lean = dp_tune(DP_T_GNB_LEAN) != 0;
+    a.xcd_pair = dp_tune(DP_T_XCD_MAP) != 0;
     a.add1 = add1; a.add2 = add2; a.add_scale = add_scale;
     a.b.dx1 = (float*)dx1; a.b.dx2 = dx2; a.b.out_fmt = out_fmt;
     const int items = (H * W + a.PL - 1) / a.PL;

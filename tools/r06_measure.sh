@@ -39,6 +39,41 @@ abv() {   # abv <env var> <value A> <value B> <label> <bench args...>: same-box 
   done; lap "ab_$label"
 }
 case "$STAGE" in
+xcdpair)   # XCD-aware workgroup maps of the secondary kernels (one-pass GroupNorm backward, gn_finalize_cols, flash attention)
+  timeout 600 python -m pytest tests/test_gpu_grad.py tests/test_gpu_ops.py -m gpu -q -x -k "group_norm or attention or gemm" > "$O/tests.log" 2>&1; echo "rc=$?" >> "$O/tests.log"; lap tests
+  grep -E "passed|failed|^FAILED|^E  " "$O/tests.log" | head
+  timeout 200 python - > "$O/xcd_probe.log" 2>&1 <<'PY'
+import torch, sys
+sys.path.insert(0, ".")
+from diffpure_amd import ops
+def t(fn, n=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+B, H, C, G = 64, 256, 256, 32
+cs = torch.randn(B * H * H // 64, 2, C, device="cuda")
+x = ops.Act(torch.empty(B, H, H, C, device="cuda", dtype=torch.float16), ops.ColStats(cs, 64, C))
+del cs
+for v in (0, 1, 0, 1):
+    with ops.tuning(DP_XCD_MAP=v):
+        print("gn_finalize_cols 256^2 x 256 B=64, XCD map", v, ": %.1f us" % t(lambda: ops.group_norm_stats(x, G, 1e-5)))
+del x
+for (B, hw, c, heads, layout) in ((64, 32, 512, 8, "legacy"), (64, 16, 1024, 16, "legacy"), (256, 16, 256, 1, "split")):
+    qkv = torch.randn(B, hw * hw, 3 * c, device="cuda").half()
+    for v in (0, 1, 0, 1):
+        with ops.tuning(DP_XCD_MAP=v):
+            print(f"attention_fused B={B} T={hw*hw} C={c} heads={heads}, XCD map {v}: %.1f us" % t(lambda: ops.attention_fused(qkv, heads, layout, operand_hw=(hw, hw))))
+PY
+  cat "$O/xcd_probe.log"
+  abv DP_XCD_MAP 0 1 guided_t20_xcd --t 20 --steps 1 --warmup 1 --no-conv-profile
+  abv DP_XCD_MAP 0 1 cifar_t50_xcd --workload cifar32_ncsnpp --t 50 --steps 1 --warmup 1 --no-conv-profile
+  abv DP_XCD_MAP 0 1 guided_adj_b32_t5_xcd --workload imagenet256_guided_sde_adjoint --batch 32 --t 5 --steps 1 --warmup 0 --no-conv-profile
+  abv DP_XCD_MAP 0 1 cifar_adj_t20_xcd --workload cifar32_ncsnpp_adjoint --t 20 --steps 1 --warmup 1 --no-conv-profile
+  ;;
 final2)   # adjoint workloads at HEAD (after the one-pass kernel's addend prefetch)
   for B in 4 64; do
     timeout 500 python bench.py --workload imagenet256_guided_sde_adjoint --batch $B --steps 1 --warmup 0 --no-cpu-baseline --no-resident-call > "$O/bench_guided_sde_adjoint_b$B.json" 2> "$O/bench_guided_sde_adjoint_b$B.err"; lap bench_guided_sde_adjoint_b$B
